@@ -1,0 +1,86 @@
+"""Build the native libraries in-tree (no JIT cache: the .so files travel with the gpurun snapshot).
+
+  dnascent_amd/lib/libdnascent_hip.so   HIP kernels + the C-ABI of include/dnascent_hip.h   (hipcc, gfx950)
+  dnascent_amd/lib/libdnascent_host.so  host side above the C-ABI (g++): synthetic generator, read
+                                        model, CIGAR flattening, .detect writer, batch driver
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib")
+HIP_SO = os.path.join(LIB, "libdnascent_hip.so")
+HOST_SO = os.path.join(LIB, "libdnascent_host.so")
+
+HIP_SOURCES = ["dn_capi.hip", "k1_segment.hip", "k2_banded.hip", "k_scaling.hip", "k2b_viterbi.hip"]
+HOST_SOURCES = ["host/dn_synth.c", "host/dn_host.cpp"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def _all_deps(srcs):
+    deps = list(srcs)
+    for d, _, files in os.walk(CSRC):
+        deps += [os.path.join(d, f) for f in files if f.endswith((".h", ".hpp", ".cuh"))]
+    deps.append(os.path.join(ROOT, "include", "dnascent_hip.h"))
+    return deps
+
+
+def build_hip(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if not force and not _newer(HIP_SO, _all_deps(srcs)):
+        return HIP_SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # -ffp-contract=off: the reference arithmetic has no FMA contraction (Makefile:6 plain -O2 on x86-64);
+    # every fused multiply-add in the kernels is written explicitly.
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-fno-fast-math", "-Wall", "-Wno-unused-function",
+           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", HIP_SO] + srcs
+    _run(cmd)
+    return HIP_SO
+
+
+def build_host(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if not force and not _newer(HOST_SO, _all_deps(srcs)):
+        return HOST_SO
+    objs = []
+    for s in srcs:
+        o = os.path.join(LIB, os.path.basename(s) + ".o")
+        if s.endswith(".c"):
+            _run(["gcc", "-std=c99", "-O2", "-fPIC", "-ffp-contract=off", "-Wall", "-I", CSRC, "-c", s, "-o", o])
+        else:
+            _run(["g++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-fopenmp", "-Wall",
+                  "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", s, "-o", o])
+        objs.append(o)
+    _run(["g++", "-shared", "-fopenmp", "-o", HOST_SO] + objs + ["-lm", "-ldl"])
+    return HOST_SO
+
+
+def build_oracle():
+    _run(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+
+
+def build_all(force=False):
+    build_hip(force)
+    build_host(force)
+    build_oracle()
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

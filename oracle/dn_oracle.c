@@ -1,0 +1,803 @@
+/*
+ * dn_oracle.c -- CPU restatement of DNAscent `detect`'s per-read numerical path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see dn_oracle.h for the pinning status of every function).
+ * Build: gcc -std=c99 -O2 -ffp-contract=off -fPIC -shared  (no -ffast-math, no -march=native:
+ * the reference is built with plain -O2, Makefile:6-7, so no FMA contraction may happen here).
+ *
+ * The arithmetic types of every expression follow the reference exactly (float vs double,
+ * evaluation order); where the reference relies on C/C++ implicit conversions the cast is
+ * written out and the source line cited.  All citations are relative to /root/reference/src/.
+ */
+#define _GNU_SOURCE
+#include "dn_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * probability.cpp
+ * ---------------------------------------------------------------------------------------- */
+double dno_eexp(double x) { return isnan(x) ? 0.0 : exp(x); }            /* :23-31 */
+
+double dno_eln(double x, int *neg) {                                     /* :35-47 */
+    if (x == 0.0) return NAN;
+    if (x > 0.0) return log(x);
+    if (neg) *neg = 1;                                                   /* reference: throw NegativeLog() */
+    return NAN;
+}
+
+double dno_lnSum(double a, double b) {                                   /* :50-76 */
+    int na = isnan(a), nb = isnan(b);
+    if (na || nb) {
+        if (na && nb) return NAN;
+        return na ? b : a;
+    }
+    if (a > b) return a + dno_eln(1.0 + dno_eexp(b - a), NULL);
+    return b + dno_eln(1.0 + dno_eexp(a - b), NULL);
+}
+
+double dno_lnProd(double a, double b) {                                  /* :79-88 */
+    if (isnan(a) || isnan(b)) return NAN;
+    return a + b;
+}
+
+int dno_lnGreaterThan(double a, double b) {                              /* :107-131 */
+    int na = isnan(a), nb = isnan(b);
+    if (na || nb) {
+        if (na || !nb) return 0;      /* :112 */
+        if (!na || nb) return 1;      /* :115 */
+        return 0;
+    }
+    return a > b;
+}
+
+double dno_normalPDF(double mu, double sigma, double x) {                /* :145-148 */
+    return (1.0 / sqrt(2.0 * pow(sigma, 2.0) * M_PI)) * exp(-pow(x - mu, 2.0) / (2.0 * pow(sigma, 2.0)));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * data_IO.cpp:129-141  kmer2index: A0 T1 G2 C3, big-endian base 4; anything else -> 0
+ * (std::map::operator[] default-inserts 0 for an unknown one-letter key).
+ * ---------------------------------------------------------------------------------------- */
+static inline uint32_t base_code(char c) {
+    switch (c) { case 'A': return 0; case 'T': return 1; case 'G': return 2; case 'C': return 3; default: return 0; }
+}
+uint32_t dno_kmer2index(const char *kmer, unsigned k) {
+    uint32_t r = 0;
+    for (unsigned i = 0; i < k; i++) r = r * 4u + base_code(kmer[i]);
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * pod5.cpp:57-61   pA = ((float)adc + (float)offset) * (float)scale, widened to double
+ * ---------------------------------------------------------------------------------------- */
+void dno_adc_to_pa(const int16_t *adc, size_t n, float offset, float scale, double *out) {
+    for (size_t i = 0; i < n; i++) {
+        float v = ((float)adc[i] + offset) * scale;
+        out[i] = (double)v;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * scrappie/event_detection.c
+ * ---------------------------------------------------------------------------------------- */
+static void tstat_window(const double *sum, const double *sumsq, size_t n, size_t w, float *t) {
+    /* compute_tstat :60-115 */
+    const float eta = FLT_MIN;
+    const float wf = (float)w;
+    for (size_t i = 0; i < n; i++) t[i] = 0.0f;                          /* calloc :67 + :76-86 */
+    if (n < 2 * w || w < 2) return;
+    for (size_t i = w; i <= n - w; i++) {                                /* :89 inclusive upper bound */
+        double sum1 = sum[i], sumsq1 = sumsq[i];
+        if (i > w) { sum1 -= sum[i - w]; sumsq1 -= sumsq[i - w]; }       /* :92-95 */
+        float sum2 = (float)(sum[i + w] - sum[i]);                       /* :96 */
+        float sumsq2 = (float)(sumsq[i + w] - sumsq[i]);                 /* :97 */
+        float mean1 = (float)(sum1 / (double)wf);                        /* :98 double/float -> double -> float */
+        float mean2 = sum2 / wf;                                         /* :99 float/float */
+        float m1sq = mean1 * mean1, m2sq = mean2 * mean2;                /* float products */
+        float s2w = sumsq2 / wf;
+        /* :100-101  ((sumsq1/wf - m1sq) + s2w) - m2sq evaluated in double, then stored to float */
+        float var = (float)(((sumsq1 / (double)wf - (double)m1sq) + (double)s2w) - (double)m2sq);
+        var = fmaxf(var, eta);                                           /* :104 */
+        const float dm = mean2 - mean1;                                  /* :110 */
+        float vw = var / wf;
+        t[i] = (float)(fabs((double)dm) / sqrt((double)vw));             /* :111 */
+    }
+}
+
+typedef struct {
+    const float *sig; float thr; size_t win; size_t masked_to; long peak_pos; float peak_val; int valid;
+} det_t;
+
+size_t dno_detect_events(const double *raw, size_t n, dno_sevent **out,
+                         float *tstat1, float *tstat2, uint64_t *peaks_out, size_t *npeaks_out) {
+    *out = NULL;
+    if (!raw || n == 0) return 0;
+    double *sum = (double *)calloc(n + 1, sizeof(double));
+    double *sumsq = (double *)calloc(n + 1, sizeof(double));
+    float *t1 = (float *)malloc(n * sizeof(float));
+    float *t2 = (float *)malloc(n * sizeof(float));
+    uint64_t *peaks = (uint64_t *)calloc(n, sizeof(uint64_t));
+    /* compute_sum_sumsq :42-47, strictly left to right */
+    for (size_t i = 0; i < n; i++) {
+        sum[i + 1] = sum[i] + raw[i];
+        sumsq[i + 1] = sumsq[i] + raw[i] * raw[i];
+    }
+    tstat_window(sum, sumsq, n, 3, t1);                                  /* event_detection.h:19-25 defaults */
+    tstat_window(sum, sumsq, n, 6, t2);
+
+    /* short_long_peak_detector :122-198 */
+    det_t d[2] = {
+        { t1, 1.4f, 3, 0, -1, FLT_MAX, 0 },
+        { t2, 9.0f, 6, 0, -1, FLT_MAX, 0 },
+    };
+    const float peak_height = 0.2f;
+    size_t npk = 0;
+    for (size_t i = 0; i < n; i++) {
+        for (int k = 0; k < 2; k++) {
+            det_t *q = &d[k];
+            if (q->masked_to >= i) continue;                             /* :140 */
+            float v = q->sig[i];
+            if (q->peak_pos == -1) {                                     /* :146 */
+                if (v < q->peak_val) q->peak_val = v;
+                else if (v - q->peak_val > peak_height) { q->peak_val = v; q->peak_pos = (long)i; }
+            } else {
+                if (v > q->peak_val) { q->peak_val = v; q->peak_pos = (long)i; }
+                if (k == 0 && q->peak_val > q->thr) {                    /* :166-176 short dominates long */
+                    d[1].masked_to = (size_t)q->peak_pos + q->win;
+                    d[1].peak_pos = -1; d[1].peak_val = FLT_MAX; d[1].valid = 0;
+                }
+                if (q->peak_val - v > peak_height && q->peak_val > q->thr) q->valid = 1;   /* :178 */
+                if (q->valid && (i - (size_t)q->peak_pos) > q->win / 2) {                  /* :183 */
+                    peaks[npk++] = (uint64_t)q->peak_pos;
+                    q->peak_pos = -1; q->peak_val = v; q->valid = 0;
+                }
+            }
+        }
+    }
+    /* create_events :234-266 */
+    size_t ne = 1;
+    for (size_t i = 0; i < n; i++) if (peaks[i] > 0 && peaks[i] < n) ne++;
+    dno_sevent *ev = (dno_sevent *)calloc(ne, sizeof(dno_sevent));
+    for (size_t e = 0; e < ne; e++) {
+        uint64_t s = (e == 0) ? 0 : peaks[e - 1];
+        uint64_t en = (e == ne - 1) ? (uint64_t)n : peaks[e];
+        /* create_event :224-229 */
+        ev[e].start = s;
+        ev[e].length = (float)(en - s);
+        ev[e].mean = (float)(sum[en] - sum[s]) / ev[e].length;
+        const float dsq = (float)(sumsq[en] - sumsq[s]);
+        const float var = dsq / ev[e].length - ev[e].mean * ev[e].mean;
+        ev[e].stdv = sqrtf(fmaxf(var, 0.0f));
+    }
+    if (tstat1) memcpy(tstat1, t1, n * sizeof(float));
+    if (tstat2) memcpy(tstat2, t2, n * sizeof(float));
+    if (peaks_out) memcpy(peaks_out, peaks, n * sizeof(uint64_t));
+    if (npeaks_out) *npeaks_out = npk;
+    free(sum); free(sumsq); free(t1); free(t2); free(peaks);
+    *out = ev;
+    return ne;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * event_handling.cpp
+ * ---------------------------------------------------------------------------------------- */
+static int cmp_double(const void *a, const void *b) {
+    double x = *(const double *)a, y = *(const double *)b;
+    /* NaN (only reachable through 0/0 slopes, UB under std::sort in the reference) sorts last */
+    if (isnan(x)) return isnan(y) ? 0 : 1;
+    if (isnan(y)) return -1;
+    return (x < y) ? -1 : (x > y);
+}
+
+static void quantile_medians(const double *data, size_t n, double *q10) {
+    /* quantileMedians :451-475 */
+    double *s = (double *)malloc((n ? n : 1) * sizeof(double));
+    memcpy(s, data, n * sizeof(double));
+    qsort(s, n, sizeof(double), cmp_double);
+    unsigned int m = (unsigned int)(n / 10);
+    for (int i = 0; i < 10; i++) q10[i] = s[((unsigned)i * m + (unsigned)(i + 1) * m) / 2];
+    free(s);
+}
+
+void dno_quantile_scaling(const dno_model *m, const double *event_means, size_t ne,
+                          const uint32_t *rank_r, size_t nr, double *shift, double *scale) {
+    /* estimateScaling_quantiles :510-541 + linear_regression :478-507 */
+    double *mm = (double *)malloc((nr ? nr : 1) * sizeof(double));
+    for (size_t i = 0; i < nr; i++) mm[i] = m->mean[rank_r[i]];
+    double sq[10], mq[10];
+    quantile_medians(event_means, ne, sq);
+    quantile_medians(mm, nr, mq);
+    free(mm);
+    double sx = 0., sx2 = 0., sy = 0., sxy = 0.;
+    const int n = 10;
+    for (int i = 0; i < n; i++) {            /* x = model quantiles, y = signal quantiles (:535) */
+        sx = sx + mq[i];
+        sx2 = sx2 + mq[i] * mq[i];
+        sy = sy + sq[i];
+        sxy = sxy + mq[i] * sq[i];
+    }
+    double slope = (n * sxy - sx * sy) / (n * sx2 - sx * sx);
+    double icpt = (sy - slope * sx) / n;
+    *shift = icpt;   /* :537 */
+    *scale = slope;  /* :538 */
+}
+
+int dno_theil_sen(const dno_model *m, const double *sig, const uint32_t *rank, size_t n,
+                  double in_shift, double in_scale, double *out_shift, double *out_scale,
+                  double *slope_med, double *icpt_med) {
+    /* estimateScaling_theilSen :24-110.  returns 1 if refinement ran, 0 if skipped (:33) */
+    const size_t maxPoints = 1000, trimSize = 50;
+    if (slope_med) *slope_med = NAN;
+    if (icpt_med) *icpt_med = NAN;
+    *out_shift = in_shift; *out_scale = in_scale;
+    if (n < maxPoints) return 0;
+    size_t eff = n - 2 * trimSize;
+    size_t skip = 1, npts = eff;
+    if (eff > maxPoints) { skip = eff / maxPoints; npts = maxPoints; }
+    double *x = (double *)malloc(npts * sizeof(double)), *y = (double *)malloc(npts * sizeof(double));
+    size_t i = trimSize;
+    for (size_t j = 0; j < npts; j++) {
+        x[j] = (sig[i] - in_shift) / in_scale;
+        y[j] = m->mean[rank[i]];
+        i += skip;
+    }
+    size_t ns = npts * (npts - 1) / 2;
+    double *sl = (double *)malloc((ns ? ns : 1) * sizeof(double));
+    size_t c = 0;
+    for (size_t a = 0; a < npts; a++)
+        for (size_t b = a + 1; b < npts; b++) {
+            double dy = y[a] - y[b], dx = x[a] - x[b];
+            sl[c++] = dy / dx;
+        }
+    qsort(sl, ns, sizeof(double), cmp_double);
+    double smed = sl[ns / 2];
+    double *ic = (double *)malloc(npts * sizeof(double));
+    for (size_t a = 0; a < npts; a++) {
+        double prod = smed * x[a];          /* :83  y - slope*x, product rounded before the subtraction */
+        ic[a] = y[a] - prod;
+    }
+    qsort(ic, npts, sizeof(double), cmp_double);
+    double imed = ic[npts / 2];
+    free(x); free(y); free(sl); free(ic);
+    if (slope_med) *slope_med = smed;
+    if (icpt_med) *icpt_med = imed;
+    if (smed == 0.) { *out_shift = -1.; *out_scale = -1.; return 1; }   /* :90-95 */
+    double scale_corr = 1. / smed;                                      /* :98-101 */
+    double shift_corr = -imed / smed;
+    *out_shift = in_shift + (shift_corr * in_scale);
+    *out_scale = in_scale * scale_corr;
+    return 1;
+}
+
+typedef struct { double C; double inv_unused; float lisp; } lpm_const;
+
+static inline float lp_match(const dno_model *m, uint32_t rank, double ev_mean, double shift, double scale) {
+    /* logProbabilityMatch :116-137 (static model: sigma == 0.14 for every k-mer) */
+    double mu = m->mean[rank];
+    double sigma = m->sigma;
+    double x = (ev_mean - shift) / scale;
+    float a = (float)((x - mu) / sigma);                                 /* :133 */
+    static float lisp = 0.0f; static int init = 0;
+    if (!init) { lisp = (float)log(0.3989422804014327); init = 1; }      /* :134 static const float */
+    float t = -0.5f * a;                                                 /* :135  (-0.5f * a) * a in float */
+    t = t * a;
+    double p = ((double)lisp - log(sigma)) + (double)t;
+    return (float)p;                                                     /* :136 return type float */
+}
+
+typedef struct { int ev, km; } ekp;
+
+int dno_normalise(const dno_model *m, const dno_read *r, dno_norm *o) {
+    memset(o, 0, sizeof(*o));
+    o->ts_slope = NAN; o->ts_intercept = NAN;
+    const size_t k = DNO_K;
+    if (r->n_base < k + 1 || r->n_ref < k || r->n_raw < 16) { o->status = DNO_FAIL_TOO_SHORT; return o->status; }
+
+    /* ---- normaliseEvents :544-575 : segmentation + event build ---- */
+    dno_sevent *et = NULL;
+    size_t etn = dno_detect_events(r->raw, r->n_raw, &et, NULL, NULL, NULL, NULL);
+    o->n_scrappie = etn;
+    o->events = (dno_event *)malloc((etn ? etn : 1) * sizeof(dno_event));
+    double *event_means = (double *)malloc((etn ? etn : 1) * sizeof(double));
+    size_t ne = 0;
+    unsigned int rawStart = 0;
+    double mean = 0.;
+    for (unsigned int i = 0; i < etn; i++) {
+        if (et[i].mean > 0.) {
+            if (i > 0) {
+                uint64_t last = et[i].start - 1;                         /* :563 */
+                if (last > (uint64_t)r->n_raw - 1) last = (uint64_t)r->n_raw - 1;
+                o->events[ne].mean = mean;
+                o->events[ne].raw_start = rawStart;
+                o->events[ne].raw_len = (last >= rawStart) ? (uint32_t)(last - rawStart + 1) : 0;
+                event_means[ne] = mean;
+                ne++;
+                mean = (double)et[i].mean;                               /* :570 float -> double */
+                rawStart = (unsigned int)et[i].start;
+            }
+        }
+    }
+    free(et);
+    o->n_events = ne;
+
+    /* ---- k-mer ranks :578-592 ---- */
+    o->n_kq = r->n_base - k + 1;
+    o->rank_q = (uint32_t *)malloc(o->n_kq * sizeof(uint32_t));
+    for (size_t i = 0; i < o->n_kq; i++) o->rank_q[i] = dno_kmer2index(r->basecall + i, k);
+    o->n_kr = r->n_ref - k + 1;
+    o->rank_r = (uint32_t *)malloc(o->n_kr * sizeof(uint32_t));
+    for (size_t i = 0; i < o->n_kr; i++) o->rank_r[i] = dno_kmer2index(r->refseq + i, k);
+
+    /* ---- rough scaling :595 ---- */
+    dno_quantile_scaling(m, event_means, ne, o->rank_r, o->n_kr, &o->q_shift, &o->q_scale);
+    free(event_means);
+    const double shift = o->q_shift, scale = o->q_scale;
+
+    /* ---- adaptive_banded_simple_event_align :148-448 ---- */
+    const size_t n_events = ne, n_kmers = o->n_kq;
+    const int W = DNO_BANDWIDTH, half = W / 2;
+    if (n_events < 1) { o->status = DNO_FAIL_TOO_SHORT; return o->status; }
+    const double epk = (double)n_events / (double)n_kmers;               /* :174 */
+    const double p_stay = 1 - (1 / (epk + 1));
+    const double lp_skip = log(1e-30);
+    const double lp_stay = log(p_stay);
+    const double lp_step = log(1.0 - exp(lp_skip) - exp(lp_stay));
+    const double lp_trim = log(0.01);
+    const size_t n_bands = (n_events + 1) + (n_kmers + 1);
+    o->n_bands = n_bands;
+    float *sc = (float *)malloc(n_bands * W * sizeof(float));
+    uint8_t *tr = (uint8_t *)calloc(n_bands * W, 1);
+    ekp *ll = (ekp *)malloc(n_bands * sizeof(ekp));
+    for (size_t i = 0; i < n_bands * (size_t)W; i++) sc[i] = -INFINITY;
+#define SC(b, off) sc[(size_t)(b) * W + (off)]
+#define TR(b, off) tr[(size_t)(b) * W + (off)]
+    ll[0].ev = half - 1; ll[0].km = -1 - half;                           /* :213-215 */
+    ll[1].ev = ll[0].ev + 1; ll[1].km = ll[0].km;
+    SC(0, (-1) - ll[0].km) = 0.0f;                                       /* :218-221 */
+    { int fo = ll[1].ev - 0; SC(1, fo) = (float)lp_trim; TR(1, fo) = 1; }/* :224-228 */
+    uint64_t fills = 0;
+    for (size_t b = 2; b < n_bands; b++) {
+        float lo = SC(b - 1, 0), hi = SC(b - 1, W - 1);                  /* :237-247 */
+        int lo_ob = (lo == -INFINITY), hi_ob = (hi == -INFINITY);
+        int right = (lo_ob && hi_ob) ? ((b % 2) == 1) : (lo < hi);
+        if (right) { ll[b].ev = ll[b - 1].ev; ll[b].km = ll[b - 1].km + 1; }
+        else { ll[b].ev = ll[b - 1].ev + 1; ll[b].km = ll[b - 1].km; }
+        int trim_off = (-1) - ll[b].km;                                  /* :256-265 */
+        if (trim_off >= 0 && trim_off < W) {
+            unsigned int e = (unsigned int)(ll[b].ev - trim_off);
+            if (e < n_events) { SC(b, trim_off) = (float)(lp_trim * (double)(e + 1u)); TR(b, trim_off) = 1; }
+            else SC(b, trim_off) = -INFINITY;
+        }
+        int kmin = 0 - ll[b].km, kmax = (int)n_kmers - ll[b].km;         /* :269-278 */
+        int emin = ll[b].ev - ((int)n_events - 1), emax = ll[b].ev + 1;
+        int omin = kmin > emin ? kmin : emin; if (omin < 0) omin = 0;
+        int omax = kmax < emax ? kmax : emax; if (omax > W) omax = W;
+        for (int off = omin; off < omax; off++) {
+            int e = ll[b].ev - off, km = ll[b].km + off;
+            int ou = ll[b - 1].ev - (e - 1);
+            int ol = (km - 1) - ll[b - 1].km;
+            int od = (km - 1) - ll[b - 2].km;
+            float up = (ou >= 0 && ou < W) ? SC(b - 1, ou) : -INFINITY;
+            float left = (ol >= 0 && ol < W) ? SC(b - 1, ol) : -INFINITY;
+            float diag = (od >= 0 && od < W) ? SC(b - 2, od) : -INFINITY;
+            float em = lp_match(m, o->rank_q[km], o->events[e].mean, shift, scale);
+            float s_d = (float)(((double)diag + lp_step) + (double)em);  /* :296-298 */
+            float s_u = (float)(((double)up + lp_stay) + (double)em);
+            float s_l = (float)((double)left + lp_skip);
+            float mx = s_d; uint8_t from = 0;                            /* :300-306 */
+            mx = s_u > mx ? s_u : mx;
+            from = (mx == s_u) ? 1 : from;
+            mx = s_l > mx ? s_l : mx;
+            from = (mx == s_l) ? 2 : from;
+            SC(b, off) = mx; TR(b, off) = from;
+            fills++;
+        }
+    }
+    o->fills = fills;
+
+    /* end cell :324-340 */
+    float best = -INFINITY; int cur_e = 0; int cur_k = (int)n_kmers - 1; int found = 0;
+    for (unsigned int e = 0; e < n_events; e++) {
+        size_t b = (size_t)(e + 1) + (size_t)(cur_k + 1);
+        int off = ll[b].ev - (int)e;
+        if (off >= 0 && off < W) {
+            float s = (float)((double)SC(b, off) + (double)(n_events - e) * lp_trim);
+            if (s > best) { best = s; cur_e = (int)e; found = 1; }
+        }
+    }
+    o->end_event = cur_e;
+    if (!found) {   /* reference would read trace[][] out of bounds here (UB); we fail the read */
+        free(sc); free(tr); free(ll);
+        o->status = DNO_FAIL_NO_END_CELL; return o->status;
+    }
+
+    /* backtrack :356-412 */
+    size_t cap = n_events + n_kmers + 2;
+    o->aln_event = (uint32_t *)malloc(cap * sizeof(uint32_t));
+    o->aln_kmer = (uint32_t *)malloc(cap * sizeof(uint32_t));
+    o->cleaned_sig = (double *)malloc(cap * sizeof(double));
+    o->cleaned_rank = (uint32_t *)malloc(cap * sizeof(uint32_t));
+    double sum_em = 0., n_al = 0.;
+    int gap = 0, max_gap = 0;
+    double buf_total = 0.; size_t buf_n = 0;     /* signalBuffer + vectorMean (common.h:185) */
+    size_t na = 0, nc = 0;
+    int bad = 0;
+    while (cur_k >= 0 && cur_e >= 0) {
+        o->aln_event[na] = (uint32_t)cur_e; o->aln_kmer[na] = (uint32_t)cur_k; na++;
+        float lp = lp_match(m, o->rank_q[cur_k], o->events[cur_e].mean, shift, scale);
+        sum_em += (double)lp;
+        n_al += 1;
+        size_t b = (size_t)(cur_e + 1) + (size_t)(cur_k + 1);
+        int off = ll[b].ev - cur_e;
+        if (off < 0 || off >= W) { bad = 1; break; }   /* reference: UB (path left the band) */
+        uint8_t from = TR(b, off);
+        if (from == 0) {
+            buf_total += o->events[cur_e].mean; buf_n++;
+            int32_t q2r = r->query2ref[cur_k];
+            if (q2r >= 0) {                                              /* :386 queryToRef.count() */
+                unsigned int posOnRef = (unsigned int)q2r;
+                if (posOnRef < o->n_kr) {
+                    o->cleaned_rank[nc] = o->rank_r[posOnRef];
+                    o->cleaned_sig[nc] = buf_total / (double)buf_n;
+                    nc++;
+                }
+            }
+            buf_total = 0.; buf_n = 0;
+            cur_k -= 1; cur_e -= 1; gap = 0;
+        } else if (from == 1) {
+            buf_total += o->events[cur_e].mean; buf_n++;
+            cur_e -= 1; gap = 0;
+        } else {
+            cur_k -= 1; gap += 1; if (gap > max_gap) max_gap = gap;
+        }
+    }
+    free(sc); free(tr); free(ll);
+#undef SC
+#undef TR
+    if (bad) { o->status = DNO_FAIL_NO_END_CELL; return o->status; }
+    /* std::reverse :413 */
+    for (size_t i = 0; i < na / 2; i++) {
+        uint32_t t = o->aln_event[i]; o->aln_event[i] = o->aln_event[na - 1 - i]; o->aln_event[na - 1 - i] = t;
+        t = o->aln_kmer[i]; o->aln_kmer[i] = o->aln_kmer[na - 1 - i]; o->aln_kmer[na - 1 - i] = t;
+    }
+    o->n_aln = na; o->n_cleaned = nc;
+    o->avg_log_emission = sum_em / n_al;                                 /* :420 */
+    o->spanned = (o->aln_kmer[0] == 0 && o->aln_kmer[na - 1] == n_kmers - 1);
+    o->max_gap = max_gap;
+
+    int qc_fail = 0;
+    if (o->avg_log_emission < -2.0 || !o->spanned || max_gap > 5) qc_fail = 1;   /* :433 config.h:41 */
+    if (nc < 1000) qc_fail = 1;                                                  /* :438 */
+
+    /* ---- Theil-Sen :601-604 (runs even when QC failed; result only matters if it passed) ---- */
+    dno_theil_sen(m, o->cleaned_sig, o->cleaned_rank, nc, shift, scale, &o->shift, &o->scale,
+                  &o->ts_slope, &o->ts_intercept);
+    o->events_per_base = (double)etn / (double)(r->n_base - k);          /* :606 */
+    if (qc_fail) o->status = DNO_FAIL_BANDED_QC;
+    else if (o->shift == -1.) o->status = DNO_FAIL_SCALING;
+    else o->status = DNO_OK;
+    return o->status;
+}
+
+void dno_norm_free(dno_norm *n) {
+    free(n->events); free(n->rank_q); free(n->rank_r); free(n->aln_event); free(n->aln_kmer);
+    free(n->cleaned_sig); free(n->cleaned_rank);
+    memset(n, 0, sizeof(*n));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * alignment.cpp:166-516  builtinViterbi  (NaN == log 0)
+ * ---------------------------------------------------------------------------------------- */
+static inline double vmax(const double *v, int n, int *arg) {
+    /* lnVecMax :166-175 / lnArgMax :178-190: first wins ties, NaN never wins */
+    double mv = v[0]; int a = 0;
+    for (int i = 1; i < n; i++) if (dno_lnGreaterThan(v[i], mv)) { mv = v[i]; a = i; }
+    *arg = a; return mv;
+}
+
+size_t dno_viterbi(const dno_model *m, const double *obs, size_t T, const char *seq, size_t seqlen,
+                   double shift, double scale, double events_per_base,
+                   double *score, uint8_t *state, uint32_t *pos, int *err) {
+    int neg = 0;
+    const double D2D = dno_eln(0.3, &neg), D2M = dno_eln(0.7, &neg), I2M = dno_eln(0.999, &neg);   /* config.h:42 */
+    const double M2D = dno_eln(0.0025, &neg), M2I = dno_eln(0.001, &neg), I2I = dno_eln(0.001, &neg);
+    const double iM2M = dno_eln(1. - (1. / events_per_base), &neg);      /* :207 */
+    const double eM2M = dno_eln(1.0 - M2D - M2I - iM2M, &neg);           /* :208 sic: log values subtracted */
+    const double eM2MorD = dno_lnSum(eM2M, M2D);
+    const double eOrI = dno_lnSum(eM2M, iM2M);
+    if (neg) { if (err) *err = DNO_FAIL_NEGATIVE_LOG; *score = NAN; return 0; }
+    if (err) *err = 0;
+    const size_t N = seqlen - DNO_K + 1;
+    double *mu = (double *)malloc(N * sizeof(double));
+    for (size_t i = 0; i < N; i++) mu[i] = m->mean[dno_kmer2index(seq + i, DNO_K)];
+    /* predecessor codes per (column, position) */
+    uint8_t *bI = (uint8_t *)calloc((T + 1) * N, 1), *bM = (uint8_t *)calloc((T + 1) * N, 1), *bD = (uint8_t *)calloc((T + 1) * N, 1);
+    double *buf = (double *)malloc(6 * N * sizeof(double));
+    double *Ic = buf, *Dc = buf + N, *Mc = buf + 2 * N, *Ip = buf + 3 * N, *Dp = buf + 4 * N, *Mp = buf + 5 * N;
+    for (size_t i = 0; i < 6 * N; i++) buf[i] = NAN;
+    double start_prev = 0.0;
+    Dp[0] = dno_lnProd(start_prev, M2D);                                 /* :241 */
+    for (size_t i = 1; i < N; i++) Dp[i] = Dp[i - 1] + D2D;              /* :246-251 */
+    /* bD column 0: i==0 -> START (code 2), else D_{i-1} (code 1) */
+    bD[0] = 2; for (size_t i = 1; i < N; i++) bD[i] = 1;
+    for (size_t t = 0; t < T; t++) {
+        for (size_t i = 0; i < N; i++) { Ic[i] = NAN; Mc[i] = NAN; Dc[i] = NAN; }
+        const double xs = (obs[t] - shift) / scale;
+        uint8_t *cI = bI + (t + 1) * N, *cM = bM + (t + 1) * N, *cD = bD + (t + 1) * N;
+        int a; double v[4];
+        double e0 = dno_eln(dno_normalPDF(mu[0], m->sigma, xs), NULL);   /* :273 */
+        v[0] = Ip[0] + I2I + 0.0; v[1] = Mp[0] + M2I + 0.0; v[2] = start_prev + M2I + 0.0;   /* :278-285 */
+        Ic[0] = vmax(v, 3, &a); cI[0] = (uint8_t)a;                      /* 0:I0 1:M0 2:START */
+        v[0] = Mp[0] + iM2M + e0; v[1] = start_prev + eOrI + e0;         /* :305-310 */
+        Mc[0] = vmax(v, 2, &a); cM[0] = (uint8_t)(a == 0 ? 2 : 4);       /* 2:M_i 4:START */
+        Dc[0] = dno_lnProd(NAN, M2D); cD[0] = 2;                         /* :326-328 */
+        for (size_t i = 1; i < N; i++) {
+            double e = dno_eln(dno_normalPDF(mu[i], m->sigma, xs), NULL);/* :347 */
+            v[0] = Ip[i] + I2I + 0.0; v[1] = Mp[i] + M2I + 0.0;          /* :351-356 */
+            Ic[i] = vmax(v, 2, &a); cI[i] = (uint8_t)a;
+            v[0] = Ip[i - 1] + I2M + e; v[1] = Mp[i - 1] + eM2M + e;     /* :372-381 */
+            v[2] = Mp[i] + iM2M + e;    v[3] = Dp[i - 1] + D2M + e;
+            Mc[i] = vmax(v, 4, &a); cM[i] = (uint8_t)a;                  /* 0:I_{i-1} 1:M_{i-1} 2:M_i 3:D_{i-1} */
+        }
+        for (size_t i = 1; i < N; i++) {                                 /* :405-427 silent deletions */
+            v[0] = Mc[i - 1] + M2D; v[1] = Dc[i - 1] + D2D;
+            Dc[i] = vmax(v, 2, &a); cD[i] = (uint8_t)a;                  /* 0:M_{i-1} 1:D_{i-1} (same column) */
+        }
+        double *tp;
+        tp = Ip; Ip = Ic; Ic = tp; tp = Mp; Mp = Mc; Mc = tp; tp = Dp; Dp = Dc; Dc = tp;
+        start_prev = NAN;                                                /* :432 start_curr stays NaN */
+    }
+    /* after the loop *_prev hold the last column (== *_curr in the reference; for T==0 the reference reads the
+     * never-written *_curr = NaN, reproduced here) */
+    double vend[3]; int a;
+    if (T == 0) { vend[0] = NAN; vend[1] = NAN; vend[2] = NAN; }
+    else { vend[0] = Dp[N - 1]; vend[1] = Mp[N - 1] + eM2MorD; vend[2] = Ip[N - 1] + I2M; }   /* :447-458 */
+    *score = vmax(vend, 3, &a);
+    /* traceback :460-509 */
+    size_t n = 0;
+    int st = a;                 /* 0 D, 1 M, 2 I */
+    size_t i = N - 1, col = T;
+    int done = 0;
+    size_t guard = 3 * N * (T + 1) + 8;
+    while (!done && guard--) {
+        state[n] = (uint8_t)st; pos[n] = (uint32_t)i; n++;
+        if (st == 0) {
+            uint8_t c = bD[col * N + i];
+            if (c == 2) done = 1;
+            else if (c == 0) { st = 1; i = i - 1; }
+            else { st = 0; i = i - 1; }
+            /* column unchanged (backtraceT = t+1) */
+        } else if (st == 1) {
+            uint8_t c = bM[col * N + i];
+            if (c == 4) done = 1;
+            else if (c == 0) { st = 2; i = i - 1; }
+            else if (c == 1) { st = 1; i = i - 1; }
+            else if (c == 2) { st = 1; }
+            else { st = 0; i = i - 1; }
+            col = col - 1;
+        } else {
+            uint8_t c = bI[col * N + i];
+            if (c == 2) done = 1;
+            else if (c == 0) st = 2;
+            else st = 1;
+            col = col - 1;
+        }
+    }
+    for (size_t q = 0; q < n / 2; q++) {
+        uint8_t ts = state[q]; state[q] = state[n - 1 - q]; state[n - 1 - q] = ts;
+        uint32_t tp = pos[q]; pos[q] = pos[n - 1 - q]; pos[n - 1 - q] = tp;
+    }
+    free(mu); free(bI); free(bM); free(bD); free(buf);
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * alignment.cpp:519-744  eventalign  (+ reads.h:292-372 feature/tensor packing)
+ * ---------------------------------------------------------------------------------------- */
+static int ref_defined(const char *s, size_t n) {                        /* referenceDefined :519-544 */
+    for (size_t i = 0; i < n; i++) if (s[i] != 'A' && s[i] != 'T' && s[i] != 'G' && s[i] != 'C') return 0;
+    return 1;
+}
+
+static uint32_t sub_index(const char *p, int n) {                        /* reads.h:112-138 without the +1 */
+    uint32_t r = 0; for (int i = 0; i < n; i++) r = r * 4u + base_code(p[i]); return r;
+}
+
+int dno_eventalign(const dno_model *m, const dno_read *r, const dno_norm *nm, dno_align *o) {
+    memset(o, 0, sizeof(*o));
+    const unsigned k = DNO_K, totalW = 50;
+    const size_t n_ref = r->n_ref;
+    size_t cap = n_ref + 16;
+    o->coord = (uint32_t *)malloc(cap * 4); o->query_idx = (uint32_t *)malloc(cap * 4); o->ref_idx = (uint32_t *)malloc(cap * 4);
+    o->indel_score = (int32_t *)malloc(cap * 4); o->kmer = (char *)malloc(cap * 9); o->n_signal = (uint32_t *)calloc(cap, 4);
+    o->signal = (float *)calloc(cap * DNO_RAWDEPTH, sizeof(float));
+    o->core = (float *)malloc(cap * 4); o->residual = (float *)malloc(cap * 4);
+    size_t wcap = n_ref / 8 + 16;
+    o->win_ref = (uint32_t *)malloc(wcap * 4); o->win_len = (uint32_t *)malloc(wcap * 4); o->win_T = (uint32_t *)malloc(wcap * 4);
+    o->win_score = (double *)malloc(wcap * 8);
+    size_t tcap = 4096;
+    uint32_t *taken = (uint32_t *)malloc(tcap * 4);
+    double *tmeans = (double *)malloc(tcap * 8);
+    uint8_t *lst = NULL; uint32_t *lpos = NULL; size_t lcap = 0;
+    int readHead = 0;
+    unsigned int ri = 0;
+    int rc = DNO_OK;
+    while (ri < n_ref - k + 1) {                                         /* :556 */
+        unsigned int toEnd = (unsigned int)(n_ref - ri);
+        unsigned int W = toEnd < totalW ? toEnd : totalW;
+        if ((double)toEnd > 1.5 * totalW) {                              /* :564 */
+            const char *snip = r->refseq + ri;                           /* substr(ri, 1.5*W) = 75 */
+            size_t sl = (size_t)(1.5 * W);
+            if (!ref_defined(snip, sl)) { ri += W; continue; }
+            const double lim = 1.5 * W - k - 1;                          /* :574 evaluated before W changes */
+            for (unsigned int i = W; (double)i < lim; i++) {
+                double mu = m->mean[dno_kmer2index(snip + i, k)];
+                double mb = m->mean[dno_kmer2index(snip + i - 1, k)];
+                double mf = m->mean[dno_kmer2index(snip + i + 1, k)];
+                double g1 = fabs(mu - mf), g2 = fabs(mu - mb);
+                if (g1 > 0.75 && g2 > 0.75) { W = i + k; break; }
+            }
+        }
+        const char *seq = r->refseq + ri;
+        if (!ref_defined(seq, W)) { ri += W; continue; }                 /* :599-604 */
+        const uint32_t qlo = r->ref2query[ri], qhi = r->ref2query[ri + W - k + 1];
+        size_t nt = 0; int first = 1;
+        for (unsigned int j = (unsigned int)readHead; j < nm->n_aln; j++) {      /* :611-632 */
+            uint32_t q = nm->aln_kmer[j];
+            if (qlo <= q && q < qhi) {
+                if (first) { readHead = (int)j; first = 0; }
+                double em = nm->events[nm->aln_event[j]].mean;
+                if (0. < em && em < 250.) {
+                    if (nt == tcap) { tcap *= 2; taken = (uint32_t *)realloc(taken, tcap * 4); tmeans = (double *)realloc(tmeans, tcap * 8); }
+                    taken[nt] = nm->aln_event[j]; tmeans[nt] = em; nt++;
+                }
+            }
+            if (q >= qhi) break;
+        }
+        int querySpan = (int)(qhi - qlo);
+        int indelScore = querySpan - (int)(W - k + 1);                   /* :635-638 */
+        if (nt < 2) { ri += W; continue; }                               /* :641 */
+        int coord0 = r->is_reverse ? (r->ref_end - (int)ri - (int)(k / 2)) : (r->ref_start + (int)ri + (int)(k / 2));
+        const size_t N = W - k + 1;
+        if (nt + N + 2 > lcap) { lcap = 2 * (nt + N + 2); lst = (uint8_t *)realloc(lst, lcap); lpos = (uint32_t *)realloc(lpos, lcap * 4); }
+        double vs; int verr = 0;
+        size_t nl = dno_viterbi(m, tmeans, nt, seq, W, nm->shift, nm->scale, nm->events_per_base, &vs, lst, lpos, &verr);
+        if (verr) { rc = verr; break; }
+        if (o->n_windows == wcap) {
+            wcap *= 2;
+            o->win_ref = (uint32_t *)realloc(o->win_ref, wcap * 4); o->win_len = (uint32_t *)realloc(o->win_len, wcap * 4);
+            o->win_T = (uint32_t *)realloc(o->win_T, wcap * 4); o->win_score = (double *)realloc(o->win_score, wcap * 8);
+        }
+        o->win_ref[o->n_windows] = ri; o->win_len[o->n_windows] = W; o->win_T[o->n_windows] = (uint32_t)nt;
+        o->win_score[o->n_windows] = vs;
+        o->n_windows++; o->sum_TN += (uint64_t)nt * N; if (!isnan(vs)) o->score_sum += vs;
+        size_t lastM_ev = 0, lastM_ref = 0, evIdx = 0;                   /* :655-672 */
+        for (size_t i = 0; i < nl; i++) {
+            if (lst[i] == 1) { lastM_ev = evIdx; lastM_ref = lpos[i]; }
+            if (lst[i] != 0) evIdx++;
+        }
+        evIdx = 0;
+        for (size_t i = 0; i < nl; i++) {                                /* :676-736 */
+            if (lst[i] == 0) continue;
+            uint32_t p = lpos[i];
+            const char *kmerStrand = r->refseq + ri + p;
+            unsigned int coord = r->is_reverse ? (unsigned int)(coord0 - (int)p - 1) : (unsigned int)(coord0 + (int)p);
+            unsigned int idxRef = ri + p + k / 2;
+            unsigned int idxQ = r->ref2query[idxRef];
+            if (lst[i] == 1) {
+                const dno_event *ev = &nm->events[taken[evIdx]];
+                for (uint32_t s = 0; s < ev->raw_len; s++) {
+                    double scaled = (r->raw[ev->raw_start + s] - nm->shift) / nm->scale;   /* :705 */
+                    /* addSignal reads.h:292-304 (std::map keyed by coord; first touch fixes the metadata) */
+                    size_t idx = (size_t)-1;
+                    if (o->n_pos > 0) {
+                        unsigned int lastc = o->coord[o->n_pos - 1];
+                        if (lastc == coord) idx = o->n_pos - 1;
+                        else if (r->is_reverse ? (coord > lastc) : (coord < lastc)) {
+                            /* non-monotonic coordinate: emulate the map lookup */
+                            for (size_t z = o->n_pos; z-- > 0;) if (o->coord[z] == coord) { idx = z; break; }
+                        }
+                    }
+                    if (idx == (size_t)-1) {
+                        if (o->n_pos == cap) { rc = DNO_FAIL_TOO_SHORT; goto done; }
+                        idx = o->n_pos++;
+                        o->coord[idx] = coord; o->query_idx[idx] = idxQ; o->ref_idx[idx] = idxRef;
+                        o->indel_score[idx] = indelScore; memcpy(o->kmer + idx * 9, kmerStrand, 9);
+                        o->n_signal[idx] = 0;
+                    }
+                    if (o->n_signal[idx] < DNO_RAWDEPTH) o->signal[idx * DNO_RAWDEPTH + o->n_signal[idx]] = (float)scaled;  /* reads.h:156 */
+                    o->n_signal[idx]++;
+                }
+            }
+            evIdx++;
+        }
+        readHead += (int)lastM_ev + 1;                                   /* :739-740 */
+        ri += (unsigned int)lastM_ref + 1;
+    }
+done:
+    for (size_t i = 0; i < o->n_pos; i++) {
+        const char *km = o->kmer + i * 9;
+        o->core[i] = (float)(sub_index(km + 2, 5) + 1u);                 /* reads.h:112-124 */
+        char rs[4] = { km[0], km[1], km[7], km[8] };
+        o->residual[i] = (float)(sub_index(rs, 4) + 1u);                 /* reads.h:125-138 */
+    }
+    free(taken); free(tmeans); free(lst); free(lpos);
+    return rc;
+}
+
+void dno_align_free(dno_align *a) {
+    free(a->coord); free(a->query_idx); free(a->ref_idx); free(a->indel_score); free(a->kmer); free(a->n_signal);
+    free(a->signal); free(a->core); free(a->residual); free(a->win_ref); free(a->win_len); free(a->win_T); free(a->win_score);
+    memset(a, 0, sizeof(*a));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * detect.cpp:684-727 human-readable record
+ * ---------------------------------------------------------------------------------------- */
+static char comp(char c) {                                               /* common.h:91 (ACGT subset) */
+    switch (c) { case 'A': return 'T'; case 'T': return 'A'; case 'G': return 'C'; case 'C': return 'G'; default: return c; }
+}
+
+size_t dno_format_detect(const char *read_id, const char *contig, const dno_read *r,
+                         const dno_align *a, const float *probs, char *buf, size_t cap) {
+    size_t len = 0;
+    char line[256];
+    int n = snprintf(line, sizeof line, ">%s %s %d %d %s\n", read_id, contig, r->ref_start, r->ref_end, r->is_reverse ? "rev" : "fwd");
+    if (len + (size_t)n <= cap) memcpy(buf + len, line, (size_t)n);
+    len += (size_t)n;
+    /* tensors are in creation order; fwd emits in that order, rev reverses the lines (detect.cpp:722) so both ascend */
+    for (size_t q = 0; q < a->n_pos; q++) {
+        size_t i = r->is_reverse ? (a->n_pos - 1 - q) : q;
+        const char *km = a->kmer + i * 9;
+        if (km[4] != 'T') continue;                                      /* :690 */
+        char ks[10];
+        if (r->is_reverse) { for (int z = 0; z < 9; z++) ks[z] = comp(km[8 - z]); }
+        else memcpy(ks, km, 9);
+        ks[9] = 0;
+        /* std::to_string(float) == "%f" of the value promoted to double (:698) */
+        n = snprintf(line, sizeof line, "%u\t%f\t%f\t%s\n", a->coord[i], (double)probs[i * 3 + 2], (double)probs[i * 3 + 1], ks);
+        if (len + (size_t)n <= cap) memcpy(buf + len, line, (size_t)n);
+        len += (size_t)n;
+    }
+    return len;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * htsInterface.cpp:59-157 parseCigar (std::map semantics flattened; later writes win)
+ * ---------------------------------------------------------------------------------------- */
+int dno_parse_cigar(const uint32_t *ops, const uint32_t *lens, size_t n_ops, int is_reverse,
+                    uint32_t *ref2query, uint8_t *ref2del, size_t n_ref_cap,
+                    int32_t *query2ref, size_t n_q_cap) {
+    for (size_t i = 0; i < n_q_cap; i++) query2ref[i] = -1;
+    int qp = 0, rp = 0;
+    for (size_t c = 0; c < n_ops; c++) {
+        size_t i = is_reverse ? (n_ops - 1 - c) : c;                     /* :69 reversed walk for rev strand */
+        const int op = (int)ops[i], ol = (int)lens[i];
+        if (op == 0 || op == 7 || op == 8) {                             /* M,=,X */
+            for (int j = rp; j < rp + ol; j++) {
+                if ((size_t)j < n_ref_cap) { ref2query[j] = (uint32_t)qp; ref2del[j] = 0; }
+                if ((size_t)qp < n_q_cap) query2ref[qp] = j;
+                qp++;
+            }
+            rp += ol;
+        } else if (op == 2 || op == 3) {                                 /* D,N */
+            for (int j = rp; j < rp + ol; j++) {
+                if ((size_t)j < n_ref_cap) { ref2query[j] = (uint32_t)qp; ref2del[j] = 1; }
+                if ((size_t)qp < n_q_cap) query2ref[qp] = j;
+            }
+            rp += ol;
+        } else if (op == 4 || op == 1) {                                 /* S,I : sic, writes ref slots ahead */
+            for (int j = rp; j < rp + ol; j++) {
+                if ((size_t)j < n_ref_cap) { ref2query[j] = (uint32_t)qp; ref2del[j] = 0; }
+                if ((size_t)qp < n_q_cap) query2ref[qp] = j;
+                qp++;
+            }
+        }
+    }
+    return rp;
+}
