@@ -48,7 +48,8 @@ def build_hip(force=False):
     # -ffp-contract=off: the reference arithmetic has no FMA contraction (Makefile:6 plain -O2 on x86-64);
     # every fused multiply-add in the kernels is written explicitly.
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-fno-fast-math", "-Wall", "-Wno-unused-function",
+           "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
+           "-fhip-fp32-correctly-rounded-divide-sqrt",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", HIP_SO] + srcs
     _run(cmd)
     return HIP_SO
@@ -56,6 +57,7 @@ def build_hip(force=False):
 
 def build_host(force=False):
     os.makedirs(LIB, exist_ok=True)
+    build_hip(False)
     srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if not force and not _newer(HOST_SO, _all_deps(srcs)):
         return HOST_SO
@@ -68,7 +70,9 @@ def build_host(force=False):
             _run(["g++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-fopenmp", "-Wall",
                   "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", s, "-o", o])
         objs.append(o)
-    _run(["g++", "-shared", "-fopenmp", "-o", HOST_SO] + objs + ["-lm", "-ldl"])
+    # the host side calls the C-ABI: link it against libdnascent_hip.so sitting next to it
+    _run(["g++", "-shared", "-fopenmp", "-o", HOST_SO] + objs +
+         ["-L", LIB, "-ldnascent_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-ldl"])
     return HOST_SO
 
 

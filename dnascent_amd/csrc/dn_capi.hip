@@ -1,0 +1,547 @@
+// dn_capi.hip -- implementation of the C-ABI declared in include/dnascent_hip.h.
+// Owns the device memory of one batch (SoA in HBM, per-read offsets), orders the stage kernels on one HIP
+// stream and exposes the intermediate taps the parity tests read.  No CPU fallback anywhere.
+#include "dnascent_hip.h"
+#include "dn_dev.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+// kernel launchers (k1_segment.hip, k_scaling.hip, k2_banded.hip, k2b_viterbi.hip)
+void k1_launch_scan(const BatchDev &, hipStream_t);
+void k1_launch_tstat(const BatchDev &, unsigned, hipStream_t);
+void k1_launch_detect(const BatchDev &, unsigned, hipStream_t);
+void k1_launch_events(const BatchDev &, hipStream_t);
+void ks_launch_ranks(const BatchDev &, unsigned, hipStream_t);
+void ks_launch_quantile(const BatchDev &, hipStream_t);
+void ks_launch_prep(const BatchDev &, unsigned, hipStream_t);
+void ks_launch_theilsen(const BatchDev &, hipStream_t);
+int k2_selftest_run(hipStream_t);
+void k2_launch_fill(const BatchDev &, const void *, const void *, bool, hipStream_t);
+void k2_launch_chase(const BatchDev &, uint8_t *, hipStream_t);
+void k2_launch_post(const BatchDev &, const uint8_t *, float *, const void *, hipStream_t);
+
+struct BandConstsH { double lp_stay, lp_step; };
+struct FillConstsH { double lp_skip, lp_trim, C, sigma, rsigma; };
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+};
+
+struct ProfRec { int k; hipEvent_t a, b; };
+
+}  // namespace
+
+struct dn_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool use_dpp = true;
+    std::string err;
+    size_t dev_bytes = 0;
+    std::vector<void *> allocs;
+    std::vector<std::pair<void *, size_t>> alloc_sizes;
+    // model
+    double *d_model = nullptr; double sigma = 0.14; bool have_model = false;
+    // batch
+    BatchDev B{};
+    bool have_batch = false;
+    int stage = 0;   // 0 none, 1 uploaded, 2 segmented, 3 rough scaled, 4 banded, 5 theil-sen, 6 eventaligned
+    std::vector<uint64_t> h_samp_off, h_base_off, h_ref_off, h_chunk_off, h_ev_off, h_aln_off, h_trace_off;
+    unsigned max_samples = 0, max_chunks = 0, max_len = 0, max_evcap = 0;
+    std::vector<ReadRes> h_res;
+    DevBuf trace, bandc;
+    uint8_t *d_path_from = nullptr; float *d_path_lp = nullptr;
+    uint64_t *d_trace_off = nullptr;
+    FillConstsH fc{};
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> pending;
+    double prof_ms[DN_K_COUNT] = {0};
+    uint32_t prof_n[DN_K_COUNT] = {0};
+};
+
+static int fail(dn_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+#define HIPCHK(c, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) return fail((c), DN_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+static int dalloc(dn_ctx *c, T **p, size_t n) {
+    void *q = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(c, DN_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    c->allocs.push_back(q); c->alloc_sizes.push_back({q, bytes}); c->dev_bytes += bytes;
+    *p = (T *)q;
+    return DN_OK;
+}
+static void dfree_all(dn_ctx *c) {
+    for (void *p : c->allocs) hipFree(p);
+    c->allocs.clear(); c->alloc_sizes.clear();
+}
+static int dgrow(dn_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return DN_OK;
+    if (b.p) { hipFree(b.p); c->dev_bytes -= b.cap; }
+    b.p = nullptr; b.cap = 0;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) return fail(c, DN_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    b.cap = bytes; c->dev_bytes += bytes;
+    return DN_OK;
+}
+
+static const char *KNAMES[DN_K_COUNT] = { "k1_scan", "k1_tstat", "k1_detect", "k1_events", "k_ranks", "k_quantile", "k_prep",
+                                          "k2_fill", "k2_chase+k2_post", "k_theilsen", "k2b_viterbi" };
+
+struct Timed {
+    dn_ctx *c; int k; hipEvent_t a = nullptr, b = nullptr;
+    Timed(dn_ctx *c_, int k_) : c(c_), k(k_) {
+        if (c->prof) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
+    }
+    ~Timed() {
+        if (c->prof) { hipEventRecord(b, c->stream); c->pending.push_back({k, a, b}); }
+    }
+};
+
+static void prof_collect(dn_ctx *c) {
+    if (c->pending.empty()) return;
+    hipStreamSynchronize(c->stream);
+    for (auto &p : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->prof_ms[p.k] += ms; c->prof_n[p.k]++; }
+        hipEventDestroy(p.a); hipEventDestroy(p.b);
+    }
+    c->pending.clear();
+}
+
+template <class T>
+static int upload(dn_ctx *c, const T **dst, const T *src, size_t n) {
+    T *d = nullptr;
+    int rc = dalloc(c, &d, n);
+    if (rc) return rc;
+    if (n) HIPCHK(c, hipMemcpyAsync(d, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *dst = d;
+    return DN_OK;
+}
+
+template <class T>
+static int d2h(dn_ctx *c, T *dst, const T *src, size_t n) {
+    if (!dst || n == 0) return DN_OK;
+    HIPCHK(c, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DN_OK;
+}
+
+extern "C" {
+
+int dn_abi_version(void) { return DN_ABI_VERSION; }
+
+int dn_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *dn_kernel_name(int k) { return (k >= 0 && k < DN_K_COUNT) ? KNAMES[k] : "?"; }
+
+int dn_ctx_create(int device, void *hip_stream, dn_ctx **out) {
+    if (!out) return DN_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return DN_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return DN_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return DN_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return DN_ERR_HIP;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "dnascent_hip: device %d is %s, this library is built for gfx950 only\n", device, prop.gcnArchName);
+        return DN_ERR_NO_DEVICE;
+    }
+    dn_ctx *c = new dn_ctx();
+    c->device = device;
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DN_ERR_HIP; }
+        c->own_stream = true;
+    }
+    const int st = k2_selftest_run(c->stream);
+    if (st != 1) {
+        // wave-shift DPP did not behave as specified: refuse rather than compute wrong bands
+        const char *force = getenv("DN_FORCE_SHFL");
+        if (!(force && force[0] == '1')) {
+            fprintf(stderr, "dnascent_hip: wave-shift DPP self-test failed (%d); set DN_FORCE_SHFL=1 to use ds_bpermute shifts\n", st);
+            if (c->own_stream) hipStreamDestroy(c->stream);
+            delete c;
+            return DN_ERR_HIP;
+        }
+    }
+    {
+        const char *force = getenv("DN_FORCE_SHFL");
+        c->use_dpp = !(force && force[0] == '1');
+    }
+    *out = c;
+    return DN_OK;
+}
+
+void dn_ctx_destroy(dn_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    dfree_all(c);
+    if (c->trace.p) hipFree(c->trace.p);
+    if (c->bandc.p) hipFree(c->bandc.p);
+    if (c->d_model) hipFree(c->d_model);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *dn_last_error(const dn_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int dn_sync(dn_ctx *c) {
+    if (!c) return DN_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DN_OK;
+}
+
+size_t dn_device_bytes(const dn_ctx *c) { return c ? c->dev_bytes : 0; }
+
+int dn_load_pore_model(dn_ctx *c, const double *mean, double sigma) {
+    if (!c || !mean || !(sigma > 0.)) return DN_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_model) {
+        HIPCHK(c, hipMalloc((void **)&c->d_model, DN_NKMER * sizeof(double)));
+        c->dev_bytes += DN_NKMER * sizeof(double);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_model, mean, DN_NKMER * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->sigma = sigma;
+    c->have_model = true;
+    // constants of logProbabilityMatch (event_handling.cpp:134-135) and the band penalties (:179-183), computed with the
+    // host libm exactly as the reference computes them
+    const float lisp = (float)log(0.3989422804014327);
+    c->fc.C = (double)lisp - log(sigma);
+    c->fc.sigma = sigma;
+    c->fc.rsigma = 1.0 / sigma;
+    c->fc.lp_skip = log(1e-30);
+    c->fc.lp_trim = log(0.01);
+    return DN_OK;
+}
+
+int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
+    if (!c || !d || d->n_reads == 0) return DN_ERR_ARG;
+    if (!c->have_model) return fail(c, DN_ERR_STATE, "dn_load_pore_model must be called first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    dfree_all(c);
+    c->dev_bytes = DN_NKMER * sizeof(double) + c->trace.cap + c->bandc.cap;
+    c->have_batch = false; c->stage = 0;
+    const uint32_t n = d->n_reads;
+    if (n > 65535) return fail(c, DN_ERR_ARG, "at most 65535 reads per batch (grid.y)");
+    BatchDev &B = c->B;
+    memset(&B, 0, sizeof(B));
+    B.n_reads = (int)n;
+    B.model_mean = c->d_model; B.sigma = c->sigma;
+    c->h_samp_off.assign(d->adc_off, d->adc_off + n + 1);
+    c->h_base_off.assign(d->basecall_off, d->basecall_off + n + 1);
+    c->h_ref_off.assign(d->refseq_off, d->refseq_off + n + 1);
+    const uint64_t S = c->h_samp_off[n], NB = c->h_base_off[n], NR = c->h_ref_off[n];
+    c->h_chunk_off.assign(n + 1, 0); c->h_ev_off.assign(n + 1, 0); c->h_aln_off.assign(n + 1, 0);
+    c->max_samples = c->max_chunks = c->max_len = c->max_evcap = 0;
+    for (uint32_t r = 0; r < n; r++) {
+        const uint64_t ns = c->h_samp_off[r + 1] - c->h_samp_off[r];
+        const uint64_t nb = c->h_base_off[r + 1] - c->h_base_off[r];
+        const uint64_t nr = c->h_ref_off[r + 1] - c->h_ref_off[r];
+        if (ns >= (1ull << 31) || nb >= (1ull << 31)) return fail(c, DN_ERR_ARG, "read %u too long", r);
+        if (ns < 16 || nb < DN_K + 1 || nr < DN_K) return fail(c, DN_ERR_ARG, "read %u too short (samples %llu, bases %llu, ref %llu)", r,
+                                                                  (unsigned long long)ns, (unsigned long long)nb, (unsigned long long)nr);
+        const uint64_t nch = (ns + DN_SEG_CHUNK - 1) / DN_SEG_CHUNK;
+        const uint64_t evcap = ns / 2 + 8;
+        c->h_chunk_off[r + 1] = c->h_chunk_off[r] + nch;
+        c->h_ev_off[r + 1] = c->h_ev_off[r] + evcap;
+        c->h_aln_off[r + 1] = c->h_aln_off[r] + evcap + nb + 8;
+        c->max_samples = std::max<unsigned>(c->max_samples, (unsigned)ns);
+        c->max_chunks = std::max<unsigned>(c->max_chunks, (unsigned)nch);
+        c->max_len = std::max<unsigned>(c->max_len, (unsigned)std::max(nb, nr));
+        c->max_evcap = std::max<unsigned>(c->max_evcap, (unsigned)evcap);
+    }
+    const uint64_t NCH = c->h_chunk_off[n], NEV = c->h_ev_off[n], NAL = c->h_aln_off[n];
+    int rc;
+#define UP(field, src, cnt) if ((rc = upload(c, &B.field, src, (size_t)(cnt)))) return rc
+    UP(adc, d->adc, S);                  UP(samp_off, c->h_samp_off.data(), n + 1);
+    UP(cal_off, d->cal_offset, n);       UP(cal_scale, d->cal_scale, n);
+    UP(basecall, d->basecall, NB);       UP(base_off, c->h_base_off.data(), n + 1);
+    UP(refseq, d->refseq, NR);           UP(ref_off, c->h_ref_off.data(), n + 1);
+    UP(ref2query, d->ref2query, NR);     UP(query2ref, d->query2ref, NB + n);
+    UP(ref2del, d->ref2del, NR);
+    UP(ref_start, d->ref_start, n);      UP(ref_end, d->ref_end, n);
+    UP(is_rev, d->is_reverse, n);
+    UP(chunk_off, c->h_chunk_off.data(), n + 1);
+    UP(ev_off, c->h_ev_off.data(), n + 1);
+    UP(aln_off, c->h_aln_off.data(), n + 1);
+#undef UP
+#define AL(field, cnt) if ((rc = dalloc(c, &B.field, (size_t)(cnt)))) return rc
+    AL(psum, S); AL(t1, S); AL(t2, S);
+    AL(chunk_npk, NCH); AL(chunk_peaks, NCH * DN_SEG_PEAKCAP); AL(chunk_in, NCH); AL(chunk_out, NCH);
+    AL(et_start, NEV); AL(et_mean, NEV); AL(ev_mean, NEV); AL(ev_start, NEV); AL(ev_len, NEV); AL(ev_x, NEV);
+    AL(rank_q, NB); AL(rank_r, NR); AL(mu_q, NB);
+    AL(aln_event, NAL); AL(aln_kmer, NAL); AL(cl_sig, NAL); AL(cl_rank, NAL);
+    AL(res, n);
+#undef AL
+    if ((rc = dalloc(c, &c->d_path_from, (size_t)NAL))) return rc;
+    if ((rc = dalloc(c, &c->d_path_lp, (size_t)NAL))) return rc;
+    if ((rc = dalloc(c, &c->d_trace_off, (size_t)n + 1))) return rc;
+    HIPCHK(c, hipMemsetAsync(B.res, 0, n * sizeof(ReadRes), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->h_res.assign(n, ReadRes{});
+    c->have_batch = true; c->stage = 1;
+    return DN_OK;
+}
+
+static int need(dn_ctx *c, int stage, const char *what) {
+    if (!c) return DN_ERR_ARG;
+    if (!c->have_batch || c->stage < stage) return fail(c, DN_ERR_STATE, "%s called before its input stage ran", what);
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return fail(c, DN_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    return DN_OK;
+}
+
+int dn_run_segment(dn_ctx *c) {
+    int rc = need(c, 1, "dn_run_segment"); if (rc) return rc;
+    { Timed t(c, DN_K_SCAN);   k1_launch_scan(c->B, c->stream); }
+    { Timed t(c, DN_K_TSTAT);  k1_launch_tstat(c->B, c->max_samples, c->stream); }
+    { Timed t(c, DN_K_DETECT); k1_launch_detect(c->B, c->max_chunks, c->stream); }
+    { Timed t(c, DN_K_EVENTS); k1_launch_events(c->B, c->stream); }
+    { Timed t(c, DN_K_RANKS);  ks_launch_ranks(c->B, c->max_len, c->stream); }
+    HIPCHK(c, hipGetLastError());
+    c->stage = 2;
+    return DN_OK;
+}
+
+int dn_run_rough_scaling(dn_ctx *c) {
+    int rc = need(c, 2, "dn_run_rough_scaling"); if (rc) return rc;
+    { Timed t(c, DN_K_QUANTILE); ks_launch_quantile(c->B, c->stream); }
+    HIPCHK(c, hipGetLastError());
+    c->stage = 3;
+    return DN_OK;
+}
+
+int dn_run_banded(dn_ctx *c) {
+    int rc = need(c, 3, "dn_run_banded"); if (rc) return rc;
+    const uint32_t n = (uint32_t)c->B.n_reads;
+    // the trace size depends on the number of events found on the device: one small D2H + host-side offsets.
+    HIPCHK(c, hipMemcpyAsync(c->h_res.data(), c->B.res, n * sizeof(ReadRes), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->h_trace_off.assign(n + 1, 0);
+    std::vector<BandConstsH> bc(n);
+    unsigned max_events = 1;
+    for (uint32_t r = 0; r < n; r++) {
+        const ReadRes &R = c->h_res[r];
+        if (R.seg_overflow) return fail(c, DN_ERR_OVERFLOW, "segmentation workspace overflow in read %u", r);
+        const uint64_t E = R.n_events, K = R.n_kq;
+        c->h_trace_off[r + 1] = c->h_trace_off[r] + (E + K + 2 + 64);
+        max_events = std::max<unsigned>(max_events, (unsigned)E);
+        // event_handling.cpp:174-182, with the host libm (the reference's own calls)
+        const double epk = (double)E / (double)K;
+        const double p_stay = 1 - (1 / (epk + 1));
+        const double lp_skip = log(1e-30);
+        const double lp_stay = log(p_stay);
+        bc[r].lp_stay = lp_stay;
+        bc[r].lp_step = log(1.0 - exp(lp_skip) - exp(lp_stay));
+    }
+    const size_t tbytes = (size_t)c->h_trace_off[n] * DN_TROW;
+    if ((rc = dgrow(c, c->trace, tbytes))) return rc;
+    if ((rc = dgrow(c, c->bandc, n * sizeof(BandConstsH)))) return rc;
+    c->B.trace = (uint8_t *)c->trace.p;
+    c->B.trace_off = c->d_trace_off;
+    HIPCHK(c, hipMemcpyAsync(c->d_trace_off, c->h_trace_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->bandc.p, bc.data(), n * sizeof(BandConstsH), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // bc is a local
+    { Timed t(c, DN_K_PREP);       ks_launch_prep(c->B, max_events, c->stream); }
+    { Timed t(c, DN_K_BAND_FILL);  k2_launch_fill(c->B, c->bandc.p, &c->fc, c->use_dpp, c->stream); }
+    { Timed t(c, DN_K_BAND_TRACE); k2_launch_chase(c->B, c->d_path_from, c->stream);
+                                   k2_launch_post(c->B, c->d_path_from, c->d_path_lp, &c->fc, c->stream); }
+    HIPCHK(c, hipGetLastError());
+    c->stage = 4;
+    return DN_OK;
+}
+
+int dn_run_theilsen(dn_ctx *c) {
+    int rc = need(c, 4, "dn_run_theilsen"); if (rc) return rc;
+    { Timed t(c, DN_K_THEILSEN); ks_launch_theilsen(c->B, c->stream); }
+    HIPCHK(c, hipGetLastError());
+    c->stage = 5;
+    return DN_OK;
+}
+
+int dn_run_normalise(dn_ctx *c) {
+    int rc;
+    if ((rc = dn_run_segment(c))) return rc;
+    if ((rc = dn_run_rough_scaling(c))) return rc;
+    if ((rc = dn_run_banded(c))) return rc;
+    return dn_run_theilsen(c);
+}
+
+int dn_run_eventalign(dn_ctx *c) {
+    int rc = need(c, 5, "dn_run_eventalign"); if (rc) return rc;
+    return fail(c, DN_ERR_STATE, "dn_run_eventalign: windowed Viterbi kernel not built into this library yet");
+}
+
+static int fetch_res(dn_ctx *c) {
+    const uint32_t n = (uint32_t)c->B.n_reads;
+    HIPCHK(c, hipMemcpyAsync(c->h_res.data(), c->B.res, n * sizeof(ReadRes), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DN_OK;
+}
+
+int dn_get_summaries(dn_ctx *c, dn_read_summary *out) {
+    int rc = need(c, 1, "dn_get_summaries"); if (rc) return rc;
+    if (!out) return DN_ERR_ARG;
+    if ((rc = fetch_res(c))) return rc;
+    for (int r = 0; r < c->B.n_reads; r++) {
+        const ReadRes &R = c->h_res[r];
+        dn_read_summary &s = out[r];
+        memset(&s, 0, sizeof(s));
+        s.status = R.status;
+        s.n_samples = (uint32_t)(c->h_samp_off[r + 1] - c->h_samp_off[r]);
+        s.n_scrappie = R.n_scrappie; s.n_events = R.n_events;
+        s.n_kmers_query = R.n_kq; s.n_kmers_ref = R.n_kr;
+        s.n_bands = R.n_bands; s.band_cells = (uint64_t)R.n_bands * DN_BANDWIDTH;
+        s.rough_shift = R.q_shift; s.rough_scale = R.q_scale;
+        s.end_event = R.end_event; s.n_aligned = R.n_aligned;
+        s.avg_log_emission = R.avg_log_emission; s.spanned = R.spanned; s.max_gap = R.max_gap; s.n_cleaned = R.n_cleaned;
+        s.ts_slope = R.ts_slope; s.ts_intercept = R.ts_intercept;
+        s.shift = R.shift; s.scale = R.scale; s.events_per_base = R.events_per_base;
+        s.n_positions = R.n_positions; s.n_windows = R.n_windows; s.detector_rechecks = R.rechecks;
+    }
+    return DN_OK;
+}
+
+#define CHECK_READ(stage_, name_)                                     \
+    int rc = need(c, stage_, name_); if (rc) return rc;              \
+    if (read >= (uint32_t)c->B.n_reads) return DN_ERR_ARG;
+
+int dn_get_prefix_sums(dn_ctx *c, uint32_t read, double *sum, double *sumsq) {
+    CHECK_READ(2, "dn_get_prefix_sums");
+    const uint64_t s0 = c->h_samp_off[read]; const size_t n = (size_t)(c->h_samp_off[read + 1] - s0);
+    std::vector<double2> tmp(n);
+    if ((rc = d2h(c, tmp.data(), c->B.psum + s0, n))) return rc;
+    if (sum) { sum[0] = 0.; for (size_t i = 0; i < n; i++) sum[i + 1] = tmp[i].x; }
+    if (sumsq) { sumsq[0] = 0.; for (size_t i = 0; i < n; i++) sumsq[i + 1] = tmp[i].y; }
+    return DN_OK;
+}
+
+int dn_get_tstats(dn_ctx *c, uint32_t read, float *a, float *b) {
+    CHECK_READ(2, "dn_get_tstats");
+    const uint64_t s0 = c->h_samp_off[read]; const size_t n = (size_t)(c->h_samp_off[read + 1] - s0);
+    if ((rc = d2h(c, a, c->B.t1 + s0, n))) return rc;
+    return d2h(c, b, c->B.t2 + s0, n);
+}
+
+int dn_get_scrappie_events(dn_ctx *c, uint32_t read, uint32_t *start, float *length, float *mean) {
+    CHECK_READ(2, "dn_get_scrappie_events");
+    if ((rc = fetch_res(c))) return rc;
+    const size_t n = c->h_res[read].n_scrappie; const uint64_t e0 = c->h_ev_off[read];
+    std::vector<uint32_t> st(n);
+    if ((rc = d2h(c, st.data(), c->B.et_start + e0, n))) return rc;
+    if (start) memcpy(start, st.data(), n * sizeof(uint32_t));
+    if (length) {
+        const uint32_t ns = (uint32_t)(c->h_samp_off[read + 1] - c->h_samp_off[read]);
+        for (size_t i = 0; i < n; i++) {
+            const uint64_t en = (i + 1 < n) ? st[i + 1] : ns;
+            length[i] = (float)(uint64_t)(en - (uint64_t)st[i]);
+        }
+    }
+    return d2h(c, mean, c->B.et_mean + e0, n);
+}
+
+int dn_get_events(dn_ctx *c, uint32_t read, double *mean, uint32_t *raw_start, uint32_t *raw_len) {
+    CHECK_READ(2, "dn_get_events");
+    if ((rc = fetch_res(c))) return rc;
+    const size_t n = c->h_res[read].n_events; const uint64_t e0 = c->h_ev_off[read];
+    if ((rc = d2h(c, mean, c->B.ev_mean + e0, n))) return rc;
+    if ((rc = d2h(c, raw_start, c->B.ev_start + e0, n))) return rc;
+    return d2h(c, raw_len, c->B.ev_len + e0, n);
+}
+
+int dn_get_kmer_ranks(dn_ctx *c, uint32_t read, uint32_t *rq, uint32_t *rr) {
+    CHECK_READ(2, "dn_get_kmer_ranks");
+    const uint64_t b0 = c->h_base_off[read], f0 = c->h_ref_off[read];
+    const size_t nq = (size_t)(c->h_base_off[read + 1] - b0) - DN_K + 1, nr = (size_t)(c->h_ref_off[read + 1] - f0) - DN_K + 1;
+    if ((rc = d2h(c, rq, c->B.rank_q + b0, nq))) return rc;
+    return d2h(c, rr, c->B.rank_r + f0, nr);
+}
+
+int dn_get_alignment(dn_ctx *c, uint32_t read, uint32_t *ev, uint32_t *km) {
+    CHECK_READ(4, "dn_get_alignment");
+    if ((rc = fetch_res(c))) return rc;
+    const ReadRes &R = c->h_res[read];
+    const uint64_t a0 = c->h_aln_off[read] + R.aln_begin;
+    if ((rc = d2h(c, ev, c->B.aln_event + a0, R.n_aligned))) return rc;
+    return d2h(c, km, c->B.aln_kmer + a0, R.n_aligned);
+}
+
+int dn_get_cleaned(dn_ctx *c, uint32_t read, double *sig, uint32_t *rank) {
+    CHECK_READ(4, "dn_get_cleaned");
+    if ((rc = fetch_res(c))) return rc;
+    const ReadRes &R = c->h_res[read];
+    const uint64_t a0 = c->h_aln_off[read];
+    if ((rc = d2h(c, sig, c->B.cl_sig + a0, R.n_cleaned))) return rc;
+    return d2h(c, rank, c->B.cl_rank + a0, R.n_cleaned);
+}
+
+int dn_get_trace(dn_ctx *c, uint32_t read, uint8_t *trace, int32_t *band_event, int32_t *band_kmer) {
+    CHECK_READ(4, "dn_get_trace");
+    if ((rc = fetch_res(c))) return rc;
+    const size_t nb = c->h_res[read].n_bands;
+    std::vector<uint8_t> rows(nb * DN_TROW);
+    if ((rc = d2h(c, rows.data(), c->B.trace + c->h_trace_off[read] * DN_TROW, nb * DN_TROW))) return rc;
+    for (size_t b = 0; b < nb; b++) {
+        const uint8_t *p = rows.data() + b * DN_TROW;
+        if (trace) memcpy(trace + b * DN_BANDWIDTH, p, DN_BANDWIDTH);
+        int32_t ev; memcpy(&ev, p + 104, 4);          // ll.event_idx; ll.event_idx + ll.kmer_idx == band - 2 for every band
+        if (band_event) band_event[b] = ev;
+        if (band_kmer) band_kmer[b] = (int32_t)b - 2 - ev;
+    }
+    return DN_OK;
+}
+
+int dn_get_positions(dn_ctx *c, uint32_t, uint32_t *, uint32_t *, uint32_t *, int32_t *, char *, uint32_t *, float *, float *, float *) {
+    return fail(c, DN_ERR_STATE, "dn_get_positions: eventalign has not run");
+}
+int dn_get_windows(dn_ctx *c, uint32_t, uint32_t *, uint32_t *, uint32_t *, double *) {
+    return fail(c, DN_ERR_STATE, "dn_get_windows: eventalign has not run");
+}
+
+int dn_profile_enable(dn_ctx *c, int on) { if (!c) return DN_ERR_ARG; c->prof = on != 0; return DN_OK; }
+int dn_profile_reset(dn_ctx *c) {
+    if (!c) return DN_ERR_ARG;
+    prof_collect(c);
+    for (int i = 0; i < DN_K_COUNT; i++) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+    return DN_OK;
+}
+int dn_profile_get(dn_ctx *c, int k, double *ms, uint32_t *launches) {
+    if (!c || k < 0 || k >= DN_K_COUNT) return DN_ERR_ARG;
+    prof_collect(c);
+    if (ms) *ms = c->prof_ms[k];
+    if (launches) *launches = c->prof_n[k];
+    return DN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// dn_dev.h -- device-side batch layout (SoA in HBM with per-read offsets) and shared device helpers.
+// gfx950 only.  Kernels are built with -ffp-contract=off: every fused multiply-add is written as fma().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DN_W 100            // band width (config.h:41)
+#define DN_TROW 128         // bytes per stored trace row: 100 trace bytes + band metadata, one full 128-B line
+#define DN_K 9
+#define DN_SEG_CHUNK 256    // samples per speculative detector chunk
+#define DN_SEG_WARM 192     // warm-up samples run before a chunk to reach the detector's true state
+#define DN_SEG_PEAKCAP 128  // peaks per chunk (peaks are >= 2 samples apart)
+
+struct DetState {           // one scrappie Detector (event_detection.c:10-21)
+    int masked_to;
+    int peak_pos;           // -1 == DEF_PEAK_POS
+    float peak_val;
+    int valid;
+};
+struct SegState { DetState s, l; };
+
+struct ReadRes {            // per-read scalars produced on device (mirrors dn_read_summary)
+    int status;
+    unsigned n_samples, n_scrappie, n_events, n_kq, n_kr, n_bands;
+    double q_shift, q_scale;
+    int end_event;
+    unsigned n_aligned;
+    double avg_log_emission; int spanned; int max_gap; unsigned n_cleaned;
+    double ts_slope, ts_intercept;
+    double shift, scale, events_per_base;
+    unsigned n_positions, n_windows, rechecks, aln_begin;   // aln_begin: first valid slot of the (back-filled) alignment array
+    float end_score;
+    int seg_overflow;
+};
+
+struct BatchDev {
+    int n_reads;
+    // ---- inputs (uploaded) ----
+    const int16_t *adc;      const uint64_t *samp_off;     // [n+1]
+    const float *cal_off;    const float *cal_scale;
+    const char *basecall;    const uint64_t *base_off;     // [n+1]
+    const char *refseq;      const uint64_t *ref_off;      // [n+1]
+    const uint32_t *ref2query;                              // at ref_off
+    const int32_t *query2ref;                               // at base_off[r] + r
+    const uint8_t *ref2del;
+    const int32_t *ref_start, *ref_end;
+    const uint8_t *is_rev;
+    const double *model_mean; double sigma;
+    // ---- K1 workspace ----
+    double2 *psum;           // [samples]  psum[i] = {sum[i+1], sumsq[i+1]}  (sum[0] = 0 is implicit)
+    float *t1, *t2;          // [samples]
+    const uint64_t *chunk_off;   // [n+1] detector chunk offsets
+    unsigned *chunk_npk;     // [chunks]
+    unsigned *chunk_peaks;   // [chunks * DN_SEG_PEAKCAP]
+    SegState *chunk_in, *chunk_out;   // [chunks]
+    // scrappie events + DNAscent events; capacity per read = ev_off[r+1]-ev_off[r]
+    const uint64_t *ev_off;  // [n+1]
+    unsigned *et_start; float *et_mean;     // scrappie event_t (start, mean); length = start[i+1]-start[i]
+    double *ev_mean; unsigned *ev_start, *ev_len;   // r.events
+    double *ev_x;            // (mean - shift)/scale with the rough scaling
+    // ---- k-mer ranks ----
+    unsigned *rank_q;        // at base_off
+    unsigned *rank_r;        // at ref_off
+    double *mu_q;            // model mean of rank_q (gathered once)
+    // ---- banded alignment ----
+    const uint64_t *trace_off;   // [n+1] in rows of DN_TROW bytes
+    uint8_t *trace;
+    unsigned *aln_event, *aln_kmer;   // capacity per read: (ev cap + n_kq + 2), at aln_off
+    const uint64_t *aln_off;
+    double *cl_sig; unsigned *cl_rank;    // cleaned signals / ranks (at aln_off)
+    ReadRes *res;
+};
+
+// ----------------------------------------------------------------------------------------------
+// helpers
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned base_code(char c) {      // data_IO.cpp:131  A0 T1 G2 C3, others 0
+    return c == 'T' ? 1u : (c == 'G' ? 2u : (c == 'C' ? 3u : 0u));
+}
+
+// order-preserving map double -> uint64 (total order == '<' on non-NaN doubles; -0 sorts just below +0)
+__device__ __forceinline__ unsigned long long dkey(double x) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dkey_inv(unsigned long long k) {
+    unsigned long long u = (k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+__device__ __forceinline__ float neg_inf() { return __int_as_float(0xff800000); }
+
+// uniform (scalar) broadcast of one lane's value
+__device__ __forceinline__ float bcast_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double bcast_d(double v, int lane) {
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}

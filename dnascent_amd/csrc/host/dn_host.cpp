@@ -1,0 +1,180 @@
+// dn_host.cpp -- host side above the C-ABI: read model, CIGAR flattening, batch packing, stage drivers.
+#include "dn_host.h"
+
+#include <string.h>
+
+#include <algorithm>
+
+namespace DNAscent {
+
+std::string reverseComplement(const std::string &s) {
+    // common.h:91-150: reverse, then complement (IUPAC codes the reference maps are kept; anything else is dropped there,
+    // which cannot happen for A/C/G/T/N input)
+    std::string out(s.rbegin(), s.rend());
+    for (char &c : out) {
+        switch (c) {
+            case 'A': c = 'T'; break; case 'T': c = 'A'; break; case 'G': c = 'C'; break; case 'C': c = 'G'; break;
+            case 'U': c = 'A'; break; case 'Y': c = 'R'; break; case 'R': c = 'Y'; break; case 'K': c = 'M'; break;
+            case 'M': c = 'K'; break; case 'B': c = 'V'; break; case 'D': c = 'H'; break; case 'H': c = 'D'; break;
+            case 'V': c = 'B'; break; default: break;   // N, S, W stay
+        }
+    }
+    return out;
+}
+
+int parseCigar(const std::vector<uint32_t> &ops, const std::vector<uint32_t> &lens, bool isReverse, size_t queryLen,
+               std::vector<uint32_t> &ref2query, std::vector<int32_t> &query2ref, std::vector<uint8_t> &ref2del) {
+    // htsInterface.cpp:59-157.  The reference fills three std::maps; insertions / soft clips write map slots AHEAD of
+    // the current reference position (:99-107) that later ops overwrite, and leave query2ref entries pointing past the
+    // insertion point.  Replaying the same writes on arrays reproduces every lookup the hot path performs.
+    size_t refLen = 0, maxAhead = 0;
+    for (size_t i = 0; i < ops.size(); i++) {
+        if (ops[i] == 0 || ops[i] == 7 || ops[i] == 8 || ops[i] == 2 || ops[i] == 3) refLen += lens[i];
+        else if (ops[i] == 1 || ops[i] == 4) maxAhead = std::max<size_t>(maxAhead, lens[i]);
+    }
+    std::vector<uint32_t> r2q(refLen + maxAhead + 1, 0);
+    std::vector<uint8_t> r2d(refLen + maxAhead + 1, 0);
+    query2ref.assign(queryLen + 1, -1);
+    int qp = 0, rp = 0;
+    const size_t n = ops.size();
+    for (size_t c = 0; c < n; c++) {
+        const size_t i = isReverse ? (n - 1 - c) : c;                       // :69
+        const int op = (int)ops[i], ol = (int)lens[i];
+        if (op == 0 || op == 7 || op == 8) {                                 // BAM_CMATCH / CEQUAL / CDIFF
+            for (int j = rp; j < rp + ol; j++) {
+                r2q[j] = (uint32_t)qp; r2d[j] = 0;
+                if ((size_t)qp <= queryLen) query2ref[qp] = j;
+                qp++;
+            }
+            rp += ol;
+        } else if (op == 2 || op == 3) {                                     // BAM_CDEL / CREF_SKIP
+            for (int j = rp; j < rp + ol; j++) {
+                r2q[j] = (uint32_t)qp; r2d[j] = 1;
+                if ((size_t)qp <= queryLen) query2ref[qp] = j;
+            }
+            rp += ol;
+        } else if (op == 4 || op == 1) {                                     // BAM_CSOFT_CLIP / CINS
+            for (int j = rp; j < rp + ol; j++) {
+                r2q[j] = (uint32_t)qp; r2d[j] = 0;
+                if ((size_t)qp <= queryLen) query2ref[qp] = j;
+                qp++;
+            }
+        }                                                                    // hard clips / padding: ignored
+    }
+    ref2query.assign(r2q.begin(), r2q.begin() + refLen);
+    ref2del.assign(r2d.begin(), r2d.begin() + refLen);
+    return (int)refLen;
+}
+
+void ReadBatch::clear() { *this = ReadBatch(); }
+
+int ReadBatch::add(const ReadInput &in) {
+    // ---- signal slice (pod5.cpp:75-93) ----
+    size_t lo = 0, hi = in.n_adc;
+    if (in.signalLength > 0) {
+        if (in.isSplit) { lo = (size_t)(in.signalStartCoord + in.signalTrim); hi = (size_t)(in.signalStartCoord + in.signalLength); }
+        else { lo = (size_t)in.signalTrim; hi = (size_t)in.signalLength; }
+        hi = std::min(hi, in.n_adc); lo = std::min(lo, hi);
+    }
+    if (hi - lo < 16 || in.querySeq.size() < DN_KMER + 1) return -1;
+    std::vector<uint32_t> r2q; std::vector<int32_t> q2r; std::vector<uint8_t> r2d;
+    const int refLen = parseCigar(in.cigarOp, in.cigarLen, in.isReverse, in.querySeq.size(), r2q, q2r, r2d);
+    if (refLen < DN_KMER || (size_t)refLen != in.refSlice.size()) return -1;
+    // ---- sequencing direction (reads.h:280-286) ----
+    const std::string bc = in.isReverse ? reverseComplement(in.querySeq) : in.querySeq;
+    const std::string rs = in.isReverse ? reverseComplement(in.refSlice) : in.refSlice;
+
+    readID.push_back(in.readID); contig.push_back(in.contig);
+    adc.insert(adc.end(), in.adc + lo, in.adc + hi); adc_off.push_back(adc.size());
+    cal_offset.push_back(in.cal_offset); cal_scale.push_back(in.cal_scale);
+    basecall.insert(basecall.end(), bc.begin(), bc.end()); basecall_off.push_back(basecall.size());
+    refseq.insert(refseq.end(), rs.begin(), rs.end()); refseq_off.push_back(refseq.size());
+    ref2query.insert(ref2query.end(), r2q.begin(), r2q.end());
+    ref2del.insert(ref2del.end(), r2d.begin(), r2d.end());
+    query2ref.insert(query2ref.end(), q2r.begin(), q2r.end());               // queryLen + 1 entries
+    ref_start.push_back(in.refStart); ref_end.push_back(in.refStart + refLen);
+    is_reverse.push_back(in.isReverse ? 1 : 0);
+    return (int)readID.size() - 1;
+}
+
+dn_batch_desc ReadBatch::desc() const {
+    dn_batch_desc d;
+    memset(&d, 0, sizeof d);
+    d.n_reads = (uint32_t)readID.size();
+    d.adc = adc.data(); d.adc_off = adc_off.data();
+    d.cal_offset = cal_offset.data(); d.cal_scale = cal_scale.data();
+    d.basecall = basecall.data(); d.basecall_off = basecall_off.data();
+    d.refseq = refseq.data(); d.refseq_off = refseq_off.data();
+    d.ref2query = ref2query.data(); d.query2ref = query2ref.data(); d.ref2del = ref2del.data();
+    d.ref_start = ref_start.data(); d.ref_end = ref_end.data(); d.is_reverse = is_reverse.data();
+    return d;
+}
+
+int normaliseEvents(dn_ctx *ctx, ReadBatch &batch) {
+    if (batch.size() == 0) return DN_OK;
+    const dn_batch_desc d = batch.desc();
+    int rc = dn_batch_upload(ctx, &d);
+    if (rc) return rc;
+    if ((rc = dn_run_normalise(ctx))) return rc;
+    batch.summary.resize(batch.size());
+    return dn_get_summaries(ctx, batch.summary.data());
+}
+
+int eventalign(dn_ctx *ctx, ReadBatch &batch) {
+    int rc = dn_run_eventalign(ctx);
+    if (rc) return rc;
+    batch.summary.resize(batch.size());
+    return dn_get_summaries(ctx, batch.summary.data());
+}
+
+}  // namespace DNAscent
+
+// ------------------------------------------------------------------------------------------------
+// flat C wrappers for the Python test / bench harness (ctypes)
+// ------------------------------------------------------------------------------------------------
+using DNAscent::ReadBatch;
+using DNAscent::ReadInput;
+
+extern "C" {
+
+void *dnh_batch_new(void) { return new ReadBatch(); }
+void dnh_batch_free(void *b) { delete (ReadBatch *)b; }
+void dnh_batch_clear(void *b) { ((ReadBatch *)b)->clear(); }
+uint32_t dnh_batch_size(void *b) { return (uint32_t)((ReadBatch *)b)->size(); }
+uint64_t dnh_batch_samples(void *b) { return ((ReadBatch *)b)->totalSamples(); }
+
+// sequences are given in BAM / FASTA (reference-forward) orientation, exactly what the reference reads from disk
+int dnh_batch_add(void *b, const char *read_id, const char *contig, const int16_t *adc, uint64_t n_adc, float cal_offset,
+                  float cal_scale, int signal_length, int signal_trim, int signal_start, int is_split, const char *query_seq,
+                  uint32_t n_query, const char *ref_slice, uint32_t n_ref, const uint32_t *cigar_op, const uint32_t *cigar_len,
+                  uint32_t n_cigar, int ref_start, int is_reverse) {
+    ReadInput in;
+    in.readID = read_id; in.contig = contig;
+    in.adc = adc; in.n_adc = (size_t)n_adc; in.cal_offset = cal_offset; in.cal_scale = cal_scale;
+    in.signalLength = signal_length; in.signalTrim = signal_trim; in.signalStartCoord = signal_start; in.isSplit = is_split != 0;
+    in.querySeq.assign(query_seq, n_query); in.refSlice.assign(ref_slice, n_ref);
+    in.cigarOp.assign(cigar_op, cigar_op + n_cigar); in.cigarLen.assign(cigar_len, cigar_len + n_cigar);
+    in.refStart = ref_start; in.isReverse = is_reverse != 0;
+    return ((ReadBatch *)b)->add(in);
+}
+
+void dnh_batch_desc(void *b, dn_batch_desc *out) { *out = ((ReadBatch *)b)->desc(); }
+
+// flattened CIGAR maps of read i (for host-logic tests)
+int dnh_batch_maps(void *b, uint32_t i, uint32_t *ref2query, int32_t *query2ref, uint8_t *ref2del) {
+    ReadBatch *B = (ReadBatch *)b;
+    if (i >= B->size()) return -1;
+    const uint64_t f0 = B->refseq_off[i], f1 = B->refseq_off[i + 1], q0 = B->basecall_off[i] + i, q1 = B->basecall_off[i + 1] + i + 1;
+    if (ref2query) memcpy(ref2query, B->ref2query.data() + f0, (f1 - f0) * 4);
+    if (ref2del) memcpy(ref2del, B->ref2del.data() + f0, (f1 - f0));
+    if (query2ref) memcpy(query2ref, B->query2ref.data() + q0, (q1 - q0) * 4);
+    return 0;
+}
+
+int dnh_revcomp(const char *in, uint32_t n, char *out) {
+    const std::string r = DNAscent::reverseComplement(std::string(in, n));
+    memcpy(out, r.data(), r.size());
+    return (int)r.size();
+}
+
+}  // extern "C"

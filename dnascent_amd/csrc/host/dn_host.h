@@ -1,0 +1,67 @@
+// dn_host.h -- C++ host side above the C-ABI (include/dnascent_hip.h).
+//
+// Mirrors the reference's per-read interface for the `detect` hot path with batch semantics:
+//
+//   reference (one read per OpenMP thread, detect.cpp:852-907)      here (one batch per call)
+//   ------------------------------------------------------------    ------------------------------------------
+//   DNAscent::read r(record, hdr, index, reference)  reads.h:210     DNAscent::ReadBatch::add(ReadInput)
+//   pod5_getSignal(r)                                pod5.cpp:24     ReadInput::adc + calibration (+ ts/ns/sp trimming)
+//   normaliseEvents(r, false)                  event_handling.h:13   DNAscent::normaliseEvents(ctx, batch)
+//   r.eventAlignment.size() == 0  -> failed          detect.cpp:879  batch.summary[i].status != DN_READ_OK
+//   eventalign(r, windowLength_align)                alignment.h:22   DNAscent::eventalign(ctx, batch)
+//
+// The host keeps only flat arrays; every node-based container of the reference (std::map refToQuery,
+// vector<event>, ...) is flattened once here and lives in HBM afterwards.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "dnascent_hip.h"
+
+namespace DNAscent {
+
+struct ReadInput {                     // what reads.h:210-287 + pod5.cpp:24-93 extract from BAM + POD5 + FASTA
+    std::string readID, contig;
+    const int16_t *adc = nullptr; size_t n_adc = 0;     // complete stored signal of the (parent) read
+    float cal_offset = 0.f, cal_scale = 1.f;            // pod5 calibration
+    // Dorado tags (reads.h:222-253); signalLength <= 0 means "no trimming" (pod5.cpp:76)
+    int signalLength = -1, signalTrim = 0, signalStartCoord = 0; bool isSplit = false;
+    std::string querySeq;                               // BAM query sequence, reference-forward orientation (htsInterface.cpp:160)
+    std::string refSlice;                               // reference[contig].substr(refStart, refEnd-refStart), forward orientation
+    std::vector<uint32_t> cigarOp, cigarLen;            // BAM order
+    int refStart = 0; bool isReverse = false;
+};
+
+// htsInterface.cpp:59-157 flattened: ref2query[refLen], ref2del[refLen], query2ref[queryLen+1] (-1 = absent key)
+int parseCigar(const std::vector<uint32_t> &ops, const std::vector<uint32_t> &lens, bool isReverse, size_t queryLen,
+               std::vector<uint32_t> &ref2query, std::vector<int32_t> &query2ref, std::vector<uint8_t> &ref2del);
+
+std::string reverseComplement(const std::string &s);    // common.h:91
+
+class ReadBatch {
+public:
+    void clear();
+    // returns the index of the read in the batch, or -1 if the read is rejected (empty signal / too short), mirroring
+    // the reference's filters (detect.cpp:839, pod5.cpp:64)
+    int add(const ReadInput &in);
+    size_t size() const { return readID.size(); }
+    dn_batch_desc desc() const;
+    uint64_t totalSamples() const { return adc_off.empty() ? 0 : adc_off.back(); }
+
+    std::vector<std::string> readID, contig;
+    std::vector<int16_t> adc; std::vector<uint64_t> adc_off{0};
+    std::vector<float> cal_offset, cal_scale;
+    std::vector<char> basecall; std::vector<uint64_t> basecall_off{0};
+    std::vector<char> refseq; std::vector<uint64_t> refseq_off{0};
+    std::vector<uint32_t> ref2query; std::vector<int32_t> query2ref; std::vector<uint8_t> ref2del;
+    std::vector<int32_t> ref_start, ref_end; std::vector<uint8_t> is_reverse;
+    std::vector<dn_read_summary> summary;               // filled by normaliseEvents / eventalign
+};
+
+// normaliseEvents for every read of the batch (event_handling.h:13).  Throws nothing: returns a DN_* code.
+int normaliseEvents(dn_ctx *ctx, ReadBatch &batch);
+int eventalign(dn_ctx *ctx, ReadBatch &batch);
+
+}  // namespace DNAscent

@@ -1,0 +1,339 @@
+// k1_segment.hip -- K1: raw int16 signal -> scrappie events -> DNAscent events, per read, on gfx950.
+//
+// Replaces detect_events (scrappie/event_detection.c:268-319) and the event build of normaliseEvents
+// (event_handling.cpp:546-575) with results bit-identical to the reference:
+//
+//   k1_scan     serial fp64 prefix sums of x and x*x (event_detection.c:42-47).  Rounding of a running fp64
+//               sum depends on the order of the additions, so the order is kept: ONE LANE PER READ walks its
+//               read left to right (64 reads per wavefront, 16-B loads of 8 samples, 16-B {sum,sumsq} stores).
+//               int16 -> pA is fused in: ((float)adc + offset) * scale in fp32, widened (pod5.cpp:60).
+//   k1_tstat    the two windowed t-statistics (event_detection.c:60-115), one thread per sample; the mixed
+//               float/double expression order of the reference is written out cast by cast.
+//   k1_detect   the short/long peak detector (event_detection.c:122-198) is a serial state machine.  It is run
+//               SPECULATIVELY: one lane per 256-sample chunk starts DN_SEG_WARM samples early from the default
+//               state; after a common emitted peak the state no longer depends on history, so the state at the
+//               chunk start is almost always the true one.
+//   k1_events   verifies every chunk hand-off exactly (state in == previous state out), recomputes the rare
+//               chunk whose speculation missed (so the result is exact, never approximate), compacts the peaks,
+//               forms event means from the prefix sums (event_detection.c:213-266) and applies the event-build
+//               quirks of event_handling.cpp:549-575 (first mean 0.0, last event dropped, mean <= 0 merged).
+#include "dn_dev.h"
+#include <float.h>
+
+// ------------------------------------------------------------------------------------------------
+// k1_scan: one lane per read
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k1_scan(BatchDev B) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= B.n_reads) return;
+    const uint64_t s0 = B.samp_off[r];
+    const unsigned n = (unsigned)(B.samp_off[r + 1] - s0);
+    const int16_t *a = B.adc + s0;
+    double2 *out = B.psum + s0;
+    const float off = B.cal_off[r], sc = B.cal_scale[r];
+    double s = 0.0, q = 0.0;
+    unsigned i = 0;
+#define STEP(ADC)                                                   \
+    {                                                               \
+        float v = ((float)(ADC) + off) * sc;   /* pod5.cpp:60 */    \
+        double x = (double)v;                                       \
+        s = s + x;                             /* :45 */            \
+        q = q + x * x;                         /* :46 */            \
+        out[i] = make_double2(s, q);                                \
+        i++;                                                        \
+    }
+    while (i < n && ((reinterpret_cast<uintptr_t>(a + i)) & 15u)) STEP(a[i]);
+    // 32 samples (4 x 16-B loads) per round; the NEXT round's loads are issued before this round's 32 stores, so
+    // the wait that guards them is vmcnt(32): it never drains the stores just issued (vmcnt is in-order on gfx950)
+    if (i + 32 <= n) {
+        int4 c0 = *reinterpret_cast<const int4 *>(a + i), c1 = *reinterpret_cast<const int4 *>(a + i + 8);
+        int4 c2 = *reinterpret_cast<const int4 *>(a + i + 16), c3 = *reinterpret_cast<const int4 *>(a + i + 24);
+        while (true) {
+            const bool more = (i + 64 <= n);
+            int4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+            if (more) {
+                n0 = *reinterpret_cast<const int4 *>(a + i + 32); n1 = *reinterpret_cast<const int4 *>(a + i + 40);
+                n2 = *reinterpret_cast<const int4 *>(a + i + 48); n3 = *reinterpret_cast<const int4 *>(a + i + 56);
+            }
+            const int w[16] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w };
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                STEP((int16_t)(w[j] & 0xffff));
+                STEP((int16_t)(w[j] >> 16));
+            }
+            if (!more) break;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        }
+    }
+    while (i < n) STEP(a[i]);
+#undef STEP
+}
+
+// ------------------------------------------------------------------------------------------------
+// k1_tstat: one thread per sample
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double2 prefix_at(const double2 *P, unsigned j) {   // {sum[j], sumsq[j]}
+    return j == 0 ? make_double2(0.0, 0.0) : P[j - 1];
+}
+
+__device__ __forceinline__ float tstat_at(const double2 *P, unsigned n, unsigned i, unsigned w) {
+    if (n < 2 * w) return 0.0f;                                  // :76-81
+    if (i < w || i > n - w) return 0.0f;                         // :83-86, loop bound :89 is inclusive
+    const float wf = (float)w;
+    const double2 a = prefix_at(P, i - w), b = prefix_at(P, i), c = prefix_at(P, i + w);
+    const double sum1 = b.x - a.x, sumsq1 = b.y - a.y;           // :90-95 (sum[0] == 0, so i == w is the same expression)
+    const float sum2 = (float)(c.x - b.x);                       // :96
+    const float sumsq2 = (float)(c.y - b.y);                     // :97
+    const float mean1 = (float)(sum1 / (double)wf);              // :98
+    const float mean2 = sum2 / wf;                               // :99
+    const float m1sq = mean1 * mean1, m2sq = mean2 * mean2;
+    const float s2w = sumsq2 / wf;
+    float var = (float)(((sumsq1 / (double)wf - (double)m1sq) + (double)s2w) - (double)m2sq);   // :100-101
+    var = fmaxf(var, FLT_MIN);                                   // :104
+    const float dm = mean2 - mean1;                              // :110
+    const float vw = var / wf;
+    return (float)(fabs((double)dm) / sqrt((double)vw));         // :111
+}
+
+__global__ __launch_bounds__(256) void k1_tstat(BatchDev B) {
+    const int r = blockIdx.y;
+    const uint64_t s0 = B.samp_off[r];
+    const unsigned n = (unsigned)(B.samp_off[r + 1] - s0);
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double2 *P = B.psum + s0;
+    B.t1[s0 + i] = tstat_at(P, n, i, 3);                          // event_detection.h:19-25
+    B.t2[s0 + i] = tstat_at(P, n, i, 6);
+}
+
+// ------------------------------------------------------------------------------------------------
+// peak detector state machine (event_detection.c:136-195), shared by the speculative pass and the exact redo
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ SegState seg_initial() {
+    SegState st;
+    st.s.masked_to = 0; st.s.peak_pos = -1; st.s.peak_val = FLT_MAX; st.s.valid = 0;
+    st.l = st.s;
+    return st;
+}
+
+template <bool EMIT>
+__device__ __forceinline__ void seg_step(SegState &st, int i, float v1, float v2, unsigned *pk, unsigned &npk) {
+    const float peak_height = 0.2f;
+    // short detector: window 3, threshold 1.4
+    if (!(st.s.masked_to >= i)) {                                 // :140
+        const float v = v1;
+        if (st.s.peak_pos == -1) {
+            if (v < st.s.peak_val) st.s.peak_val = v;
+            else if (v - st.s.peak_val > peak_height) { st.s.peak_val = v; st.s.peak_pos = i; }
+        } else {
+            if (v > st.s.peak_val) { st.s.peak_val = v; st.s.peak_pos = i; }
+            if (st.s.peak_val > 1.4f) {                           // :166-176 short dominates long
+                st.l.masked_to = st.s.peak_pos + 3;
+                st.l.peak_pos = -1; st.l.peak_val = FLT_MAX; st.l.valid = 0;
+            }
+            if (st.s.peak_val - v > peak_height && st.s.peak_val > 1.4f) st.s.valid = 1;
+            if (st.s.valid && (i - st.s.peak_pos) > 1) {          // window_length / 2 == 1
+                if (EMIT) { if (npk < DN_SEG_PEAKCAP) pk[npk] = (unsigned)st.s.peak_pos; npk++; }
+                st.s.peak_pos = -1; st.s.peak_val = v; st.s.valid = 0;
+            }
+        }
+    }
+    // long detector: window 6, threshold 9.0
+    if (!(st.l.masked_to >= i)) {
+        const float v = v2;
+        if (st.l.peak_pos == -1) {
+            if (v < st.l.peak_val) st.l.peak_val = v;
+            else if (v - st.l.peak_val > peak_height) { st.l.peak_val = v; st.l.peak_pos = i; }
+        } else {
+            if (v > st.l.peak_val) { st.l.peak_val = v; st.l.peak_pos = i; }
+            if (st.l.peak_val - v > peak_height && st.l.peak_val > 9.0f) st.l.valid = 1;
+            if (st.l.valid && (i - st.l.peak_pos) > 3) {          // window_length / 2 == 3
+                if (EMIT) { if (npk < DN_SEG_PEAKCAP) pk[npk] = (unsigned)st.l.peak_pos; npk++; }
+                st.l.peak_pos = -1; st.l.peak_val = v; st.l.valid = 0;
+            }
+        }
+    }
+}
+
+// states compare equal if they behave identically from sample `at` on
+__device__ __forceinline__ bool seg_equal(const SegState &a, const SegState &b, int at) {
+    const int am = a.l.masked_to >= at ? a.l.masked_to : -1, bm = b.l.masked_to >= at ? b.l.masked_to : -1;
+    return a.s.peak_pos == b.s.peak_pos && __float_as_int(a.s.peak_val) == __float_as_int(b.s.peak_val) &&
+           a.s.valid == b.s.valid && am == bm && a.l.peak_pos == b.l.peak_pos &&
+           __float_as_int(a.l.peak_val) == __float_as_int(b.l.peak_val) && a.l.valid == b.l.valid;
+}
+
+__global__ __launch_bounds__(64) void k1_detect(BatchDev B) {
+    const int r = blockIdx.y;
+    const uint64_t s0 = B.samp_off[r];
+    const int n = (int)(B.samp_off[r + 1] - s0);
+    const uint64_t c0 = B.chunk_off[r];
+    const int nch = (int)(B.chunk_off[r + 1] - c0);
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= nch) return;
+    const float *t1 = B.t1 + s0, *t2 = B.t2 + s0;
+    const int beg = c * DN_SEG_CHUNK;
+    const int end = min(beg + DN_SEG_CHUNK, n);
+    SegState st = seg_initial();
+    unsigned dummy = 0;
+    if (c > 0) {
+        const int w0 = max(beg - DN_SEG_WARM, 1);                // sample 0 is always masked (:140), so 1 is a clean start
+        for (int i = w0; i < beg; i++) seg_step<false>(st, i, t1[i], t2[i], nullptr, dummy);
+    }
+    B.chunk_in[c0 + c] = st;
+    unsigned *pk = B.chunk_peaks + (c0 + c) * DN_SEG_PEAKCAP;
+    unsigned npk = 0;
+    for (int i = beg; i < end; i++) seg_step<true>(st, i, t1[i], t2[i], pk, npk);
+    B.chunk_npk[c0 + c] = npk;
+    B.chunk_out[c0 + c] = st;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k1_events: one wavefront per read
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k1_events(BatchDev B, unsigned *scratch_u32 /* aliases cl_rank: kept-index list */) {
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint64_t s0 = B.samp_off[r];
+    const int n = (int)(B.samp_off[r + 1] - s0);
+    const uint64_t c0 = B.chunk_off[r];
+    const int nch = (int)(B.chunk_off[r + 1] - c0);
+    const uint64_t e0 = B.ev_off[r];
+    const unsigned ecap = (unsigned)(B.ev_off[r + 1] - e0);
+    const float *t1 = B.t1 + s0, *t2 = B.t2 + s0;
+    const double2 *P = B.psum + s0;
+    ReadRes &R = B.res[r];
+
+    // ---- 1. exact verification of the speculative hand-offs ----
+    int any_bad = 0;
+    for (int c = 1 + lane; c < nch; c += 64) {
+        const SegState a = B.chunk_out[c0 + c - 1], b = B.chunk_in[c0 + c];
+        if (!seg_equal(a, b, c * DN_SEG_CHUNK)) any_bad = 1;
+    }
+    unsigned rechecks = 0;
+    if (__any(any_bad)) {
+        // slow path (rare): walk the chain, redo every chunk whose assumed start state was wrong
+        SegState tru = B.chunk_out[c0];
+        for (int c = 1; c < nch; c++) {
+            const SegState in = B.chunk_in[c0 + c];
+            if (seg_equal(tru, in, c * DN_SEG_CHUNK)) { tru = B.chunk_out[c0 + c]; continue; }
+            SegState st = tru;
+            const int beg = c * DN_SEG_CHUNK, end = min(beg + DN_SEG_CHUNK, n);
+            unsigned *pk = B.chunk_peaks + (c0 + c) * DN_SEG_PEAKCAP;
+            unsigned npk = 0;
+            // lane 0 redoes the chunk from the true state and stores; its end state is broadcast below
+            if (lane == 0) {
+                for (int i = beg; i < end; i++) seg_step<true>(st, i, t1[i], t2[i], pk, npk);
+                B.chunk_npk[c0 + c] = npk;
+                B.chunk_out[c0 + c] = st;
+            }
+            // broadcast lane 0's end state
+            st.s.masked_to = __shfl(st.s.masked_to, 0); st.s.peak_pos = __shfl(st.s.peak_pos, 0);
+            st.s.peak_val = __shfl(st.s.peak_val, 0);   st.s.valid = __shfl(st.s.valid, 0);
+            st.l.masked_to = __shfl(st.l.masked_to, 0); st.l.peak_pos = __shfl(st.l.peak_pos, 0);
+            st.l.peak_val = __shfl(st.l.peak_val, 0);   st.l.valid = __shfl(st.l.valid, 0);
+            tru = st;
+            rechecks++;
+        }
+        __threadfence_block();
+    }
+    __syncthreads();
+
+    // ---- 2. compact the peaks: et_start[0] = 0, et_start[1 + j] = j-th peak ----
+    unsigned *et_start = B.et_start + e0;
+    float *et_mean = B.et_mean + e0;
+    unsigned running = 0;
+    int overflow = 0;
+    for (int cb = 0; cb < nch; cb += 64) {
+        const int c = cb + lane;
+        unsigned cnt = (c < nch) ? B.chunk_npk[c0 + c] : 0u;
+        if (cnt > DN_SEG_PEAKCAP) { overflow = 1; cnt = DN_SEG_PEAKCAP; }
+        const unsigned incl = wave_incl_scan(cnt, lane);
+        const unsigned pre = running + incl - cnt;
+        if (c < nch) {
+            const unsigned *pk = B.chunk_peaks + (c0 + c) * DN_SEG_PEAKCAP;
+            for (unsigned j = 0; j < cnt; j++) {
+                const unsigned slot = 1 + pre + j;
+                if (slot < ecap) et_start[slot] = pk[j];
+            }
+        }
+        running += __shfl(incl, 63);
+    }
+    if (lane == 0) et_start[0] = 0;
+    unsigned n_et = 1 + running;                                  // create_events :242-247 (every recorded peak satisfies 0 < p < n)
+    if (n_et > ecap) { overflow = 1; n_et = ecap; }
+    overflow = __any(overflow);
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- 3. scrappie event means (create_event :224-226) ----
+    for (unsigned e = lane; e < n_et; e += 64) {
+        const unsigned st = et_start[e];
+        const unsigned en = (e + 1 < n_et) ? et_start[e + 1] : (unsigned)n;
+        const double2 a = prefix_at(P, st), b = prefix_at(P, en);
+        const float length = (float)(unsigned long long)((unsigned long long)en - (unsigned long long)st);
+        et_mean[e] = (float)(b.x - a.x) / length;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- 4. DNAscent event build (event_handling.cpp:549-575) ----
+    // kept scrappie indices: i > 0 && et[i].mean > 0.  Event j: mean/rawStart of the PREVIOUS kept index
+    // (0.0 / 0 for the first), raw span up to et[kept_j].start - 1.
+    unsigned kept_total = 0;
+    for (unsigned eb = 0; eb < n_et; eb += 64) {
+        const unsigned e = eb + lane;
+        const int keep = (e < n_et) && (e > 0) && ((double)et_mean[e] > 0.);
+        const unsigned long long m = __ballot(keep);
+        const unsigned pos = kept_total + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep) scratch_u32[e0 + pos] = e;
+        kept_total += __popcll(m);
+    }
+    __threadfence_block();
+    __syncthreads();
+    double *ev_mean = B.ev_mean + e0;
+    unsigned *ev_start = B.ev_start + e0, *ev_len = B.ev_len + e0;
+    for (unsigned j = lane; j < kept_total; j += 64) {
+        const unsigned i = scratch_u32[e0 + j];
+        double mean = 0.;
+        unsigned rs = 0;
+        if (j > 0) { const unsigned ip = scratch_u32[e0 + j - 1]; mean = (double)et_mean[ip]; rs = et_start[ip]; }
+        unsigned last = et_start[i] - 1u;                         // :563 (et[i].start >= 1 for i > 0)
+        if (last > (unsigned)n - 1u) last = (unsigned)n - 1u;
+        ev_mean[j] = mean;
+        ev_start[j] = rs;
+        ev_len[j] = (last >= rs) ? (last - rs + 1u) : 0u;
+    }
+    if (lane == 0) {
+        R.n_samples = (unsigned)n;
+        R.n_scrappie = n_et;
+        R.n_events = kept_total;
+        R.rechecks = rechecks;
+        R.seg_overflow = overflow;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers (called from dn_capi.hip)
+// ------------------------------------------------------------------------------------------------
+void k1_launch_scan(const BatchDev &B, hipStream_t st) {
+    hipLaunchKernelGGL(k1_scan, dim3((B.n_reads + 63) / 64), dim3(64), 0, st, B);
+}
+void k1_launch_tstat(const BatchDev &B, unsigned max_samples, hipStream_t st) {
+    hipLaunchKernelGGL(k1_tstat, dim3((max_samples + 255) / 256, B.n_reads), dim3(256), 0, st, B);
+}
+void k1_launch_detect(const BatchDev &B, unsigned max_chunks, hipStream_t st) {
+    hipLaunchKernelGGL(k1_detect, dim3((max_chunks + 63) / 64, B.n_reads), dim3(64), 0, st, B);
+}
+void k1_launch_events(const BatchDev &B, hipStream_t st) {
+    hipLaunchKernelGGL(k1_events, dim3(B.n_reads), dim3(64), 0, st, B, B.cl_rank);
+}

@@ -1,0 +1,325 @@
+// k_scaling.hip -- k-mer ranks, rough quantile scaling, Theil-Sen refinement (gfx950).
+//
+//   k_ranks     kmer2index (data_IO.cpp:129-141: A0 T1 G2 C3, big-endian base 4, unknown -> 0) for every
+//               query / reference 9-mer (event_handling.cpp:578-592), plus the gathered model mean of each
+//               query k-mer (feeds the banded kernel without a dependent table lookup).
+//   k_quantile  estimateScaling_quantiles (event_handling.cpp:510-541).  The reference sorts both arrays only to
+//               read 10 order statistics each (quantileMedians :451-475); here they are found exactly by an
+//               8-pass MSB radix select over order-preserving 64-bit keys, 10 targets at once, histograms in
+//               LDS.  The OLS of linear_regression (:478-507) is then one thread.
+//   k_prep      x_e = (mean_e - shift) / scale in fp64 (the division of event_handling.cpp:130, hoisted:
+//               it only depends on the event).
+//   k_theilsen  estimateScaling_theilSen (event_handling.cpp:24-110): <= 1000 points, all pairwise slopes,
+//               the upper median slope and the median intercept.  A median is an order statistic, so no sort is
+//               needed: slopes are regenerated on the fly in three passes (11-bit, 11-bit LDS histograms, then
+//               an in-LDS finish on the few survivors).  fp64 '/' on gfx950 is IEEE, so each slope has the
+//               reference's bits.
+#include "dn_dev.h"
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ranks(BatchDev B) {
+    const int r = blockIdx.y;
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    const uint64_t b0 = B.base_off[r];
+    const unsigned nb = (unsigned)(B.base_off[r + 1] - b0);
+    const uint64_t f0 = B.ref_off[r];
+    const unsigned nf = (unsigned)(B.ref_off[r + 1] - f0);
+    if (nb >= DN_K && i < nb - DN_K + 1) {
+        const char *s = B.basecall + b0 + i;
+        unsigned v = 0;
+#pragma unroll
+        for (int j = 0; j < DN_K; j++) v = v * 4u + base_code(s[j]);
+        B.rank_q[b0 + i] = v;
+        B.mu_q[b0 + i] = B.model_mean[v];
+    }
+    if (nf >= DN_K && i < nf - DN_K + 1) {
+        const char *s = B.refseq + f0 + i;
+        unsigned v = 0;
+#pragma unroll
+        for (int j = 0; j < DN_K; j++) v = v * 4u + base_code(s[j]);
+        B.rank_r[f0 + i] = v;
+    }
+    if (i == 0) {
+        B.res[r].n_kq = nb >= DN_K ? nb - DN_K + 1 : 0;
+        B.res[r].n_kr = nf >= DN_K ? nf - DN_K + 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 10-target radix select.  val(i) is supplied by a functor so the model means are gathered on the fly.
+// ------------------------------------------------------------------------------------------------
+template <class F>
+__device__ void select10(F val, unsigned n, double *out10, unsigned (*hist)[256], unsigned long long *prefix,
+                         unsigned *rank_in) {
+    const int tid = threadIdx.x;
+    const unsigned m = n / 10u;                                   // quantileMedians :467
+    if (tid < 10) {
+        prefix[tid] = 0ull;
+        rank_in[tid] = ((unsigned)tid * m + (unsigned)(tid + 1) * m) / 2u;   // :470
+    }
+    __syncthreads();
+    for (int pass = 7; pass >= 0; pass--) {
+        for (int j = tid; j < 10 * 256; j += 256) (&hist[0][0])[j] = 0u;
+        __syncthreads();
+        unsigned long long pf[10];
+#pragma unroll
+        for (int t = 0; t < 10; t++) pf[t] = prefix[t];
+        const int sh = 8 * (pass + 1);
+        for (unsigned i = tid; i < n; i += 256) {
+            const unsigned long long key = dkey(val(i));
+            const unsigned digit = (unsigned)(key >> (8 * pass)) & 255u;
+            const unsigned long long hi = (pass == 7) ? 0ull : (key >> sh);
+#pragma unroll
+            for (int t = 0; t < 10; t++) {
+                const unsigned long long ph = (pass == 7) ? 0ull : (pf[t] >> sh);
+                if (hi == ph) atomicAdd(&hist[t][digit], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < 10) {
+            unsigned want = rank_in[tid], cum = 0; unsigned d = 255;
+            for (unsigned b = 0; b < 256; b++) {
+                const unsigned h = hist[tid][b];
+                if (want < cum + h) { d = b; break; }
+                cum += h;
+            }
+            rank_in[tid] = want - cum;
+            prefix[tid] |= ((unsigned long long)d) << (8 * pass);
+        }
+        __syncthreads();
+    }
+    if (tid < 10) out10[tid] = dkey_inv(prefix[tid]);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_quantile(BatchDev B) {
+    __shared__ unsigned hist[10][256];
+    __shared__ unsigned long long prefix[10];
+    __shared__ unsigned rank_in[10];
+    __shared__ double sq[10], mq[10];
+    const int r = blockIdx.x;
+    ReadRes &R = B.res[r];
+    const unsigned ne = R.n_events, nr = R.n_kr;
+    if (ne == 0 || nr == 0) {
+        if (threadIdx.x == 0) { R.q_shift = 0.; R.q_scale = 1.; R.status = 5; }
+        return;
+    }
+    const double *em = B.ev_mean + B.ev_off[r];
+    const unsigned *rr = B.rank_r + B.ref_off[r];
+    const double *model = B.model_mean;
+    select10([=](unsigned i) { return em[i]; }, ne, sq, hist, prefix, rank_in);           // signal quantiles :532
+    select10([=](unsigned i) { return model[rr[i]]; }, nr, mq, hist, prefix, rank_in);    // model quantiles  :533
+    if (threadIdx.x == 0) {
+        // linear_regression(x = model quantiles, y = signal quantiles) :478-507, :535
+        double sx = 0., sx2 = 0., sy = 0., sxy = 0.;
+        const int n = 10;
+        for (int i = 0; i < n; i++) {
+            sx = sx + mq[i];
+            sx2 = sx2 + mq[i] * mq[i];
+            sy = sy + sq[i];
+            sxy = sxy + mq[i] * sq[i];
+        }
+        const double slope = ((double)n * sxy - sx * sy) / ((double)n * sx2 - sx * sx);
+        const double icpt = (sy - slope * sx) / (double)n;
+        R.q_shift = icpt;                                         // :537
+        R.q_scale = slope;                                        // :538
+        R.status = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prep(BatchDev B) {
+    const int r = blockIdx.y;
+    const unsigned e = blockIdx.x * 256 + threadIdx.x;
+    const ReadRes &R = B.res[r];
+    if (e >= R.n_events) return;
+    const uint64_t e0 = B.ev_off[r];
+    B.ev_x[e0 + e] = (B.ev_mean[e0 + e] - R.q_shift) / R.q_scale; // event_handling.cpp:130
+}
+
+// ------------------------------------------------------------------------------------------------
+// Theil-Sen
+// ------------------------------------------------------------------------------------------------
+#define TS_MAXP 1000
+#define TS_CAND 2048
+
+__device__ __forceinline__ void pair_from_index(unsigned p, unsigned np, unsigned &a, unsigned &b) {
+    // p enumerates pairs (a,b), a<b, in the reference's push order (:67-75): row a holds np-1-a pairs
+    // row start s(a) = a*(2*np - a - 1)/2.  Solve by float estimate + correction.
+    const double n2 = 2.0 * np - 1.0;
+    double af = (n2 - sqrt(n2 * n2 - 8.0 * (double)p)) * 0.5;
+    unsigned aa = (unsigned)af;
+    if (aa >= np - 1) aa = np - 2;
+    while ((unsigned long long)aa * (2ull * np - aa - 1ull) / 2ull > p) aa--;
+    while ((unsigned long long)(aa + 1) * (2ull * np - (aa + 1) - 1ull) / 2ull <= p) aa++;
+    a = aa;
+    b = aa + 1 + (unsigned)(p - (unsigned long long)aa * (2ull * np - aa - 1ull) / 2ull);
+}
+
+__global__ __launch_bounds__(256) void k_theilsen(BatchDev B, const double *host_consts /* unused */) {
+    __shared__ double x[TS_MAXP], y[TS_MAXP];
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned long long cand[TS_CAND];
+    __shared__ unsigned ncand, sel_digit, sel_rank, sel_digit2;
+    __shared__ unsigned long long icpt_key[1024];
+    const int r = blockIdx.x;
+    const int tid = threadIdx.x;
+    ReadRes &R = B.res[r];
+    const uint64_t a0 = B.aln_off[r];
+    const double *sig = B.cl_sig + a0;
+    const unsigned *rk = B.cl_rank + a0;
+    const unsigned n = R.n_cleaned;
+    const double shift = R.q_shift, scale = R.q_scale;
+    const uint64_t b0 = B.base_off[r];
+    const unsigned nbase = (unsigned)(B.base_off[r + 1] - b0);
+    if (tid == 0) {
+        R.events_per_base = (double)R.n_scrappie / (double)(nbase - DN_K);   // :606
+        R.ts_slope = __longlong_as_double(0x7ff8000000000000ll);
+        R.ts_intercept = __longlong_as_double(0x7ff8000000000000ll);
+        R.shift = shift; R.scale = scale;
+    }
+    if (R.status == 3 || R.status == 5) return;                   // nothing aligned
+    if (n < TS_MAXP) return;                                      // :33 (such a read already failed the n_cleaned QC, :438)
+    const unsigned eff = n - 100u;                                // trimSize 50 at both ends :35
+    unsigned skip = 1, np = eff;
+    if (eff > TS_MAXP) { skip = eff / TS_MAXP; np = TS_MAXP; }
+    for (unsigned j = tid; j < np; j += 256) {
+        const unsigned i = 50u + j * skip;
+        x[j] = (sig[i] - shift) / scale;                          // :51
+        y[j] = B.model_mean[rk[i]];                               // :58-61
+    }
+    const unsigned long long ns = (unsigned long long)np * (np - 1) / 2ull;
+    const unsigned target = (unsigned)(ns / 2ull);                // :78 slopes[size/2]
+    // ---- pass 1: top 11 bits of the key ----
+    for (int j = tid; j < 2048; j += 256) hist[j] = 0;
+    if (tid == 0) ncand = 0;
+    __syncthreads();
+    for (unsigned a = 0; a + 1 < np; a++) {
+        const double xa = x[a], ya = y[a];
+        for (unsigned b = a + 1 + tid; b < np; b += 256) {
+            const double s = (ya - y[b]) / (xa - x[b]);           // :70-73
+            atomicAdd(&hist[(unsigned)(dkey(s) >> 53)], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned cum = 0, d = 2047;
+        for (unsigned b = 0; b < 2048; b++) { if (target < cum + hist[b]) { d = b; break; } cum += hist[b]; }
+        sel_digit = d; sel_rank = target - cum;
+    }
+    __syncthreads();
+    const unsigned d1 = sel_digit;
+    // ---- pass 2: next 11 bits within the selected bin ----
+    for (int j = tid; j < 2048; j += 256) hist[j] = 0;
+    __syncthreads();
+    for (unsigned a = 0; a + 1 < np; a++) {
+        const double xa = x[a], ya = y[a];
+        for (unsigned b = a + 1 + tid; b < np; b += 256) {
+            const unsigned long long k = dkey((ya - y[b]) / (xa - x[b]));
+            if ((unsigned)(k >> 53) == d1) atomicAdd(&hist[(unsigned)(k >> 42) & 2047u], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned want = sel_rank, cum = 0, d = 2047;
+        for (unsigned b = 0; b < 2048; b++) { if (want < cum + hist[b]) { d = b; break; } cum += hist[b]; }
+        sel_digit2 = d; sel_rank = want - cum;
+    }
+    __syncthreads();
+    const unsigned d2 = sel_digit2;
+    const unsigned long long top22 = ((unsigned long long)d1 << 11) | d2;
+    // ---- pass 3: collect the survivors, finish by rank counting in LDS ----
+    for (unsigned a = 0; a + 1 < np; a++) {
+        const double xa = x[a], ya = y[a];
+        for (unsigned b = a + 1 + tid; b < np; b += 256) {
+            const unsigned long long k = dkey((ya - y[b]) / (xa - x[b]));
+            if ((k >> 42) == top22) {
+                const unsigned slot = atomicAdd(&ncand, 1u);
+                if (slot < TS_CAND) cand[slot] = k;
+            }
+        }
+    }
+    __syncthreads();
+    unsigned nc = ncand;
+    double slope_med;
+    __shared__ unsigned long long slope_key;
+    if (nc <= TS_CAND) {
+        const unsigned want = sel_rank;
+        for (unsigned i = tid; i < nc; i += 256) {
+            const unsigned long long k = cand[i];
+            unsigned less = 0, eq = 0;
+            for (unsigned j = 0; j < nc; j++) { const unsigned long long o = cand[j]; less += (o < k); eq += (o == k); }
+            if (less <= want && want < less + eq) slope_key = k;   // all writers hold the same key value
+        }
+        __syncthreads();
+    } else {
+        // more than TS_CAND slopes share 22 leading bits (degenerate data): finish with 42 more bits, 1 bit per pass
+        if (tid == 0) slope_key = 0ull;
+        __shared__ unsigned cnt0;
+        unsigned long long pref = top22 << 42; unsigned want = sel_rank;
+        for (int bit = 41; bit >= 0; bit--) {
+            if (tid == 0) cnt0 = 0;
+            __syncthreads();
+            unsigned local = 0;
+            for (unsigned a = 0; a + 1 < np; a++) {
+                const double xa = x[a], ya = y[a];
+                for (unsigned b = a + 1 + tid; b < np; b += 256) {
+                    const unsigned long long k = dkey((ya - y[b]) / (xa - x[b]));
+                    if ((k >> (bit + 1)) == (pref >> (bit + 1)) && !((k >> bit) & 1ull)) local++;
+                }
+            }
+            atomicAdd(&cnt0, local);
+            __syncthreads();
+            const unsigned c0 = cnt0;
+            if (want >= c0) { want -= c0; pref |= (1ull << bit); }
+            __syncthreads();
+        }
+        if (tid == 0) slope_key = pref;
+        __syncthreads();
+    }
+    slope_med = dkey_inv(slope_key);
+    // ---- intercepts :79-87 : median of y - slope*x over <= 1000 points (rank np/2) ----
+    for (unsigned j = tid; j < np; j += 256) {
+        const double prod = slope_med * x[j];                     // product rounded, then subtracted (no contraction)
+        icpt_key[j] = dkey(y[j] - prod);
+    }
+    __syncthreads();
+    __shared__ unsigned long long icpt_sel;
+    {
+        const unsigned want = np / 2u;
+        for (unsigned i = tid; i < np; i += 256) {
+            const unsigned long long k = icpt_key[i];
+            unsigned less = 0, eq = 0;
+            for (unsigned j = 0; j < np; j++) { const unsigned long long o = icpt_key[j]; less += (o < k); eq += (o == k); }
+            if (less <= want && want < less + eq) icpt_sel = k;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double icpt_med = dkey_inv(icpt_sel);
+        R.ts_slope = slope_med; R.ts_intercept = icpt_med;
+        if (slope_med == 0.) {                                    // :90-95
+            R.shift = -1.; R.scale = -1.;
+            if (R.status == 0) R.status = 2;
+        } else {
+            const double scale_corr = 1. / slope_med;             // :98-101
+            const double shift_corr = -icpt_med / slope_med;
+            R.shift = shift + (shift_corr * scale);
+            R.scale = scale * scale_corr;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+void ks_launch_ranks(const BatchDev &B, unsigned max_len, hipStream_t st) {
+    hipLaunchKernelGGL(k_ranks, dim3((max_len + 255) / 256, B.n_reads), dim3(256), 0, st, B);
+}
+void ks_launch_quantile(const BatchDev &B, hipStream_t st) {
+    hipLaunchKernelGGL(k_quantile, dim3(B.n_reads), dim3(256), 0, st, B);
+}
+void ks_launch_prep(const BatchDev &B, unsigned max_events, hipStream_t st) {
+    hipLaunchKernelGGL(k_prep, dim3((max_events + 255) / 256, B.n_reads), dim3(256), 0, st, B);
+}
+void ks_launch_theilsen(const BatchDev &B, hipStream_t st) {
+    hipLaunchKernelGGL(k_theilsen, dim3(B.n_reads), dim3(256), 0, st, B, (const double *)nullptr);
+}

@@ -1,0 +1,192 @@
+"""ctypes binding of the C-ABI (include/dnascent_hip.h -> dnascent_amd/lib/libdnascent_hip.so).
+
+There is no fallback: if the library is missing, or no gfx950 device is usable, creating a Context raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+DN_OK = 0
+K_NAMES = ["DN_K_SCAN", "DN_K_TSTAT", "DN_K_DETECT", "DN_K_EVENTS", "DN_K_RANKS", "DN_K_QUANTILE", "DN_K_PREP",
+           "DN_K_BAND_FILL", "DN_K_BAND_TRACE", "DN_K_THEILSEN", "DN_K_VITERBI"]
+DN_K_COUNT = len(K_NAMES)
+for _i, _n in enumerate(K_NAMES):
+    globals()[_n] = _i
+
+# every symbol include/dnascent_hip.h declares (tests/test_abi.py checks the export list against the header)
+SYMBOLS = ["dn_abi_version", "dn_device_count", "dn_ctx_create", "dn_ctx_destroy", "dn_last_error", "dn_sync",
+           "dn_load_pore_model", "dn_batch_upload", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded",
+           "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_get_summaries", "dn_get_prefix_sums",
+           "dn_get_tstats", "dn_get_scrappie_events", "dn_get_events", "dn_get_kmer_ranks", "dn_get_alignment",
+           "dn_get_cleaned", "dn_get_trace", "dn_get_positions", "dn_get_windows", "dn_profile_enable", "dn_profile_get",
+           "dn_profile_reset", "dn_kernel_name", "dn_device_bytes"]
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("adc", C.c_void_p), ("adc_off", C.c_void_p), ("cal_offset", C.c_void_p),
+                ("cal_scale", C.c_void_p), ("basecall", C.c_void_p), ("basecall_off", C.c_void_p), ("refseq", C.c_void_p),
+                ("refseq_off", C.c_void_p), ("ref2query", C.c_void_p), ("query2ref", C.c_void_p), ("ref2del", C.c_void_p),
+                ("ref_start", C.c_void_p), ("ref_end", C.c_void_p), ("is_reverse", C.c_void_p)]
+
+
+SUMMARY_DTYPE = np.dtype([
+    ("status", "<i4"), ("n_samples", "<u4"), ("n_scrappie", "<u4"), ("n_events", "<u4"), ("n_kmers_query", "<u4"),
+    ("n_kmers_ref", "<u4"), ("n_bands", "<u4"), ("band_cells", "<u8"), ("rough_shift", "<f8"), ("rough_scale", "<f8"),
+    ("end_event", "<i4"), ("n_aligned", "<u4"), ("avg_log_emission", "<f8"), ("spanned", "<i4"), ("max_gap", "<i4"),
+    ("n_cleaned", "<u4"), ("ts_slope", "<f8"), ("ts_intercept", "<f8"), ("shift", "<f8"), ("scale", "<f8"),
+    ("events_per_base", "<f8"), ("n_positions", "<u4"), ("n_windows", "<u4"), ("detector_rechecks", "<u4"),
+    ("reserved", "<u4")], align=True)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_build.HIP_SO):
+            raise RuntimeError("libdnascent_hip.so missing: run `python -m dnascent_amd.build` (there is no CPU fallback)")
+        L = C.CDLL(_build.HIP_SO)
+        L.dn_abi_version.restype = C.c_int
+        L.dn_device_count.restype = C.c_int
+        L.dn_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.dn_ctx_destroy.argtypes = [C.c_void_p]
+        L.dn_last_error.restype = C.c_char_p
+        L.dn_last_error.argtypes = [C.c_void_p]
+        L.dn_load_pore_model.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
+        L.dn_batch_upload.argtypes = [C.c_void_p, C.POINTER(BatchDesc)]
+        for n in ("dn_sync", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded", "dn_run_theilsen", "dn_run_normalise",
+                  "dn_run_eventalign", "dn_profile_reset"):
+            getattr(L, n).argtypes = [C.c_void_p]
+        L.dn_get_summaries.argtypes = [C.c_void_p, C.c_void_p]
+        L.dn_get_prefix_sums.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.dn_get_tstats.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.dn_get_scrappie_events.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dn_get_events.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dn_get_kmer_ranks.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.dn_get_alignment.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.dn_get_cleaned.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.dn_get_trace.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dn_get_positions.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 9
+        L.dn_get_windows.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 4
+        L.dn_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        L.dn_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        L.dn_kernel_name.restype = C.c_char_p
+        L.dn_kernel_name.argtypes = [C.c_int]
+        L.dn_device_bytes.restype = C.c_size_t
+        L.dn_device_bytes.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class DnError(RuntimeError):
+    pass
+
+
+class Context:
+    """One device context (one per GPU / per rank)."""
+
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        rc = lib().dn_ctx_create(device, stream, C.byref(self.h))
+        if rc != DN_OK:
+            raise DnError("dn_ctx_create(device=%d) failed with %d: no usable gfx950 device (no CPU fallback)" % (device, rc))
+        self.n_reads = 0
+        self._keep = None
+
+    def _chk(self, rc, what):
+        if rc != DN_OK:
+            raise DnError("%s failed (%d): %s" % (what, rc, lib().dn_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            lib().dn_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_pore_model(self, mean, sigma=0.14):
+        m = np.ascontiguousarray(mean, np.float64)
+        assert m.shape[0] == 262144
+        self._chk(lib().dn_load_pore_model(self.h, m.ctypes.data, sigma), "dn_load_pore_model")
+
+    def upload(self, desc, n_reads, keep=None):
+        self._keep = keep
+        self._chk(lib().dn_batch_upload(self.h, C.byref(desc)), "dn_batch_upload")
+        self.n_reads = n_reads
+
+    def run(self, stage):
+        self._chk(getattr(lib(), "dn_run_" + stage)(self.h), "dn_run_" + stage)
+
+    def sync(self):
+        self._chk(lib().dn_sync(self.h), "dn_sync")
+
+    def summaries(self):
+        out = np.zeros(self.n_reads, SUMMARY_DTYPE)
+        self._chk(lib().dn_get_summaries(self.h, out.ctypes.data), "dn_get_summaries")
+        return out
+
+    # ---- taps -------------------------------------------------------------------------------
+    def prefix_sums(self, r, n):
+        a = np.zeros(n + 1); b = np.zeros(n + 1)
+        self._chk(lib().dn_get_prefix_sums(self.h, r, a.ctypes.data, b.ctypes.data), "dn_get_prefix_sums")
+        return a, b
+
+    def tstats(self, r, n):
+        a = np.zeros(n, np.float32); b = np.zeros(n, np.float32)
+        self._chk(lib().dn_get_tstats(self.h, r, a.ctypes.data, b.ctypes.data), "dn_get_tstats")
+        return a, b
+
+    def scrappie_events(self, r, n):
+        st = np.zeros(n, np.uint32); ln = np.zeros(n, np.float32); mn = np.zeros(n, np.float32)
+        self._chk(lib().dn_get_scrappie_events(self.h, r, st.ctypes.data, ln.ctypes.data, mn.ctypes.data), "dn_get_scrappie_events")
+        return st, ln, mn
+
+    def events(self, r, n):
+        mean = np.zeros(n); st = np.zeros(n, np.uint32); ln = np.zeros(n, np.uint32)
+        self._chk(lib().dn_get_events(self.h, r, mean.ctypes.data, st.ctypes.data, ln.ctypes.data), "dn_get_events")
+        return mean, st, ln
+
+    def kmer_ranks(self, r, nq, nr):
+        q = np.zeros(nq, np.uint32); f = np.zeros(nr, np.uint32)
+        self._chk(lib().dn_get_kmer_ranks(self.h, r, q.ctypes.data, f.ctypes.data), "dn_get_kmer_ranks")
+        return q, f
+
+    def alignment(self, r, n):
+        e = np.zeros(n, np.uint32); k = np.zeros(n, np.uint32)
+        self._chk(lib().dn_get_alignment(self.h, r, e.ctypes.data, k.ctypes.data), "dn_get_alignment")
+        return e, k
+
+    def cleaned(self, r, n):
+        s = np.zeros(n); k = np.zeros(n, np.uint32)
+        self._chk(lib().dn_get_cleaned(self.h, r, s.ctypes.data, k.ctypes.data), "dn_get_cleaned")
+        return s, k
+
+    def trace(self, r, n_bands):
+        t = np.zeros(n_bands * 100, np.uint8); e = np.zeros(n_bands, np.int32); k = np.zeros(n_bands, np.int32)
+        self._chk(lib().dn_get_trace(self.h, r, t.ctypes.data, e.ctypes.data, k.ctypes.data), "dn_get_trace")
+        return t.reshape(n_bands, 100), e, k
+
+    # ---- measurement ------------------------------------------------------------------------
+    def profile(self, on=True):
+        lib().dn_profile_enable(self.h, int(on))
+
+    def profile_reset(self):
+        lib().dn_profile_reset(self.h)
+
+    def profile_get(self):
+        out = {}
+        for k in range(DN_K_COUNT):
+            ms = C.c_double(0); n = C.c_uint32(0)
+            lib().dn_profile_get(self.h, k, C.byref(ms), C.byref(n))
+            out[lib().dn_kernel_name(k).decode()] = (ms.value, n.value)
+        return out
+
+    def device_bytes(self):
+        return int(lib().dn_device_bytes(self.h))

@@ -1,0 +1,93 @@
+"""ctypes binding of the C++ host side (csrc/host/dn_host.cpp): DNAscent::ReadBatch and CIGAR flattening."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+from . import hip as _hip
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_build.HOST_SO):
+            raise RuntimeError("libdnascent_host.so missing: run `python -m dnascent_amd.build`")
+        L = C.CDLL(_build.HOST_SO)
+        L.dnh_batch_new.restype = C.c_void_p
+        L.dnh_batch_free.argtypes = [C.c_void_p]
+        L.dnh_batch_clear.argtypes = [C.c_void_p]
+        L.dnh_batch_size.restype = C.c_uint32
+        L.dnh_batch_size.argtypes = [C.c_void_p]
+        L.dnh_batch_samples.restype = C.c_uint64
+        L.dnh_batch_samples.argtypes = [C.c_void_p]
+        L.dnh_batch_add.restype = C.c_int
+        L.dnh_batch_add.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_float, C.c_float, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                    C.c_void_p, C.c_uint32, C.c_int, C.c_int]
+        L.dnh_batch_desc.argtypes = [C.c_void_p, C.POINTER(_hip.BatchDesc)]
+        L.dnh_batch_maps.restype = C.c_int
+        L.dnh_batch_maps.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dnh_revcomp.restype = C.c_int
+        L.dnh_revcomp.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def revcomp(seq_u8):
+    s = np.ascontiguousarray(seq_u8, np.uint8)
+    out = np.zeros_like(s)
+    lib().dnh_revcomp(s.ctypes.data, s.shape[0], out.ctypes.data)
+    return out
+
+
+class ReadBatch:
+    """DNAscent::ReadBatch: reads packed as SoA, ready for dn_batch_upload."""
+
+    def __init__(self):
+        self.h = C.c_void_p(lib().dnh_batch_new())
+        self.reads = []
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().dnh_batch_free(self.h)
+        except Exception:
+            pass
+
+    def add_synth(self, sr, signal_length=-1, signal_trim=0, signal_start=0, is_split=False):
+        """Add a synth.SynthRead.  The generator emits strand-direction sequences; the host API takes what a BAM / FASTA
+        hold (reference-forward orientation), so reverse reads are reverse-complemented back first."""
+        q = revcomp(sr.basecall) if sr.is_reverse else sr.basecall
+        f = revcomp(sr.refseq) if sr.is_reverse else sr.refseq
+        q = np.ascontiguousarray(q); f = np.ascontiguousarray(f)
+        adc = np.ascontiguousarray(sr.adc)
+        rc = lib().dnh_batch_add(self.h, sr.read_id.encode(), sr.contig.encode(), adc.ctypes.data, adc.shape[0],
+                                 sr.cal_offset, sr.cal_scale, signal_length, signal_trim, signal_start, int(is_split),
+                                 q.ctypes.data, q.shape[0], f.ctypes.data, f.shape[0], sr.cigar_op.ctypes.data,
+                                 sr.cigar_len.ctypes.data, sr.cigar_op.shape[0], sr.ref_start, int(sr.is_reverse))
+        if rc >= 0:
+            self.reads.append(sr)
+        return rc
+
+    def size(self):
+        return int(lib().dnh_batch_size(self.h))
+
+    def samples(self):
+        return int(lib().dnh_batch_samples(self.h))
+
+    def desc(self):
+        d = _hip.BatchDesc()
+        lib().dnh_batch_desc(self.h, C.byref(d))
+        return d
+
+    def maps(self, i, n_ref, n_query):
+        r2q = np.zeros(n_ref, np.uint32); q2r = np.zeros(n_query + 1, np.int32); r2d = np.zeros(n_ref, np.uint8)
+        rc = lib().dnh_batch_maps(self.h, i, r2q.ctypes.data, q2r.ctypes.data, r2d.ctypes.data)
+        assert rc == 0
+        return r2q, q2r, r2d
+
+    def upload(self, ctx):
+        ctx.upload(self.desc(), self.size(), keep=self)

@@ -1,0 +1,139 @@
+/*
+ * dnascent_hip.h -- C-ABI of the MI355X-native `DNAscent detect` hot path (libdnascent_hip.so).
+ *
+ * The reference has no plugin / FFI layer: its seams are ordinary C++ calls inside one OpenMP loop
+ * (detect.cpp:852-907).  Each entry point below replaces one of those seams for a whole BATCH of reads
+ * (the reference processes one read per OpenMP thread); the citation names the reference interface it
+ * stands in for.  All paths are relative to /root/reference/src/.
+ *
+ * Conventions: int return codes (0 = DN_OK, <0 = error, text via dn_last_error), caller-owned host
+ * buffers, library-owned device memory, no exceptions and no torch / HIP types across the boundary.
+ * A context is single-producer; stages of one batch are stream-ordered on the context's HIP stream.
+ * There is NO CPU fallback: every dn_run_* fails with DN_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef DNASCENT_HIP_H
+#define DNASCENT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DN_ABI_VERSION 1
+#define DN_KMER 9            /* config.h:45 */
+#define DN_NKMER 262144      /* 4^9, data_IO.cpp:177 */
+#define DN_BANDWIDTH 100     /* config.h:41 AdaptiveBanded_Params.bandwidth */
+#define DN_RAWDEPTH 20       /* reads.h:12 */
+
+enum {
+    DN_OK = 0,
+    DN_ERR_NO_DEVICE = -1,
+    DN_ERR_HIP = -2,
+    DN_ERR_ARG = -3,
+    DN_ERR_STATE = -4,       /* stage called out of order */
+    DN_ERR_OVERFLOW = -5     /* a device workspace bound was exceeded (reported, never silently truncated) */
+};
+
+/* per-read status after normalise / eventalign (detect.cpp:879-894: such reads are counted as failed and skipped) */
+enum {
+    DN_READ_OK = 0,
+    DN_READ_FAIL_BANDED_QC = 1,   /* event_handling.cpp:433-441 */
+    DN_READ_FAIL_SCALING = 2,     /* event_handling.cpp:90-95,604 */
+    DN_READ_FAIL_NO_END_CELL = 3, /* path left the band / no end cell: undefined behaviour in the reference */
+    DN_READ_FAIL_NEGATIVE_LOG = 4,/* probability.cpp:45 NegativeLog */
+    DN_READ_FAIL_TOO_SHORT = 5
+};
+
+typedef struct dn_ctx dn_ctx;
+
+/* ---- lifecycle (replaces model_load_gpu_twoInputs' device selection, tensor.cpp:66-106) ---- */
+int dn_abi_version(void);
+int dn_device_count(void);
+/* hip_stream: NULL = the context creates its own stream; otherwise a hipStream_t owned by the caller */
+int dn_ctx_create(int device, void *hip_stream, dn_ctx **out);
+void dn_ctx_destroy(dn_ctx *ctx);
+const char *dn_last_error(const dn_ctx *ctx);
+int dn_sync(dn_ctx *ctx);
+
+/* ---- model (replaces Global_Config::configure_DNA_R10 -> import_poreModel_staticStdv, config.h:44-52, data_IO.cpp:144) ---- */
+int dn_load_pore_model(dn_ctx *ctx, const double *mean /* [DN_NKMER] kmer2index order */, double sigma /* 0.14 */);
+
+/* ---- batch upload: the fields of DNAscent::read that normaliseEvents / eventalign consume (reads.h:178-207) ----
+ * All sequences are in sequencing direction (after reads.h:280-286).  Arrays are concatenated over reads;
+ * *_off have n_reads+1 entries.  ref2query / ref2del share refseq_off; query2ref holds n_base+1 entries per
+ * read (-1 = key absent in the reference's std::map) starting at basecall_off[r] + r. */
+typedef struct {
+    uint32_t n_reads;
+    const int16_t *adc;            const uint64_t *adc_off;       /* pod5.cpp:55-56 raw samples, already trimmed (pod5.cpp:75-93) */
+    const float *cal_offset;       const float *cal_scale;        /* pod5.cpp:60 */
+    const char *basecall;          const uint64_t *basecall_off;  /* r.basecall */
+    const char *refseq;            const uint64_t *refseq_off;    /* r.referenceSeqMappedTo */
+    const uint32_t *ref2query;     const int32_t *query2ref;      /* r.refToQuery / r.queryToRef (htsInterface.cpp:59) */
+    const uint8_t *ref2del;                                       /* r.refToDel */
+    const int32_t *ref_start;      const int32_t *ref_end;        /* r.refStart / r.refEnd */
+    const uint8_t *is_reverse;                                    /* r.isReverse */
+} dn_batch_desc;
+
+int dn_batch_upload(dn_ctx *ctx, const dn_batch_desc *batch);    /* H2D; sizes every workspace */
+
+/* ---- stages (stream-ordered; each works on the uploaded batch) ---- */
+int dn_run_segment(dn_ctx *ctx);        /* detect_events (scrappie/event_detection.c:268) + event build + k-mer ranks (event_handling.cpp:546-592) */
+int dn_run_rough_scaling(dn_ctx *ctx);  /* estimateScaling_quantiles (event_handling.cpp:510) */
+int dn_run_banded(dn_ctx *ctx);         /* adaptive_banded_simple_event_align (event_handling.cpp:148): fill, backtrack, QC */
+int dn_run_theilsen(dn_ctx *ctx);       /* estimateScaling_theilSen (event_handling.cpp:24) + eventsPerBase (:606) */
+int dn_run_normalise(dn_ctx *ctx);      /* normaliseEvents (event_handling.h:13) == the four stages above */
+int dn_run_eventalign(dn_ctx *ctx);     /* eventalign (alignment.h:22): windowed Viterbi + feature fill + tensor packing (reads.h:305-372) */
+
+/* ---- per-read results ---- */
+typedef struct {
+    int32_t status;                 /* DN_READ_* */
+    uint32_t n_samples;
+    uint32_t n_scrappie;            /* et.n */
+    uint32_t n_events;              /* r.events.size() */
+    uint32_t n_kmers_query, n_kmers_ref;
+    uint32_t n_bands;
+    uint64_t band_cells;            /* n_bands * DN_BANDWIDTH */
+    double rough_shift, rough_scale;/* after estimateScaling_quantiles */
+    int32_t end_event;              /* event chosen at event_handling.cpp:329-340 */
+    uint32_t n_aligned;             /* r.eventAlignment.size() before the QC clear */
+    double avg_log_emission; int32_t spanned; int32_t max_gap; uint32_t n_cleaned;   /* :420-441 */
+    double ts_slope, ts_intercept;  /* Theil-Sen medians (NaN when refinement was skipped, :33) */
+    double shift, scale, events_per_base;   /* r.scalings */
+    uint32_t n_positions;           /* r.refCoordToAP.size() after eventalign */
+    uint32_t n_windows;             /* builtinViterbi calls */
+    uint32_t detector_rechecks;     /* speculative segmentation chunks that had to be recomputed (diagnostic) */
+    uint32_t reserved;
+} dn_read_summary;
+
+int dn_get_summaries(dn_ctx *ctx, dn_read_summary *out /* [n_reads] */);
+
+/* ---- intermediate taps (parity tests; sizes from dn_read_summary; NULL pointers are skipped) ---- */
+int dn_get_prefix_sums(dn_ctx *ctx, uint32_t read, double *sum /* [n+1] */, double *sumsq /* [n+1] */);
+int dn_get_tstats(dn_ctx *ctx, uint32_t read, float *t_short, float *t_long /* [n_samples] */);
+int dn_get_scrappie_events(dn_ctx *ctx, uint32_t read, uint32_t *start, float *length, float *mean /* [n_scrappie] */);
+int dn_get_events(dn_ctx *ctx, uint32_t read, double *mean, uint32_t *raw_start, uint32_t *raw_len /* [n_events] */);
+int dn_get_kmer_ranks(dn_ctx *ctx, uint32_t read, uint32_t *rank_query, uint32_t *rank_ref);
+int dn_get_alignment(dn_ctx *ctx, uint32_t read, uint32_t *event_idx, uint32_t *kmer_idx /* [n_aligned] */);
+int dn_get_cleaned(dn_ctx *ctx, uint32_t read, double *signal, uint32_t *rank /* [n_cleaned], backtrack order */);
+int dn_get_trace(dn_ctx *ctx, uint32_t read, uint8_t *trace /* [n_bands*100] */, int32_t *band_event /* [n_bands] ll.event_idx */,
+                 int32_t *band_kmer /* [n_bands] */);
+/* eventalign outputs, creation order == sequencing direction (reads.h:305-372) */
+int dn_get_positions(dn_ctx *ctx, uint32_t read, uint32_t *coord, uint32_t *query_idx, uint32_t *ref_idx, int32_t *indel_score,
+                     char *kmer9, uint32_t *n_signal, float *signal20, float *core, float *residual);
+int dn_get_windows(dn_ctx *ctx, uint32_t read, uint32_t *ref_index, uint32_t *window_len, uint32_t *n_obs, double *score);
+
+/* ---- measurement ---- */
+enum { DN_K_SCAN = 0, DN_K_TSTAT, DN_K_DETECT, DN_K_EVENTS, DN_K_RANKS, DN_K_QUANTILE, DN_K_PREP, DN_K_BAND_FILL,
+       DN_K_BAND_TRACE, DN_K_THEILSEN, DN_K_VITERBI, DN_K_COUNT };
+int dn_profile_enable(dn_ctx *ctx, int on);     /* HIP events around every kernel launch on the context's stream */
+int dn_profile_get(dn_ctx *ctx, int kernel, double *total_ms, uint32_t *launches);
+int dn_profile_reset(dn_ctx *ctx);
+const char *dn_kernel_name(int kernel);
+size_t dn_device_bytes(const dn_ctx *ctx);      /* HBM currently held by the context */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,66 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dnascent_hip.h declares; host logic (CIGAR maps,
+read orientation, trimming) matches the oracle.  No compute call is made here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+from dnascent_amd import build, hip, host, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    if not os.path.exists(build.HIP_SO):
+        build.build_hip()
+    hdr = open(os.path.join(ROOT, "include", "dnascent_hip.h")).read()
+    declared = set(re.findall(r"\b(dn_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 28
+    L = hip.lib()
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert set(hip.SYMBOLS) == declared
+    assert L.dn_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    if hip.lib().dn_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(hip.DnError):
+        hip.Context(0)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(is_reverse=True), dict(ins_rate=0.05, del_rate=0.05),
+                                dict(is_reverse=True, ins_rate=0.05, del_rate=0.05, soft_clip_head=30, soft_clip_tail=7)])
+def test_cigar_flattening_matches_oracle(model, kw):
+    r = synth.make_read(5, 2000, model=model, **kw)
+    b = host.ReadBatch()
+    assert b.add_synth(r) == 0
+    r2q, q2r, r2d = b.maps(0, r.refseq.shape[0], r.basecall.shape[0])
+    o_r2q, o_q2r, o_r2d = po.parse_cigar(r.cigar_op, r.cigar_len, r.is_reverse, r.basecall.shape[0])
+    assert np.array_equal(r2q, o_r2q) and np.array_equal(q2r, o_q2r) and np.array_equal(r2d, o_r2d)
+
+
+def test_batch_keeps_sequencing_direction(model):
+    r = synth.make_read(6, 1500, model=model, is_reverse=True)
+    b = host.ReadBatch()
+    b.add_synth(r)
+    d = b.desc()
+    import ctypes as C
+    got = C.string_at(d.refseq, r.refseq.shape[0])
+    assert got == r.refseq.tobytes()           # reverse-complemented back into sequencing direction (reads.h:280-286)
+    got = C.string_at(d.basecall, r.basecall.shape[0])
+    assert got == r.basecall.tobytes()
+
+
+def test_dorado_trimming(model):
+    r = synth.make_read(7, 1500, model=model)
+    n = r.adc.shape[0]
+    b = host.ReadBatch()
+    b.add_synth(r, signal_length=n - 100, signal_trim=50)                       # pod5.cpp:88-92
+    assert b.samples() == n - 150
+    b.add_synth(r, signal_length=2000, signal_trim=10, signal_start=300, is_split=True)   # pod5.cpp:79-86
+    assert b.samples() == (n - 150) + 1990
+    assert b.add_synth(r, signal_length=5, signal_trim=0) == -1                 # nothing left: rejected
