@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- raw-signal Msamples/s of the `detect` hot path on MI355X (BASELINE.json metric).
+
+Workload at N=1 (BASELINE.json configs[1]): 1 000 synthetic 20 kb R10.4.1 reads on one MI355X, banded-HMM scope
+(CNN stubbed): one STEP = one pass of normaliseEvents (segmentation -> rough scaling -> adaptive banded alignment +
+backtrack + QC -> Theil-Sen) over the batch, inputs already resident in HBM.  For N>1 every rank owns its own 1 000
+reads (reads shard with no data-path collective: weak scaling); value = samples of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.  The `roofline` object is for the dominant kernel (k2_fill, the banded DP): achieved =
+ALGORITHMIC bytes per launch (n_bands*100 trace bytes + 4*(E+K) input bytes + 9*n_aligned backtrack
+bytes, summed over the reads of the launch) / that kernel's mean launch duration measured with HIP events on the
+library's stream inside the timed region.  `cpu_baseline` times the oracle (our CPU restatement, kind "port") on a
+bounded sample of the same reads on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_batch(n_reads, n_bases, seed0, model):
+    from dnascent_amd import host, synth
+    batch = host.ReadBatch()
+    reads = []
+    for i in range(n_reads):
+        r = synth.make_read(seed0 + i, n_bases, model=model, is_reverse=bool(i & 1), sub_rate=0.002, ins_rate=0.001,
+                            del_rate=0.001)
+        assert batch.add_synth(r) >= 0
+        reads.append(r)
+    return batch, reads
+
+
+def cpu_baseline(reads, model, budget_s=20.0):
+    """Oracle (CPU restatement of the reference path) on a bounded sample, one read per thread like detect.cpp:852."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    from concurrent.futures import ThreadPoolExecutor
+    cores = os.cpu_count() or 1
+
+    def one(r):
+        o = po.OracleRead(r, model)      # includes int16 -> pA and CIGAR flattening, as the GPU path does
+        o.normalise()
+        n = r.n_samples()
+        o.free()
+        return n
+
+    t0 = time.time()
+    one(reads[0])
+    per = max(time.time() - t0, 1e-3)
+    n = int(max(cores, min(len(reads), budget_s / per * cores)))
+    n = min(n, len(reads))
+    sample = reads[:n]
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:      # ctypes releases the GIL inside the oracle
+        samples = sum(ex.map(one, sample))
+    dt = time.time() - t0
+    return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d of the %d-base reads of the workload, oracle normaliseEvents (CNN excluded), %.1f s" % (n, reads[0].refseq.shape[0], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=1000)
+    ap.add_argument("--bases", type=int, default=20000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from dnascent_amd import hip, synth
+    model = synth.pore_model()
+    ctx = hip.Context(local_rank if world > 1 else 0)
+    ctx.load_pore_model(model, 0.14)
+    batch, reads = make_batch(args.reads, args.bases, 1000003 * (rank + 1), model)
+    batch.upload(ctx)                      # inputs resident in HBM before the timed region
+    samples_per_step = batch.samples()
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        ctx.run("normalise")
+    barrier()
+    ctx.profile(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.run("normalise")
+    ctx.sync()
+    if dist is not None:
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    barrier()
+    prof = ctx.profile_get()
+    ctx.profile(False)
+    summ = ctx.summaries()
+
+    total_samples = float(samples_per_step)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        s = torch.tensor([total_samples], dtype=torch.float64, device="cuda")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        total_samples = float(s.item())
+
+    if rank == 0:
+        fill_ms, fill_n = prof["k2_fill"]
+        ok = summ["status"] != 5
+        alg_bytes = float(np.sum(summ["n_bands"][ok].astype(np.float64) * 100.0 +
+                                 4.0 * (summ["n_events"][ok].astype(np.float64) + summ["n_kmers_query"][ok]) +
+                                 9.0 * summ["n_aligned"][ok]))
+        fill_s = (fill_ms / max(fill_n, 1)) / 1e3
+        achieved = alg_bytes / fill_s / 1e9 if fill_s > 0 else 0.0
+        out = {
+            "metric": "raw-signal Msamples/sec (whole node) on `detect`",
+            "value": total_samples * args.steps / dt / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32/f64",
+            "data": "synthetic",
+            "config": {"workload": "%d synthetic %d kb R10.4.1 reads per GPU, banded-HMM scope (segmentation + rough scaling + "
+                                   "adaptive banded alignment + backtrack/QC + Theil-Sen), CNN stubbed" % (args.reads, args.bases // 1000),
+                       "reads_per_gpu": args.reads, "bases_per_read": args.bases, "samples_per_gpu_step": int(samples_per_step),
+                       "reads_passing_qc": int(np.sum(summ["status"] == 0)), "parallelism": "reads sharded, %d rank(s)" % world},
+            "roofline": {"bound": "hbm", "kernel": "k2_fill", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": fill_ms / max(fill_n, 1)},
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(reads, model)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,20 @@ __global__ __launch_bounds__(256) void k_ranks(BatchDev B) {
     }
 }
 
+// wave-aggregated histogram update: lanes of a wavefront that hit the same bin are combined into ONE LDS atomic.
+// Scaled signal and slope values share their leading key bits, so plain atomics would serialise on one address.
+__device__ __forceinline__ void hist_add_agg(unsigned *hist, unsigned bin, bool active) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+        const unsigned long long same = __ballot(active && bin == b);
+        if (lane == leader) atomicAdd(&hist[b], (unsigned)__popcll(same));
+        todo &= ~same;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 10-target radix select.  val(i) is supplied by a functor so the model means are gathered on the fly.
 // ------------------------------------------------------------------------------------------------
@@ -65,14 +79,18 @@ __device__ void select10(F val, unsigned n, double *out10, unsigned (*hist)[256]
 #pragma unroll
         for (int t = 0; t < 10; t++) pf[t] = prefix[t];
         const int sh = 8 * (pass + 1);
-        for (unsigned i = tid; i < n; i += 256) {
-            const unsigned long long key = dkey(val(i));
+        const unsigned nround = (n + 255u) & ~255u;
+        for (unsigned i = tid; i < nround; i += 256) {
+            const bool act = i < n;
+            const unsigned long long key = act ? dkey(val(i)) : 0ull;
             const unsigned digit = (unsigned)(key >> (8 * pass)) & 255u;
             const unsigned long long hi = (pass == 7) ? 0ull : (key >> sh);
 #pragma unroll
             for (int t = 0; t < 10; t++) {
                 const unsigned long long ph = (pass == 7) ? 0ull : (pf[t] >> sh);
-                if (hi == ph) atomicAdd(&hist[t][digit], 1u);
+                const bool hit = act && (hi == ph);
+                if (pass >= 5) hist_add_agg(hist[t], digit, hit);      // leading bytes: nearly every value shares them
+                else if (hit) atomicAdd(&hist[t][digit], 1u);
             }
         }
         __syncthreads();
@@ -196,9 +214,11 @@ __global__ __launch_bounds__(256) void k_theilsen(BatchDev B, const double *host
     __syncthreads();
     for (unsigned a = 0; a + 1 < np; a++) {
         const double xa = x[a], ya = y[a];
-        for (unsigned b = a + 1 + tid; b < np; b += 256) {
-            const double s = (ya - y[b]) / (xa - x[b]);           // :70-73
-            atomicAdd(&hist[(unsigned)(dkey(s) >> 53)], 1u);
+        for (unsigned b0 = a + 1; b0 < np; b0 += 256) {
+            const unsigned b = b0 + tid;
+            const bool act = b < np;
+            const double s = act ? (ya - y[b]) / (xa - x[b]) : 0.0;   // :70-73
+            hist_add_agg(hist, (unsigned)(dkey(s) >> 53), act);       // sign + exponent: a handful of bins get everything
         }
     }
     __syncthreads();

@@ -16,14 +16,15 @@ SPECS = [
     # seed, bases, kwargs
     (101, 1500, dict()),
     (102, 3000, dict(is_reverse=True)),
-    (103, 5000, dict(sub_rate=0.02, ins_rate=0.01, del_rate=0.01)),
-    (104, 5000, dict(is_reverse=True, sub_rate=0.03, ins_rate=0.02, del_rate=0.02, soft_clip_head=25, soft_clip_tail=40)),
+    (103, 5000, dict(sub_rate=0.003, ins_rate=0.001, del_rate=0.001)),
+    (104, 5000, dict(is_reverse=True, sub_rate=0.003, ins_rate=0.002, del_rate=0.002, soft_clip_head=25, soft_clip_tail=40)),
+    (111, 4000, dict(sub_rate=0.03, ins_rate=0.02, del_rate=0.02)),   # heavy basecall errors: fails the banded QC (max_gap)
     (105, 4000, dict(n_unknown=3)),
     (106, 3000, dict(noise_pa=6.5)),            # banded QC failure (~6 pA is where reads start to fail)
     (107, 900, dict()),                         # < 1000 cleaned points: fails :438, Theil-Sen skipped
-    (108, 20000, dict(sub_rate=0.01)),
+    (108, 20000, dict(sub_rate=0.002)),
     (109, 2500, dict(noise_pa=3.5, is_reverse=True)),
-    (110, 12000, dict(ins_rate=0.03, del_rate=0.03)),
+    (110, 12000, dict(ins_rate=0.004, del_rate=0.004)),
 ]
 
 
