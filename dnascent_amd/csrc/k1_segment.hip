@@ -10,7 +10,7 @@
 //   k1_tstat    the two windowed t-statistics (event_detection.c:60-115), one thread per sample; the mixed
 //               float/double expression order of the reference is written out cast by cast.
 //   k1_detect   the short/long peak detector (event_detection.c:122-198) is a serial state machine.  It is run
-//               SPECULATIVELY: one lane per 256-sample chunk starts DN_SEG_WARM samples early from the default
+//               SPECULATIVELY: one lane per DN_SEG_CHUNK-sample chunk starts DN_SEG_WARM samples early from the default
 //               state; after a common emitted peak the state no longer depends on history, so the state at the
 //               chunk start is almost always the true one.
 //   k1_events   verifies every chunk hand-off exactly (state in == previous state out), recomputes the rare
@@ -56,11 +56,17 @@ __global__ __launch_bounds__(64) void k1_scan(BatchDev B) {
                 n2 = *reinterpret_cast<const int4 *>(a + i + 48); n3 = *reinterpret_cast<const int4 *>(a + i + 56);
             }
             const int w[16] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w };
+            double2 *o = out + i;                                  // constant offsets from one base: no per-store address math
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                STEP((int16_t)(w[j] & 0xffff));
-                STEP((int16_t)(w[j] >> 16));
+            for (int j = 0; j < 32; j++) {
+                const int16_t av = (j & 1) ? (int16_t)(w[j >> 1] >> 16) : (int16_t)(w[j >> 1] & 0xffff);
+                float v = ((float)av + off) * sc;
+                double x = (double)v;
+                s = s + x;
+                q = q + x * x;
+                o[j] = make_double2(s, q);
             }
+            i += 32;
             if (!more) break;
             c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         }
@@ -163,29 +169,75 @@ __device__ __forceinline__ bool seg_equal(const SegState &a, const SegState &b, 
            __float_as_int(a.l.peak_val) == __float_as_int(b.l.peak_val) && a.l.valid == b.l.valid;
 }
 
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };   // 16-byte load that only needs 4-byte alignment
+
+#define SEG_TILE 32                      // samples per lane per LDS tile
+#define SEG_STREAM (DN_SEG_WARM + DN_SEG_CHUNK)
+
 __global__ __launch_bounds__(64) void k1_detect(BatchDev B) {
+    // One wavefront = 64 consecutive chunks of one read, one chunk per lane.  Lane l walks samples
+    // [c*CHUNK - WARM, c*CHUNK + CHUNK): a stream strided by CHUNK samples between lanes.  The two t-statistic streams
+    // are staged through LDS in tiles of 64 rows x 32 samples, loaded with coalesced 16-byte loads (8 lanes cover one
+    // row's 128 bytes) and read back one row per lane (row stride 33 words: conflict-free).
+    __shared__ float tile1[64 * 33], tile2[64 * 33];
     const int r = blockIdx.y;
+    const int lane = threadIdx.x;
     const uint64_t s0 = B.samp_off[r];
     const int n = (int)(B.samp_off[r + 1] - s0);
     const uint64_t c0 = B.chunk_off[r];
     const int nch = (int)(B.chunk_off[r + 1] - c0);
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= nch) return;
+    const int cbase = blockIdx.x * 64;
+    if (cbase >= nch) return;
+    const int c = cbase + lane;
+    const bool have = c < nch;
     const float *t1 = B.t1 + s0, *t2 = B.t2 + s0;
-    const int beg = c * DN_SEG_CHUNK;
-    const int end = min(beg + DN_SEG_CHUNK, n);
     SegState st = seg_initial();
-    unsigned dummy = 0;
-    if (c > 0) {
-        const int w0 = max(beg - DN_SEG_WARM, 1);                // sample 0 is always masked (:140), so 1 is a clean start
-        for (int i = w0; i < beg; i++) seg_step<false>(st, i, t1[i], t2[i], nullptr, dummy);
-    }
-    B.chunk_in[c0 + c] = st;
-    unsigned *pk = B.chunk_peaks + (c0 + c) * DN_SEG_PEAKCAP;
+    unsigned *pk = B.chunk_peaks + (c0 + (have ? c : 0)) * DN_SEG_PEAKCAP;
     unsigned npk = 0;
-    for (int i = beg; i < end; i++) seg_step<true>(st, i, t1[i], t2[i], pk, npk);
-    B.chunk_npk[c0 + c] = npk;
-    B.chunk_out[c0 + c] = st;
+    const int my0 = c * DN_SEG_CHUNK - DN_SEG_WARM;              // sample index of stream position 0 of this lane
+    const int lrow = lane >> 3, lcol = (lane & 7) * 4;
+    for (int t = 0; t < SEG_STREAM / SEG_TILE; t++) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const int row = p * 8 + lrow;
+            const int idx = (cbase + row) * DN_SEG_CHUNK - DN_SEG_WARM + t * SEG_TILE + lcol;
+            f4u a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+            if (idx >= 0 && idx + 3 < n) {
+                a = *reinterpret_cast<const f4u *>(t1 + idx);
+                b = *reinterpret_cast<const f4u *>(t2 + idx);
+            } else {
+                float ta[4], tb[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const int i = idx + q; const bool ok = i >= 0 && i < n; ta[q] = ok ? t1[i] : 0.f; tb[q] = ok ? t2[i] : 0.f; }
+                a.x = ta[0]; a.y = ta[1]; a.z = ta[2]; a.w = ta[3]; b.x = tb[0]; b.y = tb[1]; b.z = tb[2]; b.w = tb[3];
+            }
+            float *d1 = tile1 + row * 33 + lcol, *d2 = tile2 + row * 33 + lcol;
+            d1[0] = a.x; d1[1] = a.y; d1[2] = a.z; d1[3] = a.w;
+            d2[0] = b.x; d2[1] = b.y; d2[2] = b.z; d2[3] = b.w;
+        }
+        __syncthreads();
+        if (t * SEG_TILE == DN_SEG_WARM && have) B.chunk_in[c0 + c] = st;       // state at the chunk start
+        const bool emit = t * SEG_TILE >= DN_SEG_WARM;
+        const float *r1 = tile1 + lane * 33, *r2 = tile2 + lane * 33;
+        if (emit) {
+#pragma unroll 8
+            for (int j = 0; j < SEG_TILE; j++) {
+                const int i = my0 + t * SEG_TILE + j;
+                if (i >= 1 && i < n) seg_step<true>(st, i, r1[j], r2[j], pk, npk);
+            }
+        } else {
+#pragma unroll 8
+            for (int j = 0; j < SEG_TILE; j++) {
+                const int i = my0 + t * SEG_TILE + j;
+                if (i >= 1 && i < n) seg_step<false>(st, i, r1[j], r2[j], nullptr, npk);   // sample 0 is always masked (:140)
+            }
+        }
+    }
+    if (have) {
+        B.chunk_npk[c0 + c] = npk;
+        B.chunk_out[c0 + c] = st;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -249,24 +301,28 @@ __global__ __launch_bounds__(64) void k1_events(BatchDev B, unsigned *scratch_u3
     __syncthreads();
 
     // ---- 2. compact the peaks: et_start[0] = 0, et_start[1 + j] = j-th peak ----
+    __shared__ unsigned pre[4096];                                // exclusive prefix of peaks per chunk (<= 4M samples / read)
     unsigned *et_start = B.et_start + e0;
     float *et_mean = B.et_mean + e0;
     unsigned running = 0;
-    int overflow = 0;
-    for (int cb = 0; cb < nch; cb += 64) {
+    int overflow = nch > 4096;
+    for (int cb = 0; cb < nch && cb < 4096; cb += 64) {
         const int c = cb + lane;
         unsigned cnt = (c < nch) ? B.chunk_npk[c0 + c] : 0u;
         if (cnt > DN_SEG_PEAKCAP) { overflow = 1; cnt = DN_SEG_PEAKCAP; }
         const unsigned incl = wave_incl_scan(cnt, lane);
-        const unsigned pre = running + incl - cnt;
-        if (c < nch) {
-            const unsigned *pk = B.chunk_peaks + (c0 + c) * DN_SEG_PEAKCAP;
-            for (unsigned j = 0; j < cnt; j++) {
-                const unsigned slot = 1 + pre + j;
-                if (slot < ecap) et_start[slot] = pk[j];
-            }
-        }
+        if (c < nch && c < 4096) pre[c] = running + incl - cnt;
         running += __shfl(incl, 63);
+    }
+    __syncthreads();
+    for (int c = 0; c < nch && c < 4096; c++) {                   // one chunk at a time, lanes copy its peaks coalesced
+        const unsigned base = pre[c];
+        const unsigned cnt = ((c + 1 < nch && c + 1 < 4096) ? pre[c + 1] : running) - base;
+        const unsigned *pk = B.chunk_peaks + (c0 + c) * DN_SEG_PEAKCAP;
+        for (unsigned j = lane; j < cnt; j += 64) {
+            const unsigned slot = 1 + base + j;
+            if (slot < ecap) et_start[slot] = pk[j];
+        }
     }
     if (lane == 0) et_start[0] = 0;
     unsigned n_et = 1 + running;                                  // create_events :242-247 (every recorded peak satisfies 0 < p < n)

@@ -11,8 +11,8 @@
 //               it only depends on the event).
 //   k_theilsen  estimateScaling_theilSen (event_handling.cpp:24-110): <= 1000 points, all pairwise slopes,
 //               the upper median slope and the median intercept.  A median is an order statistic, so no sort is
-//               needed: slopes are regenerated on the fly in three passes (11-bit, 11-bit LDS histograms, then
-//               an in-LDS finish on the few survivors).  fp64 '/' on gfx950 is IEEE, so each slope has the
+//               needed: slopes are regenerated on the fly in four passes (three 11-bit MSB histograms in LDS,
+//               then an in-LDS finish on the few survivors that share 33 leading key bits).  fp64 '/' on gfx950 is IEEE, so each slope has the
 //               reference's bits.
 #include "dn_dev.h"
 
@@ -63,8 +63,8 @@ __device__ __forceinline__ void hist_add_agg(unsigned *hist, unsigned bin, bool 
 // 10-target radix select.  val(i) is supplied by a functor so the model means are gathered on the fly.
 // ------------------------------------------------------------------------------------------------
 template <class F>
-__device__ void select10(F val, unsigned n, double *out10, unsigned (*hist)[256], unsigned long long *prefix,
-                         unsigned *rank_in) {
+__device__ __forceinline__ void select10(F val, unsigned n, double *out10, unsigned (*hist)[256], unsigned long long *prefix,
+                                         unsigned *rank_in) {
     const int tid = threadIdx.x;
     const unsigned m = n / 10u;                                   // quantileMedians :467
     if (tid < 10) {
@@ -75,29 +75,30 @@ __device__ void select10(F val, unsigned n, double *out10, unsigned (*hist)[256]
     for (int pass = 7; pass >= 0; pass--) {
         for (int j = tid; j < 10 * 256; j += 256) (&hist[0][0])[j] = 0u;
         __syncthreads();
-        unsigned long long pf[10];
-#pragma unroll
-        for (int t = 0; t < 10; t++) pf[t] = prefix[t];
+        // targets are in rank order, so equal prefixes are adjacent: one histogram per distinct prefix (group).
+        // In the leading passes every target shares one prefix and the element loop does a single compare + atomic.
         const int sh = 8 * (pass + 1);
-        const unsigned nround = (n + 255u) & ~255u;
-        for (unsigned i = tid; i < nround; i += 256) {
-            const bool act = i < n;
-            const unsigned long long key = act ? dkey(val(i)) : 0ull;
+        unsigned long long gp[10]; int ng = 0;
+#pragma unroll
+        for (int t = 0; t < 10; t++) {
+            const unsigned long long ph = (pass == 7) ? 0ull : (prefix[t] >> sh);
+            if (ng == 0 || gp[ng - 1] != ph) gp[ng++] = ph;
+        }
+        for (unsigned i = tid; i < n; i += 256) {
+            const unsigned long long key = dkey(val(i));
             const unsigned digit = (unsigned)(key >> (8 * pass)) & 255u;
             const unsigned long long hi = (pass == 7) ? 0ull : (key >> sh);
-#pragma unroll
-            for (int t = 0; t < 10; t++) {
-                const unsigned long long ph = (pass == 7) ? 0ull : (pf[t] >> sh);
-                const bool hit = act && (hi == ph);
-                if (pass >= 5) hist_add_agg(hist[t], digit, hit);      // leading bytes: nearly every value shares them
-                else if (hit) atomicAdd(&hist[t][digit], 1u);
-            }
+            for (int g = 0; g < ng; g++)
+                if (hi == gp[g]) { atomicAdd(&hist[g][digit], 1u); break; }
         }
         __syncthreads();
         if (tid < 10) {
+            const unsigned long long ph = (pass == 7) ? 0ull : (prefix[tid] >> sh);
+            int g = 0;
+            for (int q = 0; q < ng; q++) if (gp[q] == ph) g = q;
             unsigned want = rank_in[tid], cum = 0; unsigned d = 255;
             for (unsigned b = 0; b < 256; b++) {
-                const unsigned h = hist[tid][b];
+                const unsigned h = hist[g][b];
                 if (want < cum + h) { d = b; break; }
                 cum += h;
             }
@@ -159,27 +160,31 @@ __global__ __launch_bounds__(256) void k_prep(BatchDev B) {
 // Theil-Sen
 // ------------------------------------------------------------------------------------------------
 #define TS_MAXP 1000
-#define TS_CAND 2048
+#define TS_CAND 1024
 
-__device__ __forceinline__ void pair_from_index(unsigned p, unsigned np, unsigned &a, unsigned &b) {
-    // p enumerates pairs (a,b), a<b, in the reference's push order (:67-75): row a holds np-1-a pairs
-    // row start s(a) = a*(2*np - a - 1)/2.  Solve by float estimate + correction.
-    const double n2 = 2.0 * np - 1.0;
-    double af = (n2 - sqrt(n2 * n2 - 8.0 * (double)p)) * 0.5;
-    unsigned aa = (unsigned)af;
-    if (aa >= np - 1) aa = np - 2;
-    while ((unsigned long long)aa * (2ull * np - aa - 1ull) / 2ull > p) aa--;
-    while ((unsigned long long)(aa + 1) * (2ull * np - (aa + 1) - 1ull) / 2ull <= p) aa++;
-    a = aa;
-    b = aa + 1 + (unsigned)(p - (unsigned long long)aa * (2ull * np - aa - 1ull) / 2ull);
+// visit every pair (a < b) of the np points: wave w takes rows a = w, w+4, ...; lanes stride over b
+template <class F>
+__device__ __forceinline__ void for_each_slope(const double *x, const double *y, unsigned np, F f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (unsigned a = wave; a + 1 < np; a += 4) {
+        const double xa = x[a], ya = y[a];
+        for (unsigned b0 = a + 1; b0 < np; b0 += 64) {
+            const unsigned b = b0 + lane;
+            const bool act = b < np;
+            const double s = act ? (ya - y[b]) / (xa - x[b]) : 0.0;   // event_handling.cpp:70-73, IEEE fp64 division
+            f(dkey(s), act);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_theilsen(BatchDev B, const double *host_consts /* unused */) {
     __shared__ double x[TS_MAXP], y[TS_MAXP];
     __shared__ unsigned hist[2048];
     __shared__ unsigned long long cand[TS_CAND];
-    __shared__ unsigned ncand, sel_digit, sel_rank, sel_digit2;
+    __shared__ unsigned ncand, sel_digit, sel_rank;
     __shared__ unsigned long long icpt_key[1024];
+    __shared__ unsigned long long slope_key, icpt_sel;
+    __shared__ unsigned cnt0;
     const int r = blockIdx.x;
     const int tid = threadIdx.x;
     ReadRes &R = B.res[r];
@@ -207,64 +212,45 @@ __global__ __launch_bounds__(256) void k_theilsen(BatchDev B, const double *host
         y[j] = B.model_mean[rk[i]];                               // :58-61
     }
     const unsigned long long ns = (unsigned long long)np * (np - 1) / 2ull;
-    const unsigned target = (unsigned)(ns / 2ull);                // :78 slopes[size/2]
-    // ---- pass 1: top 11 bits of the key ----
-    for (int j = tid; j < 2048; j += 256) hist[j] = 0;
+    unsigned want = (unsigned)(ns / 2ull);                        // :78 slopes[size/2]
+    // ---- three 11-bit MSB histogram passes narrow the median to one value of the top 33 key bits ----
+    unsigned long long pref = 0ull;                               // selected leading bits so far (right aligned)
+    for (int pass = 0; pass < 3; pass++) {
+        const int lo_bit = 53 - 11 * pass;                        // digit = key bits [lo_bit+10 : lo_bit]
+        for (int j = tid; j < 2048; j += 256) hist[j] = 0;
+        __syncthreads();
+        if (pass == 0) {
+            // sign + exponent: a handful of bins take everything -> wave-aggregated atomics
+            for_each_slope(x, y, np, [&](unsigned long long k, bool act) { hist_add_agg(hist, (unsigned)(k >> 53), act); });
+        } else {
+            const unsigned long long want_hi = pref;
+            for_each_slope(x, y, np, [&](unsigned long long k, bool act) {
+                if (act && (k >> (lo_bit + 11)) == want_hi) atomicAdd(&hist[(unsigned)(k >> lo_bit) & 2047u], 1u);
+            });
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned cum = 0, d = 2047;
+            for (unsigned b = 0; b < 2048; b++) { if (want < cum + hist[b]) { d = b; break; } cum += hist[b]; }
+            sel_digit = d; sel_rank = want - cum;
+        }
+        __syncthreads();
+        pref = (pref << 11) | sel_digit;
+        want = sel_rank;
+        __syncthreads();
+    }
+    // ---- collect the survivors (they share 33 leading bits), finish by rank counting in LDS ----
     if (tid == 0) ncand = 0;
     __syncthreads();
-    for (unsigned a = 0; a + 1 < np; a++) {
-        const double xa = x[a], ya = y[a];
-        for (unsigned b0 = a + 1; b0 < np; b0 += 256) {
-            const unsigned b = b0 + tid;
-            const bool act = b < np;
-            const double s = act ? (ya - y[b]) / (xa - x[b]) : 0.0;   // :70-73
-            hist_add_agg(hist, (unsigned)(dkey(s) >> 53), act);       // sign + exponent: a handful of bins get everything
+    for_each_slope(x, y, np, [&](unsigned long long k, bool act) {
+        if (act && (k >> 31) == pref) {
+            const unsigned slot = atomicAdd(&ncand, 1u);
+            if (slot < TS_CAND) cand[slot] = k;
         }
-    }
+    });
     __syncthreads();
-    if (tid == 0) {
-        unsigned cum = 0, d = 2047;
-        for (unsigned b = 0; b < 2048; b++) { if (target < cum + hist[b]) { d = b; break; } cum += hist[b]; }
-        sel_digit = d; sel_rank = target - cum;
-    }
-    __syncthreads();
-    const unsigned d1 = sel_digit;
-    // ---- pass 2: next 11 bits within the selected bin ----
-    for (int j = tid; j < 2048; j += 256) hist[j] = 0;
-    __syncthreads();
-    for (unsigned a = 0; a + 1 < np; a++) {
-        const double xa = x[a], ya = y[a];
-        for (unsigned b = a + 1 + tid; b < np; b += 256) {
-            const unsigned long long k = dkey((ya - y[b]) / (xa - x[b]));
-            if ((unsigned)(k >> 53) == d1) atomicAdd(&hist[(unsigned)(k >> 42) & 2047u], 1u);
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        unsigned want = sel_rank, cum = 0, d = 2047;
-        for (unsigned b = 0; b < 2048; b++) { if (want < cum + hist[b]) { d = b; break; } cum += hist[b]; }
-        sel_digit2 = d; sel_rank = want - cum;
-    }
-    __syncthreads();
-    const unsigned d2 = sel_digit2;
-    const unsigned long long top22 = ((unsigned long long)d1 << 11) | d2;
-    // ---- pass 3: collect the survivors, finish by rank counting in LDS ----
-    for (unsigned a = 0; a + 1 < np; a++) {
-        const double xa = x[a], ya = y[a];
-        for (unsigned b = a + 1 + tid; b < np; b += 256) {
-            const unsigned long long k = dkey((ya - y[b]) / (xa - x[b]));
-            if ((k >> 42) == top22) {
-                const unsigned slot = atomicAdd(&ncand, 1u);
-                if (slot < TS_CAND) cand[slot] = k;
-            }
-        }
-    }
-    __syncthreads();
-    unsigned nc = ncand;
-    double slope_med;
-    __shared__ unsigned long long slope_key;
+    const unsigned nc = ncand;
     if (nc <= TS_CAND) {
-        const unsigned want = sel_rank;
         for (unsigned i = tid; i < nc; i += 256) {
             const unsigned long long k = cand[i];
             unsigned less = 0, eq = 0;
@@ -273,45 +259,38 @@ __global__ __launch_bounds__(256) void k_theilsen(BatchDev B, const double *host
         }
         __syncthreads();
     } else {
-        // more than TS_CAND slopes share 22 leading bits (degenerate data): finish with 42 more bits, 1 bit per pass
-        if (tid == 0) slope_key = 0ull;
-        __shared__ unsigned cnt0;
-        unsigned long long pref = top22 << 42; unsigned want = sel_rank;
-        for (int bit = 41; bit >= 0; bit--) {
+        // > TS_CAND slopes share 33 leading bits (degenerate data): resolve the remaining 31 bits one per pass
+        unsigned long long full = pref << 31;
+        for (int bit = 30; bit >= 0; bit--) {
             if (tid == 0) cnt0 = 0;
             __syncthreads();
             unsigned local = 0;
-            for (unsigned a = 0; a + 1 < np; a++) {
-                const double xa = x[a], ya = y[a];
-                for (unsigned b = a + 1 + tid; b < np; b += 256) {
-                    const unsigned long long k = dkey((ya - y[b]) / (xa - x[b]));
-                    if ((k >> (bit + 1)) == (pref >> (bit + 1)) && !((k >> bit) & 1ull)) local++;
-                }
-            }
+            for_each_slope(x, y, np, [&](unsigned long long k, bool act) {
+                if (act && (k >> (bit + 1)) == (full >> (bit + 1)) && !((k >> bit) & 1ull)) local++;
+            });
             atomicAdd(&cnt0, local);
             __syncthreads();
             const unsigned c0 = cnt0;
-            if (want >= c0) { want -= c0; pref |= (1ull << bit); }
+            if (want >= c0) { want -= c0; full |= (1ull << bit); }
             __syncthreads();
         }
-        if (tid == 0) slope_key = pref;
+        if (tid == 0) slope_key = full;
         __syncthreads();
     }
-    slope_med = dkey_inv(slope_key);
+    const double slope_med = dkey_inv(slope_key);
     // ---- intercepts :79-87 : median of y - slope*x over <= 1000 points (rank np/2) ----
     for (unsigned j = tid; j < np; j += 256) {
         const double prod = slope_med * x[j];                     // product rounded, then subtracted (no contraction)
         icpt_key[j] = dkey(y[j] - prod);
     }
     __syncthreads();
-    __shared__ unsigned long long icpt_sel;
     {
-        const unsigned want = np / 2u;
+        const unsigned wanti = np / 2u;
         for (unsigned i = tid; i < np; i += 256) {
             const unsigned long long k = icpt_key[i];
             unsigned less = 0, eq = 0;
             for (unsigned j = 0; j < np; j++) { const unsigned long long o = icpt_key[j]; less += (o < k); eq += (o == k); }
-            if (less <= want && want < less + eq) icpt_sel = k;
+            if (less <= wanti && wanti < less + eq) icpt_sel = k;
         }
     }
     __syncthreads();
