@@ -4,9 +4,9 @@
 // (event_handling.cpp:546-575) with results bit-identical to the reference:
 //
 //   k1_scan     serial fp64 prefix sums of x and x*x (event_detection.c:42-47).  Rounding of a running fp64
-//               sum depends on the order of the additions, so the order is kept: ONE LANE PER READ walks its
-//               read left to right (64 reads per wavefront, 16-B loads of 8 samples, 16-B {sum,sumsq} stores).
-//               int16 -> pA is fused in: ((float)adc + offset) * scale in fp32, widened (pod5.cpp:60).
+//               sum depends on the order of the additions, so the order is kept; one wavefront per read does the
+//               conversion (int16 -> pA in fp32, widened, pod5.cpp:60), squares and stores 64 wide and only the
+//               two dependent adds per sample serially, through LDS.
 //   k1_tstat    the two windowed t-statistics (event_detection.c:60-115), one thread per sample; the mixed
 //               float/double expression order of the reference is written out cast by cast.
 //   k1_detect   the short/long peak detector (event_detection.c:122-198) is a serial state machine.  It is run
@@ -21,58 +21,79 @@
 #include <float.h>
 
 // ------------------------------------------------------------------------------------------------
-// k1_scan: one lane per read
+// k1_scan: one wavefront per read.
+// The running fp64 sums must be accumulated strictly left to right (their rounding depends on the order), so per
+// sample there is an irreducible serial part: s += x; q += x*x.  Everything else is done 64 lanes wide: a chunk of
+// 256 samples is loaded coalesced (4 per lane), converted int16 -> pA (fp32, pod5.cpp:60) -> fp64, squared, and
+// parked in LDS as {x, x*x}; the serial pass then costs one broadcast ds_read_b128, two dependent adds and one
+// ds_write_b128 per sample (executed wave-uniformly), and the {sum, sumsq} pairs leave LDS through coalesced
+// 16-byte stores (1 KiB per wavefront store).
 // ------------------------------------------------------------------------------------------------
+#define SCAN_CHUNK 256
+
+#define LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")   /* one wavefront per block: LDS ops are in order */
+
 __global__ __launch_bounds__(64) void k1_scan(BatchDev B) {
-    const int r = blockIdx.x * 64 + threadIdx.x;
-    if (r >= B.n_reads) return;
+    __shared__ double2 buf[SCAN_CHUNK];
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x;
     const uint64_t s0 = B.samp_off[r];
     const unsigned n = (unsigned)(B.samp_off[r + 1] - s0);
     const int16_t *a = B.adc + s0;
     double2 *out = B.psum + s0;
     const float off = B.cal_off[r], sc = B.cal_scale[r];
     double s = 0.0, q = 0.0;
-    unsigned i = 0;
-#define STEP(ADC)                                                   \
-    {                                                               \
-        float v = ((float)(ADC) + off) * sc;   /* pod5.cpp:60 */    \
-        double x = (double)v;                                       \
-        s = s + x;                             /* :45 */            \
-        q = q + x * x;                         /* :46 */            \
-        out[i] = make_double2(s, q);                                \
-        i++;                                                        \
-    }
-    while (i < n && ((reinterpret_cast<uintptr_t>(a + i)) & 15u)) STEP(a[i]);
-    // 32 samples (4 x 16-B loads) per round; the NEXT round's loads are issued before this round's 32 stores, so
-    // the wait that guards them is vmcnt(32): it never drains the stores just issued (vmcnt is in-order on gfx950)
-    if (i + 32 <= n) {
-        int4 c0 = *reinterpret_cast<const int4 *>(a + i), c1 = *reinterpret_cast<const int4 *>(a + i + 8);
-        int4 c2 = *reinterpret_cast<const int4 *>(a + i + 16), c3 = *reinterpret_cast<const int4 *>(a + i + 24);
-        while (true) {
-            const bool more = (i + 64 <= n);
-            int4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
-            if (more) {
-                n0 = *reinterpret_cast<const int4 *>(a + i + 32); n1 = *reinterpret_cast<const int4 *>(a + i + 40);
-                n2 = *reinterpret_cast<const int4 *>(a + i + 48); n3 = *reinterpret_cast<const int4 *>(a + i + 56);
-            }
-            const int w[16] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w };
-            double2 *o = out + i;                                  // constant offsets from one base: no per-store address math
+    // samples of the next chunk are fetched while the current one is summed
+    int16_t nxt[4];
 #pragma unroll
-            for (int j = 0; j < 32; j++) {
-                const int16_t av = (j & 1) ? (int16_t)(w[j >> 1] >> 16) : (int16_t)(w[j >> 1] & 0xffff);
-                float v = ((float)av + off) * sc;
-                double x = (double)v;
-                s = s + x;
-                q = q + x * x;
-                o[j] = make_double2(s, q);
-            }
-            i += 32;
-            if (!more) break;
-            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    for (int j = 0; j < 4; j++) { const unsigned i = (unsigned)lane * 4u + j; nxt[j] = i < n ? a[i] : (int16_t)0; }
+    for (unsigned base = 0; base < n; base += SCAN_CHUNK) {
+        const unsigned cnt = min((unsigned)SCAN_CHUNK, n - base);
+        // ---- parallel: convert + square, 4 consecutive samples per lane ----
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float v = ((float)nxt[j] + off) * sc;            // pod5.cpp:60
+            const double x = (double)v;
+            buf[lane * 4 + j] = make_double2(x, x * x);
         }
+        {
+            const unsigned nb = base + SCAN_CHUNK;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const unsigned i = nb + (unsigned)lane * 4u + j; nxt[j] = i < n ? a[i] : (int16_t)0; }
+        }
+        LDS_FENCE();
+        // ---- serial, order-exact (event_detection.c:45-46); LDS reads are issued 16 at a time ----
+        const unsigned full = cnt & ~15u;
+        for (unsigned g = 0; g < full; g += 16) {
+            double2 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = buf[g + j];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                s = s + v[j].x;
+                q = q + v[j].y;
+                v[j] = make_double2(s, q);
+            }
+            if (lane == 0) {                                       // one writer: 64 lanes storing to one address serialise
+#pragma unroll
+                for (int j = 0; j < 16; j++) buf[g + j] = v[j];
+            }
+        }
+        for (unsigned i = full; i < cnt; i++) {
+            const double2 v = buf[i];
+            s = s + v.x;
+            q = q + v.y;
+            if (lane == 0) buf[i] = make_double2(s, q);
+        }
+        LDS_FENCE();
+        // ---- parallel: coalesced write-out (1 KiB per wavefront store) ----
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned i = (unsigned)j * 64u + (unsigned)lane;
+            if (i < cnt) out[base + i] = buf[i];
+        }
+        LDS_FENCE();
     }
-    while (i < n) STEP(a[i]);
-#undef STEP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -382,7 +403,7 @@ __global__ __launch_bounds__(64) void k1_events(BatchDev B, unsigned *scratch_u3
 // launch helpers (called from dn_capi.hip)
 // ------------------------------------------------------------------------------------------------
 void k1_launch_scan(const BatchDev &B, hipStream_t st) {
-    hipLaunchKernelGGL(k1_scan, dim3((B.n_reads + 63) / 64), dim3(64), 0, st, B);
+    hipLaunchKernelGGL(k1_scan, dim3(B.n_reads), dim3(64), 0, st, B);
 }
 void k1_launch_tstat(const BatchDev &B, unsigned max_samples, hipStream_t st) {
     hipLaunchKernelGGL(k1_tstat, dim3((max_samples + 255) / 256, B.n_reads), dim3(256), 0, st, B);
