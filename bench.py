@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--reads", type=int, default=1000)
     ap.add_argument("--bases", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="batches in flight per GPU (each on its own context/stream/workspace); every stage is latency-bound "
+                         "at <= 1 wavefront per SIMD for a 1000-read batch, so consecutive steps are overlapped")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -90,33 +93,62 @@ def main():
 
     from dnascent_amd import hip, synth
     model = synth.pore_model()
-    ctx = hip.Context(local_rank if world > 1 else 0)
-    ctx.load_pore_model(model, 0.14)
+    dev = local_rank if world > 1 else 0
+    nctx = max(1, min(args.inflight, args.steps))
+    ctxs = [hip.Context(dev) for _ in range(nctx)]
     batch, reads = make_batch(args.reads, args.bases, 1000003 * (rank + 1), model)
-    batch.upload(ctx)                      # inputs resident in HBM before the timed region
+    for c in ctxs:
+        c.load_pore_model(model, 0.14)
+        batch.upload(c)                    # inputs resident in HBM before the timed region (one copy per in-flight slot)
+    ctx = ctxs[0]
     samples_per_step = batch.samples()
 
+    def sync_all():
+        for c in ctxs:
+            c.sync()
+
     def barrier():
-        ctx.sync()
+        sync_all()
         if dist is not None:
             torch.cuda.synchronize()
             dist.barrier()
 
-    for _ in range(args.warmup):
-        ctx.run("normalise")
+    def run_steps(k):
+        """k steps in total; slot j runs steps j, j+nctx, ... on its own host thread (dn_run_banded syncs its stream)."""
+        if nctx == 1:
+            for _ in range(k):
+                ctx.run("normalise")
+            ctx.sync()
+            return
+        import threading
+
+        def worker(j):
+            for _ in range(j, k, nctx):
+                ctxs[j].run("normalise")
+            ctxs[j].sync()
+        th = [threading.Thread(target=worker, args=(j,)) for j in range(nctx)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    run_steps(max(args.warmup, nctx if args.warmup else 0))
     barrier()
-    ctx.profile(True)
-    ctx.profile_reset()
+    for c in ctxs:
+        c.profile(True)
+        c.profile_reset()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.run("normalise")
-    ctx.sync()
+    run_steps(args.steps)
     if dist is not None:
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     barrier()
-    prof = ctx.profile_get()
-    ctx.profile(False)
+    prof = {}
+    for c in ctxs:
+        for k, v in c.profile_get().items():
+            a = prof.get(k, (0.0, 0))
+            prof[k] = (a[0] + v[0], a[1] + v[1])
+        c.profile(False)
     summ = ctx.summaries()
 
     total_samples = float(samples_per_step)
@@ -152,16 +184,17 @@ def main():
             "config": {"workload": "%d synthetic %d kb R10.4.1 reads per GPU, banded-HMM scope (segmentation + rough scaling + "
                                    "adaptive banded alignment + backtrack/QC + Theil-Sen), CNN stubbed" % (args.reads, args.bases // 1000),
                        "reads_per_gpu": args.reads, "bases_per_read": args.bases, "samples_per_gpu_step": int(samples_per_step),
-                       "reads_passing_qc": int(np.sum(summ["status"] == 0)), "parallelism": "reads sharded, %d rank(s)" % world},
+                       "reads_passing_qc": int(np.sum(summ["status"] == 0)), "parallelism": "reads sharded, %d rank(s), %d batches in flight per GPU" % (world, nctx)},
             "roofline": {"bound": "hbm", "kernel": "k2_fill", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": fill_ms / max(fill_n, 1)},
-            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
+            "kernel_ms_per_launch": {k: v[0] / v[1] for k, v in prof.items() if v[1]},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(reads, model)
         print(json.dumps(out), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -62,28 +62,29 @@ __global__ __launch_bounds__(64) void k1_scan(BatchDev B) {
             for (int j = 0; j < 4; j++) { const unsigned i = nb + (unsigned)lane * 4u + j; nxt[j] = i < n ? a[i] : (int16_t)0; }
         }
         LDS_FENCE();
-        // ---- serial, order-exact (event_detection.c:45-46); LDS reads are issued 16 at a time ----
-        const unsigned full = cnt & ~15u;
-        for (unsigned g = 0; g < full; g += 16) {
-            double2 v[16];
+        // ---- serial, order-exact (event_detection.c:45-46), in lane 0 only: every LDS access then moves 16 bytes, not
+        //      64 x 16; reads are issued 16 at a time ----
+        if (lane == 0) {
+            const unsigned full = cnt & ~15u;
+            for (unsigned g = 0; g < full; g += 16) {
+                double2 v[16];
 #pragma unroll
-            for (int j = 0; j < 16; j++) v[j] = buf[g + j];
+                for (int j = 0; j < 16; j++) v[j] = buf[g + j];
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                s = s + v[j].x;
-                q = q + v[j].y;
-                v[j] = make_double2(s, q);
-            }
-            if (lane == 0) {                                       // one writer: 64 lanes storing to one address serialise
+                for (int j = 0; j < 16; j++) {
+                    s = s + v[j].x;
+                    q = q + v[j].y;
+                    v[j] = make_double2(s, q);
+                }
 #pragma unroll
                 for (int j = 0; j < 16; j++) buf[g + j] = v[j];
             }
-        }
-        for (unsigned i = full; i < cnt; i++) {
-            const double2 v = buf[i];
-            s = s + v.x;
-            q = q + v.y;
-            if (lane == 0) buf[i] = make_double2(s, q);
+            for (unsigned i = full; i < cnt; i++) {
+                const double2 v = buf[i];
+                s = s + v.x;
+                q = q + v.y;
+                buf[i] = make_double2(s, q);
+            }
         }
         LDS_FENCE();
         // ---- parallel: coalesced write-out (1 KiB per wavefront store) ----

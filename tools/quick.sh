@@ -7,5 +7,5 @@ tail -1 gpurun_out/bench_quick.log | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('value %.1f Msamples/s  %.2f ms/step  roofline frac %.4f' % (d['value'], d['ms_per_step'], d['roofline']['frac']))
-for k,v in d['kernel_ms_per_step'].items(): print('  %-18s %8.3f' % (k,v))
+for k,v in d['kernel_ms_per_launch'].items(): print('  %-18s %8.3f' % (k,v))
 " || tail -20 gpurun_out/bench_quick.log
