@@ -151,14 +151,12 @@ def main():
         c.profile(False)
     summ = ctx.summaries()
 
+    # the only collectives of the path: MAX of the elapsed time, SUM of the counters (dnascent_amd/shard.py)
+    from dnascent_amd import shard
     total_samples = float(samples_per_step)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        s = torch.tensor([total_samples], dtype=torch.float64, device="cuda")
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        total_samples = float(s.item())
+        dt = shard.reduce_max(dist, dt, device="cuda")
+        total_samples = shard.reduce_counters(dist, [total_samples], device="cuda")[0]
 
     if rank == 0:
         fill_ms, fill_n = prof["k2_fill"]

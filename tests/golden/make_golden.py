@@ -1,0 +1,71 @@
+"""Generate the golden vectors under tests/golden/ from the REFERENCE's own code.
+
+Runs only where /root/reference exists (this container): oracle/_ref/libref.so is the reference's
+scrappie/event_detection.c and probability.cpp compiled in place (oracle/Makefile).  The outputs are data only:
+inputs (seeded synthetic int16 signals + calibration) and the reference's results for them.
+
+    python tests/golden/make_golden.py
+
+Files:
+  ref_segmentation.npz   for each case: adc (int16), cal_offset, cal_scale -> reference detect_events (start, length,
+                         mean, stdv) with the reference's default detector parameters (event_detection.h:19-25)
+  ref_logspace.npz       argument grids -> reference eexp / eln / lnSum / lnProd / lnGreaterThan / normalPDF (bit patterns)
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import pyoracle as po  # noqa: E402
+from dnascent_amd import synth  # noqa: E402
+
+
+def main():
+    ref = po.ref()
+    if ref is None:
+        raise SystemExit("oracle/_ref/libref.so missing: run `make -C oracle` where /root/reference exists")
+    model = synth.pore_model()
+    out = {}
+    cases = [(901, 1200, dict()), (902, 2500, dict(noise_pa=3.0)), (903, 4000, dict(is_reverse=True)),
+             (904, 1500, dict(noise_pa=6.5)), (905, 6000, dict(mean_dwell=8.0))]
+    out["n_cases"] = np.int64(len(cases))
+    for i, (seed, nb, kw) in enumerate(cases):
+        r = synth.make_read(seed, nb, model=model, **kw)
+        raw = ((r.adc.astype(np.float32) + np.float32(r.cal_offset)) * np.float32(r.cal_scale)).astype(np.float64)  # pod5.cpp:60
+        st, ln, mn, sd = po.ref_detect_events(raw)
+        out["adc_%d" % i] = r.adc
+        out["cal_%d" % i] = np.array([r.cal_offset, r.cal_scale], np.float32)
+        out["start_%d" % i] = st.astype(np.uint32)
+        out["length_%d" % i] = ln
+        out["mean_%d" % i] = mn
+        out["stdv_%d" % i] = sd
+    np.savez_compressed(os.path.join(HERE, "ref_segmentation.npz"), **out)
+
+    rng = np.random.default_rng(20251002)
+    xs = np.concatenate([[0.0, -0.0, 1.0, 1e-320, 5e-324, 1e308, np.inf, -np.inf, np.nan, 0.14, 745.2, -745.2, -708.5, 709.9],
+                         rng.normal(0, 50, 200), -np.abs(rng.normal(0, 400, 100))])
+    eexp = np.array([ref.ref_eexp(float(x)) for x in xs])
+    eln = []
+    eln_neg = []
+    for x in xs:
+        neg = C.c_int(0)
+        eln.append(ref.ref_eln(float(x), C.byref(neg))); eln_neg.append(neg.value)
+    a = xs[:64]; b = xs[32:96]
+    lnsum = np.array([[ref.ref_lnSum(float(u), float(v)) for v in b] for u in a])
+    lnprod = np.array([[ref.ref_lnProd(float(u), float(v)) for v in b] for u in a])
+    lngt = np.array([[ref.ref_lnGreaterThan(float(u), float(v)) for v in b] for u in a], np.int8)
+    mu = rng.normal(0, 1, 400); x = rng.normal(0, 3, 400)
+    x[:8] = [5.3, 5.4, 5.5, 6.0, 40.0, -40.0, 1e6, 0.0]
+    npdf = np.array([ref.ref_normalPDF(float(m), 0.14, float(v)) for m, v in zip(mu, x)])
+    np.savez_compressed(os.path.join(HERE, "ref_logspace.npz"), xs=xs, eexp=eexp, eln=np.array(eln), eln_neg=np.array(eln_neg, np.int8),
+                        a=a, b=b, lnsum=lnsum, lnprod=lnprod, lngt=lngt, mu=mu, x=x, npdf=npdf)
+    for f in ("ref_segmentation.npz", "ref_logspace.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

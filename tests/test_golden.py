@@ -1,0 +1,74 @@
+"""Golden vectors generated from the compiled REFERENCE (tests/golden/make_golden.py) -- these travel to the GPU box,
+where neither /root/reference nor (necessarily) oracle/_ref exists.
+
+CPU: the oracle reproduces them bit for bit.  GPU (-m gpu): the HIP segmentation reproduces them bit for bit.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+
+
+def test_oracle_segmentation_matches_reference_goldens():
+    g = np.load(os.path.join(G, "ref_segmentation.npz"))
+    for i in range(int(g["n_cases"])):
+        cal = g["cal_%d" % i]
+        raw = po.adc_to_pa(g["adc_%d" % i], float(cal[0]), float(cal[1]))
+        ev = po.detect_events(raw)
+        assert np.array_equal(ev["start"], g["start_%d" % i].astype(np.uint64))
+        for f in ("length", "mean", "stdv"):
+            assert np.array_equal(_bits(ev[f]), _bits(g["%s_%d" % (f, i)])), (i, f)
+
+
+def test_oracle_logspace_matches_reference_goldens():
+    g = np.load(os.path.join(G, "ref_logspace.npz"))
+    o = po.oracle()
+    assert np.array_equal(_bits(np.array([o.dno_eexp(float(x)) for x in g["xs"]])), _bits(g["eexp"]))
+    for x, want, wneg in zip(g["xs"], g["eln"], g["eln_neg"]):
+        neg = C.c_int(0)
+        got = o.dno_eln(float(x), C.byref(neg))
+        assert np.float64(got).tobytes() == np.float64(want).tobytes() and neg.value == wneg
+    for i, u in enumerate(g["a"]):
+        for j, v in enumerate(g["b"]):
+            assert np.float64(o.dno_lnSum(float(u), float(v))).tobytes() == np.float64(g["lnsum"][i, j]).tobytes()
+            assert np.float64(o.dno_lnProd(float(u), float(v))).tobytes() == np.float64(g["lnprod"][i, j]).tobytes()
+            assert o.dno_lnGreaterThan(float(u), float(v)) == g["lngt"][i, j]
+    got = np.array([o.dno_normalPDF(float(m), 0.14, float(v)) for m, v in zip(g["mu"], g["x"])])
+    assert np.array_equal(_bits(got), _bits(g["npdf"]))
+
+
+@pytest.mark.gpu
+def test_hip_segmentation_matches_reference_goldens(model):
+    """The device segmentation (through the C-ABI) against the reference's own detect_events output."""
+    from dnascent_amd import hip, host, synth
+    g = np.load(os.path.join(G, "ref_segmentation.npz"))
+    n = int(g["n_cases"])
+    # same generator calls as make_golden.py (the adc arrays are also stored in the fixture and compared)
+    cases = [(901, 1200, dict()), (902, 2500, dict(noise_pa=3.0)), (903, 4000, dict(is_reverse=True)),
+             (904, 1500, dict(noise_pa=6.5)), (905, 6000, dict(mean_dwell=8.0))]
+    reads = [synth.make_read(s, nb, model=model, **kw) for s, nb, kw in cases]
+    b = host.ReadBatch()
+    for i, r in enumerate(reads):
+        assert np.array_equal(r.adc, g["adc_%d" % i])
+        b.add_synth(r)
+    ctx = hip.Context(0)
+    ctx.load_pore_model(model)
+    b.upload(ctx)
+    ctx.run("segment")
+    s = ctx.summaries()
+    for i in range(n):
+        st, ln, mn = ctx.scrappie_events(i, int(s["n_scrappie"][i]))
+        assert np.array_equal(st, g["start_%d" % i])
+        assert np.array_equal(_bits(ln), _bits(g["length_%d" % i]))
+        assert np.array_equal(_bits(mn), _bits(g["mean_%d" % i]))
+    ctx.close()
