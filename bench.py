@@ -166,6 +166,13 @@ def main():
                                  9.0 * summ["n_aligned"][ok]))
         fill_s = (fill_ms / max(fill_n, 1)) / 1e3
         achieved = alg_bytes / fill_s / 1e9 if fill_s > 0 else 0.0
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (cannot be collected inside a timed run)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_k2_fill.json")))
+            if pm["workload"] == {"reads": args.reads, "bases": args.bases}:
+                traffic = pm["write_bytes"] + pm["fetch_bytes_corrected"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "raw-signal Msamples/sec (whole node) on `detect`",
             "value": total_samples * args.steps / dt / 1e6,
@@ -184,7 +191,7 @@ def main():
                        "reads_per_gpu": args.reads, "bases_per_read": args.bases, "samples_per_gpu_step": int(samples_per_step),
                        "reads_passing_qc": int(np.sum(summ["status"] == 0)), "parallelism": "reads sharded, %d rank(s), %d batches in flight per GPU" % (world, nctx)},
             "roofline": {"bound": "hbm", "kernel": "k2_fill", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": fill_ms / max(fill_n, 1)},
             "kernel_ms_per_launch": {k: v[0] / v[1] for k, v in prof.items() if v[1]},
         }
