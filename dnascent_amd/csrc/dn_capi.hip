@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -26,9 +27,14 @@ int k2_selftest_run(hipStream_t);
 void k2_launch_fill(const BatchDev &, const void *, const void *, bool, hipStream_t);
 void k2_launch_chase(const BatchDev &, uint8_t *, hipStream_t);
 void k2_launch_post(const BatchDev &, const uint8_t *, float *, const void *, hipStream_t);
+void k2b_launch(const BatchDev &, const void *, const void *, const void *, unsigned, hipStream_t);
 
 struct BandConstsH { double lp_stay, lp_step; };
 struct FillConstsH { double lp_skip, lp_trim, C, sigma, rsigma; };
+struct VitConstsH { double D2D, D2M, I2M, M2D, M2I, I2I; double c, d2, rd2; double initD[66]; };
+struct VitReadH { double iM2M, eM2M, eM2MorD, eOrI; };
+struct EaDevH { unsigned *coord, *qidx, *ridx; int *indel; unsigned *nsig; float *sig, *core, *resid;
+                unsigned *win_ref, *win_len, *win_T; double *win_score; };
 
 namespace {
 
@@ -62,6 +68,7 @@ struct dn_ctx {
     uint8_t *d_path_from = nullptr; float *d_path_lp = nullptr;
     uint64_t *d_trace_off = nullptr;
     FillConstsH fc{};
+    VitConstsH vc{}; EaDevH ea{}; VitReadH *d_vitread = nullptr; unsigned max_ref = 0;
     // profiling
     bool prof = false;
     std::vector<ProfRec> pending;
@@ -240,6 +247,16 @@ int dn_load_pore_model(dn_ctx *c, const double *mean, double sigma) {
     c->fc.rsigma = 1.0 / sigma;
     c->fc.lp_skip = log(1e-30);
     c->fc.lp_trim = log(0.01);
+    // builtinViterbi's fixed transitions (alignment.cpp:199-204, config.h:42) and normalPDF's constants as the reference
+    // build evaluates them (probability.cpp:145-148 with pow(v, 2.0) folded to v*v), all with the host libm
+    VitConstsH &v = c->vc;
+    v.D2D = log(0.3); v.D2M = log(0.7); v.I2M = log(0.999); v.M2D = log(0.0025); v.M2I = log(0.001); v.I2I = log(0.001);
+    const double s2 = sigma * sigma;
+    v.d2 = s2 + s2;
+    v.rd2 = 1.0 / v.d2;
+    v.c = 1.0 / sqrt(M_PI * v.d2);
+    v.initD[0] = 0.0 + v.M2D;                                   // alignment.cpp:241
+    for (int i = 1; i < 66; i++) v.initD[i] = v.initD[i - 1] + v.D2D;   // :246-251
     return DN_OK;
 }
 
@@ -307,6 +324,13 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     if ((rc = dalloc(c, &c->d_path_from, (size_t)NAL))) return rc;
     if ((rc = dalloc(c, &c->d_path_lp, (size_t)NAL))) return rc;
     if ((rc = dalloc(c, &c->d_trace_off, (size_t)n + 1))) return rc;
+    if ((rc = dalloc(c, &c->ea.coord, (size_t)NR)) || (rc = dalloc(c, &c->ea.qidx, (size_t)NR)) || (rc = dalloc(c, &c->ea.ridx, (size_t)NR)) ||
+        (rc = dalloc(c, &c->ea.indel, (size_t)NR)) || (rc = dalloc(c, &c->ea.nsig, (size_t)NR)) || (rc = dalloc(c, &c->ea.sig, (size_t)NR * DN_RAWDEPTH)) ||
+        (rc = dalloc(c, &c->ea.core, (size_t)NR)) || (rc = dalloc(c, &c->ea.resid, (size_t)NR)) || (rc = dalloc(c, &c->ea.win_ref, (size_t)NR)) ||
+        (rc = dalloc(c, &c->ea.win_len, (size_t)NR)) || (rc = dalloc(c, &c->ea.win_T, (size_t)NR)) || (rc = dalloc(c, &c->ea.win_score, (size_t)NR)) ||
+        (rc = dalloc(c, &c->d_vitread, (size_t)n))) return rc;
+    c->max_ref = 0;
+    for (uint32_t r = 0; r < n; r++) c->max_ref = std::max<unsigned>(c->max_ref, (unsigned)(c->h_ref_off[r + 1] - c->h_ref_off[r]));
     HIPCHK(c, hipMemsetAsync(B.res, 0, n * sizeof(ReadRes), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->h_res.assign(n, ReadRes{});
@@ -398,9 +422,46 @@ int dn_run_normalise(dn_ctx *c) {
     return dn_run_theilsen(c);
 }
 
+static double h_eln(double x, int *neg) {            // probability.cpp:35-47
+    if (x == 0.0) return NAN;
+    if (x > 0.0) return log(x);
+    *neg = 1; return NAN;
+}
+static double h_lnSum(double a, double b) {           // probability.cpp:50-76
+    const bool na = std::isnan(a), nb = std::isnan(b);
+    if (na || nb) { if (na && nb) return NAN; return na ? b : a; }
+    int neg = 0;
+    if (a > b) return a + h_eln(1.0 + (std::isnan(b - a) ? 0.0 : exp(b - a)), &neg);
+    return b + h_eln(1.0 + (std::isnan(a - b) ? 0.0 : exp(a - b)), &neg);
+}
+
 int dn_run_eventalign(dn_ctx *c) {
     int rc = need(c, 5, "dn_run_eventalign"); if (rc) return rc;
-    return fail(c, DN_ERR_STATE, "dn_run_eventalign: windowed Viterbi kernel not built into this library yet");
+    const uint32_t n = (uint32_t)c->B.n_reads;
+    // per-read transitions depend on eventsPerBase (alignment.cpp:207-210): one small D2H, host libm, one small H2D
+    HIPCHK(c, hipMemcpyAsync(c->h_res.data(), c->B.res, n * sizeof(ReadRes), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<VitReadH> vr(n);
+    std::vector<int> newstat(n, -1);
+    for (uint32_t r = 0; r < n; r++) {
+        const ReadRes &R = c->h_res[r];
+        int neg = 0;
+        const double iM2M = h_eln(1. - (1. / R.events_per_base), &neg);                 // :207
+        const double eM2M = h_eln(1.0 - c->vc.M2D - c->vc.M2I - iM2M, &neg);            // :208 (sic: log values)
+        vr[r].iM2M = iM2M; vr[r].eM2M = eM2M;
+        vr[r].eM2MorD = h_lnSum(eM2M, c->vc.M2D);                                        // :209
+        vr[r].eOrI = h_lnSum(eM2M, iM2M);                                                // :210
+        if (R.status == 0 && neg) newstat[r] = DN_READ_FAIL_NEGATIVE_LOG;                // the reference throws NegativeLog
+    }
+    for (uint32_t r = 0; r < n; r++)
+        if (newstat[r] >= 0) HIPCHK(c, hipMemcpyAsync(&c->B.res[r].status, &newstat[r], sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_vitread, vr.data(), n * sizeof(VitReadH), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->ea.sig, 0, (size_t)c->h_ref_off[n] * DN_RAWDEPTH * sizeof(float), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // vr / newstat are locals
+    { Timed t(c, DN_K_VITERBI); k2b_launch(c->B, &c->ea, c->d_vitread, &c->vc, c->max_ref, c->stream); }
+    HIPCHK(c, hipGetLastError());
+    c->stage = 6;
+    return DN_OK;
 }
 
 static int fetch_res(dn_ctx *c) {
@@ -522,11 +583,34 @@ int dn_get_trace(dn_ctx *c, uint32_t read, uint8_t *trace, int32_t *band_event, 
     return DN_OK;
 }
 
-int dn_get_positions(dn_ctx *c, uint32_t, uint32_t *, uint32_t *, uint32_t *, int32_t *, char *, uint32_t *, float *, float *, float *) {
-    return fail(c, DN_ERR_STATE, "dn_get_positions: eventalign has not run");
+int dn_get_positions(dn_ctx *c, uint32_t read, uint32_t *coord, uint32_t *query_idx, uint32_t *ref_idx, int32_t *indel_score, char *kmer9,
+                     uint32_t *n_signal, float *signal20, float *core, float *residual) {
+    CHECK_READ(6, "dn_get_positions");
+    if ((rc = fetch_res(c))) return rc;
+    const size_t np = c->h_res[read].n_positions; const uint64_t f0 = c->h_ref_off[read];
+    if ((rc = d2h(c, coord, c->ea.coord + f0, np)) || (rc = d2h(c, query_idx, c->ea.qidx + f0, np)) ||
+        (rc = d2h(c, indel_score, c->ea.indel + f0, np)) || (rc = d2h(c, n_signal, c->ea.nsig + f0, np)) ||
+        (rc = d2h(c, signal20, c->ea.sig + f0 * DN_RAWDEPTH, np * DN_RAWDEPTH)) || (rc = d2h(c, core, c->ea.core + f0, np)) ||
+        (rc = d2h(c, residual, c->ea.resid + f0, np))) return rc;
+    std::vector<uint32_t> ri(np);
+    if ((rc = d2h(c, ri.data(), c->ea.ridx + f0, np))) return rc;
+    if (ref_idx) memcpy(ref_idx, ri.data(), np * sizeof(uint32_t));
+    if (kmer9) {   // the 9-mer of a position is the reference slice around its index (alignment.cpp:683)
+        const size_t nr = (size_t)(c->h_ref_off[read + 1] - f0);
+        std::vector<char> ref(nr);
+        if ((rc = d2h(c, ref.data(), c->B.refseq + f0, nr))) return rc;
+        for (size_t i = 0; i < np; i++) memcpy(kmer9 + 9 * i, ref.data() + ri[i] - DN_KMER / 2, 9);
+    }
+    return DN_OK;
 }
-int dn_get_windows(dn_ctx *c, uint32_t, uint32_t *, uint32_t *, uint32_t *, double *) {
-    return fail(c, DN_ERR_STATE, "dn_get_windows: eventalign has not run");
+
+int dn_get_windows(dn_ctx *c, uint32_t read, uint32_t *ref_index, uint32_t *window_len, uint32_t *n_obs, double *score) {
+    CHECK_READ(6, "dn_get_windows");
+    if ((rc = fetch_res(c))) return rc;
+    const size_t nw = c->h_res[read].n_windows; const uint64_t f0 = c->h_ref_off[read];
+    if ((rc = d2h(c, ref_index, c->ea.win_ref + f0, nw)) || (rc = d2h(c, window_len, c->ea.win_len + f0, nw)) ||
+        (rc = d2h(c, n_obs, c->ea.win_T + f0, nw))) return rc;
+    return d2h(c, score, c->ea.win_score + f0, nw);
 }
 
 int dn_profile_enable(dn_ctx *c, int on) { if (!c) return DN_ERR_ARG; c->prof = on != 0; return DN_OK; }

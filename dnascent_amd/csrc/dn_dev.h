@@ -7,6 +7,7 @@
 #define DN_W 100            // band width (config.h:41)
 #define DN_TROW 128         // bytes per stored trace row: 100 trace bytes + band metadata, one full 128-B line
 #define DN_K 9
+#define DN_RAWDEPTH_DEV 20 // reads.h:12 RAWDEPTH
 #define DN_SEG_CHUNK 1024   // samples per speculative detector chunk
 #define DN_SEG_WARM 192     // warm-up samples run before a chunk to reach the detector's true state
 #define DN_SEG_PEAKCAP 512  // peaks per chunk (peaks are >= 2 samples apart)

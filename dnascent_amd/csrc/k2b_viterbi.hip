@@ -1,0 +1,316 @@
+// k2b_viterbi.hip -- K2b: eventalign (alignment.cpp:547-744) = window walk + builtinViterbi (alignment.cpp:193-516)
+// + feature fill (reads.h:292-304) + tensor packing (reads.h:112-172), on gfx950.
+//
+// The windows of a read form a serial chain (the next one starts at the last match of the previous one,
+// alignment.cpp:739-740), so ONE WAVEFRONT PER READ walks them.  Inside a window the Viterbi lattice
+// (T observations x N <= 65 positions x {I, M, D}) is swept by ANTI-DIAGONALS: cell (t, i) needs (t-1, i-1), (t-1, i)
+// and -- through the silent deletion chain D(t,i) <- D(t,i-1), alignment.cpp:405-427 -- (t, i-1), so all cells with
+// t + i = const are independent.  Lane i owns position i and advances one observation per step; what it needs from
+// lane i-1 arrives through wave-shift DPP.  This removes the reference's per-column serial pass over positions
+// exactly: every value is produced by the same fp64 operations in the same order, only scheduled differently.
+// NaN is log(0) as in probability.cpp; arg-max is "first wins, NaN never wins" (alignment.cpp:166-190).
+// Backtrace codes live in LDS (1 byte per cell); the traceback and the feature fill are wave-uniform.
+//
+// Emission: eln(normalPDF(mu, 0.14, x)) with normalPDF as the reference BUILD computes it (GCC folds pow(v, 2.0) into
+// v*v): (1/sqrt(2 s^2 pi)) * exp(-(x-mu)^2 / (2 s^2)), then log.  exp/log are the ROCm device-library fp64 functions
+// (<= 1 ulp) where the reference calls glibc: scores can differ in the last bits (tolerance stated in the tests), the
+// arg-max decisions are compared exactly.
+#include "dn_dev.h"
+
+#define VT_TMAX 512          // observations per window held in LDS (a window spans <= 65 positions, ~2.2 events each)
+#define VT_NS 66             // backtrace row stride (positions per window <= 65)
+
+struct VitConsts {           // alignment.cpp:199-204 (host libm), normalPDF constants, deletion chain before the first event
+    double D2D, D2M, I2M, M2D, M2I, I2I;
+    double c, d2, rd2;       // 1/sqrt(2 s^2 pi), 2 s^2, RN(1/(2 s^2))
+    double initD[VT_NS];     // D_prev[i] of alignment.cpp:241-251: M2D, then + D2D sequentially
+};
+struct VitRead { double iM2M, eM2M, eM2MorD, eOrI; };   // alignment.cpp:207-210, per read (host libm)
+
+struct EaDev {               // outputs, all at ref_off[r] (capacity = reference length of the read)
+    unsigned *coord, *qidx, *ridx; int *indel; unsigned *nsig; float *sig /* x20 */, *core, *resid;
+    unsigned *win_ref, *win_len, *win_T; double *win_score;
+};
+
+__device__ __forceinline__ double qnan() { return __longlong_as_double(0x7ff8000000000000ll); }
+// lnGreaterThan (probability.cpp:107-131): NaN is never greater, anything is greater than NaN
+__device__ __forceinline__ bool ln_gt(double a, double b) { return (a == a) && !(a <= b); }
+
+__device__ __forceinline__ double shl_prev_d(double v, double fill, int lane) {    // lane l <- lane l-1, lane 0 <- fill
+    long long b = __double_as_longlong(v), f = __double_as_longlong(fill);
+    int lo = __builtin_amdgcn_update_dpp((int)(f & 0xffffffffll), (int)(b & 0xffffffffll), 0x138, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp((int)(f >> 32), (int)(b >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// one lattice cell.  is0: position 0 (different transitions, alignment.cpp:278-328).  start: start_prev (0 at t == 0, NaN after)
+__device__ __forceinline__ void vit_cell(const bool is0, const double start, const double Ip, const double Mp, const double lI2,
+                                         const double lM2, const double lD2, const double lM1, const double lD1, const double e,
+                                         const VitConsts &vc, const VitRead &vr, double &In, double &Mn, double &Dn, unsigned &code) {
+    const double NaN = qnan();
+    // insertion (alignment.cpp:278-285 / :351-356): candidates I_i, M_i, (START for position 0)
+    double bi = Ip + vc.I2I + 0.0; unsigned ci = 0;
+    { const double v = Mp + vc.M2I + 0.0; if (ln_gt(v, bi)) { bi = v; ci = 1; } }
+    { const double v = is0 ? (start + vc.M2I + 0.0) : NaN; if (ln_gt(v, bi)) { bi = v; ci = 2; } }
+    // match (:305-310 / :372-381): I_{i-1}, M_{i-1}, M_i, D_{i-1};  position 0: M_0, START
+    double bm; unsigned cm;
+    {
+        const double v0 = is0 ? NaN : (lI2 + vc.I2M + e);
+        const double v1 = is0 ? NaN : (lM2 + vr.eM2M + e);
+        const double v2 = Mp + vr.iM2M + e;
+        const double v3 = is0 ? (start + vr.eOrI + e) : (lD2 + vc.D2M + e);
+        bm = v0; cm = 0;
+        if (ln_gt(v1, bm)) { bm = v1; cm = 1; }
+        if (ln_gt(v2, bm)) { bm = v2; cm = 2; }
+        if (ln_gt(v3, bm)) { bm = v3; cm = 3; }
+        if (is0) cm = (cm == 3) ? 4u : 2u;              // position 0: {M_0 (code 2), START (code 4)}, first wins / all-NaN -> M_0
+    }
+    // silent deletion (:326-328 / :408-413): M(t, i-1), D(t, i-1);  position 0: NaN from START
+    double bd = lM1 + vc.M2D; unsigned cd = 0;
+    { const double v = lD1 + vc.D2D; if (ln_gt(v, bd)) { bd = v; cd = 1; } }
+    if (is0) { bd = NaN; cd = 2; }
+    In = bi; Mn = bm; Dn = bd;
+    code = ci | (cm << 2) | (cd << 5);
+}
+
+__device__ __forceinline__ double emission(double x, double mu, const VitConsts &vc) {
+    const double d = x - mu;
+    const double sq = d * d;                              // pow(d, 2.0) as compiled in the reference
+    const double n = -sq;
+    const double q = n * vc.rd2;                          // exact n / d2 (FMA-corrected reciprocal, see k2_banded.hip)
+    const double rem = fma(-q, vc.d2, n);
+    const double arg = fma(rem, vc.rd2, q);
+    const double p = vc.c * exp(arg);                     // probability.cpp:147
+    return (p == 0.0) ? qnan() : log(p);                  // eln, probability.cpp:35-47 (p is never negative)
+}
+
+__global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const VitRead *vrs, VitConsts vc) {
+    __shared__ double xs[VT_TMAX];                        // scaled observations of the window
+    __shared__ unsigned tk[VT_TMAX];                      // their event indices
+    __shared__ unsigned short lab[VT_TMAX + VT_NS + 8];   // traceback labels (state << 8 | pos), reverse order
+    __shared__ unsigned char bt[(VT_TMAX + 1) * VT_NS];   // backtrace codes: I 2 bits | M 3 bits | D 2 bits
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x;
+    ReadRes &R = B.res[r];
+    if (R.status != 0) { if (lane == 0) { R.n_positions = 0; R.n_windows = 0; } return; }
+    const VitRead vr = vrs[r];
+    const double NaN = qnan();
+    const uint64_t f0 = B.ref_off[r];
+    const int n_ref = (int)(B.ref_off[r + 1] - f0);
+    const char *ref = B.refseq + f0;
+    const unsigned *r2q = B.ref2query + f0;
+    const unsigned *rank_r = B.rank_r + f0;
+    const uint64_t a0 = B.aln_off[r] + R.aln_begin;
+    const unsigned *ae = B.aln_event + a0, *ak = B.aln_kmer + a0;
+    const unsigned n_aln = R.n_aligned;
+    const uint64_t e0 = B.ev_off[r];
+    const double *ev_mean = B.ev_mean + e0;
+    const unsigned *ev_start = B.ev_start + e0, *ev_len = B.ev_len + e0;
+    const int16_t *adc = B.adc + B.samp_off[r];
+    const float cal_off = B.cal_off[r], cal_sc = B.cal_scale[r];
+    const double shift = R.shift, scale = R.scale;
+    const int is_rev = B.is_rev[r], ref_start = B.ref_start[r], ref_end = B.ref_end[r];
+    const double *model = B.model_mean;
+
+    unsigned readHead = 0; int ri = 0;
+    unsigned npos = 0, nwin = 0;
+    unsigned cur_coord = 0xffffffffu; unsigned cur_cnt = 0; unsigned cur_slot = 0;
+    int fail = 0;
+
+    while (ri < n_ref - (DN_K - 1)) {                     // alignment.cpp:556
+        const int toEnd = n_ref - ri;
+        int W = toEnd < 50 ? toEnd : 50;
+        if ((double)toEnd > 75.0) {                       // :564 break-point search in a 75-base look-ahead
+            int bad = 0;
+            for (int j = lane; j < 75; j += 64) { const char c = ref[ri + j]; bad |= !(c == 'A' || c == 'T' || c == 'G' || c == 'C'); }
+            if (__any(bad)) { ri += W; continue; }        // :569-572
+            bool hit = false;
+            if (lane < 15) {                              // i = 50 .. 64 (:574)
+                const int i = 50 + lane;
+                const double m = model[rank_r[ri + i]], mb = model[rank_r[ri + i - 1]], mf = model[rank_r[ri + i + 1]];
+                hit = (fabs(m - mf) > 0.75) && (fabs(m - mb) > 0.75);
+            }
+            const unsigned long long hm = __ballot(hit);
+            if (hm) W = 50 + (__ffsll((long long)hm) - 1) + DN_K;   // :591
+        }
+        {
+            int bad = 0;
+            for (int j = lane; j < W; j += 64) { const char c = ref[ri + j]; bad |= !(c == 'A' || c == 'T' || c == 'G' || c == 'C'); }
+            if (__any(bad)) { ri += W; continue; }        // :599-604
+        }
+        const int N = W - (DN_K - 1);
+        const unsigned qlo = r2q[ri], qhi = r2q[ri + W - DN_K + 1];
+        // ---- events rough-aligned to the window (:611-632), order-preserving compaction ----
+        unsigned nt = 0; bool first = true;
+        for (unsigned j = readHead; j < n_aln; j += 64) {
+            const unsigned jj = j + lane;
+            const bool in = jj < n_aln;
+            const unsigned q = in ? ak[jj] : 0u;
+            const unsigned long long stopm = __ballot(in && q >= qhi);
+            const int limit = stopm ? (__ffsll((long long)stopm) - 1) : 64;
+            const bool inw = in && lane < limit && qlo <= q && q < qhi;
+            const unsigned long long wm = __ballot(inw);
+            if (first && wm) { readHead = j + (unsigned)(__ffsll((long long)wm) - 1); first = false; }
+            unsigned e_idx = 0; double mean = 0.;
+            if (inw) { e_idx = ae[jj]; mean = ev_mean[e_idx]; }
+            const bool take = inw && (0. < mean) && (mean < 250.);      // :624
+            const unsigned long long tm = __ballot(take);
+            const unsigned p = nt + (unsigned)__popcll(tm & ((1ull << lane) - 1ull));
+            if (take && p < VT_TMAX) { tk[p] = e_idx; xs[p] = (mean - shift) / scale; }
+            nt += (unsigned)__popcll(tm);
+            if (stopm) break;
+        }
+        const int indel = (int)(qhi - qlo) - (int)(W - DN_K + 1);       // :635-638
+        if (nt < 2) { ri += W; continue; }                // :641
+        if (nt > VT_TMAX) { fail = 6; break; }
+        const int T = (int)nt;
+        __syncthreads();
+        const int coord0 = is_rev ? (ref_end - ri - DN_K / 2) : (ref_start + ri + DN_K / 2);
+
+        // ---- Viterbi, anti-diagonal sweep: lane i = position i, time t = d - i ----
+        const bool is0 = lane == 0;
+        const double mu = (lane < N) ? model[rank_r[ri + lane]] : 0.0;
+        double I1 = NaN, M1 = NaN, D1 = (lane < VT_NS) ? vc.initD[lane] : NaN;       // own last results (init column, :234-251)
+        double oI2 = I1, oM2 = M1, oD2 = D1;                                       // own results one step earlier (tail cell only)
+        double sI1 = NaN, sM1 = NaN, sD1 = shl_prev_d(D1, NaN, lane);              // lane i-1's results of the last step
+        double sI2 = sI1, sM2 = sM1, sD2 = sD1;                                    // ... and of the step before
+        // tail cell: position 64 (only when N == 65), kept in lane 63
+        const bool tail = N == 65;
+        const double mu64 = tail ? model[rank_r[ri + 64]] : 0.0;
+        double tI = NaN, tM = NaN, tD = vc.initD[64];
+        const int nsteps = T + N - 1;
+        for (int d = 0; d < nsteps; d++) {       // N == 65: nsteps = T + 64 also covers the tail cell's last step
+            if (tail) {
+                const int t64 = d - 64;
+                if (t64 >= 0 && t64 < T) {                 // uses lane 63's results of steps d-1 (time t64) and d-2 (time t64-1)
+                    const double e = emission(xs[t64], mu64, vc);
+                    double In, Mn, Dn; unsigned code;
+                    vit_cell(false, NaN, tI, tM, oI2, oM2, oD2, M1, D1, e, vc, vr, In, Mn, Dn, code);
+                    tI = In; tM = Mn; tD = Dn;
+                    if (lane == 63) bt[(t64 + 1) * VT_NS + 64] = (unsigned char)code;
+                }
+            }
+            const int t = d - lane;
+            const bool act = (t >= 0) && (t < T) && (lane < N) && (lane < 64);
+            double In = I1, Mn = M1, Dn = D1; unsigned code = 0;
+            {
+                const double x = xs[act ? t : 0];
+                const double e = emission(x, mu, vc);
+                const double start = (t == 0) ? 0.0 : NaN;                          // :235, :432
+                double a, b, c2;
+                vit_cell(is0, start, I1, M1, sI2, sM2, sD2, sM1, sD1, e, vc, vr, a, b, c2, code);
+                if (act) { In = a; Mn = b; Dn = c2; }
+            }
+            if (act) bt[(t + 1) * VT_NS + lane] = (unsigned char)code;
+            oI2 = I1; oM2 = M1; oD2 = D1;
+            I1 = In; M1 = Mn; D1 = Dn;
+            sI2 = sI1; sM2 = sM1; sD2 = sD1;
+            sI1 = shl_prev_d(I1, NaN, lane); sM1 = shl_prev_d(M1, NaN, lane); sD1 = shl_prev_d(D1, NaN, lane);
+        }
+        __syncthreads();
+        // ---- termination (:446-476) ----
+        double fD, fM, fI;
+        if (tail) { fD = bcast_d(tD, 63); fM = bcast_d(tM, 63); fI = bcast_d(tI, 63); }
+        else { fD = bcast_d(D1, N - 1); fM = bcast_d(M1, N - 1); fI = bcast_d(I1, N - 1); }
+        double score = fD; int st = 0;
+        { const double v = fM + vr.eM2MorD; if (ln_gt(v, score)) { score = v; st = 1; } }
+        { const double v = fI + vc.I2M; if (ln_gt(v, score)) { score = v; st = 2; } }
+        // ---- traceback (:460-509), wave-uniform; labels stored in reverse order ----
+        int nlab = 0, i = N - 1, col = T;
+        int nonD = 0, firstM_seen = -1, lastM_ref = 0;
+        bool done = false;
+        int guard = 3 * N * (T + 1) + 8;
+        while (!done && guard-- > 0 && nlab < VT_TMAX + VT_NS + 8) {
+            lab[nlab++] = (unsigned short)((st << 8) | i);
+            if (st != 0) {
+                if (st == 1 && firstM_seen < 0) { firstM_seen = nonD; lastM_ref = i; }
+                nonD++;
+            }
+            if (st == 0) {
+                const unsigned cdx = (col == 0) ? (i == 0 ? 2u : 1u) : ((bt[col * VT_NS + i] >> 5) & 3u);
+                if (cdx == 2) done = true; else if (cdx == 0) { st = 1; i -= 1; } else { st = 0; i -= 1; }
+            } else if (st == 1) {
+                const unsigned cmx = (bt[col * VT_NS + i] >> 2) & 7u;
+                if (cmx == 4) done = true; else if (cmx == 0) { st = 2; i -= 1; } else if (cmx == 1) { st = 1; i -= 1; }
+                else if (cmx == 2) { st = 1; } else { st = 0; i -= 1; }
+                col -= 1;
+            } else {
+                const unsigned cix = bt[col * VT_NS + i] & 3u;
+                if (cix == 2) done = true; else if (cix == 0) st = 2; else st = 1;
+                col -= 1;
+            }
+            if (col < 0 || i < 0) done = true;             // cannot happen for a finite score; guards NaN lattices
+        }
+        const int lastM_ev = (firstM_seen >= 0) ? (nonD - 1 - firstM_seen) : 0;    // :655-672
+        if (firstM_seen < 0) lastM_ref = 0;
+        // ---- window log ----
+        if (lane == 0) {
+            O.win_ref[f0 + nwin] = (unsigned)ri; O.win_len[f0 + nwin] = (unsigned)W; O.win_T[f0 + nwin] = (unsigned)T;
+            O.win_score[f0 + nwin] = score;
+        }
+        nwin++;
+        // ---- feature fill (:676-736 -> reads.h:292-304): every raw sample of an event labelled M goes to its position ----
+        int evIdx = 0;
+        for (int k = nlab - 1; k >= 0; k--) {
+            const unsigned L = lab[k];
+            const int lst = (int)(L >> 8), p = (int)(L & 0xff);
+            if (lst == 0) continue;
+            if (lst == 1) {
+                const unsigned coord = is_rev ? (unsigned)(coord0 - p - 1) : (unsigned)(coord0 + p);
+                if (coord != cur_coord) {
+                    cur_coord = coord; cur_cnt = 0; cur_slot = npos++;
+                    if (lane == 0) {
+                        const unsigned idxRef = (unsigned)(ri + p + DN_K / 2);
+                        O.coord[f0 + cur_slot] = coord; O.ridx[f0 + cur_slot] = idxRef; O.qidx[f0 + cur_slot] = r2q[idxRef];
+                        O.indel[f0 + cur_slot] = indel;
+                    }
+                    // (the signal array is zero-filled before the launch: zero padding of reads.h:162-168)
+                }
+                const unsigned e_idx = tk[evIdx];
+                const unsigned rs = ev_start[e_idx], rl = ev_len[e_idx];
+                for (unsigned j0 = 0; j0 < rl && cur_cnt + j0 < DN_RAWDEPTH_DEV; j0 += 64) {
+                    const unsigned j = j0 + lane;
+                    const unsigned slot = cur_cnt + j;
+                    if (j < rl && slot < DN_RAWDEPTH_DEV) {
+                        const float v = ((float)adc[rs + j] + cal_off) * cal_sc;         // pod5.cpp:60
+                        const double scaled = ((double)v - shift) / scale;               // alignment.cpp:705
+                        O.sig[(f0 + cur_slot) * DN_RAWDEPTH_DEV + slot] = (float)scaled; // reads.h:156
+                    }
+                }
+                cur_cnt += rl;
+                if (lane == 0) O.nsig[f0 + cur_slot] = cur_cnt;
+            }
+            evIdx++;
+        }
+        readHead += (unsigned)lastM_ev + 1u;                // :739-740
+        ri += lastM_ref + 1;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        R.n_positions = fail ? 0u : npos;
+        R.n_windows = nwin;
+        if (fail) R.status = fail;
+    }
+}
+
+// core / residual indices of every aligned position (reads.h:112-138, +1), one thread per position
+__global__ __launch_bounds__(256) void k2b_features(BatchDev B, EaDev O) {
+    const int r = blockIdx.y;
+    const unsigned p = blockIdx.x * 256 + threadIdx.x;
+    if (B.res[r].status != 0 || p >= B.res[r].n_positions) return;
+    const uint64_t f0 = B.ref_off[r];
+    const char *km = B.refseq + f0 + O.ridx[f0 + p] - DN_K / 2;
+    unsigned core = 0, res = 0;
+#pragma unroll
+    for (int j = 2; j < 7; j++) core = core * 4u + base_code(km[j]);
+    res = ((base_code(km[0]) * 4u + base_code(km[1])) * 4u + base_code(km[7])) * 4u + base_code(km[8]);
+    O.core[f0 + p] = (float)(core + 1u);
+    O.resid[f0 + p] = (float)(res + 1u);
+}
+
+void k2b_launch(const BatchDev &B, const void *ea, const void *vr, const void *vc, unsigned max_ref, hipStream_t st) {
+    const EaDev O = *reinterpret_cast<const EaDev *>(ea);
+    const VitConsts V = *reinterpret_cast<const VitConsts *>(vc);
+    hipLaunchKernelGGL(k2b_eventalign, dim3(B.n_reads), dim3(64), 0, st, B, O, (const VitRead *)vr, V);
+    hipLaunchKernelGGL(k2b_features, dim3((max_ref + 255) / 256, B.n_reads), dim3(256), 0, st, B, O);
+}

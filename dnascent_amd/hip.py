@@ -173,6 +173,22 @@ class Context:
         self._chk(lib().dn_get_trace(self.h, r, t.ctypes.data, e.ctypes.data, k.ctypes.data), "dn_get_trace")
         return t.reshape(n_bands, 100), e, k
 
+    def positions(self, r, n):
+        d = dict(coord=np.zeros(n, np.uint32), query_idx=np.zeros(n, np.uint32), ref_idx=np.zeros(n, np.uint32),
+                 indel=np.zeros(n, np.int32), n_signal=np.zeros(n, np.uint32), signal=np.zeros((n, 20), np.float32),
+                 core=np.zeros(n, np.float32), residual=np.zeros(n, np.float32))
+        km = np.zeros(n * 9, np.uint8)
+        self._chk(lib().dn_get_positions(self.h, r, d["coord"].ctypes.data, d["query_idx"].ctypes.data, d["ref_idx"].ctypes.data,
+                                         d["indel"].ctypes.data, km.ctypes.data, d["n_signal"].ctypes.data, d["signal"].ctypes.data,
+                                         d["core"].ctypes.data, d["residual"].ctypes.data), "dn_get_positions")
+        d["kmer"] = np.frombuffer(km.tobytes(), dtype="S9").copy() if n else np.zeros(0, "S9")
+        return d
+
+    def windows(self, r, n):
+        a = np.zeros(n, np.uint32); b = np.zeros(n, np.uint32); t = np.zeros(n, np.uint32); s = np.zeros(n)
+        self._chk(lib().dn_get_windows(self.h, r, a.ctypes.data, b.ctypes.data, t.ctypes.data, s.ctypes.data), "dn_get_windows")
+        return a, b, t, s
+
     # ---- measurement ------------------------------------------------------------------------
     def profile(self, on=True):
         lib().dn_profile_enable(self.h, int(on))
