@@ -31,7 +31,7 @@ void k2b_launch(const BatchDev &, const void *, const void *, const void *, unsi
 
 struct BandConstsH { double lp_stay, lp_step; };
 struct FillConstsH { double lp_skip, lp_trim, C, sigma, rsigma; };
-struct VitConstsH { double D2D, D2M, I2M, M2D, M2I, I2I; double c, d2, rd2; double initD[66]; };
+struct VitConstsH { double D2D, D2M, I2M, M2D, M2I, I2I; double c, d2, rd2, logc; double initD[66]; };
 struct VitReadH { double iM2M, eM2M, eM2MorD, eOrI; };
 struct EaDevH { unsigned *coord, *qidx, *ridx; int *indel; unsigned *nsig; float *sig, *core, *resid;
                 unsigned *win_ref, *win_len, *win_T; double *win_score; };
@@ -255,6 +255,7 @@ int dn_load_pore_model(dn_ctx *c, const double *mean, double sigma) {
     v.d2 = s2 + s2;
     v.rd2 = 1.0 / v.d2;
     v.c = 1.0 / sqrt(M_PI * v.d2);
+    v.logc = log(v.c);
     v.initD[0] = 0.0 + v.M2D;                                   // alignment.cpp:241
     for (int i = 1; i < 66; i++) v.initD[i] = v.initD[i - 1] + v.D2D;   // :246-251
     return DN_OK;

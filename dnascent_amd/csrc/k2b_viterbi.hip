@@ -22,7 +22,7 @@
 
 struct VitConsts {           // alignment.cpp:199-204 (host libm), normalPDF constants, deletion chain before the first event
     double D2D, D2M, I2M, M2D, M2I, I2I;
-    double c, d2, rd2;       // 1/sqrt(2 s^2 pi), 2 s^2, RN(1/(2 s^2))
+    double c, d2, rd2, logc; // 1/sqrt(2 s^2 pi), 2 s^2, RN(1/(2 s^2)), log(c)
     double initD[VT_NS];     // D_prev[i] of alignment.cpp:241-251: M2D, then + D2D sequentially
 };
 struct VitRead { double iM2M, eM2M, eM2MorD, eOrI; };   // alignment.cpp:207-210, per read (host libm)
@@ -32,9 +32,14 @@ struct EaDev {               // outputs, all at ref_off[r] (capacity = reference
     unsigned *win_ref, *win_len, *win_T; double *win_score;
 };
 
-__device__ __forceinline__ double qnan() { return __longlong_as_double(0x7ff8000000000000ll); }
-// lnGreaterThan (probability.cpp:107-131): NaN is never greater, anything is greater than NaN
-__device__ __forceinline__ bool ln_gt(double a, double b) { return (a == a) && !(a <= b); }
+// log(0) is NaN in the reference (probability.cpp) and every use of it is one of: NaN + x = NaN, and lnGreaterThan
+// (probability.cpp:107-131: NaN is never greater, anything is greater than NaN, first wins ties).  Writing log(0) as
+// -infinity instead gives the identical lattice: -inf + x = -inf for the finite x that occur, and "a > b" on the
+// extended reals IS lnGreaterThan.  So the kernel carries -inf, one compare per arg-max step, and converts back to NaN
+// where a value leaves the kernel (the window score).
+__device__ __forceinline__ double qnan() { return __longlong_as_double(0xfff0000000000000ll); }     // -inf, see above
+__device__ __forceinline__ double real_nan() { return __longlong_as_double(0x7ff8000000000000ll); }
+__device__ __forceinline__ bool ln_gt(double a, double b) { return a > b; }
 
 __device__ __forceinline__ double shl_prev_d(double v, double fill, int lane) {    // lane l <- lane l-1, lane 0 <- fill
     long long b = __double_as_longlong(v), f = __double_as_longlong(fill);
@@ -43,32 +48,24 @@ __device__ __forceinline__ double shl_prev_d(double v, double fill, int lane) { 
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
-// one lattice cell.  is0: position 0 (different transitions, alignment.cpp:278-328).  start: start_prev (0 at t == 0, NaN after)
-__device__ __forceinline__ void vit_cell(const bool is0, const double start, const double Ip, const double Mp, const double lI2,
-                                         const double lM2, const double lD2, const double lM1, const double lD1, const double e,
+// one lattice cell (alignment.cpp:278-285/:351-356 insertion, :305-310/:372-381 match, :326-328/:408-413 deletion).
+// Position 0 has no left neighbour and may come from START instead; it is expressed through the INPUTS so the cell has
+// no per-lane special case: for lane 0 the shifted-in left values are log(0), `s0` carries start_prev (0 at t == 0, log(0)
+// after; log(0) for every other lane) and tr3 is eOrI instead of D2M.  The codes a position-0 cell records are
+// re-read accordingly in the traceback (M: 3 means START, else M_0;  D: always START).
+// ("+ insProb" with insProb == 0.0 is dropped: it can only change the sign of an exact zero.)
+__device__ __forceinline__ void vit_cell(const double s0, const double l3, const double tr3, const double Ip, const double Mp,
+                                         const double lI2, const double lM2, const double lM1, const double lD1, const double e,
                                          const VitConsts &vc, const VitRead &vr, double &In, double &Mn, double &Dn, unsigned &code) {
-    const double NaN = qnan();
-    // insertion (alignment.cpp:278-285 / :351-356): candidates I_i, M_i, (START for position 0)
-    double bi = Ip + vc.I2I + 0.0; unsigned ci = 0;
-    { const double v = Mp + vc.M2I + 0.0; if (ln_gt(v, bi)) { bi = v; ci = 1; } }
-    { const double v = is0 ? (start + vc.M2I + 0.0) : NaN; if (ln_gt(v, bi)) { bi = v; ci = 2; } }
-    // match (:305-310 / :372-381): I_{i-1}, M_{i-1}, M_i, D_{i-1};  position 0: M_0, START
-    double bm; unsigned cm;
-    {
-        const double v0 = is0 ? NaN : (lI2 + vc.I2M + e);
-        const double v1 = is0 ? NaN : (lM2 + vr.eM2M + e);
-        const double v2 = Mp + vr.iM2M + e;
-        const double v3 = is0 ? (start + vr.eOrI + e) : (lD2 + vc.D2M + e);
-        bm = v0; cm = 0;
-        if (ln_gt(v1, bm)) { bm = v1; cm = 1; }
-        if (ln_gt(v2, bm)) { bm = v2; cm = 2; }
-        if (ln_gt(v3, bm)) { bm = v3; cm = 3; }
-        if (is0) cm = (cm == 3) ? 4u : 2u;              // position 0: {M_0 (code 2), START (code 4)}, first wins / all-NaN -> M_0
-    }
-    // silent deletion (:326-328 / :408-413): M(t, i-1), D(t, i-1);  position 0: NaN from START
+    double bi = Ip + vc.I2I; unsigned ci = 0;
+    { const double v = Mp + vc.M2I; if (ln_gt(v, bi)) { bi = v; ci = 1; } }
+    { const double v = s0 + vc.M2I; if (ln_gt(v, bi)) { bi = v; ci = 2; } }
+    double bm = lI2 + vc.I2M + e; unsigned cm = 0;
+    { const double v = lM2 + vr.eM2M + e; if (ln_gt(v, bm)) { bm = v; cm = 1; } }
+    { const double v = Mp + vr.iM2M + e;  if (ln_gt(v, bm)) { bm = v; cm = 2; } }
+    { const double v = l3 + tr3 + e;      if (ln_gt(v, bm)) { bm = v; cm = 3; } }
     double bd = lM1 + vc.M2D; unsigned cd = 0;
     { const double v = lD1 + vc.D2D; if (ln_gt(v, bd)) { bd = v; cd = 1; } }
-    if (is0) { bd = NaN; cd = 2; }
     In = bi; Mn = bm; Dn = bd;
     code = ci | (cm << 2) | (cd << 5);
 }
@@ -80,14 +77,25 @@ __device__ __forceinline__ double emission(double x, double mu, const VitConsts 
     const double q = n * vc.rd2;                          // exact n / d2 (FMA-corrected reciprocal, see k2_banded.hip)
     const double rem = fma(-q, vc.d2, n);
     const double arg = fma(rem, vc.rd2, q);
-    const double p = vc.c * exp(arg);                     // probability.cpp:147
-    return (p == 0.0) ? qnan() : log(p);                  // eln, probability.cpp:35-47 (p is never negative)
+    // eln(c * exp(arg)) (probability.cpp:147, :35-47).  Where exp() is a normal number this equals log(c) + arg to
+    // within the few ulps that separate any two correct implementations of exp/log (the reference's is glibc); where exp
+    // goes subnormal (arg < -708.4) the reference's result loses precision and at arg < -745.13 it is log(0): there the
+    // literal exp -> log chain is evaluated (rare: |x - mu| > 37 sigma).
+    double e = vc.logc + arg;
+    if (__any(arg < -708.0)) {
+        const double p = vc.c * exp(arg);
+        const double slow = (p == 0.0) ? qnan() : log(p);
+        e = (arg < -708.0) ? slow : e;
+    }
+    return e;
 }
 
 __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const VitRead *vrs, VitConsts vc) {
     __shared__ double xs[VT_TMAX];                        // scaled observations of the window
-    __shared__ unsigned tk[VT_TMAX];                      // their event indices
-    __shared__ unsigned short lab[VT_TMAX + VT_NS + 8];   // traceback labels (state << 8 | pos), reverse order
+    __shared__ unsigned tk_start[VT_TMAX], tk_len[VT_TMAX];   // raw span of each taken event (event.raw, reads.h:68-72)
+    __shared__ unsigned ev_slot[VT_TMAX], ev_cnt0[VT_TMAX];   // label pass: position slot of an M-labelled event / samples before it
+    __shared__ unsigned ps_p[VT_NS], ps_cnt[VT_NS];           // positions created by this window: lattice position, sample count
+    __shared__ unsigned short evlab[VT_TMAX];             // label of the state that emitted observation t: state << 8 | position
     __shared__ unsigned char bt[(VT_TMAX + 1) * VT_NS];   // backtrace codes: I 2 bits | M 3 bits | D 2 bits
     const int r = blockIdx.x;
     const int lane = threadIdx.x;
@@ -114,7 +122,6 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
 
     unsigned readHead = 0; int ri = 0;
     unsigned npos = 0, nwin = 0;
-    unsigned cur_coord = 0xffffffffu; unsigned cur_cnt = 0; unsigned cur_slot = 0;
     int fail = 0;
 
     while (ri < n_ref - (DN_K - 1)) {                     // alignment.cpp:556
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             const bool take = inw && (0. < mean) && (mean < 250.);      // :624
             const unsigned long long tm = __ballot(take);
             const unsigned p = nt + (unsigned)__popcll(tm & ((1ull << lane) - 1ull));
-            if (take && p < VT_TMAX) { tk[p] = e_idx; xs[p] = (mean - shift) / scale; }
+            if (take && p < VT_TMAX) { tk_start[p] = ev_start[e_idx]; tk_len[p] = ev_len[e_idx]; xs[p] = (mean - shift) / scale; }
             nt += (unsigned)__popcll(tm);
             if (stopm) break;
         }
@@ -170,6 +177,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
         // ---- Viterbi, anti-diagonal sweep: lane i = position i, time t = d - i ----
         const bool is0 = lane == 0;
         const double mu = (lane < N) ? model[rank_r[ri + lane]] : 0.0;
+        const double tr3 = is0 ? vr.eOrI : vc.D2M;
         double I1 = NaN, M1 = NaN, D1 = (lane < VT_NS) ? vc.initD[lane] : NaN;       // own last results (init column, :234-251)
         double oI2 = I1, oM2 = M1, oD2 = D1;                                       // own results one step earlier (tail cell only)
         double sI1 = NaN, sM1 = NaN, sD1 = shl_prev_d(D1, NaN, lane);              // lane i-1's results of the last step
@@ -178,32 +186,28 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
         const bool tail = N == 65;
         const double mu64 = tail ? model[rank_r[ri + 64]] : 0.0;
         double tI = NaN, tM = NaN, tD = vc.initD[64];
-        const int nsteps = T + N - 1;
-        for (int d = 0; d < nsteps; d++) {       // N == 65: nsteps = T + 64 also covers the tail cell's last step
+        const int nsteps = T + N - 1;                      // N == 65: T + 64 steps also cover the tail cell's last step
+#pragma unroll 2
+        for (int d = 0; d < nsteps; d++) {
             if (tail) {
                 const int t64 = d - 64;
                 if (t64 >= 0 && t64 < T) {                 // uses lane 63's results of steps d-1 (time t64) and d-2 (time t64-1)
                     const double e = emission(xs[t64], mu64, vc);
                     double In, Mn, Dn; unsigned code;
-                    vit_cell(false, NaN, tI, tM, oI2, oM2, oD2, M1, D1, e, vc, vr, In, Mn, Dn, code);
+                    vit_cell(NaN, oD2, vc.D2M, tI, tM, oI2, oM2, M1, D1, e, vc, vr, In, Mn, Dn, code);
                     tI = In; tM = Mn; tD = Dn;
                     if (lane == 63) bt[(t64 + 1) * VT_NS + 64] = (unsigned char)code;
                 }
+                oI2 = I1; oM2 = M1; oD2 = D1;
             }
             const int t = d - lane;
-            const bool act = (t >= 0) && (t < T) && (lane < N) && (lane < 64);
-            double In = I1, Mn = M1, Dn = D1; unsigned code = 0;
-            {
-                const double x = xs[act ? t : 0];
-                const double e = emission(x, mu, vc);
-                const double start = (t == 0) ? 0.0 : NaN;                          // :235, :432
-                double a, b, c2;
-                vit_cell(is0, start, I1, M1, sI2, sM2, sD2, sM1, sD1, e, vc, vr, a, b, c2, code);
-                if (act) { In = a; Mn = b; Dn = c2; }
-            }
-            if (act) bt[(t + 1) * VT_NS + lane] = (unsigned char)code;
-            oI2 = I1; oM2 = M1; oD2 = D1;
-            I1 = In; M1 = Mn; D1 = Dn;
+            const bool act = (t >= 0) && (t < T) && (lane < N);
+            const double e = emission(xs[act ? t : 0], mu, vc);
+            const double s0 = (is0 && t == 0) ? 0.0 : NaN;                          // start_prev (:235, :432), position 0 only
+            const double l3 = is0 ? s0 : sD2;
+            double a, b, c2; unsigned code;
+            vit_cell(s0, l3, tr3, I1, M1, sI2, sM2, sM1, sD1, e, vc, vr, a, b, c2, code);
+            if (act) { bt[(t + 1) * VT_NS + lane] = (unsigned char)code; I1 = a; M1 = b; D1 = c2; }
             sI2 = sI1; sM2 = sM1; sD2 = sD1;
             sI1 = shl_prev_d(I1, NaN, lane); sM1 = shl_prev_d(M1, NaN, lane); sD1 = shl_prev_d(D1, NaN, lane);
         }
@@ -215,72 +219,121 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
         double score = fD; int st = 0;
         { const double v = fM + vr.eM2MorD; if (ln_gt(v, score)) { score = v; st = 1; } }
         { const double v = fI + vc.I2M; if (ln_gt(v, score)) { score = v; st = 2; } }
-        // ---- traceback (:460-509), wave-uniform; labels stored in reverse order ----
-        int nlab = 0, i = N - 1, col = T;
-        int nonD = 0, firstM_seen = -1, lastM_ref = 0;
-        bool done = false;
-        int guard = 3 * N * (T + 1) + 8;
-        while (!done && guard-- > 0 && nlab < VT_TMAX + VT_NS + 8) {
-            lab[nlab++] = (unsigned short)((st << 8) | i);
-            if (st != 0) {
-                if (st == 1 && firstM_seen < 0) { firstM_seen = nonD; lastM_ref = i; }
-                nonD++;
+        // ---- traceback (:460-509), wave-uniform.  Every emitting state (M or I) visited at column col emitted observation
+        // col-1, so the walk writes one label per observation; silent D states only move along the column. ----
+        {
+            int i = N - 1, col = T;
+            bool done = false;
+            int guard = 3 * N * (T + 1) + 8;
+            while (!done && guard-- > 0) {
+                const unsigned code = (col > 0) ? bt[col * VT_NS + i] : 0u;
+                if (st == 0) {
+                    const unsigned cdx = (i == 0) ? 2u : ((col == 0) ? 1u : ((code >> 5) & 3u));    // D_0 always comes from START
+                    if (cdx == 2) done = true; else { st = (cdx == 0) ? 1 : 0; i -= 1; }
+                } else if (col <= 0) {
+                    done = true;                             // only reachable in an all-log(0) lattice
+                } else {
+                    if (lane == 0) evlab[col - 1] = (unsigned short)((st << 8) | i);
+                    if (st == 1) {
+                        unsigned cmx = (code >> 2) & 7u;
+                        if (i == 0) cmx = (cmx == 3u) ? 4u : 2u;                 // position 0: {M_0, START}
+                        if (cmx == 4) done = true;
+                        else { st = (cmx == 0) ? 2 : ((cmx == 3) ? 0 : 1); i -= (cmx != 2) ? 1 : 0; }
+                    } else {
+                        const unsigned cix = code & 3u;
+                        if (cix == 2) done = true; else st = (cix == 0) ? 2 : 1;
+                    }
+                    col -= 1;
+                }
+                if (col < 0 || i < 0) done = true;          // cannot happen for a finite score; guards all-log(0) lattices
             }
-            if (st == 0) {
-                const unsigned cdx = (col == 0) ? (i == 0 ? 2u : 1u) : ((bt[col * VT_NS + i] >> 5) & 3u);
-                if (cdx == 2) done = true; else if (cdx == 0) { st = 1; i -= 1; } else { st = 0; i -= 1; }
-            } else if (st == 1) {
-                const unsigned cmx = (bt[col * VT_NS + i] >> 2) & 7u;
-                if (cmx == 4) done = true; else if (cmx == 0) { st = 2; i -= 1; } else if (cmx == 1) { st = 1; i -= 1; }
-                else if (cmx == 2) { st = 1; } else { st = 0; i -= 1; }
-                col -= 1;
-            } else {
-                const unsigned cix = bt[col * VT_NS + i] & 3u;
-                if (cix == 2) done = true; else if (cix == 0) st = 2; else st = 1;
-                col -= 1;
-            }
-            if (col < 0 || i < 0) done = true;             // cannot happen for a finite score; guards NaN lattices
         }
-        const int lastM_ev = (firstM_seen >= 0) ? (nonD - 1 - firstM_seen) : 0;    // :655-672
-        if (firstM_seen < 0) lastM_ref = 0;
+        __syncthreads();
         // ---- window log ----
         if (lane == 0) {
             O.win_ref[f0 + nwin] = (unsigned)ri; O.win_len[f0 + nwin] = (unsigned)W; O.win_T[f0 + nwin] = (unsigned)T;
-            O.win_score[f0 + nwin] = score;
+            O.win_score[f0 + nwin] = (score == qnan()) ? real_nan() : score;   // log(0) leaves the kernel as NaN
         }
         nwin++;
-        // ---- feature fill (:676-736 -> reads.h:292-304): every raw sample of an event labelled M goes to its position ----
-        int evIdx = 0;
-        for (int k = nlab - 1; k >= 0; k--) {
-            const unsigned L = lab[k];
-            const int lst = (int)(L >> 8), p = (int)(L & 0xff);
-            if (lst == 0) continue;
-            if (lst == 1) {
-                const unsigned coord = is_rev ? (unsigned)(coord0 - p - 1) : (unsigned)(coord0 + p);
-                if (coord != cur_coord) {
-                    cur_coord = coord; cur_cnt = 0; cur_slot = npos++;
-                    if (lane == 0) {
-                        const unsigned idxRef = (unsigned)(ri + p + DN_K / 2);
-                        O.coord[f0 + cur_slot] = coord; O.ridx[f0 + cur_slot] = idxRef; O.qidx[f0 + cur_slot] = r2q[idxRef];
-                        O.indel[f0 + cur_slot] = indel;
-                    }
-                    // (the signal array is zero-filled before the launch: zero padding of reads.h:162-168)
+        // ---- feature fill (:676-736 -> reads.h:292-304), parallel over the observations of the window.
+        // Every raw sample of an event labelled M goes to the position of that label; consecutive M labels with the same
+        // lattice position share one AlignedPosition (coordinates rise strictly, so a window never reopens an older one).
+        // Per event: is it the first M of its position (-> slot number by prefix count) and how many samples of the same
+        // position precede it (-> segmented prefix sum).  64 observations per round, carries in scalars. ----
+        const unsigned slot0 = npos;
+        int lastM_ev = 0, lastM_ref = 0;                    // :655-672 (0, 0 when the path holds no match)
+        {
+            int carry_pos = -1;                             // lattice position of the last M label seen so far
+            unsigned carry_cnt = 0;                         // samples accumulated in that position
+            unsigned carry_slots = 0;                       // positions created so far in this window
+            for (int base = 0; base < T; base += 64) {
+                const int e = base + lane;
+                const bool in = e < T;
+                const unsigned L = in ? evlab[e] : 0u;
+                const bool isM = in && ((L >> 8) == 1u);
+                const int p = (int)(L & 0xffu);
+                const unsigned len = isM ? tk_len[e] : 0u;
+                const unsigned long long mm = __ballot(isM);
+                // position of the previous M label (this round or carried)
+                const unsigned long long below = mm & ((1ull << lane) - 1ull);
+                const int pl = below ? (63 - __clzll((long long)below)) : 0;
+                const int pv = __shfl((int)L, pl) & 0xff;                          // (all lanes take part in the shuffle)
+                const int prev_p = below ? pv : carry_pos;
+                const bool head = isM && (p != prev_p);
+                const unsigned long long hm = __ballot(head);
+                const unsigned slot = slot0 + carry_slots + (unsigned)__popcll(hm & ((2ull << lane) - 1ull)) - 1u;   // valid for M lanes
+                // samples before this event inside its position: inclusive scan of len restarted at heads
+                unsigned run = len;
+#pragma unroll
+                for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                    const unsigned up = __shfl_up(run, dlt);
+                    // add the partial sum of the lanes [lane-2*dlt+1 .. lane-dlt] unless a head lies in (lane-dlt, lane]
+                    const unsigned long long span = (lane >= dlt) ? (((2ull << lane) - 1ull) & ~((2ull << (lane - dlt)) - 1ull)) : ~0ull;
+                    if (lane >= dlt && !(hm & span)) run += up;
                 }
-                const unsigned e_idx = tk[evIdx];
-                const unsigned rs = ev_start[e_idx], rl = ev_len[e_idx];
-                for (unsigned j0 = 0; j0 < rl && cur_cnt + j0 < DN_RAWDEPTH_DEV; j0 += 64) {
-                    const unsigned j = j0 + lane;
-                    const unsigned slot = cur_cnt + j;
-                    if (j < rl && slot < DN_RAWDEPTH_DEV) {
-                        const float v = ((float)adc[rs + j] + cal_off) * cal_sc;         // pod5.cpp:60
-                        const double scaled = ((double)v - shift) / scale;               // alignment.cpp:705
-                        O.sig[(f0 + cur_slot) * DN_RAWDEPTH_DEV + slot] = (float)scaled; // reads.h:156
-                    }
+                const unsigned long long hb = hm & ((2ull << lane) - 1ull);       // heads at or below this lane
+                const unsigned before = run - len + (hb ? 0u : carry_cnt);       // no head yet in this round: the carried position continues
+                if (isM) { ev_slot[e] = slot; ev_cnt0[e] = before; }
+                else if (in) ev_slot[e] = 0xffffffffu;
+                if (head) ps_p[slot - slot0] = (unsigned)p;
+                // last M of each position in this round records the running count (later rounds may overwrite with more)
+                const unsigned long long above = mm & ~((2ull << lane) - 1ull);
+                bool last_of_pos = false;
+                if (isM) {
+                    if (!above) last_of_pos = true;
+                    else { const int nl = __ffsll((long long)above) - 1; last_of_pos = ((hm >> nl) & 1ull) != 0ull; }
                 }
-                cur_cnt += rl;
-                if (lane == 0) O.nsig[f0 + cur_slot] = cur_cnt;
+                if (last_of_pos) ps_cnt[slot - slot0] = before + len;
+                // carries
+                if (mm) {
+                    const int ll = 63 - __clzll((long long)mm);
+                    carry_pos = (int)(__shfl((int)L, ll) & 0xff);
+                    carry_cnt = __shfl(before + len, ll);
+                    lastM_ev = base + ll; lastM_ref = carry_pos;
+                }
+                carry_slots += (unsigned)__popcll(hm);
             }
-            evIdx++;
+            npos += carry_slots;
+            const int n_new = (int)carry_slots;
+            __syncthreads();
+            for (int e = lane; e < T; e += 64) {            // samples: one lane per event
+                const unsigned slot = ev_slot[e];
+                if (slot == 0xffffffffu) continue;
+                const unsigned c0 = ev_cnt0[e], rs = tk_start[e], rl = tk_len[e];
+                for (unsigned j = 0; j < rl && c0 + j < DN_RAWDEPTH_DEV; j++) {
+                    const float v = ((float)adc[rs + j] + cal_off) * cal_sc;             // pod5.cpp:60
+                    const double scaled = ((double)v - shift) / scale;                   // alignment.cpp:705
+                    O.sig[(f0 + slot) * DN_RAWDEPTH_DEV + c0 + j] = (float)scaled;       // reads.h:156
+                }
+            }
+            for (int q = lane; q < n_new; q += 64) {        // position records: one lane per new position
+                const unsigned p = ps_p[q];
+                const unsigned idxRef = (unsigned)(ri + (int)p + DN_K / 2);
+                const unsigned slot = slot0 + (unsigned)q;
+                O.coord[f0 + slot] = is_rev ? (unsigned)(coord0 - (int)p - 1) : (unsigned)(coord0 + (int)p);
+                O.ridx[f0 + slot] = idxRef; O.qidx[f0 + slot] = r2q[idxRef];
+                O.indel[f0 + slot] = indel; O.nsig[f0 + slot] = ps_cnt[q];
+            }
         }
         readHead += (unsigned)lastM_ev + 1u;                // :739-740
         ri += lastM_ref + 1;
