@@ -28,6 +28,10 @@ void k2_launch_fill(const BatchDev &, const void *, const void *, bool, hipStrea
 void k2_launch_chase(const BatchDev &, uint8_t *, hipStream_t);
 void k2_launch_post(const BatchDev &, const uint8_t *, float *, const void *, hipStream_t);
 void k2b_launch(const BatchDev &, const void *, const void *, const void *, unsigned, hipStream_t);
+struct CnnRows { const unsigned *row_off; const uint8_t *valid; unsigned rows, r0, r1; };
+struct CnnRun { const dn_cnn_op *ops; int n_ops; const float *wts; float *buf[8]; int n_buf; CnnRows rows; uint8_t *valid;
+                 const float *core, *resid, *sig; float *probs; unsigned max_pos; };
+int k3_run(const BatchDev &, const CnnRun &, hipStream_t);
 
 struct BandConstsH { double lp_stay, lp_step; };
 struct FillConstsH { double lp_skip, lp_trim, C, sigma, rsigma; };
@@ -68,6 +72,8 @@ struct dn_ctx {
     uint8_t *d_path_from = nullptr; float *d_path_lp = nullptr;
     uint64_t *d_trace_off = nullptr;
     FillConstsH fc{};
+    std::vector<dn_cnn_op> cnn_ops; float *d_cnn_w = nullptr; size_t cnn_nw = 0; int cnn_nbuf = 0; DevBuf cnn_buf[8], cnn_valid, cnn_rowoff;
+    float *d_probs = nullptr;
     VitConstsH vc{}; EaDevH ea{}; VitReadH *d_vitread = nullptr; unsigned max_ref = 0;
     // profiling
     bool prof = false;
@@ -113,7 +119,7 @@ static int dgrow(dn_ctx *c, DevBuf &b, size_t bytes) {
 }
 
 static const char *KNAMES[DN_K_COUNT] = { "k1_scan", "k1_tstat", "k1_detect", "k1_events", "k_ranks", "k_quantile", "k_prep",
-                                          "k2_fill", "k2_chase+k2_post", "k_theilsen", "k2b_viterbi" };
+                                          "k2_fill", "k2_chase+k2_post", "k_theilsen", "k2b_viterbi", "k3_cnn" };
 
 struct Timed {
     dn_ctx *c; int k; hipEvent_t a = nullptr, b = nullptr;
@@ -214,6 +220,10 @@ void dn_ctx_destroy(dn_ctx *c) {
     if (c->trace.p) hipFree(c->trace.p);
     if (c->bandc.p) hipFree(c->bandc.p);
     if (c->d_model) hipFree(c->d_model);
+    if (c->d_cnn_w) hipFree(c->d_cnn_w);
+    for (auto &b : c->cnn_buf) if (b.p) hipFree(b.p);
+    if (c->cnn_valid.p) hipFree(c->cnn_valid.p);
+    if (c->cnn_rowoff.p) hipFree(c->cnn_rowoff.p);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -329,7 +339,7 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
         (rc = dalloc(c, &c->ea.indel, (size_t)NR)) || (rc = dalloc(c, &c->ea.nsig, (size_t)NR)) || (rc = dalloc(c, &c->ea.sig, (size_t)NR * DN_RAWDEPTH)) ||
         (rc = dalloc(c, &c->ea.core, (size_t)NR)) || (rc = dalloc(c, &c->ea.resid, (size_t)NR)) || (rc = dalloc(c, &c->ea.win_ref, (size_t)NR)) ||
         (rc = dalloc(c, &c->ea.win_len, (size_t)NR)) || (rc = dalloc(c, &c->ea.win_T, (size_t)NR)) || (rc = dalloc(c, &c->ea.win_score, (size_t)NR)) ||
-        (rc = dalloc(c, &c->d_vitread, (size_t)n))) return rc;
+        (rc = dalloc(c, &c->d_vitread, (size_t)n)) || (rc = dalloc(c, &c->d_probs, (size_t)NR * 3))) return rc;
     c->max_ref = 0;
     for (uint32_t r = 0; r < n; r++) c->max_ref = std::max<unsigned>(c->max_ref, (unsigned)(c->h_ref_off[r + 1] - c->h_ref_off[r]));
     HIPCHK(c, hipMemsetAsync(B.res, 0, n * sizeof(ReadRes), c->stream));
@@ -612,6 +622,85 @@ int dn_get_windows(dn_ctx *c, uint32_t read, uint32_t *ref_index, uint32_t *wind
     if ((rc = d2h(c, ref_index, c->ea.win_ref + f0, nw)) || (rc = d2h(c, window_len, c->ea.win_len + f0, nw)) ||
         (rc = d2h(c, n_obs, c->ea.win_T + f0, nw))) return rc;
     return d2h(c, score, c->ea.win_score + f0, nw);
+}
+
+int dn_load_cnn(dn_ctx *c, const dn_cnn_op *ops, uint32_t n_ops, const float *weights, uint64_t n_weights, uint32_t n_buffers) {
+    if (!c || !ops || !weights || n_ops == 0 || n_buffers == 0 || n_buffers > 8) return DN_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (uint32_t i = 0; i < n_ops; i++) {
+        const dn_cnn_op &o = ops[i];
+        if (o.op < DN_CNN_ENCODE_GRU || o.op > DN_CNN_DENSE_SOFTMAX) return fail(c, DN_ERR_ARG, "cnn op %u: unknown type %d", i, o.op);
+        if (o.cin > 256 || o.cout > 256) return fail(c, DN_ERR_ARG, "cnn op %u: more than 256 channels", i);
+        if (o.op == DN_CNN_CONV && (o.cin % 32 || o.cout % 64 || !(o.k & 1))) return fail(c, DN_ERR_ARG, "cnn op %u: conv shape not supported", i);
+    }
+    if (c->d_cnn_w) { hipFree(c->d_cnn_w); c->dev_bytes -= c->cnn_nw * sizeof(float); c->d_cnn_w = nullptr; }
+    HIPCHK(c, hipMalloc((void **)&c->d_cnn_w, n_weights * sizeof(float)));
+    c->cnn_nw = n_weights; c->dev_bytes += n_weights * sizeof(float);
+    HIPCHK(c, hipMemcpyAsync(c->d_cnn_w, weights, n_weights * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cnn_ops.assign(ops, ops + n_ops);
+    c->cnn_nbuf = (int)n_buffers;
+    return DN_OK;
+}
+
+// activation rows resident per pass: 4 buffers x 256 channels x 4 B = 4 KiB per row -> 16 GiB of HBM at the default cap
+static uint64_t cnn_row_cap() {
+    const char *e = getenv("DN_CNN_ROWS");
+    const uint64_t v = e ? strtoull(e, nullptr, 10) : (4ull << 20);
+    return std::max<uint64_t>(v, 1024);
+}
+
+int dn_run_cnn(dn_ctx *c) {
+    int rc = need(c, 6, "dn_run_cnn"); if (rc) return rc;
+    if (c->cnn_ops.empty()) return fail(c, DN_ERR_STATE, "dn_load_cnn must be called first");
+    const uint32_t n = (uint32_t)c->B.n_reads;
+    if ((rc = fetch_res(c))) return rc;                      // rows per read = positions found by eventalign (small D2H)
+    // reads are packed end to end, CNN_PAD (8) zero rows around each; passes of at most cnn_row_cap() rows
+    const uint64_t cap = cnn_row_cap();
+    std::vector<unsigned> row_off(n, 0u);
+    struct Pass { uint32_t r0, r1; unsigned rows, max_pos; };
+    std::vector<Pass> passes;
+    uint64_t rows = 8; unsigned max_pos = 1; uint32_t r0 = 0; uint64_t max_rows = 0;
+    for (uint32_t r = 0; r < n; r++) {
+        const unsigned np = c->h_res[r].status == 0 ? c->h_res[r].n_positions : 0;
+        if (rows + np + 8 > cap && r > r0) {
+            const uint64_t rr = (rows + 127) / 128 * 128;
+            passes.push_back({ r0, r, (unsigned)rr, max_pos }); max_rows = std::max(max_rows, rr);
+            r0 = r; rows = 8; max_pos = 1;
+        }
+        row_off[r] = (unsigned)rows;
+        rows += np + 8;
+        if (rows >= (1ull << 31)) return fail(c, DN_ERR_OVERFLOW, "read %u has too many positions for one CNN pass", r);
+        max_pos = std::max(max_pos, np);
+    }
+    { const uint64_t rr = (rows + 127) / 128 * 128; passes.push_back({ r0, n, (unsigned)rr, max_pos }); max_rows = std::max(max_rows, rr); }
+    for (int b = 0; b < c->cnn_nbuf; b++)
+        if ((rc = dgrow(c, c->cnn_buf[b], (size_t)max_rows * 256 * sizeof(float)))) return rc;
+    if ((rc = dgrow(c, c->cnn_valid, (size_t)max_rows)) || (rc = dgrow(c, c->cnn_rowoff, n * sizeof(unsigned)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->cnn_rowoff.p, row_off.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));           // row_off is a local
+    Timed t(c, DN_K_CNN);
+    for (const Pass &ps : passes) {
+        HIPCHK(c, hipMemsetAsync(c->cnn_valid.p, 0, (size_t)ps.rows, c->stream));
+        CnnRun run{};
+        run.ops = c->cnn_ops.data(); run.n_ops = (int)c->cnn_ops.size(); run.wts = c->d_cnn_w;
+        for (int b = 0; b < c->cnn_nbuf; b++) run.buf[b] = (float *)c->cnn_buf[b].p;
+        run.n_buf = c->cnn_nbuf;
+        run.rows.row_off = (const unsigned *)c->cnn_rowoff.p; run.rows.valid = (const uint8_t *)c->cnn_valid.p; run.rows.rows = ps.rows;
+        run.rows.r0 = ps.r0; run.rows.r1 = ps.r1;
+        run.valid = (uint8_t *)c->cnn_valid.p;
+        run.core = c->ea.core; run.resid = c->ea.resid; run.sig = c->ea.sig; run.probs = c->d_probs; run.max_pos = ps.max_pos;
+        if (k3_run(c->B, run, c->stream)) return fail(c, DN_ERR_ARG, "unsupported op in the CNN description");
+    }
+    HIPCHK(c, hipGetLastError());
+    c->stage = 7;
+    return DN_OK;
+}
+
+int dn_get_probabilities(dn_ctx *c, uint32_t read, float *probs) {
+    CHECK_READ(7, "dn_get_probabilities");
+    if ((rc = fetch_res(c))) return rc;
+    return d2h(c, probs, c->d_probs + c->h_ref_off[read] * 3, (size_t)c->h_res[read].n_positions * 3);
 }
 
 int dn_profile_enable(dn_ctx *c, int on) { if (!c) return DN_ERR_ARG; c->prof = on != 0; return DN_OK; }

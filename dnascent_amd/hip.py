@@ -11,7 +11,7 @@ from . import build as _build
 
 DN_OK = 0
 K_NAMES = ["DN_K_SCAN", "DN_K_TSTAT", "DN_K_DETECT", "DN_K_EVENTS", "DN_K_RANKS", "DN_K_QUANTILE", "DN_K_PREP",
-           "DN_K_BAND_FILL", "DN_K_BAND_TRACE", "DN_K_THEILSEN", "DN_K_VITERBI"]
+           "DN_K_BAND_FILL", "DN_K_BAND_TRACE", "DN_K_THEILSEN", "DN_K_VITERBI", "DN_K_CNN"]
 DN_K_COUNT = len(K_NAMES)
 for _i, _n in enumerate(K_NAMES):
     globals()[_n] = _i
@@ -19,7 +19,7 @@ for _i, _n in enumerate(K_NAMES):
 # every symbol include/dnascent_hip.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = ["dn_abi_version", "dn_device_count", "dn_ctx_create", "dn_ctx_destroy", "dn_last_error", "dn_sync",
            "dn_load_pore_model", "dn_batch_upload", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded",
-           "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_get_summaries", "dn_get_prefix_sums",
+           "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_load_cnn", "dn_run_cnn", "dn_get_probabilities", "dn_get_summaries", "dn_get_prefix_sums",
            "dn_get_tstats", "dn_get_scrappie_events", "dn_get_events", "dn_get_kmer_ranks", "dn_get_alignment",
            "dn_get_cleaned", "dn_get_trace", "dn_get_positions", "dn_get_windows", "dn_profile_enable", "dn_profile_get",
            "dn_profile_reset", "dn_kernel_name", "dn_device_bytes"]
@@ -30,6 +30,37 @@ class BatchDesc(C.Structure):
                 ("cal_scale", C.c_void_p), ("basecall", C.c_void_p), ("basecall_off", C.c_void_p), ("refseq", C.c_void_p),
                 ("refseq_off", C.c_void_p), ("ref2query", C.c_void_p), ("query2ref", C.c_void_p), ("ref2del", C.c_void_p),
                 ("ref_start", C.c_void_p), ("ref_end", C.c_void_p), ("is_reverse", C.c_void_p)]
+
+
+class CnnOp(C.Structure):
+    _fields_ = [("op", C.c_int32), ("src", C.c_int32), ("dst", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("k", C.c_int32),
+                ("cin", C.c_int32), ("cout", C.c_int32), ("relu", C.c_int32), ("reserved", C.c_int32), ("w", C.c_int64),
+                ("scale", C.c_int64), ("shift", C.c_int64), ("aux", C.c_int64 * 6)]
+
+
+CNN_OPCODE = {"encode_gru": 0, "conv": 1, "dwconv": 2, "add_relu": 3, "dense_softmax": 4}
+
+
+def cnn_ops_from_description(desc):
+    """dnascent_amd.cnn_model description (dict) -> array of dn_cnn_op."""
+    ops = (CnnOp * len(desc["ops"]))()
+    for i, o in enumerate(desc["ops"]):
+        c = ops[i]
+        c.op = CNN_OPCODE[o["op"]]
+        if o["op"] == "encode_gru":
+            c.dst = o["dst"]; c.cout = o["cout"]
+            for j, k in enumerate(("g1_kernel", "g1_recurrent", "g1_bias", "g2_kernel", "g2_recurrent", "g2_bias")):
+                c.aux[j] = o[k]
+        elif o["op"] == "conv":
+            c.src, c.dst, c.k, c.cin, c.cout, c.relu = o["src"], o["dst"], o["k"], o["cin"], o["cout"], int(o["relu"])
+            c.w, c.scale, c.shift = o["w"], o["scale"], o["shift"]
+        elif o["op"] == "dwconv":
+            c.src, c.dst, c.k, c.cin, c.cout, c.w = o["src"], o["dst"], o["k"], o["c"], o["c"], o["w"]
+        elif o["op"] == "add_relu":
+            c.a, c.b, c.dst, c.cin, c.cout = o["a"], o["b"], o["dst"], o["c"], o["c"]
+        elif o["op"] == "dense_softmax":
+            c.src, c.cin, c.cout, c.w, c.shift = o["src"], o["cin"], o["cout"], o["w"], o["b"]
+    return ops
 
 
 SUMMARY_DTYPE = np.dtype([
@@ -60,6 +91,9 @@ def lib():
         for n in ("dn_sync", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded", "dn_run_theilsen", "dn_run_normalise",
                   "dn_run_eventalign", "dn_profile_reset"):
             getattr(L, n).argtypes = [C.c_void_p]
+        L.dn_load_cnn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32]
+        L.dn_run_cnn.argtypes = [C.c_void_p]
+        L.dn_get_probabilities.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.dn_get_summaries.argtypes = [C.c_void_p, C.c_void_p]
         L.dn_get_prefix_sums.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.dn_get_tstats.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -115,6 +149,16 @@ class Context:
         m = np.ascontiguousarray(mean, np.float64)
         assert m.shape[0] == 262144
         self._chk(lib().dn_load_pore_model(self.h, m.ctypes.data, sigma), "dn_load_pore_model")
+
+    def load_cnn(self, desc, blob):
+        ops = cnn_ops_from_description(desc)
+        w = np.ascontiguousarray(blob, np.float32)
+        self._chk(lib().dn_load_cnn(self.h, ops, len(desc["ops"]), w.ctypes.data, w.shape[0], desc["n_buffers"]), "dn_load_cnn")
+
+    def probabilities(self, r, n):
+        p = np.zeros((n, 3), np.float32)
+        self._chk(lib().dn_get_probabilities(self.h, r, p.ctypes.data), "dn_get_probabilities")
+        return p
 
     def upload(self, desc, n_reads, keep=None):
         self._keep = keep

@@ -86,6 +86,25 @@ int dn_run_theilsen(dn_ctx *ctx);       /* estimateScaling_theilSen (event_handl
 int dn_run_normalise(dn_ctx *ctx);      /* normaliseEvents (event_handling.h:13) == the four stages above */
 int dn_run_eventalign(dn_ctx *ctx);     /* eventalign (alignment.h:22): windowed Viterbi + feature fill + tensor packing (reads.h:305-372) */
 
+/* ---- CNN (replaces model_load_*_twoInputs + TF_SessionRun, tensor.cpp:12-106, detect.cpp:577-675) ----
+ * The network is DATA: an ordered op list over `n_buffers` activation buffers + one fp32 weight blob
+ * (dnascent_amd/cnn_model.py; the reference's SavedModel graph is absent from its checkout, only the weight shapes
+ * survive).  Inputs are the three tensors runCNN feeds (core / residual sequence, 20 raw samples per position,
+ * reads.h:305-372), already on the device after dn_run_eventalign; output = [n_positions, 3] class probabilities
+ * (0 thymidine, 1 BrdU, 2 EdU; detect.cpp:695). */
+enum { DN_CNN_ENCODE_GRU = 0, DN_CNN_CONV = 1, DN_CNN_DWCONV = 2, DN_CNN_ADD_RELU = 3, DN_CNN_DENSE_SOFTMAX = 4 };
+typedef struct {
+    int32_t op;                 /* DN_CNN_* */
+    int32_t src, dst, a, b;     /* activation buffer indices */
+    int32_t k, cin, cout, relu; /* kernel width, channels, fused ReLU */
+    int32_t reserved;
+    int64_t w, scale, shift;    /* offsets (in floats) into the weight blob: kernel, folded BatchNorm scale / shift(+bias) */
+    int64_t aux[6];             /* ENCODE_GRU: kernel/recurrent/bias offsets of the two GRUs */
+} dn_cnn_op;
+int dn_load_cnn(dn_ctx *ctx, const dn_cnn_op *ops, uint32_t n_ops, const float *weights, uint64_t n_weights, uint32_t n_buffers);
+int dn_run_cnn(dn_ctx *ctx);            /* runCNN for every read that passed eventalign */
+int dn_get_probabilities(dn_ctx *ctx, uint32_t read, float *probs /* [n_positions * 3] */);
+
 /* ---- per-read results ---- */
 typedef struct {
     int32_t status;                 /* DN_READ_* */
@@ -126,7 +145,7 @@ int dn_get_windows(dn_ctx *ctx, uint32_t read, uint32_t *ref_index, uint32_t *wi
 
 /* ---- measurement ---- */
 enum { DN_K_SCAN = 0, DN_K_TSTAT, DN_K_DETECT, DN_K_EVENTS, DN_K_RANKS, DN_K_QUANTILE, DN_K_PREP, DN_K_BAND_FILL,
-       DN_K_BAND_TRACE, DN_K_THEILSEN, DN_K_VITERBI, DN_K_COUNT };
+       DN_K_BAND_TRACE, DN_K_THEILSEN, DN_K_VITERBI, DN_K_CNN, DN_K_COUNT };
 int dn_profile_enable(dn_ctx *ctx, int on);     /* HIP events around every kernel launch on the context's stream */
 int dn_profile_get(dn_ctx *ctx, int kernel, double *total_ms, uint32_t *launches);
 int dn_profile_reset(dn_ctx *ctx);

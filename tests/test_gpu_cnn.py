@@ -1,0 +1,63 @@
+"""K3 parity: HIP CNN executor (dn_run_cnn, C-ABI) vs the stock-PyTorch fp32 rendering of the same description.
+Tolerance: 1e-4 absolute on the class probabilities (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from dnascent_amd import cnn_model, hip, host, synth
+import cnn_torch_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _run(model, specs, env_rows=None, monkeypatch=None):
+    if env_rows is not None:
+        monkeypatch.setenv("DN_CNN_ROWS", str(env_rows))
+    reads = [synth.make_read(seed, n, model=model, **kw) for seed, n, kw in specs]
+    desc, blob, ref = cnn_model.default_model()
+    ctx = hip.Context(0)
+    ctx.load_pore_model(model, 0.14)
+    ctx.load_cnn(desc, blob)
+    b = host.ReadBatch()
+    for r in reads:
+        assert b.add_synth(r) >= 0
+    b.upload(ctx)
+    ctx.run("normalise"); ctx.run("eventalign"); ctx.run("cnn")
+    ctx.sync()
+    return ctx, ref
+
+
+def _check(ctx, ref, n_reads):
+    s = ctx.summaries()
+    worst = 0.0
+    for r in range(n_reads):
+        if s["status"][r] != 0:
+            continue
+        n = int(s["n_positions"][r])
+        pos = ctx.positions(r, n)
+        got = ctx.probabilities(r, n)
+        want = cnn_torch_ref.run(ref, pos["core"], pos["residual"], pos["signal"])
+        assert got.shape == want.shape
+        worst = max(worst, float(np.abs(got - want).max()))
+        assert np.allclose(got.sum(1), 1.0, atol=1e-5)
+    return worst, s
+
+
+GOOD = dict(sub_rate=0.003, ins_rate=0.001, del_rate=0.001)
+
+
+def test_cnn_matches_torch_reference(model):
+    specs = [(100, 2500, GOOD), (101, 3600, dict(is_reverse=True)), (102, 3000, GOOD)]
+    ctx, ref = _run(model, specs)
+    worst, s = _check(ctx, ref, len(specs))
+    assert (s["status"] == 0).all() and (s["n_positions"] > 1000).all()
+    assert worst < TOL, worst
+
+
+def test_cnn_failed_read_and_multiple_passes(model, monkeypatch):
+    """A read that fails QC produces no rows; a small row cap forces several passes with the same answers."""
+    specs = [(7, 2500, GOOD), (8, 3000, dict(noise_pa=6.5)), (9, 2700, GOOD), (10, 2400, dict(is_reverse=True))]
+    ctx, ref = _run(model, specs, env_rows=4096, monkeypatch=monkeypatch)
+    worst, s = _check(ctx, ref, len(specs))
+    assert s["status"][1] != 0 and s["status"][0] == 0 and s["status"][2] == 0 and s["status"][3] == 0
+    assert worst < TOL, worst
