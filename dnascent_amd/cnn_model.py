@@ -65,7 +65,7 @@ class ModelBuilder:
         self.ops.append(op)
         return g
 
-    def conv(self, src, dst, k, cin, cout, bias=True, bn=None, relu=False, pointwise_of=None):
+    def conv(self, src, dst, k, cin, cout, bias=True, bn=None, relu=False, pointwise_of=None, add=-1):
         """Conv1D [k, cin, cout] (+bias) with an optional folded BatchNorm and ReLU in the epilogue."""
         if pointwise_of is None:
             self.n_weighted += 1
@@ -78,8 +78,8 @@ class ModelBuilder:
             s = bn["gamma"] / np.sqrt(bn["var"] + np.float32(eps))
             scale = s.astype(np.float32)
             shift = ((b - bn["mean"]) * s + bn["beta"]).astype(np.float32)
-        op = dict(op="conv", src=src, dst=dst, k=k, cin=cin, cout=cout, relu=bool(relu), w=self._put(w), scale=self._put(scale),
-                  shift=self._put(shift))
+        op = dict(op="conv", src=src, dst=dst, k=k, cin=cin, cout=cout, relu=bool(relu), add=add, w=self._put(w), scale=self._put(scale),
+                  shift=self._put(shift))            # add >= 0: residual join fused into the epilogue, y = act(conv + buf[add])
         self.ops.append(op)
         return dict(w=w, b=b, bn=bn, relu=relu)
 
@@ -132,10 +132,10 @@ def default_model(seed=2025):
             src = t2                              # the next depthwise reads t2 and overwrites t1
             c_in = cout
         bns = mb.bn(cout, gain=0.7)
-        sc = mb.conv(cur, sc_buf, k, cin, cout, bias=True, bn=bns, relu=False)
-        mb.add_relu(t2, sc_buf, cur, cout)
+        sc = mb.conv(cur, sc_buf, k, cin, cout, bias=True, bn=bns, relu=True, add=t2)     # Add + ReLU ride in the epilogue
+        sc["relu"] = False                        # the RAW shortcut layer has no activation of its own (reference rendering)
         ref["ops"].append(("block", dict(k=k, cin=cin, cout=cout, chain=chain, shortcut=sc)))
-        return cur
+        return sc_buf
 
     # NOTE on weighted-layer order: 6 separable convs with 5 BNs between them, then the shortcut conv, then
     # the two BNs (main tail, shortcut) = 14 weighted layers per block.  The builder draws them in a different order, which

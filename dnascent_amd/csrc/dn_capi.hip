@@ -629,10 +629,27 @@ int dn_load_cnn(dn_ctx *c, const dn_cnn_op *ops, uint32_t n_ops, const float *we
     HIPCHK(c, hipSetDevice(c->device));
     for (uint32_t i = 0; i < n_ops; i++) {
         const dn_cnn_op &o = ops[i];
-        if (o.op < DN_CNN_ENCODE_GRU || o.op > DN_CNN_DENSE_SOFTMAX) return fail(c, DN_ERR_ARG, "cnn op %u: unknown type %d", i, o.op);
+        if (o.op < DN_CNN_ENCODE_GRU || o.op > DN_CNN_CONV_ADD) return fail(c, DN_ERR_ARG, "cnn op %u: unknown type %d", i, o.op);
         if (o.cin > 256 || o.cout > 256) return fail(c, DN_ERR_ARG, "cnn op %u: more than 256 channels", i);
-        if (o.op == DN_CNN_CONV && (o.cin % 32 || o.cout % 64 || !(o.k & 1))) return fail(c, DN_ERR_ARG, "cnn op %u: conv shape not supported", i);
+        const uint32_t nb = n_buffers;
+        if ((uint32_t)o.src >= nb || (uint32_t)o.dst >= nb || (uint32_t)o.a >= nb || (uint32_t)o.b >= nb) return fail(c, DN_ERR_ARG, "cnn op %u: buffer index out of range", i);
+        if ((o.op == DN_CNN_CONV || o.op == DN_CNN_CONV_ADD) && (o.cin % 32 || o.cout % 64 || !(o.k & 1) || o.k > 17)) return fail(c, DN_ERR_ARG, "cnn op %u: conv shape not supported", i);
+        if (o.op == DN_CNN_DWCONV && (o.cin % 4 || (o.k != 3 && o.k != 5 && o.k != 7 && o.k != 9 && o.k != 17)))
+            return fail(c, DN_ERR_ARG, "cnn op %u: depthwise shape not supported", i);
+        if ((o.op == DN_CNN_CONV || o.op == DN_CNN_CONV_ADD) && (o.w < 0 || (uint64_t)o.w + (uint64_t)o.k * o.cin * o.cout > n_weights)) return fail(c, DN_ERR_ARG, "cnn op %u: weights out of range", i);
     }
+    // conv kernels [k][cin][cout] (Keras order) -> [k][cin / 32][cout][32]: the B tile of k3_conv is then a straight copy
+    std::vector<float> wl(weights, weights + n_weights);
+    for (uint32_t i = 0; i < n_ops; i++) {
+        const dn_cnn_op &o = ops[i];
+        if (o.op != DN_CNN_CONV && o.op != DN_CNN_CONV_ADD) continue;
+        const float *src = weights + o.w; float *dst = wl.data() + o.w;
+        for (int t = 0; t < o.k; t++)
+            for (int ci = 0; ci < o.cin; ci++)
+                for (int n = 0; n < o.cout; n++)
+                    dst[(((size_t)t * (o.cin / 32) + ci / 32) * o.cout + n) * 32 + (ci % 32)] = src[((size_t)t * o.cin + ci) * o.cout + n];
+    }
+    weights = wl.data();
     if (c->d_cnn_w) { hipFree(c->d_cnn_w); c->dev_bytes -= c->cnn_nw * sizeof(float); c->d_cnn_w = nullptr; }
     HIPCHK(c, hipMalloc((void **)&c->d_cnn_w, n_weights * sizeof(float)));
     c->cnn_nw = n_weights; c->dev_bytes += n_weights * sizeof(float);

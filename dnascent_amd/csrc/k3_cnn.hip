@@ -32,86 +32,109 @@ struct CnnRows {             // per batch
 };
 
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// v_exp_f32 / v_rcp_f32 are 1-ulp instructions: |error| of the gates ~2e-7, far inside the 1e-4 bar on the probabilities
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
+
+// GRU weights are wave-uniform: read them through the constant address space so they arrive as SGPR operands of the FMAs
+// (s_load_dwordx16 rows) instead of occupying ~2.5k vector registers per lane.
+typedef const float __attribute__((address_space(4))) *cfptr_t;
+
+// h[16] (x) W[16][48] accumulated into z r g (16 each), row by row so that every s_load fetches one contiguous row
+__device__ __forceinline__ void gru_matvec(const float (&h)[16], cfptr_t W, float (&z)[16], float (&r)[16], float (&g)[16]) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const float hj = h[j];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { z[u] = __builtin_fmaf(hj, W[j * 48 + u], z[u]); r[u] = __builtin_fmaf(hj, W[j * 48 + 16 + u], r[u]); g[u] = __builtin_fmaf(hj, W[j * 48 + 32 + u], g[u]); }
+    }
+}
 
 __global__ __launch_bounds__(64) void k3_encode(BatchDev B, const float *core, const float *resid, const float *sig, CnnRows R,
                                                 uint8_t *valid_out, float *out, const float *wts, dn_cnn_op op) {
-    __shared__ float W[2 * (48 + 768 + 96) + 768];       // g1: K[1][48] R[16][48] b[2][48]; g2: K[16][48] R[16][48] b[2][48]
-    float *K1 = W, *R1 = W + 48, *b1 = W + 48 + 768, *K2 = W + 912, *R2 = W + 912 + 768, *b2 = W + 912 + 1536;
-    for (int i = threadIdx.x; i < 48; i += 64) K1[i] = wts[op.aux[0] + i];
-    for (int i = threadIdx.x; i < 768; i += 64) { R1[i] = wts[op.aux[1] + i]; K2[i] = wts[op.aux[3] + i]; R2[i] = wts[op.aux[4] + i]; }
-    for (int i = threadIdx.x; i < 96; i += 64) { b1[i] = wts[op.aux[2] + i]; b2[i] = wts[op.aux[5] + i]; }
-    __syncthreads();
     const int r = R.r0 + blockIdx.y;
     const unsigned p = blockIdx.x * 64 + threadIdx.x;
-    if (B.res[r].status != 0 || p >= B.res[r].n_positions) return;
-    const uint64_t src = B.ref_off[r] + p;
-    const unsigned row = R.row_off[r] + p;
+    const bool live = B.res[r].status == 0 && p < B.res[r].n_positions;
+    if (__ballot(live) == 0) return;
+    cfptr_t K1 = (cfptr_t)(wts + op.aux[0]), R1 = (cfptr_t)(wts + op.aux[1]), b1 = (cfptr_t)(wts + op.aux[2]);
+    cfptr_t K2 = (cfptr_t)(wts + op.aux[3]), R2 = (cfptr_t)(wts + op.aux[4]), b2 = (cfptr_t)(wts + op.aux[5]);
+    const uint64_t src = B.ref_off[r] + (live ? p : 0);
     float h1[16], h2[16];
 #pragma unroll
     for (int u = 0; u < 16; u++) { h1[u] = 0.f; h2[u] = 0.f; }
     for (int t = 0; t < DN_RAWDEPTH_DEV; t++) {
-        const float x = sig[src * DN_RAWDEPTH_DEV + t];
-        if (x == 0.0f) continue;                          // masked time step: both layers keep their state
+        const float x = live ? sig[src * DN_RAWDEPTH_DEV + t] : 0.0f;
+        const bool on = x != 0.0f;                        // masked time step: both layers keep their state (reads.h:161)
+        if (__ballot(on) == 0) continue;
+        float z[16], rr[16], g[16];
+        // layer 1: recurrent part (+ recurrent bias), then the 1-wide input part
+#pragma unroll
+        for (int u = 0; u < 16; u++) { z[u] = b1[48 + u]; rr[u] = b1[64 + u]; g[u] = b1[80 + u]; }
+        gru_matvec(h1, R1, z, rr, g);
         float n1[16];
 #pragma unroll
         for (int u = 0; u < 16; u++) {
-            float hz = b1[48 + u], hr = b1[48 + 16 + u], hh = b1[48 + 32 + u];
-#pragma unroll
-            for (int j = 0; j < 16; j++) { hz += h1[j] * R1[j * 48 + u]; hr += h1[j] * R1[j * 48 + 16 + u]; hh += h1[j] * R1[j * 48 + 32 + u]; }
-            const float z = sigmoidf_(x * K1[u] + b1[u] + hz);
-            const float rr = sigmoidf_(x * K1[16 + u] + b1[16 + u] + hr);
-            const float c = tanhf(x * K1[32 + u] + b1[32 + u] + rr * hh);
-            n1[u] = z * h1[u] + (1.0f - z) * c;
+            const float zz = sigmoidf_(x * K1[u] + b1[u] + z[u]);
+            const float rg = sigmoidf_(x * K1[16 + u] + b1[16 + u] + rr[u]);
+            const float c = tanhf_(x * K1[32 + u] + b1[32 + u] + rg * g[u]);
+            n1[u] = zz * h1[u] + (1.0f - zz) * c;
         }
-        float n2[16];
+        // layer 2: input part into (xz, xr, xh), recurrent part into (hz, hr, hh)
+        float xz[16], xr[16], xh[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { xz[u] = b2[u]; xr[u] = b2[16 + u]; xh[u] = b2[32 + u]; z[u] = b2[48 + u]; rr[u] = b2[64 + u]; g[u] = b2[80 + u]; }
+        gru_matvec(n1, K2, xz, xr, xh);
+        gru_matvec(h2, R2, z, rr, g);
 #pragma unroll
         for (int u = 0; u < 16; u++) {
-            float xz = b2[u], xr = b2[16 + u], xh = b2[32 + u];
-            float hz = b2[48 + u], hr = b2[48 + 16 + u], hh = b2[48 + 32 + u];
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                xz += n1[j] * K2[j * 48 + u]; xr += n1[j] * K2[j * 48 + 16 + u]; xh += n1[j] * K2[j * 48 + 32 + u];
-                hz += h2[j] * R2[j * 48 + u]; hr += h2[j] * R2[j * 48 + 16 + u]; hh += h2[j] * R2[j * 48 + 32 + u];
-            }
-            const float z = sigmoidf_(xz + hz);
-            const float rr = sigmoidf_(xr + hr);
-            const float c = tanhf(xh + rr * hh);
-            n2[u] = z * h2[u] + (1.0f - z) * c;
+            const float zz = sigmoidf_(xz[u] + z[u]);
+            const float rg = sigmoidf_(xr[u] + rr[u]);
+            const float c = tanhf_(xh[u] + rg * g[u]);
+            const float n2 = zz * h2[u] + (1.0f - zz) * c;
+            h1[u] = on ? n1[u] : h1[u];
+            h2[u] = on ? n2 : h2[u];
         }
-#pragma unroll
-        for (int u = 0; u < 16; u++) { h1[u] = n1[u]; h2[u] = n2[u]; }
     }
-    float *o = out + (size_t)row * 64;
+    if (!live) return;
+    const unsigned row = R.row_off[r] + p;
+    float4 *o = reinterpret_cast<float4 *>(out + (size_t)row * 64);
 #pragma unroll
-    for (int u = 0; u < 16; u++) o[u] = h2[u];
+    for (int q = 0; q < 4; q++) o[q] = make_float4(h2[q * 4], h2[q * 4 + 1], h2[q * 4 + 2], h2[q * 4 + 3]);
     const unsigned ci = (unsigned)core[src] - 1u, ri = (unsigned)resid[src] - 1u;     // reads.h:112-138 indices are 1-based
 #pragma unroll
-    for (int j = 0; j < 5; j++) { const unsigned d = (ci >> (2 * (4 - j))) & 3u;
+    for (int j = 0; j < 5; j++) { const unsigned d = (ci >> (2 * (4 - j))) & 3u; o[4 + j] = make_float4(d == 0, d == 1, d == 2, d == 3); }
 #pragma unroll
-        for (int q = 0; q < 4; q++) o[16 + j * 4 + q] = (d == (unsigned)q) ? 1.0f : 0.0f; }
+    for (int j = 0; j < 4; j++) { const unsigned d = (ri >> (2 * (3 - j))) & 3u; o[9 + j] = make_float4(d == 0, d == 1, d == 2, d == 3); }
 #pragma unroll
-    for (int j = 0; j < 4; j++) { const unsigned d = (ri >> (2 * (3 - j))) & 3u;
-#pragma unroll
-        for (int q = 0; q < 4; q++) o[36 + j * 4 + q] = (d == (unsigned)q) ? 1.0f : 0.0f; }
-#pragma unroll
-    for (int q = 52; q < 64; q++) o[q] = 0.0f;
+    for (int q = 13; q < 16; q++) o[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     valid_out[row] = 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // implicit-GEMM Conv1D on the fp32 matrix cores
+//   workgroup = 256 threads = 2 x 2 wavefronts, tile 128 rows x BN columns, K walked in 32-deep steps (one tap, 32 input
+//   channels).  Both operands sit in LDS row-major with a 36-float pitch ([m][k] and [n][k]) so that every fragment is ONE
+//   ds_read_b128 per lane: lane (m = lane & 31, h = lane >> 5) reads k = 16 h + 4 j .. 4 j + 3 and feeds MFMA (j, q) with
+//   k = 16 h + 4 j + q -- a permutation of the 32 k's that A and B share, so the sum is unchanged.  Weights are
+//   re-laid at load time (dn_load_cnn) as [tap][cin / 32][cout][32] so the B tile is a straight float4 copy.
+//   The next step's global loads are issued before the current step's MFMAs (register prefetch) and land in the other
+//   LDS buffer: one barrier per step.
 // ---------------------------------------------------------------------------------------------------------
-template <int BN>
+#define CNN_PITCH 36
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int BN, int NBUF, bool ADD>
 __global__ __launch_bounds__(256) void k3_conv(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wt,
-                                               const float *__restrict__ scale, const float *__restrict__ shift,
-                                               const uint8_t *__restrict__ valid, int rows, int k, int cin, int cout, int relu) {
-    __shared__ float As[32][CNN_BM + 4];                  // [k][m]
-    __shared__ float Bs[32][BN + 4];                      // [k][n]
+                                                  const float *__restrict__ scale, const float *__restrict__ shift,
+                                                  const float *__restrict__ Add, const uint8_t *__restrict__ valid, int rows, int k,
+                                                  int cin, int cout, int relu) {
+    __shared__ __attribute__((aligned(16))) float As[NBUF][CNN_BM * CNN_PITCH];
+    __shared__ __attribute__((aligned(16))) float Bs[NBUF][BN * CNN_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;              // 2 x 2 wavefronts, each 64 rows x BN/2 columns
+    const int wm = wave >> 1, wn = wave & 1;              // each wavefront: 64 rows x BN/2 columns
     const int m0 = blockIdx.x * CNN_BM, n0 = blockIdx.y * BN;
     constexpr int NJ = BN / 64;                           // 32-wide column tiles per wavefront
+    constexpr int NB = BN / 32;                           // float4 B loads per thread per step
     f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -120,81 +143,125 @@ __global__ __launch_bounds__(256) void k3_conv(const float *__restrict__ X, floa
 #pragma unroll
             for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
     const int half = (k - 1) / 2;
-    const int la_m = tid >> 3, la_k = (tid & 7) * 4;      // A loader: 32 rows x 32 k per pass
-    for (int tap = 0; tap < k; tap++) {
-        for (int c0 = 0; c0 < cin; c0 += 32) {
-            __syncthreads();
+    const int cblocks = cin >> 5;
+    const int steps = k * cblocks;
+    const int l_r = tid >> 3, l_k = (tid & 7) * 4;        // loader: 32 rows x 8 float4 per pass
+    f32x4 ra[4], rb[NB];
+    bool pin[4];
+    auto gload = [&](int s) {
+        const int tap = s / cblocks, c0 = (s - tap * cblocks) << 5;
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const int m = p * 32 + la_m;
-                const int src = m0 + m + tap - half;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (src >= 0 && src < rows) v = *reinterpret_cast<const float4 *>(X + (size_t)src * cin + c0 + la_k);
-                As[la_k + 0][m] = v.x; As[la_k + 1][m] = v.y; As[la_k + 2][m] = v.z; As[la_k + 3][m] = v.w;
-            }
-            {
-                constexpr int TPR = BN / 4;               // threads per B row
-                constexpr int RPP = 256 / TPR;            // rows per pass
+        for (int p = 0; p < 4; p++) {
+            const int src = m0 + p * 32 + l_r + tap - half;
+            const bool in = src >= 0 && src < rows;       // clamped address + select: no branch around the load
+            ra[p] = *reinterpret_cast<const f32x4 *>(X + (size_t)(in ? src : m0) * cin + c0 + l_k);
+            pin[p] = in;                                  // applied at the LDS store: nothing may wait on the load before the MFMAs
+        }
+        const float *wb = Wt + ((size_t)s * cout + n0) * 32;
 #pragma unroll
-                for (int p = 0; p < 32 / RPP; p++) {
-                    const int kk = p * RPP + tid / TPR, nq = (tid % TPR) * 4;
-                    const float4 v = *reinterpret_cast<const float4 *>(Wt + ((size_t)(tap * cin + c0 + kk)) * cout + n0 + nq);
-                    *reinterpret_cast<float4 *>(&Bs[kk][nq]) = v;
-                }
-            }
-            __syncthreads();
+        for (int p = 0; p < NB; p++) rb[p] = *reinterpret_cast<const f32x4 *>(wb + (size_t)(p * 32 + l_r) * 32 + l_k);
+    };
+    auto lstore = [&](int buf) {
 #pragma unroll
-            for (int k0 = 0; k0 < 32; k0 += 2) {
-                const int kr = k0 + (lane >> 5);
-                float a[2], b[NJ];
+        for (int p = 0; p < 4; p++) *reinterpret_cast<f32x4 *>(&As[buf][(p * 32 + l_r) * CNN_PITCH + l_k]) = pin[p] ? ra[p] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < 2; i++) a[i] = As[kr][wm * 64 + i * 32 + (lane & 31)];
+        for (int p = 0; p < NB; p++) *reinterpret_cast<f32x4 *>(&Bs[buf][(p * 32 + l_r) * CNN_PITCH + l_k]) = rb[p];
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int fm = lane & 31, fh = (lane >> 5) * 16;
+    for (int s = 0; s < steps; s++) {
+        const int cur = s & (NBUF - 1), nxt = (s + 1) & (NBUF - 1);
+        gload(min(s + 1, steps - 1));                     // the last step reloads itself: unconditional keeps the prefetch in registers
+        __builtin_amdgcn_sched_barrier(0);                // keep the prefetch ABOVE the MFMAs (the scheduler otherwise sinks it)
+        const float *Ab = &As[cur][(wm * 64 + fm) * CNN_PITCH + fh];
+        const float *Bb = &Bs[cur][(wn * (BN / 2) + fm) * CNN_PITCH + fh];
 #pragma unroll
-                for (int j = 0; j < NJ; j++) b[j] = Bs[kr][wn * (BN / 2) + j * 32 + (lane & 31)];
+        for (int j4 = 0; j4 < 4; j4++) {
+            f32x4 a[2], b[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; i++) a[i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * CNN_PITCH + j4 * 4);
+#pragma unroll
+            for (int j = 0; j < NJ; j++) b[j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * CNN_PITCH + j4 * 4);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
-                    for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
+                    for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);                // ... and everything that consumes it BELOW them
+        if (NBUF == 1) __syncthreads();                   // single buffer (narrow layers: more workgroups per CU instead)
+        lstore(nxt);
+        __syncthreads();
     }
-    // epilogue: C/D layout of 32x32 tiles: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // epilogue: C/D layout of 32x32 tiles: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // Row validity of the wavefront's 64 rows is one ballot; the residual values are fetched 16 at a time (no load -> wait
+    // -> load chains).
+    const unsigned long long vmask = __ballot(valid[m0 + wm * 64 + lane] != 0);
+    const float floor_ = relu ? 0.0f : -3.402823466e38f;
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
             const float sc = scale[col], sh = shift[col];
+            const int rbase = i * 32 + 4 * (lane >> 5);
+            float *yp = Y + (size_t)(m0 + wm * 64 + rbase) * cout + col;
+            float addv[16];
+            if (ADD) {
+                const float *ap = Add + (size_t)(m0 + wm * 64 + rbase) * cout + col;
+#pragma unroll
+                for (int q = 0; q < 16; q++) addv[q] = ap[(size_t)((q & 3) + 8 * (q >> 2)) * cout];
+            }
 #pragma unroll
             for (int q = 0; q < 16; q++) {
-                const int row = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-                float y = acc[i][j][q] * sc + sh;
-                if (relu) y = fmaxf(y, 0.0f);
-                if (!valid[row]) y = 0.0f;
-                Y[(size_t)row * cout + col] = y;
+                const int ro = (q & 3) + 8 * (q >> 2);
+                float y = __builtin_fmaf(acc[i][j][q], sc, sh);
+                if (ADD) y += addv[q];
+                y = fmaxf(y, floor_);
+                y = ((vmask >> (rbase + ro)) & 1ull) ? y : 0.0f;
+                yp[(size_t)ro * cout] = y;
             }
         }
 }
 
+// depthwise part of SeparableConv1D: each thread owns 4 channels of DW_ROWS consecutive rows and slides a register window
+// over them, so every input row is read once per thread instead of k times
+#define DW_ROWS 16
+template <int KW>
 __global__ __launch_bounds__(256) void k3_dwconv(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wt,
-                                                 const uint8_t *__restrict__ valid, int rows, int k, int c) {
+                                                 const uint8_t *__restrict__ valid, int rows, int c) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int c4 = c / 4;
-    const size_t row = idx / c4;
+    const int c4 = c >> 2;
+    const long r0 = (long)(idx / c4) * DW_ROWS;
     const int ch = (int)(idx % c4) * 4;
-    if (row >= (size_t)rows) return;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid[row]) {
-        const int half = (k - 1) / 2;
-        for (int tap = 0; tap < k; tap++) {
-            const long src = (long)row + tap - half;
-            if (src < 0 || src >= rows) continue;
-            const float4 x = *reinterpret_cast<const float4 *>(X + (size_t)src * c + ch);
-            const float4 w = *reinterpret_cast<const float4 *>(Wt + (size_t)tap * c + ch);
-            acc.x += x.x * w.x; acc.y += x.y * w.y; acc.z += x.z * w.z; acc.w += x.w * w.w;
+    if (r0 >= rows) return;
+    constexpr int half = (KW - 1) / 2;
+    float4 w[KW], x[KW];
+#pragma unroll
+    for (int t = 0; t < KW; t++) w[t] = *reinterpret_cast<const float4 *>(Wt + (size_t)t * c + ch);
+    auto ld = [&](long r) { return (r >= 0 && r < rows) ? *reinterpret_cast<const float4 *>(X + (size_t)r * c + ch) : make_float4(0.f, 0.f, 0.f, 0.f); };
+#pragma unroll
+    for (int t = 0; t < KW - 1; t++) x[t + 1] = ld(r0 - half + t);
+#pragma unroll
+    for (int i = 0; i < DW_ROWS; i++) {
+#pragma unroll
+        for (int t = 0; t < KW - 1; t++) x[t] = x[t + 1];
+        x[KW - 1] = ld(r0 + i + half);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < KW; t++) {
+            acc.x = __builtin_fmaf(x[t].x, w[t].x, acc.x); acc.y = __builtin_fmaf(x[t].y, w[t].y, acc.y);
+            acc.z = __builtin_fmaf(x[t].z, w[t].z, acc.z); acc.w = __builtin_fmaf(x[t].w, w[t].w, acc.w);
+        }
+        const long row = r0 + i;
+        if (row < rows) {
+            if (!valid[row]) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(Y + (size_t)row * c + ch) = acc;
         }
     }
-    *reinterpret_cast<float4 *>(Y + row * c + ch) = acc;
 }
 
 __global__ __launch_bounds__(256) void k3_add_relu(const float *__restrict__ A, const float *__restrict__ Bv, float *__restrict__ Y, size_t n4) {
@@ -204,21 +271,41 @@ __global__ __launch_bounds__(256) void k3_add_relu(const float *__restrict__ A, 
     reinterpret_cast<float4 *>(Y)[i] = make_float4(fmaxf(a.x + b.x, 0.f), fmaxf(a.y + b.y, 0.f), fmaxf(a.z + b.z, 0.f), fmaxf(a.w + b.w, 0.f));
 }
 
-// Dense(cin -> 3) + softmax per position; writes the probabilities next to the other per-position outputs (at ref_off)
-__global__ __launch_bounds__(64) void k3_dense_softmax(BatchDev B, const float *__restrict__ X, const float *__restrict__ Wt,
+// Dense(cin -> 3) + softmax per position; writes the probabilities next to the other per-position outputs (at ref_off).
+// 16 lanes share one position (each a float4 of the row: coalesced 256-byte rows), partial dots meet by xor-shuffles.
+__global__ __launch_bounds__(256) void k3_dense_softmax(BatchDev B, const float *__restrict__ X, const float *__restrict__ Wt,
                                                        const float *__restrict__ bias, CnnRows R, int cin, float *probs) {
     const int r = R.r0 + blockIdx.y;
-    const unsigned p = blockIdx.x * 64 + threadIdx.x;
-    if (B.res[r].status != 0 || p >= B.res[r].n_positions) return;
-    const unsigned row = R.row_off[r] + p;
-    const float *x = X + (size_t)row * cin;
-    float z0 = bias[0], z1 = bias[1], z2 = bias[2];
-    for (int c = 0; c < cin; c++) { const float v = x[c]; z0 += v * Wt[c * 3 + 0]; z1 += v * Wt[c * 3 + 1]; z2 += v * Wt[c * 3 + 2]; }
-    const float m = fmaxf(z0, fmaxf(z1, z2));
-    const float e0 = expf(z0 - m), e1 = expf(z1 - m), e2 = expf(z2 - m);
-    const float s = e0 + e1 + e2;
-    float *o = probs + (B.ref_off[r] + p) * 3;
-    o[0] = e0 / s; o[1] = e1 / s; o[2] = e2 / s;
+    if (B.res[r].status != 0) return;
+    const unsigned np = B.res[r].n_positions;
+    const unsigned sub = threadIdx.x & 15;
+    const unsigned p = blockIdx.x * 64 + (threadIdx.x >> 4) * 4;          // 4 consecutive positions per 16-lane group
+    const unsigned row0 = R.row_off[r];
+    for (unsigned i = 0; i < 4; i++) {
+        const unsigned pp = p + i;
+        const bool live = pp < np;
+        float z0 = 0.f, z1 = 0.f, z2 = 0.f;
+        if (live) {
+            const float *x = X + (size_t)(row0 + pp) * cin;
+            for (int c = sub * 4; c < cin; c += 64) {
+                const float4 v = *reinterpret_cast<const float4 *>(x + c);
+                const float *w = Wt + c * 3;
+                z0 += v.x * w[0] + v.y * w[3] + v.z * w[6] + v.w * w[9];
+                z1 += v.x * w[1] + v.y * w[4] + v.z * w[7] + v.w * w[10];
+                z2 += v.x * w[2] + v.y * w[5] + v.z * w[8] + v.w * w[11];
+            }
+        }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) { z0 += __shfl_xor(z0, d); z1 += __shfl_xor(z1, d); z2 += __shfl_xor(z2, d); }
+        if (live && sub == 0) {
+            z0 += bias[0]; z1 += bias[1]; z2 += bias[2];
+            const float m = fmaxf(z0, fmaxf(z1, z2));
+            const float e0 = expf(z0 - m), e1 = expf(z1 - m), e2 = expf(z2 - m);
+            const float s = e0 + e1 + e2;
+            float *o = probs + (B.ref_off[r] + pp) * 3;
+            o[0] = e0 / s; o[1] = e1 / s; o[2] = e2 / s;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -244,18 +331,23 @@ int k3_run(const BatchDev &B, const CnnRun &c, hipStream_t st) {
                                    c.valid, c.buf[o.dst], c.wts, o);
                 break;
             case DN_CNN_CONV:
+            case DN_CNN_CONV_ADD:
                 if (o.cin % 32 || o.cout % 64) return -1;
-                if (o.cout % 128 == 0)
-                    hipLaunchKernelGGL(k3_conv<128>, dim3(rows / CNN_BM, o.cout / 128), dim3(256), 0, st, c.buf[o.src], c.buf[o.dst],
-                                       c.wts + o.w, c.wts + o.scale, c.wts + o.shift, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu);
-                else
-                    hipLaunchKernelGGL(k3_conv<64>, dim3(rows / CNN_BM, o.cout / 64), dim3(256), 0, st, c.buf[o.src], c.buf[o.dst],
-                                       c.wts + o.w, c.wts + o.scale, c.wts + o.shift, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu);
+            {
+                const float *add = o.op == DN_CNN_CONV_ADD ? c.buf[o.a] : nullptr;          // fused residual join: y = act(conv + buf[a])
+#define CONV_GO(BN_, NBUF_, ADD_) hipLaunchKernelGGL((k3_conv<BN_, NBUF_, ADD_>), dim3(rows / CNN_BM, o.cout / BN_), dim3(256), 0, st, \
+        c.buf[o.src], c.buf[o.dst], c.wts + o.w, c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu)
+                if (o.cout % 128 == 0) { if (add) CONV_GO(128, 2, true); else CONV_GO(128, 2, false); }
+                else { if (add) CONV_GO(64, 1, true); else CONV_GO(64, 1, false); }
+#undef CONV_GO
                 break;
+            }
             case DN_CNN_DWCONV: {
-                const size_t n = (size_t)rows * (o.cin / 4);
-                hipLaunchKernelGGL(k3_dwconv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c.buf[o.src], c.buf[o.dst], c.wts + o.w,
-                                   c.valid, (int)rows, o.k, o.cin);
+                const size_t n = (size_t)((rows + DW_ROWS - 1) / DW_ROWS) * (o.cin / 4);
+                const dim3 g((unsigned)((n + 255) / 256));
+#define DW_CASE(KW) case KW: hipLaunchKernelGGL(k3_dwconv<KW>, g, dim3(256), 0, st, c.buf[o.src], c.buf[o.dst], c.wts + o.w, c.valid, (int)rows, o.cin); break;
+                switch (o.k) { DW_CASE(3) DW_CASE(5) DW_CASE(7) DW_CASE(9) DW_CASE(17) default: return -1; }
+#undef DW_CASE
                 break;
             }
             case DN_CNN_ADD_RELU: {
@@ -265,7 +357,7 @@ int k3_run(const BatchDev &B, const CnnRun &c, hipStream_t st) {
             }
             case DN_CNN_DENSE_SOFTMAX:
                 if (o.cout != 3) return -1;
-                hipLaunchKernelGGL(k3_dense_softmax, dim3((c.max_pos + 63) / 64, c.rows.r1 - c.rows.r0), dim3(64), 0, st, B, c.buf[o.src], c.wts + o.w,
+                hipLaunchKernelGGL(k3_dense_softmax, dim3((c.max_pos + 63) / 64, c.rows.r1 - c.rows.r0), dim3(256), 0, st, B, c.buf[o.src], c.wts + o.w,
                                    c.wts + o.shift, c.rows, o.cin, c.probs);
                 break;
             default: return -1;

@@ -38,7 +38,7 @@ class CnnOp(C.Structure):
                 ("scale", C.c_int64), ("shift", C.c_int64), ("aux", C.c_int64 * 6)]
 
 
-CNN_OPCODE = {"encode_gru": 0, "conv": 1, "dwconv": 2, "add_relu": 3, "dense_softmax": 4}
+CNN_OPCODE = {"encode_gru": 0, "conv": 1, "dwconv": 2, "add_relu": 3, "dense_softmax": 4, "conv_add": 5}
 
 
 def cnn_ops_from_description(desc):
@@ -53,6 +53,8 @@ def cnn_ops_from_description(desc):
                 c.aux[j] = o[k]
         elif o["op"] == "conv":
             c.src, c.dst, c.k, c.cin, c.cout, c.relu = o["src"], o["dst"], o["k"], o["cin"], o["cout"], int(o["relu"])
+            if o.get("add", -1) >= 0:
+                c.op, c.a = CNN_OPCODE["conv_add"], o["add"]
             c.w, c.scale, c.shift = o["w"], o["scale"], o["shift"]
         elif o["op"] == "dwconv":
             c.src, c.dst, c.k, c.cin, c.cout, c.w = o["src"], o["dst"], o["k"], o["c"], o["c"], o["w"]

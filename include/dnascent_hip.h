@@ -92,7 +92,8 @@ int dn_run_eventalign(dn_ctx *ctx);     /* eventalign (alignment.h:22): windowed
  * survive).  Inputs are the three tensors runCNN feeds (core / residual sequence, 20 raw samples per position,
  * reads.h:305-372), already on the device after dn_run_eventalign; output = [n_positions, 3] class probabilities
  * (0 thymidine, 1 BrdU, 2 EdU; detect.cpp:695). */
-enum { DN_CNN_ENCODE_GRU = 0, DN_CNN_CONV = 1, DN_CNN_DWCONV = 2, DN_CNN_ADD_RELU = 3, DN_CNN_DENSE_SOFTMAX = 4 };
+enum { DN_CNN_ENCODE_GRU = 0, DN_CNN_CONV = 1, DN_CNN_DWCONV = 2, DN_CNN_ADD_RELU = 3, DN_CNN_DENSE_SOFTMAX = 4,
+       DN_CNN_CONV_ADD = 5 /* CONV whose epilogue adds buffer `a` before the activation (residual join) */ };
 typedef struct {
     int32_t op;                 /* DN_CNN_* */
     int32_t src, dst, a, b;     /* activation buffer indices */

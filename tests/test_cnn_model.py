@@ -20,7 +20,8 @@ def test_inventory_matches_variables_index():
 def test_struct_conversion_roundtrip():
     desc, blob, _ = cnn_model.default_model()
     ops = hip.cnn_ops_from_description(desc)
-    assert len(ops) == len(desc["ops"]) == 76
+    assert len(ops) == len(desc["ops"]) == 71
+    assert sum(1 for o in ops if o.op == hip.CNN_OPCODE["conv_add"]) == 5
     import ctypes
     assert ctypes.sizeof(hip.CnnOp) == 40 + 24 + 48
     assert ops[1].op == hip.CNN_OPCODE["conv"] and ops[1].k == 3 and ops[1].cin == 64 and ops[1].relu == 1
