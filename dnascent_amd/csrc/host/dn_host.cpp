@@ -127,6 +127,104 @@ int eventalign(dn_ctx *ctx, ReadBatch &batch) {
     return dn_get_summaries(ctx, batch.summary.data());
 }
 
+// ---- output ----------------------------------------------------------------------------------------------------
+std::string formatDetectRecord(const std::string &readID, const std::string &contig, int refStart, int refEnd, bool isReverse,
+                               size_t n, const uint32_t *coord, const char *kmer9, const float *probs, uint32_t *nCalls) {
+    std::string out = ">" + readID + " " + contig + " " + std::to_string(refStart) + " " + std::to_string(refEnd) + " " +
+                      (isReverse ? "rev" : "fwd") + "\n";
+    out.reserve(out.size() + n * 12);
+    char line[96];
+    uint32_t calls = 0;
+    for (size_t q = 0; q < n; q++) {
+        const size_t i = isReverse ? n - 1 - q : q;          // std::reverse of the line vector (:722)
+        const char *km = kmer9 + i * 9;
+        if (km[4] != 'T') continue;
+        std::string ks(km, 9);
+        if (isReverse) ks = reverseComplement(ks);
+        // std::to_string(float) formats with "%f" (6 decimals) after promotion to double
+        const int len = snprintf(line, sizeof line, "%u\t%f\t%f\t", coord[i], (double)probs[i * 3 + 2], (double)probs[i * 3 + 1]);
+        out.append(line, (size_t)len);
+        out += ks; out += '\n';
+        calls++;
+    }
+    if (nCalls) *nCalls = calls;
+    return out;
+}
+
+void modBamFields(size_t n, const uint32_t *queryIdx, const uint32_t *refIdx, const char *kmer9, const float *probs,
+                  const uint8_t *ref2del, std::string &MM, std::vector<uint8_t> &ML) {
+    // queryIndexToCalls is a std::map<unsigned, pair<float, float>>: flat (key, position) pairs, stable sort by key, the LAST
+    // entry of every key wins (operator[] assignment)
+    std::vector<std::pair<uint32_t, uint32_t>> kv;
+    for (size_t i = 0; i < n; i++) {
+        if (kmer9[i * 9 + 4] != 'T') continue;
+        if (ref2del[refIdx[i]]) continue;
+        kv.push_back({queryIdx[i], (uint32_t)i});
+    }
+    std::stable_sort(kv.begin(), kv.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) { return a.first < b.first; });
+    std::string fb = "N+b?", fe = "N+e?";
+    std::vector<uint8_t> brdu, edu;
+    unsigned prev = 0;
+    for (size_t j = 0; j < kv.size(); j++) {
+        if (j + 1 < kv.size() && kv[j + 1].first == kv[j].first) continue;
+        const unsigned q = kv[j].first, i = kv[j].second;
+        const std::string d = "," + std::to_string(q - prev);
+        fb += d; fe += d;
+        prev = q + 1;
+        edu.push_back(static_cast<uint8_t>(probs[i * 3 + 2] * 255.0));
+        brdu.push_back(static_cast<uint8_t>(probs[i * 3 + 1] * 255.0));
+    }
+    MM = fb + ";" + fe + ";";
+    ML = brdu;
+    ML.insert(ML.end(), edu.begin(), edu.end());
+}
+
+int runCNN(dn_ctx *ctx, ReadBatch &batch, bool humanReadable, std::vector<ReadCalls> &calls) {
+    int rc = dn_run_cnn(ctx);
+    if (rc) return rc;
+    const size_t n = batch.size();
+    calls.assign(n, ReadCalls());
+    std::vector<uint32_t> coord, qidx, ridx; std::vector<char> kmer; std::vector<float> probs;
+    for (size_t r = 0; r < n; r++) {
+        const dn_read_summary &s = batch.summary[r];
+        if (s.status != DN_READ_OK) continue;               // detect.cpp:879-894: failed reads are counted, not written
+        const size_t np = s.n_positions;
+        coord.resize(np); qidx.resize(np); ridx.resize(np); kmer.resize(np * 9); probs.resize(np * 3);
+        if ((rc = dn_get_positions(ctx, (uint32_t)r, coord.data(), qidx.data(), ridx.data(), nullptr, kmer.data(), nullptr, nullptr, nullptr, nullptr))) return rc;
+        if ((rc = dn_get_probabilities(ctx, (uint32_t)r, probs.data()))) return rc;
+        if (humanReadable)
+            calls[r].humanReadable_detectOut = formatDetectRecord(batch.readID[r], batch.contig[r], batch.ref_start[r], batch.ref_end[r],
+                                                                  batch.is_reverse[r] != 0, np, coord.data(), kmer.data(), probs.data(), &calls[r].nCalls);
+        else
+            modBamFields(np, qidx.data(), ridx.data(), kmer.data(), probs.data(), batch.ref2del.data() + batch.refseq_off[r], calls[r].MM, calls[r].ML);
+    }
+    return DN_OK;
+}
+
+std::string writeDetectHeader(const std::string &alignmentFilename, const std::string &refFilename, const std::string &indexFn,
+                              int threads, unsigned quality, unsigned length, bool useGPU, const std::string &startTime,
+                              const std::string &software, const std::string &version, const std::string &commit) {
+    std::string out;
+    out += "#Alignment " + alignmentFilename + "\n";
+    out += "#Genome " + refFilename + "\n";
+    out += "#Index " + indexFn + "\n";
+    out += "#Threads " + std::to_string(threads) + "\n";
+    out += std::string("#Compute ") + (useGPU ? "GPU" : "CPU") + "\n";
+    out += "#Mode CNN\n";
+    out += "#MappingQuality " + std::to_string(quality) + "\n";
+    out += "#MappingLength " + std::to_string(length) + "\n";
+    out += "#SystemStartTime " + startTime + "\n";
+    out += "#Software " + software + "\n";
+    out += "#Version " + version + "\n";
+    out += "#Commit " + commit + "\n";
+    return out;
+}
+
+bool HumanReadableWriter::open(const std::string &filename) { close(); file = fopen(filename.c_str(), "w"); return file != nullptr; }
+void HumanReadableWriter::writeHeader_HR(const std::string &header) { if (file) fwrite(header.data(), 1, header.size(), (FILE *)file); }
+void HumanReadableWriter::write(const ReadCalls &r) { if (file) fwrite(r.humanReadable_detectOut.data(), 1, r.humanReadable_detectOut.size(), (FILE *)file); }
+void HumanReadableWriter::close() { if (file) { fclose((FILE *)file); file = nullptr; } }
+
 }  // namespace DNAscent
 
 // ------------------------------------------------------------------------------------------------
@@ -169,6 +267,43 @@ int dnh_batch_maps(void *b, uint32_t i, uint32_t *ref2query, int32_t *query2ref,
     if (ref2del) memcpy(ref2del, B->ref2del.data() + f0, (f1 - f0));
     if (query2ref) memcpy(query2ref, B->query2ref.data() + q0, (q1 - q0) * 4);
     return 0;
+}
+
+// formatDetectRecord into a caller buffer; returns the record length (the required size if > cap)
+uint64_t dnh_format_detect(const char *read_id, const char *contig, int ref_start, int ref_end, int is_reverse, uint32_t n,
+                           const uint32_t *coord, const char *kmer9, const float *probs, char *buf, uint64_t cap) {
+    const std::string s = DNAscent::formatDetectRecord(read_id, contig, ref_start, ref_end, is_reverse != 0, n, coord, kmer9, probs);
+    if (s.size() <= cap) memcpy(buf, s.data(), s.size());
+    return s.size();
+}
+
+// modBamFields; returns the number of calls, MM text into mm (NUL-terminated if it fits), ML bytes into ml (2 * calls)
+int dnh_modbam(uint32_t n, const uint32_t *query_idx, const uint32_t *ref_idx, const char *kmer9, const float *probs,
+               const uint8_t *ref2del, char *mm, uint64_t mm_cap, uint8_t *ml, uint64_t ml_cap) {
+    std::string MM; std::vector<uint8_t> ML;
+    DNAscent::modBamFields(n, query_idx, ref_idx, kmer9, probs, ref2del, MM, ML);
+    if (MM.size() + 1 <= mm_cap) memcpy(mm, MM.c_str(), MM.size() + 1);
+    if (ML.size() <= ml_cap && !ML.empty()) memcpy(ml, ML.data(), ML.size());
+    return (int)(ML.size() / 2);
+}
+
+// whole output step for an uploaded + aligned batch: runCNN for every read, records appended to `path` (header first if
+// header != NULL).  Returns the number of reads written or a negative DN_* code.
+int dnh_detect_write(void *ctx, void *b, const char *path, const char *header) {
+    ReadBatch *B = (ReadBatch *)b;
+    B->summary.resize(B->size());
+    int rc = dn_get_summaries((dn_ctx *)ctx, B->summary.data());
+    if (rc) return rc;
+    std::vector<DNAscent::ReadCalls> calls;
+    if ((rc = DNAscent::runCNN((dn_ctx *)ctx, *B, true, calls))) return rc;
+    DNAscent::HumanReadableWriter w;
+    if (!w.open(path)) return DN_ERR_ARG;
+    if (header) w.writeHeader_HR(header);
+    int written = 0;
+    for (size_t i = 0; i < calls.size(); i++)
+        if (B->summary[i].status == DN_READ_OK) { w.write(calls[i]); written++; }
+    w.close();
+    return written;
 }
 
 int dnh_revcomp(const char *in, uint32_t n, char *out) {

@@ -9,6 +9,8 @@
 //   normaliseEvents(r, false)                  event_handling.h:13   DNAscent::normaliseEvents(ctx, batch)
 //   r.eventAlignment.size() == 0  -> failed          detect.cpp:879  batch.summary[i].status != DN_READ_OK
 //   eventalign(r, windowLength_align)                alignment.h:22   DNAscent::eventalign(ctx, batch)
+//   runCNN(r, session, inputOps, humanReadable)      detect.h:120     DNAscent::runCNN(ctx, batch, humanReadable, calls)
+//   writer->write(r)                                 detect.h:43      DNAscent::HumanReadableWriter::write(calls[i])
 //
 // The host keeps only flat arrays; every node-based container of the reference (std::map refToQuery,
 // vector<event>, ...) is flattened once here and lives in HBM afterwards.
@@ -63,5 +65,41 @@ public:
 // normaliseEvents for every read of the batch (event_handling.h:13).  Throws nothing: returns a DN_* code.
 int normaliseEvents(dn_ctx *ctx, ReadBatch &batch);
 int eventalign(dn_ctx *ctx, ReadBatch &batch);
+
+// ---- output side of runCNN (detect.cpp:677-731) -------------------------------------------------------------------
+struct ReadCalls {                     // what runCNN leaves on a DNAscent::read
+    std::string humanReadable_detectOut;               // ">readID contig start end strand\n" + "coord\tEdU\tBrdU\tkmer\n" ...
+    std::string MM;                                    // modbam: "N+b?,d0,d1,...;N+e?,d0,d1,...;"   (reads.h:464-488)
+    std::vector<uint8_t> ML;                           // BrdU bytes then EdU bytes, uint8(p * 255.0)    (reads.h:482-507)
+    uint32_t nCalls = 0;                               // T positions reported
+};
+
+// one record of the .detect file from the CNN outputs of a read (positions in creation order, probs [n][3]:
+// 0 thymidine, 1 BrdU, 2 EdU).  Only strand 9-mers with 'T' in the middle are reported (detect.cpp:690); reverse reads
+// print the reverse complement and their lines in reverse order (:699,722).
+std::string formatDetectRecord(const std::string &readID, const std::string &contig, int refStart, int refEnd, bool isReverse,
+                               size_t n, const uint32_t *coord, const char *kmer9, const float *probs, uint32_t *nCalls = nullptr);
+// the modbam branch (detect.cpp:704-707 + reads.h:453-512 with no pre-existing MM / ML tag): calls keyed by query index,
+// deletions skipped, later positions overwrite earlier ones with the same query index
+void modBamFields(size_t n, const uint32_t *queryIdx, const uint32_t *refIdx, const char *kmer9, const float *probs,
+                  const uint8_t *ref2del, std::string &MM, std::vector<uint8_t> &ML);
+// CNN for every read of the batch that passed eventalign, then the per-read output above; failed reads get empty calls
+int runCNN(dn_ctx *ctx, ReadBatch &batch, bool humanReadable, std::vector<ReadCalls> &calls);
+
+// writeDetectHeader (detect.cpp:196-232); the time stamp / software strings are the caller's (they are not parity data)
+std::string writeDetectHeader(const std::string &alignmentFilename, const std::string &refFilename, const std::string &indexFn,
+                              int threads, unsigned quality, unsigned length, bool useGPU, const std::string &startTime,
+                              const std::string &software, const std::string &version, const std::string &commit);
+
+class HumanReadableWriter {            // detect.h:32-60
+public:
+    ~HumanReadableWriter() { close(); }
+    bool open(const std::string &filename);
+    void writeHeader_HR(const std::string &header);
+    void write(const ReadCalls &r);
+    void close();
+private:
+    void *file = nullptr;
+};
 
 }  // namespace DNAscent

@@ -30,6 +30,14 @@ def lib():
         L.dnh_batch_desc.argtypes = [C.c_void_p, C.POINTER(_hip.BatchDesc)]
         L.dnh_batch_maps.restype = C.c_int
         L.dnh_batch_maps.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dnh_format_detect.restype = C.c_uint64
+        L.dnh_format_detect.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_char_p, C.c_uint64]
+        L.dnh_modbam.restype = C.c_int
+        L.dnh_modbam.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64,
+                                 C.c_void_p, C.c_uint64]
+        L.dnh_detect_write.restype = C.c_int
+        L.dnh_detect_write.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p]
         L.dnh_revcomp.restype = C.c_int
         L.dnh_revcomp.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         _lib = L
@@ -41,6 +49,29 @@ def revcomp(seq_u8):
     out = np.zeros_like(s)
     lib().dnh_revcomp(s.ctypes.data, s.shape[0], out.ctypes.data)
     return out
+
+
+def format_detect(read_id, contig, ref_start, ref_end, is_reverse, coord, kmer_s9, probs):
+    """DNAscent::formatDetectRecord -> bytes of one .detect record."""
+    coord = np.ascontiguousarray(coord, np.uint32); probs = np.ascontiguousarray(probs, np.float32)
+    km = np.ascontiguousarray(kmer_s9, "S9"); n = coord.shape[0]
+    cap = 128 + 64 * max(1, n)
+    buf = C.create_string_buffer(cap)
+    ln = lib().dnh_format_detect(read_id.encode(), contig.encode(), ref_start, ref_end, int(is_reverse), n, coord.ctypes.data,
+                                 km.ctypes.data, probs.ctypes.data, buf, cap)
+    assert ln <= cap
+    return buf.raw[:ln]
+
+
+def modbam(query_idx, ref_idx, kmer_s9, probs, ref2del):
+    """DNAscent::modBamFields -> (n_calls, MM text, ML bytes)."""
+    q = np.ascontiguousarray(query_idx, np.uint32); r = np.ascontiguousarray(ref_idx, np.uint32)
+    km = np.ascontiguousarray(kmer_s9, "S9"); probs = np.ascontiguousarray(probs, np.float32); d = np.ascontiguousarray(ref2del, np.uint8)
+    n = q.shape[0]
+    mm = C.create_string_buffer(16 * n + 64); ml = np.zeros(2 * n + 1, np.uint8)
+    k = lib().dnh_modbam(n, q.ctypes.data, r.ctypes.data, km.ctypes.data, probs.ctypes.data, d.ctypes.data, mm, len(mm), ml.ctypes.data,
+                         ml.shape[0])
+    return k, mm.value.decode(), ml[:2 * k].copy()
 
 
 class ReadBatch:
@@ -91,3 +122,10 @@ class ReadBatch:
 
     def upload(self, ctx):
         ctx.upload(self.desc(), self.size(), keep=self)
+
+    def detect_write(self, ctx, path, header=None):
+        """runCNN for the aligned batch + HumanReadableWriter: writes the .detect records; returns reads written."""
+        rc = lib().dnh_detect_write(ctx.h, self.h, path.encode(), header.encode() if header is not None else None)
+        if rc < 0:
+            raise _hip.DnError("dnh_detect_write failed (%d): %s" % (rc, _hip.lib().dn_last_error(ctx.h).decode()))
+        return rc

@@ -768,6 +768,51 @@ size_t dno_format_detect(const char *read_id, const char *contig, const dno_read
 }
 
 /* ------------------------------------------------------------------------------------------
+ * detect.cpp:704-707 (queryIndexToCalls) + reads.h:453-512 (writeModBamTag, no existing MM/ML)
+ * The std::map is emulated by a dense table over query indices: value = index of the LAST position
+ * that wrote the key (operator[] assignment), walk ascending.
+ * ---------------------------------------------------------------------------------------- */
+size_t dno_modbam_tags(const dno_read *r, const dno_align *a, const float *probs, char *mm, size_t mm_cap, uint8_t *ml, size_t ml_cap) {
+    size_t nq = r->n_base + 1, calls = 0;
+    for (size_t i = 0; i < a->n_pos; i++) if ((size_t)a->query_idx[i] + 1 > nq) nq = (size_t)a->query_idx[i] + 1;
+    int64_t *slot = (int64_t *)malloc(nq * sizeof(int64_t));
+    for (size_t q = 0; q < nq; q++) slot[q] = -1;
+    for (size_t i = 0; i < a->n_pos; i++) {
+        if (a->kmer[i * 9 + 4] != 'T') continue;                         /* detect.cpp:690 */
+        if (r->ref2del[a->ref_idx[i]]) continue;                         /* :704 */
+        slot[a->query_idx[i]] = (int64_t)i;                              /* :706 */
+    }
+    for (size_t q = 0; q < nq; q++) if (slot[q] >= 0) calls++;
+    /* two passes over the map: the BrdU field then the EdU field carry the same deltas (reads.h:472-476) */
+    size_t len = 0;
+    char num[32];
+    for (int field = 0; field < 2; field++) {
+        const char *head = field == 0 ? "N+b?" : "N+e?";
+        for (size_t z = 0; z < 4; z++) { if (len + 1 < mm_cap) mm[len] = head[z]; len++; }
+        unsigned prev = 0;
+        for (size_t q = 0; q < nq; q++) {
+            if (slot[q] < 0) continue;
+            int n = snprintf(num, sizeof num, ",%u", (unsigned)q - prev);
+            for (int z = 0; z < n; z++) { if (len + 1 < mm_cap) mm[len] = num[z]; len++; }
+            prev = (unsigned)q + 1;
+        }
+        if (len + 1 < mm_cap) mm[len] = ';';
+        len++;
+    }
+    if (mm_cap) mm[len < mm_cap ? len : mm_cap - 1] = 0;
+    size_t w = 0;
+    for (int field = 0; field < 2; field++)                                /* ML = BrdU calls, then EdU calls (:503-504) */
+        for (size_t q = 0; q < nq; q++) {
+            if (slot[q] < 0) continue;
+            const float p = probs[(size_t)slot[q] * 3 + (field == 0 ? 1 : 2)];
+            if (w < ml_cap) ml[w] = (uint8_t)((double)p * 255.0);          /* static_cast<uint8_t>(float * 255.0) (:482-483) */
+            w++;
+        }
+    free(slot);
+    return calls;
+}
+
+/* ------------------------------------------------------------------------------------------
  * htsInterface.cpp:59-157 parseCigar (std::map semantics flattened; later writes win)
  * ---------------------------------------------------------------------------------------- */
 int dno_parse_cigar(const uint32_t *ops, const uint32_t *lens, size_t n_ops, int is_reverse,

@@ -147,6 +147,12 @@ void dno_align_free(dno_align *a);
 size_t dno_format_detect(const char *read_id, const char *contig, const dno_read *r,
                          const dno_align *a, const float *probs, char *buf, size_t cap);
 
+/* ---- detect.cpp:704-707 + reads.h:453-512: modbam MM / ML fields of a read with no pre-existing tags ----
+ * queryIndexToCalls is a std::map keyed by query index (ascending walk, a later position with the same key overwrites);
+ * positions whose reference base is deleted in the read (refToDel) are skipped.  mm receives
+ * "N+b?,d..;N+e?,d..;" (NUL-terminated when it fits), ml the BrdU bytes followed by the EdU bytes; returns the number of calls. */
+size_t dno_modbam_tags(const dno_read *r, const dno_align *a, const float *probs, char *mm, size_t mm_cap, uint8_t *ml, size_t ml_cap);
+
 /* htsInterface.cpp:59 parseCigar, flattened to arrays.  ops: BAM op codes, lens: lengths.
  * ref2query/ref2del sized n_ref_cap, query2ref sized n_q_cap (filled with -1 first). returns ref length. */
 int dno_parse_cigar(const uint32_t *ops, const uint32_t *lens, size_t n_ops, int is_reverse,

@@ -92,6 +92,8 @@ def oracle():
         L.dno_eventalign.restype = C.c_int
         L.dno_eventalign.argtypes = [C.POINTER(Model), C.POINTER(Read), C.POINTER(Norm), C.POINTER(Align)]
         L.dno_align_free.argtypes = [C.POINTER(Align)]
+        L.dno_modbam_tags.restype = C.c_size_t
+        L.dno_modbam_tags.argtypes = [C.POINTER(Read), C.POINTER(Align), C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.dno_format_detect.restype = C.c_size_t
         L.dno_format_detect.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Read), C.POINTER(Align), C.c_void_p, C.c_void_p,
                                         C.c_size_t]
@@ -244,6 +246,13 @@ class OracleRead:
                                        C.byref(self.align), probs.ctypes.data, buf, cap)
         assert n <= cap
         return buf.raw[:n]
+
+    def modbam(self, probs):
+        probs = np.ascontiguousarray(probs, np.float32)
+        mm = C.create_string_buffer(16 * int(self.align.n_pos) + 64)
+        ml = np.zeros(2 * int(self.align.n_pos) + 1, np.uint8)
+        n = oracle().dno_modbam_tags(C.byref(self.c), C.byref(self.align), probs.ctypes.data, mm, len(mm), ml.ctypes.data, ml.shape[0])
+        return int(n), mm.value.decode(), ml[:2 * n].copy()
 
     def free(self):
         if self.norm is not None:

@@ -61,3 +61,32 @@ def test_cnn_failed_read_and_multiple_passes(model, monkeypatch):
     worst, s = _check(ctx, ref, len(specs))
     assert s["status"][1] != 0 and s["status"][0] == 0 and s["status"][2] == 0 and s["status"][3] == 0
     assert worst < TOL, worst
+
+
+def test_detect_file_matches_oracle_records(model, tmp_path):
+    """detect.cpp:852-907 for a buffer of reads through the host C++ layer: normalise -> eventalign -> runCNN -> writer.
+    Expected text = the oracle's record formatter fed with the oracle's own positions and the GPU's probabilities
+    (positions are bit-exact, test_gpu_eventalign.py), failed reads are skipped as the reference skips them."""
+    import pyoracle as po
+    specs = [(21, 2500, GOOD), (22, 3000, dict(noise_pa=6.5)), (23, 2600, dict(is_reverse=True, sub_rate=0.003, del_rate=0.003))]
+    ctx, ref = _run(model, specs)
+    reads = [synth.make_read(seed, n, model=model, **kw) for seed, n, kw in specs]
+    b = host.ReadBatch()
+    for r in reads:
+        assert b.add_synth(r) >= 0
+    b.upload(ctx)
+    ctx.run("normalise"); ctx.run("eventalign")
+    path = str(tmp_path / "out.detect")
+    header = "#Alignment a.bam\n#Genome g.fa\n"
+    written = b.detect_write(ctx, path, header)
+    s = ctx.summaries()
+    assert written == int((s["status"] == 0).sum()) == 2
+    want = header.encode()
+    for i, r in enumerate(reads):
+        if s["status"][i] != 0:
+            continue
+        o = po.OracleRead(r, model)
+        assert o.normalise() == 0 and o.eventalign() == 0
+        want += o.format_detect(ctx.probabilities(i, int(s["n_positions"][i])))
+        o.free()
+    assert open(path, "rb").read() == want

@@ -1,0 +1,72 @@
+"""Output side of runCNN (detect.cpp:677-731, reads.h:453-512): host C++ formatting vs the oracle restatement.
+
+CPU only: the positions come from the ORACLE's eventalign of small synthetic reads (forward / reverse / indels), the
+probabilities are random, so the whole text path -- T filter, EdU / BrdU column order, "%f" formatting, reverse-complement
+and line reversal for reverse reads, modbam deltas / deletions / byte quantisation -- is exercised without a GPU."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+from dnascent_amd import host, synth
+
+SPECS = [
+    (301, 2500, dict()),
+    (302, 2500, dict(is_reverse=True)),
+    (303, 2600, dict(sub_rate=0.003, ins_rate=0.001, del_rate=0.002)),
+    (304, 2600, dict(is_reverse=True, sub_rate=0.003, ins_rate=0.001, del_rate=0.002, soft_clip_head=12, soft_clip_tail=9)),
+]
+
+
+@pytest.fixture(scope="module")
+def aligned(model):
+    out = []
+    for seed, n, kw in SPECS:
+        sr = synth.make_read(seed, n, model=model, **kw)
+        o = po.OracleRead(sr, model)
+        assert o.normalise() == 0
+        assert o.eventalign() == 0
+        rng = np.random.default_rng(seed)
+        pr = rng.dirichlet((1.0, 1.0, 1.0), int(o.align.n_pos)).astype(np.float32)
+        pr[::7] = np.float32([1.0, 0.0, 0.0])                       # exact 0 / 1 and tiny values through "%f"
+        pr[3::11] = np.float32([0.0, 1.0, 0.0])
+        pr[5::13] = np.float32([1e-7, 0.9999995, 4e-7])
+        out.append((sr, o, pr))
+    yield out
+    for _, o, _ in out:
+        o.free()
+
+
+def test_detect_record_matches_oracle(aligned):
+    for sr, o, pr in aligned:
+        pos = o.positions()
+        want = o.format_detect(pr)
+        got = host.format_detect(sr.read_id, sr.contig, sr.ref_start, sr.ref_end, sr.is_reverse, pos["coord"], pos["kmer"], pr)
+        assert got == want
+        lines = got.decode().splitlines()
+        assert lines[0] == ">%s %s %d %d %s" % (sr.read_id, sr.contig, sr.ref_start, sr.ref_end, "rev" if sr.is_reverse else "fwd")
+        coords = [int(l.split("\t")[0]) for l in lines[1:]]
+        assert coords == sorted(coords) and len(coords) > 100        # both strands ascend in the file (detect.cpp:722)
+        for l in lines[1:20]:
+            f = l.split("\t")
+            assert len(f) == 4 and len(f[3]) == 9 and len(f[1].split(".")[1]) == 6
+            assert f[3][4] == ("A" if sr.is_reverse else "T")         # reverse reads print the reverse complement
+
+
+def test_modbam_fields_match_oracle(aligned):
+    for sr, o, pr in aligned:
+        pos = o.positions()
+        n_want, mm_want, ml_want = o.modbam(pr)
+        n_got, mm_got, ml_got = host.modbam(pos["query_idx"], pos["ref_idx"], pos["kmer"], pr, o.r2d)
+        assert n_got == n_want and n_got > 100
+        assert mm_got == mm_want
+        assert np.array_equal(ml_got, ml_want)
+        b, e = mm_got.rstrip(";").split(";")
+        assert b.startswith("N+b?,") and e.startswith("N+e?,") and b[4:] == e[4:]
+        assert len(b[5:].split(",")) == n_got and ml_got.shape[0] == 2 * n_got
+
+
+def test_empty_read():
+    got = host.format_detect("r", "chr", 5, 9, False, np.zeros(0, np.uint32), np.zeros(0, "S9"), np.zeros((0, 3), np.float32))
+    assert got == b">r chr 5 9 fwd\n"
+    n, mm, ml = host.modbam(np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, "S9"), np.zeros((0, 3), np.float32), np.zeros(1, np.uint8))
+    assert n == 0 and mm == "N+b?;N+e?;" and ml.shape[0] == 0
