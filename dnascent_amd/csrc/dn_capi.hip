@@ -28,10 +28,10 @@ void k2_launch_fill(const BatchDev &, const void *, const void *, bool, hipStrea
 void k2_launch_chase(const BatchDev &, uint8_t *, hipStream_t);
 void k2_launch_post(const BatchDev &, const uint8_t *, float *, const void *, hipStream_t);
 void k2b_launch(const BatchDev &, const void *, const void *, const void *, unsigned, hipStream_t);
-struct CnnRows { const unsigned *row_off; const uint8_t *valid; unsigned rows, r0, r1; };
+struct CnnRows { const unsigned *row_off; const uint8_t *valid; unsigned rows, r0, r1; const unsigned *n_pos; const uint64_t *io_off; };
 struct CnnRun { const dn_cnn_op *ops; int n_ops; const float *wts; float *buf[8]; int n_buf; CnnRows rows; uint8_t *valid;
                  const float *core, *resid, *sig; float *probs; unsigned max_pos; };
-int k3_run(const BatchDev &, const CnnRun &, hipStream_t);
+int k3_run(const CnnRun &, hipStream_t);
 
 struct BandConstsH { double lp_stay, lp_step; };
 struct FillConstsH { double lp_skip, lp_trim, C, sigma, rsigma; };
@@ -72,7 +72,7 @@ struct dn_ctx {
     uint8_t *d_path_from = nullptr; float *d_path_lp = nullptr;
     uint64_t *d_trace_off = nullptr;
     FillConstsH fc{};
-    std::vector<dn_cnn_op> cnn_ops; float *d_cnn_w = nullptr; size_t cnn_nw = 0; int cnn_nbuf = 0; DevBuf cnn_buf[8], cnn_valid, cnn_rowoff;
+    std::vector<dn_cnn_op> cnn_ops; float *d_cnn_w = nullptr; size_t cnn_nw = 0; int cnn_nbuf = 0; DevBuf cnn_buf[8], cnn_valid, cnn_rowoff, cnn_npos, cnn_iooff, cnn_in[3], cnn_out;
     float *d_probs = nullptr;
     VitConstsH vc{}; EaDevH ea{}; VitReadH *d_vitread = nullptr; unsigned max_ref = 0;
     // profiling
@@ -223,7 +223,7 @@ void dn_ctx_destroy(dn_ctx *c) {
     if (c->d_cnn_w) hipFree(c->d_cnn_w);
     for (auto &b : c->cnn_buf) if (b.p) hipFree(b.p);
     if (c->cnn_valid.p) hipFree(c->cnn_valid.p);
-    if (c->cnn_rowoff.p) hipFree(c->cnn_rowoff.p);
+    for (DevBuf *b : { &c->cnn_rowoff, &c->cnn_npos, &c->cnn_iooff, &c->cnn_in[0], &c->cnn_in[1], &c->cnn_in[2], &c->cnn_out }) if (b->p) hipFree(b->p);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -667,19 +667,18 @@ static uint64_t cnn_row_cap() {
     return std::max<uint64_t>(v, 1024);
 }
 
-int dn_run_cnn(dn_ctx *c) {
-    int rc = need(c, 6, "dn_run_cnn"); if (rc) return rc;
+// the CNN over n sequences whose input tensors (core, residual, signal) are already on the device
+static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *npos, const uint64_t *io_off, const float *d_core, const float *d_resid,
+                       const float *d_sig, float *d_probs) {
     if (c->cnn_ops.empty()) return fail(c, DN_ERR_STATE, "dn_load_cnn must be called first");
-    const uint32_t n = (uint32_t)c->B.n_reads;
-    if ((rc = fetch_res(c))) return rc;                      // rows per read = positions found by eventalign (small D2H)
-    // reads are packed end to end, CNN_PAD (8) zero rows around each; passes of at most cnn_row_cap() rows
+    // sequences are packed end to end, CNN_PAD (8) zero rows around each; passes of at most cnn_row_cap() rows
     const uint64_t cap = cnn_row_cap();
     std::vector<unsigned> row_off(n, 0u);
     struct Pass { uint32_t r0, r1; unsigned rows, max_pos; };
     std::vector<Pass> passes;
     uint64_t rows = 8; unsigned max_pos = 1; uint32_t r0 = 0; uint64_t max_rows = 0;
     for (uint32_t r = 0; r < n; r++) {
-        const unsigned np = c->h_res[r].status == 0 ? c->h_res[r].n_positions : 0;
+        const unsigned np = npos[r];
         if (rows + np + 8 > cap && r > r0) {
             const uint64_t rr = (rows + 127) / 128 * 128;
             passes.push_back({ r0, r, (unsigned)rr, max_pos }); max_rows = std::max(max_rows, rr);
@@ -687,15 +686,19 @@ int dn_run_cnn(dn_ctx *c) {
         }
         row_off[r] = (unsigned)rows;
         rows += np + 8;
-        if (rows >= (1ull << 31)) return fail(c, DN_ERR_OVERFLOW, "read %u has too many positions for one CNN pass", r);
+        if (rows >= (1ull << 31)) return fail(c, DN_ERR_OVERFLOW, "sequence %u has too many positions for one CNN pass", r);
         max_pos = std::max(max_pos, np);
     }
     { const uint64_t rr = (rows + 127) / 128 * 128; passes.push_back({ r0, n, (unsigned)rr, max_pos }); max_rows = std::max(max_rows, rr); }
+    int rc;
     for (int b = 0; b < c->cnn_nbuf; b++)
         if ((rc = dgrow(c, c->cnn_buf[b], (size_t)max_rows * 256 * sizeof(float)))) return rc;
-    if ((rc = dgrow(c, c->cnn_valid, (size_t)max_rows)) || (rc = dgrow(c, c->cnn_rowoff, n * sizeof(unsigned)))) return rc;
+    if ((rc = dgrow(c, c->cnn_valid, (size_t)max_rows)) || (rc = dgrow(c, c->cnn_rowoff, n * sizeof(unsigned))) ||
+        (rc = dgrow(c, c->cnn_npos, n * sizeof(unsigned))) || (rc = dgrow(c, c->cnn_iooff, n * sizeof(uint64_t)))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->cnn_rowoff.p, row_off.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));           // row_off is a local
+    HIPCHK(c, hipMemcpyAsync(c->cnn_npos.p, npos, n * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->cnn_iooff.p, io_off, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));           // the sources are locals of the callers
     Timed t(c, DN_K_CNN);
     for (const Pass &ps : passes) {
         HIPCHK(c, hipMemsetAsync(c->cnn_valid.p, 0, (size_t)ps.rows, c->stream));
@@ -705,13 +708,42 @@ int dn_run_cnn(dn_ctx *c) {
         run.n_buf = c->cnn_nbuf;
         run.rows.row_off = (const unsigned *)c->cnn_rowoff.p; run.rows.valid = (const uint8_t *)c->cnn_valid.p; run.rows.rows = ps.rows;
         run.rows.r0 = ps.r0; run.rows.r1 = ps.r1;
+        run.rows.n_pos = (const unsigned *)c->cnn_npos.p; run.rows.io_off = (const uint64_t *)c->cnn_iooff.p;
         run.valid = (uint8_t *)c->cnn_valid.p;
-        run.core = c->ea.core; run.resid = c->ea.resid; run.sig = c->ea.sig; run.probs = c->d_probs; run.max_pos = ps.max_pos;
-        if (k3_run(c->B, run, c->stream)) return fail(c, DN_ERR_ARG, "unsupported op in the CNN description");
+        run.core = d_core; run.resid = d_resid; run.sig = d_sig; run.probs = d_probs; run.max_pos = ps.max_pos;
+        if (k3_run(run, c->stream)) return fail(c, DN_ERR_ARG, "unsupported op in the CNN description");
     }
     HIPCHK(c, hipGetLastError());
+    return DN_OK;
+}
+
+int dn_run_cnn(dn_ctx *c) {
+    int rc = need(c, 6, "dn_run_cnn"); if (rc) return rc;
+    const uint32_t n = (uint32_t)c->B.n_reads;
+    if ((rc = fetch_res(c))) return rc;                      // rows per read = positions found by eventalign (small D2H)
+    std::vector<unsigned> npos(n);
+    for (uint32_t r = 0; r < n; r++) npos[r] = c->h_res[r].status == 0 ? c->h_res[r].n_positions : 0;
+    if ((rc = cnn_execute(c, n, npos.data(), c->h_ref_off.data(), c->ea.core, c->ea.resid, c->ea.sig, c->d_probs))) return rc;
     c->stage = 7;
     return DN_OK;
+}
+
+int dn_cnn_infer(dn_ctx *c, uint32_t n_seq, const uint32_t *len, const float *core, const float *residual, const float *signal, float *probs) {
+    if (!c || !len || !core || !residual || !signal || !probs) return DN_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint64_t> off(n_seq + 1, 0);
+    for (uint32_t i = 0; i < n_seq; i++) off[i + 1] = off[i] + len[i];
+    const size_t L = off[n_seq];
+    if (L == 0) return DN_OK;
+    int rc;
+    if ((rc = dgrow(c, c->cnn_in[0], L * sizeof(float))) || (rc = dgrow(c, c->cnn_in[1], L * sizeof(float))) ||
+        (rc = dgrow(c, c->cnn_in[2], L * DN_RAWDEPTH * sizeof(float))) || (rc = dgrow(c, c->cnn_out, L * 3 * sizeof(float)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->cnn_in[0].p, core, L * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->cnn_in[1].p, residual, L * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->cnn_in[2].p, signal, L * DN_RAWDEPTH * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if ((rc = cnn_execute(c, n_seq, len, off.data(), (const float *)c->cnn_in[0].p, (const float *)c->cnn_in[1].p, (const float *)c->cnn_in[2].p,
+                          (float *)c->cnn_out.p))) return rc;
+    return d2h(c, probs, (const float *)c->cnn_out.p, L * 3);
 }
 
 int dn_get_probabilities(dn_ctx *c, uint32_t read, float *probs) {

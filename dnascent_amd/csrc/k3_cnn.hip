@@ -28,7 +28,9 @@ struct CnnRows {             // per batch
     const unsigned *row_off; // [n_reads] first activation row of each read
     const uint8_t *valid;    // [rows] 1 for a real position, 0 for padding
     unsigned rows;           // padded to a multiple of CNN_BM
-    unsigned r0, r1;         // reads [r0, r1) are resident in this pass (row_off is only defined for them)
+    unsigned r0, r1;         // sequences [r0, r1) are resident in this pass (row_off is only defined for them)
+    const unsigned *n_pos;   // [n_seq] positions of each sequence (0 = nothing to do: failed read)
+    const uint64_t *io_off;  // [n_seq] first position of each sequence in the input tensors / the probability output
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -50,15 +52,15 @@ __device__ __forceinline__ void gru_matvec(const float (&h)[16], cfptr_t W, floa
     }
 }
 
-__global__ __launch_bounds__(64) void k3_encode(BatchDev B, const float *core, const float *resid, const float *sig, CnnRows R,
+__global__ __launch_bounds__(64) void k3_encode(const float *core, const float *resid, const float *sig, CnnRows R,
                                                 uint8_t *valid_out, float *out, const float *wts, dn_cnn_op op) {
     const int r = R.r0 + blockIdx.y;
     const unsigned p = blockIdx.x * 64 + threadIdx.x;
-    const bool live = B.res[r].status == 0 && p < B.res[r].n_positions;
+    const bool live = p < R.n_pos[r];
     if (__ballot(live) == 0) return;
     cfptr_t K1 = (cfptr_t)(wts + op.aux[0]), R1 = (cfptr_t)(wts + op.aux[1]), b1 = (cfptr_t)(wts + op.aux[2]);
     cfptr_t K2 = (cfptr_t)(wts + op.aux[3]), R2 = (cfptr_t)(wts + op.aux[4]), b2 = (cfptr_t)(wts + op.aux[5]);
-    const uint64_t src = B.ref_off[r] + (live ? p : 0);
+    const uint64_t src = R.io_off[r] + (live ? p : 0);
     float h1[16], h2[16];
 #pragma unroll
     for (int u = 0; u < 16; u++) { h1[u] = 0.f; h2[u] = 0.f; }
@@ -273,11 +275,11 @@ __global__ __launch_bounds__(256) void k3_add_relu(const float *__restrict__ A, 
 
 // Dense(cin -> 3) + softmax per position; writes the probabilities next to the other per-position outputs (at ref_off).
 // 16 lanes share one position (each a float4 of the row: coalesced 256-byte rows), partial dots meet by xor-shuffles.
-__global__ __launch_bounds__(256) void k3_dense_softmax(BatchDev B, const float *__restrict__ X, const float *__restrict__ Wt,
+__global__ __launch_bounds__(256) void k3_dense_softmax(const float *__restrict__ X, const float *__restrict__ Wt,
                                                        const float *__restrict__ bias, CnnRows R, int cin, float *probs) {
     const int r = R.r0 + blockIdx.y;
-    if (B.res[r].status != 0) return;
-    const unsigned np = B.res[r].n_positions;
+    const unsigned np = R.n_pos[r];
+    if (np == 0) return;
     const unsigned sub = threadIdx.x & 15;
     const unsigned p = blockIdx.x * 64 + (threadIdx.x >> 4) * 4;          // 4 consecutive positions per 16-lane group
     const unsigned row0 = R.row_off[r];
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(256) void k3_dense_softmax(BatchDev B, const float 
             const float m = fmaxf(z0, fmaxf(z1, z2));
             const float e0 = expf(z0 - m), e1 = expf(z1 - m), e2 = expf(z2 - m);
             const float s = e0 + e1 + e2;
-            float *o = probs + (B.ref_off[r] + pp) * 3;
+            float *o = probs + (R.io_off[r] + pp) * 3;
             o[0] = e0 / s; o[1] = e1 / s; o[2] = e2 / s;
         }
     }
@@ -320,14 +322,14 @@ struct CnnRun {
     unsigned max_pos;
 };
 
-int k3_run(const BatchDev &B, const CnnRun &c, hipStream_t st) {
+int k3_run(const CnnRun &c, hipStream_t st) {
     const unsigned rows = c.rows.rows;
     for (int i = 0; i < c.n_ops; i++) {
         const dn_cnn_op &o = c.ops[i];
         switch (o.op) {
             case DN_CNN_ENCODE_GRU:
                 hipMemsetAsync(c.buf[o.dst], 0, (size_t)rows * 64 * sizeof(float), st);
-                hipLaunchKernelGGL(k3_encode, dim3((c.max_pos + 63) / 64, c.rows.r1 - c.rows.r0), dim3(64), 0, st, B, c.core, c.resid, c.sig, c.rows,
+                hipLaunchKernelGGL(k3_encode, dim3((c.max_pos + 63) / 64, c.rows.r1 - c.rows.r0), dim3(64), 0, st, c.core, c.resid, c.sig, c.rows,
                                    c.valid, c.buf[o.dst], c.wts, o);
                 break;
             case DN_CNN_CONV:
@@ -357,7 +359,7 @@ int k3_run(const BatchDev &B, const CnnRun &c, hipStream_t st) {
             }
             case DN_CNN_DENSE_SOFTMAX:
                 if (o.cout != 3) return -1;
-                hipLaunchKernelGGL(k3_dense_softmax, dim3((c.max_pos + 63) / 64, c.rows.r1 - c.rows.r0), dim3(256), 0, st, B, c.buf[o.src], c.wts + o.w,
+                hipLaunchKernelGGL(k3_dense_softmax, dim3((c.max_pos + 63) / 64, c.rows.r1 - c.rows.r0), dim3(256), 0, st, c.buf[o.src], c.wts + o.w,
                                    c.wts + o.shift, c.rows, o.cin, c.probs);
                 break;
             default: return -1;

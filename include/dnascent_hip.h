@@ -105,6 +105,11 @@ typedef struct {
 int dn_load_cnn(dn_ctx *ctx, const dn_cnn_op *ops, uint32_t n_ops, const float *weights, uint64_t n_weights, uint32_t n_buffers);
 int dn_run_cnn(dn_ctx *ctx);            /* runCNN for every read that passed eventalign */
 int dn_get_probabilities(dn_ctx *ctx, uint32_t read, float *probs /* [n_positions * 3] */);
+/* the TF_SessionRun seam itself (detect.cpp:653): n_seq sequences given as the three host tensors runCNN builds --
+ * core [sum len], residual [sum len], signal [sum len][20] -- -> probs [sum len][3].  Needs only dn_load_cnn; it lets a
+ * maintainer keep the reference's CPU eventalign and replace just the TensorFlow call. */
+int dn_cnn_infer(dn_ctx *ctx, uint32_t n_seq, const uint32_t *len, const float *core, const float *residual, const float *signal,
+                 float *probs);
 
 /* ---- per-read results ---- */
 typedef struct {

@@ -41,3 +41,18 @@ def test_torch_rendering_is_a_distribution_and_local():
     sig2 = sig.copy(); sig2[-1] += 1.0
     p2 = cnn_torch_ref.run(ref, core, resid, sig2)
     assert np.array_equal(p[:10], p2[:10]) and not np.array_equal(p[-1], p2[-1])
+
+
+def test_torch_rendering_reproduces_golden():
+    """The committed vectors (tests/golden/make_cnn_golden.py) still come out of description + rendering: guards the model
+    builder, the weight draw order and the rendering against silent drift."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cnn_default_model.npz"))
+    _, _, ref = cnn_model.default_model()
+    o = 0
+    for n in g["lens"]:
+        n = int(n)
+        p = cnn_torch_ref.run(ref, g["core"][o:o + n], g["resid"][o:o + n], g["signal"][o:o + n])
+        assert np.abs(p - g["probs"][o:o + n]).max() < 1e-6
+        o += n
+    assert 0.02 < g["probs"][:, 2].mean() and g["probs"].std(0).min() > 0.01      # not a saturated softmax

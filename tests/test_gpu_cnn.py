@@ -90,3 +90,20 @@ def test_detect_file_matches_oracle_records(model, tmp_path):
         want += o.format_detect(ctx.probabilities(i, int(s["n_positions"][i])))
         o.free()
     assert open(path, "rb").read() == want
+
+
+def test_cnn_infer_matches_golden_vectors():
+    """dn_cnn_infer (the TF_SessionRun seam: three host tensors in, probabilities out) against the committed vectors;
+    ragged lengths incl. a 1-position sequence and positions with no signal at all."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cnn_default_model.npz"))
+    desc, blob, _ = cnn_model.default_model()
+    ctx = hip.Context(0)
+    ctx.load_cnn(desc, blob)
+    got = ctx.cnn_infer(g["lens"], g["core"], g["resid"], g["signal"])
+    assert np.abs(got - g["probs"]).max() < TOL
+    # a sequence is independent of its neighbours in the batch: same answer alone
+    n0 = int(g["lens"][0])
+    alone = ctx.cnn_infer(g["lens"][:1], g["core"][:n0], g["resid"][:n0], g["signal"][:n0])
+    assert np.array_equal(alone, got[:n0])
+    assert ctx.cnn_infer(np.zeros(0, np.uint32), np.zeros(0), np.zeros(0), np.zeros((0, 20))).shape == (0, 3)
