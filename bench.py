@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1000)
     ap.add_argument("--bases", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="batches in flight per GPU (each on its own context/stream/workspace); every stage is latency-bound "
                          "at <= 1 wavefront per SIMD for a 1000-read batch, so consecutive steps are overlapped")
     args = ap.parse_args()

@@ -32,6 +32,10 @@ struct CnnRows { const unsigned *row_off; const uint8_t *valid; unsigned rows, r
 struct CnnRun { const dn_cnn_op *ops; int n_ops; const float *wts; float *buf[8]; int n_buf; CnnRows rows; uint8_t *valid;
                  const float *core, *resid, *sig; float *probs; unsigned max_pos; };
 int k3_run(const CnnRun &, hipStream_t);
+struct HmmConstsH { double D2D, D2M, I2M, M2D, M2I, I2I, ln025, ln05; };
+struct HmmReadH { double iM2M, eM2M, endM; };
+struct HmmDevH { const double4 *unl, *ana; unsigned *poi, *n_poi, *n_ev; unsigned char *ok; double *la, *lt; };
+void k_hmm_launch(const BatchDev &, const void *, const void *, const void *, unsigned, hipStream_t);
 
 struct BandConstsH { double lp_stay, lp_step; };
 struct FillConstsH { double lp_skip, lp_trim, C, sigma, rsigma; };
@@ -74,6 +78,10 @@ struct dn_ctx {
     FillConstsH fc{};
     std::vector<dn_cnn_op> cnn_ops; float *d_cnn_w = nullptr; size_t cnn_nw = 0; int cnn_nbuf = 0; DevBuf cnn_buf[8], cnn_valid, cnn_rowoff, cnn_npos, cnn_iooff, cnn_in[3], cnn_out;
     float *d_probs = nullptr;
+    double4 *d_fit[2] = { nullptr, nullptr }; bool have_fit = false, hmm_done = false;
+    DevBuf hmm_poi, hmm_npoi, hmm_nev, hmm_ok, hmm_la, hmm_lt, hmm_reads;
+    std::vector<unsigned> h_npoi, h_nhmm;
+    std::vector<int32_t> h_ref_start, h_ref_end; std::vector<uint8_t> h_is_rev;
     VitConstsH vc{}; EaDevH ea{}; VitReadH *d_vitread = nullptr; unsigned max_ref = 0;
     // profiling
     bool prof = false;
@@ -119,7 +127,7 @@ static int dgrow(dn_ctx *c, DevBuf &b, size_t bytes) {
 }
 
 static const char *KNAMES[DN_K_COUNT] = { "k1_scan", "k1_tstat", "k1_detect", "k1_events", "k_ranks", "k_quantile", "k_prep",
-                                          "k2_fill", "k2_chase+k2_post", "k_theilsen", "k2b_viterbi", "k3_cnn" };
+                                          "k2_fill", "k2_chase+k2_post", "k_theilsen", "k2b_viterbi", "k3_cnn", "k_hmm" };
 
 struct Timed {
     dn_ctx *c; int k; hipEvent_t a = nullptr, b = nullptr;
@@ -221,6 +229,8 @@ void dn_ctx_destroy(dn_ctx *c) {
     if (c->bandc.p) hipFree(c->bandc.p);
     if (c->d_model) hipFree(c->d_model);
     if (c->d_cnn_w) hipFree(c->d_cnn_w);
+    for (auto *p : c->d_fit) if (p) hipFree(p);
+    for (DevBuf *b : { &c->hmm_poi, &c->hmm_npoi, &c->hmm_nev, &c->hmm_ok, &c->hmm_la, &c->hmm_lt, &c->hmm_reads }) if (b->p) hipFree(b->p);
     for (auto &b : c->cnn_buf) if (b.p) hipFree(b.p);
     if (c->cnn_valid.p) hipFree(c->cnn_valid.p);
     for (DevBuf *b : { &c->cnn_rowoff, &c->cnn_npos, &c->cnn_iooff, &c->cnn_in[0], &c->cnn_in[1], &c->cnn_in[2], &c->cnn_out }) if (b->p) hipFree(b->p);
@@ -289,6 +299,9 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     c->h_samp_off.assign(d->adc_off, d->adc_off + n + 1);
     c->h_base_off.assign(d->basecall_off, d->basecall_off + n + 1);
     c->h_ref_off.assign(d->refseq_off, d->refseq_off + n + 1);
+    c->h_ref_start.assign(d->ref_start, d->ref_start + n); c->h_ref_end.assign(d->ref_end, d->ref_end + n);
+    c->h_is_rev.assign(d->is_reverse, d->is_reverse + n);
+    c->hmm_done = false;
     const uint64_t S = c->h_samp_off[n], NB = c->h_base_off[n], NR = c->h_ref_off[n];
     c->h_chunk_off.assign(n + 1, 0); c->h_ev_off.assign(n + 1, 0); c->h_aln_off.assign(n + 1, 0);
     c->max_samples = c->max_chunks = c->max_len = c->max_evcap = 0;
@@ -501,6 +514,7 @@ int dn_get_summaries(dn_ctx *c, dn_read_summary *out) {
         s.ts_slope = R.ts_slope; s.ts_intercept = R.ts_intercept;
         s.shift = R.shift; s.scale = R.scale; s.events_per_base = R.events_per_base;
         s.n_positions = R.n_positions; s.n_windows = R.n_windows; s.detector_rechecks = R.rechecks;
+        s.n_hmm_calls = c->hmm_done && r < (int)c->h_nhmm.size() ? c->h_nhmm[r] : 0;
     }
     return DN_OK;
 }
@@ -750,6 +764,106 @@ int dn_get_probabilities(dn_ctx *c, uint32_t read, float *probs) {
     CHECK_READ(7, "dn_get_probabilities");
     if ((rc = fetch_res(c))) return rc;
     return d2h(c, probs, c->d_probs + c->h_ref_off[read] * 3, (size_t)c->h_res[read].n_positions * 3);
+}
+
+int dn_load_fit_models(dn_ctx *c, const double *um, const double *us, const double *am, const double *as) {
+    if (!c || !um || !us || !am || !as) return DN_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    // normalPDF's per-k-mer constants with the host libm (probability.cpp:145-148): {mu, 2 s^2, log(1/sqrt(2 s^2 pi)), 1/sqrt(2 s^2 pi)}
+    std::vector<double4> t(DN_NKMER);
+    for (int m = 0; m < 2; m++) {
+        const double *mu = m ? am : um, *sd = m ? as : us;
+        for (size_t k = 0; k < DN_NKMER; k++) {
+            if (!(sd[k] > 0.)) return fail(c, DN_ERR_ARG, "fit model %d: std of k-mer %zu is not positive", m, k);
+            const double s2 = sd[k] * sd[k], d2 = 2.0 * s2;
+            const double cc = 1.0 / sqrt(d2 * M_PI);
+            t[k] = make_double4(mu[k], d2, log(cc), cc);
+        }
+        if (!c->d_fit[m]) { HIPCHK(c, hipMalloc((void **)&c->d_fit[m], DN_NKMER * sizeof(double4))); c->dev_bytes += DN_NKMER * sizeof(double4); }
+        HIPCHK(c, hipMemcpyAsync(c->d_fit[m], t.data(), DN_NKMER * sizeof(double4), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    c->have_fit = true;
+    return DN_OK;
+}
+
+int dn_run_hmm(dn_ctx *c) {
+    int rc = need(c, 5, "dn_run_hmm"); if (rc) return rc;
+    if (!c->have_fit) return fail(c, DN_ERR_STATE, "dn_load_fit_models must be called first");
+    const uint32_t n = (uint32_t)c->B.n_reads;
+    const size_t NR = (size_t)c->h_ref_off[n];
+    if ((rc = dgrow(c, c->hmm_poi, NR * 4)) || (rc = dgrow(c, c->hmm_npoi, n * 4)) || (rc = dgrow(c, c->hmm_nev, NR * 4)) ||
+        (rc = dgrow(c, c->hmm_ok, NR)) || (rc = dgrow(c, c->hmm_la, NR * 8)) || (rc = dgrow(c, c->hmm_lt, NR * 8)) ||
+        (rc = dgrow(c, c->hmm_reads, n * sizeof(HmmReadH)))) return rc;
+    if ((rc = fetch_res(c))) return rc;
+    HmmConstsH hc;
+    hc.D2D = log(0.3); hc.D2M = log(0.7); hc.I2M = log(0.999); hc.M2D = log(0.0025); hc.M2I = log(0.001); hc.I2I = log(0.001);   // :245-250, config.h:42
+    hc.ln025 = log(0.25); hc.ln05 = log(0.5);
+    std::vector<HmmReadH> hr(n);
+    std::vector<int> newstat(n, -1);
+    for (uint32_t r = 0; r < n; r++) {
+        const ReadRes &R = c->h_res[r];
+        int neg = 0;
+        hr[r].iM2M = h_eln(1. - (1. / R.events_per_base), &neg);                         // :253
+        hr[r].eM2M = h_eln(1.0 - hc.M2D - hc.M2I - hr[r].iM2M, &neg);                     // :254 (sic: log values)
+        hr[r].endM = h_lnSum(hr[r].eM2M, hc.M2D);                                         // :366
+        if (R.status == 0 && neg) newstat[r] = DN_READ_FAIL_NEGATIVE_LOG;                 // the reference throws NegativeLog
+    }
+    for (uint32_t r = 0; r < n; r++)
+        if (newstat[r] >= 0) HIPCHK(c, hipMemcpyAsync(&c->B.res[r].status, &newstat[r], sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->hmm_reads.p, hr.data(), n * sizeof(HmmReadH), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->hmm_ok.p, 0, NR, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));           // hr / newstat are locals
+    HmmDevH H{ c->d_fit[0], c->d_fit[1], (unsigned *)c->hmm_poi.p, (unsigned *)c->hmm_npoi.p, (unsigned *)c->hmm_nev.p,
+               (unsigned char *)c->hmm_ok.p, (double *)c->hmm_la.p, (double *)c->hmm_lt.p };
+    { Timed t(c, DN_K_HMM); k_hmm_launch(c->B, &H, c->hmm_reads.p, &hc, c->max_ref, c->stream); }
+    HIPCHK(c, hipGetLastError());
+    // per-read call counts for the summaries (one flag byte per reference base back: the calls themselves stay on the device)
+    c->h_npoi.resize(n); c->h_nhmm.assign(n, 0);
+    if ((rc = d2h(c, c->h_npoi.data(), (const unsigned *)c->hmm_npoi.p, n))) return rc;
+    std::vector<unsigned char> ok(NR);
+    if ((rc = d2h(c, ok.data(), (const unsigned char *)c->hmm_ok.p, NR))) return rc;
+    for (uint32_t r = 0; r < n; r++) {
+        const unsigned char *o = ok.data() + c->h_ref_off[r];
+        unsigned k = 0;
+        for (unsigned i = 0; i < c->h_npoi[r]; i++) k += o[i];
+        c->h_nhmm[r] = k;
+    }
+    c->hmm_done = true;
+    return DN_OK;
+}
+
+int dn_get_hmm_calls(dn_ctx *c, uint32_t read, uint32_t *pos_on_ref, uint32_t *pos_on_query, int32_t *global_pos, uint32_t *n_events,
+                     double *log_analogue, double *log_thymidine, double *llr) {
+    CHECK_READ(5, "dn_get_hmm_calls");
+    if (!c->hmm_done) return fail(c, DN_ERR_STATE, "dn_get_hmm_calls before dn_run_hmm");
+    const uint64_t f0 = c->h_ref_off[read];
+    const unsigned np = c->h_npoi[read];
+    if (np == 0) return DN_OK;
+    std::vector<unsigned> poi(np), nev(np); std::vector<unsigned char> ok(np); std::vector<double> la(np), lt(np);
+    if ((rc = d2h(c, poi.data(), (const unsigned *)c->hmm_poi.p + f0, np)) || (rc = d2h(c, nev.data(), (const unsigned *)c->hmm_nev.p + f0, np)) ||
+        (rc = d2h(c, ok.data(), (const unsigned char *)c->hmm_ok.p + f0, np)) || (rc = d2h(c, la.data(), (const double *)c->hmm_la.p + f0, np)) ||
+        (rc = d2h(c, lt.data(), (const double *)c->hmm_lt.p + f0, np))) return rc;
+    const size_t nref = (size_t)(c->h_ref_off[read + 1] - f0);
+    std::vector<uint32_t> r2q;
+    if (pos_on_query) { r2q.resize(nref); if ((rc = d2h(c, r2q.data(), c->B.ref2query + f0, nref))) return rc; }
+    const bool rev = c->h_is_rev[read] != 0;
+    size_t o = 0;
+    for (unsigned q = 0; q < np; q++) {
+        const unsigned i = rev ? np - 1 - q : q;                     // std::reverse of the POIs for reverse reads (:405)
+        if (!ok[i]) continue;
+        if (pos_on_ref) pos_on_ref[o] = poi[i];
+        if (pos_on_query) pos_on_query[o] = r2q[poi[i]];
+        if (global_pos) global_pos[o] = rev ? (c->h_ref_end[read] - (int)poi[i] - 1) : (c->h_ref_start[read] + (int)poi[i]);   // :531-541
+        if (n_events) n_events[o] = nev[i];
+        // log 0 is NaN in the reference (-inf on the device); NaN - x = NaN
+        const double a = std::isinf(la[i]) ? NAN : la[i], t = std::isinf(lt[i]) ? NAN : lt[i];
+        if (log_analogue) log_analogue[o] = a;
+        if (log_thymidine) log_thymidine[o] = t;
+        if (llr) llr[o] = a - t;
+        o++;
+    }
+    return DN_OK;
 }
 
 int dn_profile_enable(dn_ctx *c, int on) { if (!c) return DN_ERR_ARG; c->prof = on != 0; return DN_OK; }

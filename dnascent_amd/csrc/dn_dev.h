@@ -30,6 +30,7 @@ struct ReadRes {            // per-read scalars produced on device (mirrors dn_r
     double ts_slope, ts_intercept;
     double shift, scale, events_per_base;
     unsigned n_positions, n_windows, rechecks, aln_begin;   // aln_begin: first valid slot of the (back-filled) alignment array
+    unsigned n_hmm_calls;    // --HMM: calls made by llAcrossRead
     float end_score;
     int seg_overflow;
 };
@@ -90,6 +91,7 @@ __device__ __forceinline__ double dkey_inv(unsigned long long k) {
 }
 
 __device__ __forceinline__ float neg_inf() { return __int_as_float(0xff800000); }
+__device__ __forceinline__ double neg_inf_d() { return __longlong_as_double(0xfff0000000000000ll); }
 
 // uniform (scalar) broadcast of one lane's value
 __device__ __forceinline__ float bcast_f(float v, int lane) {

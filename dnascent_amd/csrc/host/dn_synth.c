@@ -42,6 +42,15 @@ void dns_pore_model(uint64_t seed, double *mean) {
     }
 }
 
+void dns_fit_models(uint64_t seed, const double *static_mean, double *unl_std, double *ana_mean, double *ana_std) {
+    rng_t r = { seed ^ 0xF17F17F17ull, 0, 0.0 };
+    for (uint32_t k = 0; k < 262144u; k++) {
+        unl_std[k] = round((0.12 + 0.04 * fabs(gauss(&r))) * 1e6) / 1e6;
+        ana_mean[k] = round((static_mean[k] + 0.3 * gauss(&r)) * 1e6) / 1e6;
+        ana_std[k] = 0.15;
+    }
+}
+
 void dns_index_to_kmer(uint32_t idx, char *out9) {
     for (int i = 8; i >= 0; i--) { out9[i] = BASES[idx & 3u]; idx >>= 2; }
 }

@@ -29,6 +29,9 @@ typedef struct {
 } dns_read_out;
 
 void dns_pore_model(uint64_t seed, double *mean /* [262144] */);
+/* fit tables of the --HMM path (config.h:53-54) derived from the static table: unlabelled = (mean, 0.12 + 0.04 |N|),
+ * analogue = (mean + 0.3 N, 0.15), all rounded to 6 decimals like a text model file (data_IO.cpp:209-226) */
+void dns_fit_models(uint64_t seed, const double *static_mean, double *unl_std, double *ana_mean, double *ana_std);
 void dns_index_to_kmer(uint32_t idx, char *out9);
 size_t dns_max_samples(uint32_t n_bases);
 int dns_make_read(const double *model_mean, const dns_read_spec *sp, dns_read_out *out);

@@ -11,7 +11,7 @@ from . import build as _build
 
 DN_OK = 0
 K_NAMES = ["DN_K_SCAN", "DN_K_TSTAT", "DN_K_DETECT", "DN_K_EVENTS", "DN_K_RANKS", "DN_K_QUANTILE", "DN_K_PREP",
-           "DN_K_BAND_FILL", "DN_K_BAND_TRACE", "DN_K_THEILSEN", "DN_K_VITERBI", "DN_K_CNN"]
+           "DN_K_BAND_FILL", "DN_K_BAND_TRACE", "DN_K_THEILSEN", "DN_K_VITERBI", "DN_K_CNN", "DN_K_HMM"]
 DN_K_COUNT = len(K_NAMES)
 for _i, _n in enumerate(K_NAMES):
     globals()[_n] = _i
@@ -19,7 +19,7 @@ for _i, _n in enumerate(K_NAMES):
 # every symbol include/dnascent_hip.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = ["dn_abi_version", "dn_device_count", "dn_ctx_create", "dn_ctx_destroy", "dn_last_error", "dn_sync",
            "dn_load_pore_model", "dn_batch_upload", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded",
-           "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_load_cnn", "dn_run_cnn", "dn_get_probabilities", "dn_cnn_infer", "dn_get_summaries", "dn_get_prefix_sums",
+           "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_load_cnn", "dn_run_cnn", "dn_get_probabilities", "dn_cnn_infer", "dn_load_fit_models", "dn_run_hmm", "dn_get_hmm_calls", "dn_get_summaries", "dn_get_prefix_sums",
            "dn_get_tstats", "dn_get_scrappie_events", "dn_get_events", "dn_get_kmer_ranks", "dn_get_alignment",
            "dn_get_cleaned", "dn_get_trace", "dn_get_positions", "dn_get_windows", "dn_profile_enable", "dn_profile_get",
            "dn_profile_reset", "dn_kernel_name", "dn_device_bytes"]
@@ -71,7 +71,7 @@ SUMMARY_DTYPE = np.dtype([
     ("end_event", "<i4"), ("n_aligned", "<u4"), ("avg_log_emission", "<f8"), ("spanned", "<i4"), ("max_gap", "<i4"),
     ("n_cleaned", "<u4"), ("ts_slope", "<f8"), ("ts_intercept", "<f8"), ("shift", "<f8"), ("scale", "<f8"),
     ("events_per_base", "<f8"), ("n_positions", "<u4"), ("n_windows", "<u4"), ("detector_rechecks", "<u4"),
-    ("reserved", "<u4")], align=True)
+    ("n_hmm_calls", "<u4")], align=True)
 
 _lib = None
 
@@ -95,6 +95,9 @@ def lib():
             getattr(L, n).argtypes = [C.c_void_p]
         L.dn_load_cnn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32]
         L.dn_run_cnn.argtypes = [C.c_void_p]
+        L.dn_load_fit_models.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.dn_run_hmm.argtypes = [C.c_void_p]
+        L.dn_get_hmm_calls.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 7
         L.dn_cnn_infer.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dn_get_probabilities.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.dn_get_summaries.argtypes = [C.c_void_p, C.c_void_p]
@@ -157,6 +160,18 @@ class Context:
         ops = cnn_ops_from_description(desc)
         w = np.ascontiguousarray(blob, np.float32)
         self._chk(lib().dn_load_cnn(self.h, ops, len(desc["ops"]), w.ctypes.data, w.shape[0], desc["n_buffers"]), "dn_load_cnn")
+
+    def load_fit_models(self, unl_mean, unl_std, ana_mean, ana_std):
+        a = [np.ascontiguousarray(x, np.float64) for x in (unl_mean, unl_std, ana_mean, ana_std)]
+        assert all(x.shape == (262144,) for x in a)
+        self._chk(lib().dn_load_fit_models(self.h, *[x.ctypes.data for x in a]), "dn_load_fit_models")
+
+    def hmm_calls(self, r, n):
+        d = dict(pos_on_ref=np.zeros(n, np.uint32), pos_on_query=np.zeros(n, np.uint32), global_pos=np.zeros(n, np.int32),
+                 n_events=np.zeros(n, np.uint32), log_analogue=np.zeros(n), log_thymidine=np.zeros(n), llr=np.zeros(n))
+        self._chk(lib().dn_get_hmm_calls(self.h, r, *[d[k].ctypes.data for k in ("pos_on_ref", "pos_on_query", "global_pos", "n_events",
+                                                                                "log_analogue", "log_thymidine", "llr")]), "dn_get_hmm_calls")
+        return d
 
     def cnn_infer(self, lens, core, resid, signal):
         """dn_cnn_infer: host tensors of several sequences -> probabilities [sum(lens), 3]."""

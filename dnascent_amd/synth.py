@@ -32,6 +32,7 @@ def lib():
             raise RuntimeError("libdnascent_host.so missing: run `python -m dnascent_amd.build`")
         _lib = C.CDLL(_build.HOST_SO)
         _lib.dns_pore_model.argtypes = [C.c_uint64, C.c_void_p]
+        _lib.dns_fit_models.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.dns_max_samples.restype = C.c_size_t
         _lib.dns_max_samples.argtypes = [C.c_uint32]
         _lib.dns_make_read.argtypes = [C.c_void_p, C.POINTER(_Spec), C.POINTER(_Out)]
@@ -49,6 +50,17 @@ def pore_model(seed=12345):
         lib().dns_pore_model(seed, m.ctypes.data)
         _model_cache[seed] = m
     return _model_cache[seed]
+
+
+def fit_models(seed=12345):
+    """Synthetic fit tables for the --HMM path: (unl_mean, unl_std, ana_mean, ana_std), each [262144] float64."""
+    key = ("fit", seed)
+    if key not in _model_cache:
+        m = pore_model(seed)
+        us = np.empty(262144); am = np.empty(262144); as_ = np.empty(262144)
+        lib().dns_fit_models(seed, m.ctypes.data, us.ctypes.data, am.ctypes.data, as_.ctypes.data)
+        _model_cache[key] = (m, us, am, as_)
+    return _model_cache[key]
 
 
 class SynthRead:

@@ -111,6 +111,16 @@ int dn_get_probabilities(dn_ctx *ctx, uint32_t read, float *probs /* [n_position
 int dn_cnn_infer(dn_ctx *ctx, uint32_t n_seq, const uint32_t *len, const float *core, const float *residual, const float *signal,
                  float *probs);
 
+/* ---- `detect --HMM` (detect.cpp:885): llAcrossRead (detect.cpp:393-574) + sequenceProbability (:235-378) ----
+ * Fit models (config.h:53-54, import_poreModel_fitStdv data_IO.cpp:192): (mean, std) per 9-mer in kmer2index order.
+ * dn_run_hmm needs dn_run_normalise only (the reference does not call eventalign in this mode).  Calls come back in the
+ * order the reference emits them: ascending strand position for forward reads, descending for reverse reads (:405). */
+int dn_load_fit_models(dn_ctx *ctx, const double *unlabelled_mean, const double *unlabelled_std, const double *analogue_mean,
+                       const double *analogue_std /* each [DN_NKMER] */);
+int dn_run_hmm(dn_ctx *ctx);
+int dn_get_hmm_calls(dn_ctx *ctx, uint32_t read, uint32_t *pos_on_ref, uint32_t *pos_on_query, int32_t *global_pos /* :531-541 */,
+                     uint32_t *n_events, double *log_analogue, double *log_thymidine, double *llr /* each [n_hmm_calls] */);
+
 /* ---- per-read results ---- */
 typedef struct {
     int32_t status;                 /* DN_READ_* */
@@ -129,7 +139,7 @@ typedef struct {
     uint32_t n_positions;           /* r.refCoordToAP.size() after eventalign */
     uint32_t n_windows;             /* builtinViterbi calls */
     uint32_t detector_rechecks;     /* speculative segmentation chunks that had to be recomputed (diagnostic) */
-    uint32_t reserved;
+    uint32_t n_hmm_calls;           /* lines llAcrossRead emits (after dn_run_hmm) */
 } dn_read_summary;
 
 int dn_get_summaries(dn_ctx *ctx, dn_read_summary *out /* [n_reads] */);
@@ -151,7 +161,7 @@ int dn_get_windows(dn_ctx *ctx, uint32_t read, uint32_t *ref_index, uint32_t *wi
 
 /* ---- measurement ---- */
 enum { DN_K_SCAN = 0, DN_K_TSTAT, DN_K_DETECT, DN_K_EVENTS, DN_K_RANKS, DN_K_QUANTILE, DN_K_PREP, DN_K_BAND_FILL,
-       DN_K_BAND_TRACE, DN_K_THEILSEN, DN_K_VITERBI, DN_K_CNN, DN_K_COUNT };
+       DN_K_BAND_TRACE, DN_K_THEILSEN, DN_K_VITERBI, DN_K_CNN, DN_K_HMM, DN_K_COUNT };
 int dn_profile_enable(dn_ctx *ctx, int on);     /* HIP events around every kernel launch on the context's stream */
 int dn_profile_get(dn_ctx *ctx, int kernel, double *total_ms, uint32_t *launches);
 int dn_profile_reset(dn_ctx *ctx);

@@ -737,6 +737,175 @@ void dno_align_free(dno_align *a) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * detect.cpp:235-378  sequenceProbability: forward algorithm over 2*window positions x {I, D, M}
+ * (NaN == log 0).  Statement order, lnProd nesting and lnSum accumulation order follow the source.
+ * ---------------------------------------------------------------------------------------- */
+double dno_sequence_probability(const dno_fit_models *fm, const double *obs, size_t T, const char *seq, size_t window,
+                                int use_analogue, double shift, double scale, double events_per_base,
+                                size_t brdu_start, size_t brdu_end, int *neg) {
+    const unsigned k = DNO_K;
+    int ng = 0;
+    const double externalD2D = dno_eln(0.3, &ng), externalD2M1 = dno_eln(0.7, &ng), externalI2M1 = dno_eln(0.999, &ng);   /* :245-250, config.h:42 */
+    const double externalM12D = dno_eln(0.0025, &ng), internalM12I = dno_eln(0.001, &ng), internalI2I = dno_eln(0.001, &ng);
+    const double internalM12M1 = dno_eln(1. - (1. / events_per_base), &ng);                   /* :253 */
+    const double externalM12M1 = dno_eln(1.0 - externalM12D - internalM12I - internalM12M1, &ng);   /* :254 (sic: log values) */
+    const double ln025 = dno_eln(0.25, &ng), ln05 = dno_eln(0.5, &ng);
+    const size_t N = 2 * window;
+    double *buf = (double *)malloc(6 * N * sizeof(double));
+    double *Ic = buf, *Dc = buf + N, *Mc = buf + 2 * N, *Ip = buf + 3 * N, *Dp = buf + 4 * N, *Mp = buf + 5 * N;
+    for (size_t i = 0; i < 6 * N; i++) buf[i] = NAN;
+    double firstI_curr = NAN, firstI_prev = NAN;
+    const double start_curr = NAN; double start_prev = 0.0;
+    Dp[0] = dno_lnProd(start_prev, ln025);                                                    /* :265 */
+    for (size_t i = 1; i < N; i++) Dp[i] = dno_lnProd(Dp[i - 1], externalD2D);                /* :268-271 */
+    for (size_t t = 0; t < T; t++) {
+        for (size_t i = 0; i < N; i++) { Ic[i] = NAN; Mc[i] = NAN; Dc[i] = NAN; }
+        firstI_curr = NAN;
+        const double x = (obs[t] - shift) / scale;
+        uint32_t ki = dno_kmer2index(seq, k);
+        double matchProb = dno_eln(dno_normalPDF(fm->unl_mean[ki], fm->unl_std[ki], x), &ng);  /* :286-293 */
+        double insProb = 0.0;
+        firstI_curr = dno_lnSum(firstI_curr, dno_lnProd(dno_lnProd(start_prev, ln025), insProb));     /* :297 */
+        firstI_curr = dno_lnSum(firstI_curr, dno_lnProd(dno_lnProd(firstI_prev, ln025), insProb));    /* :298 */
+        Ic[0] = dno_lnSum(Ic[0], dno_lnProd(dno_lnProd(Ip[0], internalI2I), insProb));                /* :301 */
+        Ic[0] = dno_lnSum(Ic[0], dno_lnProd(dno_lnProd(Mp[0], internalM12I), insProb));               /* :302 */
+        Mc[0] = dno_lnSum(Mc[0], dno_lnProd(dno_lnProd(firstI_prev, ln05), matchProb));               /* :305 */
+        Mc[0] = dno_lnSum(Mc[0], dno_lnProd(dno_lnProd(Mp[0], internalM12M1), matchProb));            /* :306 */
+        Mc[0] = dno_lnSum(Mc[0], dno_lnProd(dno_lnProd(start_prev, ln05), matchProb));                /* :307 */
+        Dc[0] = dno_lnSum(Dc[0], dno_lnProd(NAN, ln025));                                             /* :310 */
+        Dc[0] = dno_lnSum(Dc[0], dno_lnProd(firstI_curr, ln025));                                     /* :311 */
+        for (size_t i = 1; i < N; i++) {
+            const char *km = seq + i;
+            ki = dno_kmer2index(km, k);
+            insProb = 0.0;
+            int hasT = 0;
+            for (unsigned z = 0; z < k; z++) if (km[z] == 'T') hasT = 1;
+            if (use_analogue && brdu_start <= i && i <= brdu_end && hasT)                              /* :319 */
+                matchProb = dno_eln(dno_normalPDF(fm->ana_mean[ki], fm->ana_std[ki], x), &ng);
+            else
+                matchProb = dno_eln(dno_normalPDF(fm->unl_mean[ki], fm->unl_std[ki], x), &ng);
+            Ic[i] = dno_lnSum(Ic[i], dno_lnProd(dno_lnProd(Ip[i], internalI2I), insProb));            /* :336 */
+            Ic[i] = dno_lnSum(Ic[i], dno_lnProd(dno_lnProd(Mp[i], internalM12I), insProb));           /* :337 */
+            Mc[i] = dno_lnSum(Mc[i], dno_lnProd(dno_lnProd(Ip[i - 1], externalI2M1), matchProb));     /* :340 */
+            Mc[i] = dno_lnSum(Mc[i], dno_lnProd(dno_lnProd(Mp[i - 1], externalM12M1), matchProb));    /* :341 */
+            Mc[i] = dno_lnSum(Mc[i], dno_lnProd(dno_lnProd(Mp[i], internalM12M1), matchProb));        /* :342 */
+            Mc[i] = dno_lnSum(Mc[i], dno_lnProd(dno_lnProd(Dp[i - 1], externalD2M1), matchProb));     /* :343 */
+        }
+        for (size_t i = 1; i < N; i++) {
+            Dc[i] = dno_lnSum(Dc[i], dno_lnProd(Mc[i - 1], externalM12D));                            /* :349 */
+            Dc[i] = dno_lnSum(Dc[i], dno_lnProd(Dc[i - 1], externalD2D));                             /* :350 */
+        }
+        memcpy(Ip, Ic, N * sizeof(double)); memcpy(Mp, Mc, N * sizeof(double)); memcpy(Dp, Dc, N * sizeof(double));
+        firstI_prev = firstI_curr;
+        start_prev = start_curr;
+    }
+    double fwd = NAN;
+    fwd = dno_lnSum(fwd, dno_lnProd(Dc[N - 1], dno_eln(1.0, &ng)));                                   /* :365 */
+    fwd = dno_lnSum(fwd, dno_lnProd(Mc[N - 1], dno_lnSum(externalM12M1, externalM12D)));              /* :366 */
+    fwd = dno_lnSum(fwd, dno_lnProd(Ic[N - 1], externalI2M1));                                        /* :367 */
+    free(buf);
+    if (neg) *neg = ng;
+    return fwd;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * detect.cpp:381-574  getPOIs + llAcrossRead.  The readHead scan over r.eventAlignment is restated
+ * as written (including: a reverse-strand snippet is only put back in forward order when the scan
+ * leaves the window through the break at :476-480).
+ * ---------------------------------------------------------------------------------------- */
+int dno_ll_across_read(const dno_fit_models *fm, const dno_read *r, const dno_norm *nm, unsigned W, dno_hmm *out) {
+    const unsigned k = DNO_K;
+    memset(out, 0, sizeof(*out));
+    const size_t L = r->n_ref;
+    if (L < 4 * (size_t)W + 1) return 0;
+    size_t npoi = 0;
+    uint32_t *poi = (uint32_t *)malloc((L + 1) * sizeof(uint32_t));
+    for (size_t i = 2 * W; i < L - 2 * W; i++) if (r->refseq[i] == 'T') poi[npoi++] = (uint32_t)i;     /* :385-388 */
+    if (r->is_reverse) for (size_t a = 0, b = npoi; a + 1 < b; a++, b--) { const uint32_t t = poi[a]; poi[a] = poi[b - 1]; poi[b - 1] = t; }   /* :405 */
+    out->pos_on_ref = (uint32_t *)malloc((npoi + 1) * sizeof(uint32_t)); out->pos_on_query = (uint32_t *)malloc((npoi + 1) * sizeof(uint32_t));
+    out->global_pos = (int32_t *)malloc((npoi + 1) * sizeof(int32_t)); out->n_events = (uint32_t *)malloc((npoi + 1) * sizeof(uint32_t));
+    out->log_analogue = (double *)malloc((npoi + 1) * sizeof(double)); out->log_thymidine = (double *)malloc((npoi + 1) * sizeof(double));
+    out->llr = (double *)malloc((npoi + 1) * sizeof(double));
+    const long n_aln = (long)nm->n_aln;
+    long readHead = r->is_reverse ? n_aln - 1 : 0;                                                    /* :402-411 */
+    double *snip = (double *)malloc(((size_t)n_aln + 1) * sizeof(double));
+    char seq[96];
+    for (size_t pi = 0; pi < npoi; pi++) {
+        const unsigned posOnRef = poi[pi];
+        const unsigned posOnQuery = r->ref2query[posOnRef];
+        const size_t slen = 2 * W + k;
+        if (posOnRef - W + slen > L) continue;                       /* substr would be short -> caught by the ACGT count below */
+        memcpy(seq, r->refseq + posOnRef - W, slen); seq[slen] = 0;
+        size_t acgt = 0;
+        for (size_t z = 0; z < slen; z++) if (seq[z] == 'A' || seq[z] == 'T' || seq[z] == 'G' || seq[z] == 'C') acgt++;
+        if (acgt != slen) continue;                                                                   /* :442 */
+        const unsigned lo = r->ref2query[posOnRef - W], hi = r->ref2query[posOnRef + W];
+        size_t ns = 0; int first = 1;
+        if (r->is_reverse) {
+            for (long j = readHead; j >= 0; j--) {                                                    /* :453-482 */
+                const unsigned q = nm->aln_kmer[j];
+                if (lo <= q && q < hi) {
+                    if (first) { readHead = j; first = 0; }
+                    const double ev = nm->events[nm->aln_event[j]].mean;
+                    if (ev > 0. && ev < 250.0) snip[ns++] = ev;
+                }
+                if (q < lo) {                                                                         /* :476-480 */
+                    for (size_t a = 0, b = ns; a + 1 < b; a++, b--) { const double t = snip[a]; snip[a] = snip[b - 1]; snip[b - 1] = t; }
+                    break;
+                }
+            }
+        } else {
+            for (long j = readHead; j < n_aln; j++) {                                                 /* :484-507 */
+                const unsigned q = nm->aln_kmer[j];
+                if (lo <= q && q < hi) {
+                    if (first) { readHead = j; first = 0; }
+                    const double ev = nm->events[nm->aln_event[j]].mean;
+                    if (ev > 0. && ev < 250.0) snip[ns++] = ev;
+                }
+                if (q >= hi) break;
+            }
+        }
+        if (ns < 2 * W - k) continue;                                                                 /* :510 */
+        int gpos = r->is_reverse ? (r->ref_end - (int)posOnRef - 1) : (r->ref_start + (int)posOnRef); /* :531-541 */
+        const size_t bs = W - k / 2, be = W + k / 2;                                                  /* :544-545 */
+        int ng = 0;
+        const double la = dno_sequence_probability(fm, snip, ns, seq, W, 1, nm->shift, nm->scale, nm->events_per_base, bs, be, &ng);
+        const double lt = dno_sequence_probability(fm, snip, ns, seq, W, 0, nm->shift, nm->scale, nm->events_per_base, 0, 0, &ng);
+        const size_t o = out->n++;
+        out->pos_on_ref[o] = posOnRef; out->pos_on_query[o] = posOnQuery; out->global_pos[o] = gpos; out->n_events[o] = (uint32_t)ns;
+        out->log_analogue[o] = la; out->log_thymidine[o] = lt; out->llr[o] = la - lt;                 /* :548 */
+    }
+    free(snip); free(poi);
+    return 0;
+}
+
+void dno_hmm_free(dno_hmm *h) {
+    free(h->pos_on_ref); free(h->pos_on_query); free(h->global_pos); free(h->n_events); free(h->log_analogue); free(h->log_thymidine); free(h->llr);
+    memset(h, 0, sizeof(*h));
+}
+
+static char comp(char c);
+size_t dno_format_hmm(const char *read_id, const char *contig, const dno_read *r, const dno_hmm *h, char *buf, size_t cap) {
+    size_t len = 0; char line[256];
+    int n = snprintf(line, sizeof line, ">%s %s %d %d %s\n", read_id, contig, r->ref_start, r->ref_end, r->is_reverse ? "rev" : "fwd");   /* :414 */
+    if (len + (size_t)n <= cap) memcpy(buf + len, line, (size_t)n);
+    len += (size_t)n;
+    for (size_t i = 0; i < h->n; i++) {
+        char kq[10], kr[10];
+        for (int z = 0; z < 9; z++) {                                  /* substr(pos - k/2, k) (:534-536), reverse complement for rev (:540-541) */
+            const long iq = (long)h->pos_on_query[i] - 4 + z, ir = (long)h->pos_on_ref[i] - 4 + z;
+            const char cq = (iq >= 0 && (size_t)iq < r->n_base) ? r->basecall[iq] : 'N', cr = (ir >= 0 && (size_t)ir < r->n_ref) ? r->refseq[ir] : 'N';
+            if (r->is_reverse) { kq[8 - z] = comp(cq); kr[8 - z] = comp(cr); } else { kq[z] = cq; kr[z] = cr; }
+        }
+        kq[9] = kr[9] = 0;
+        n = snprintf(line, sizeof line, "%d\t%f\t%s\t%s\n", h->global_pos[i], h->llr[i], kr, kq);                                           /* :571 */
+        if (len + (size_t)n <= cap) memcpy(buf + len, line, (size_t)n);
+        len += (size_t)n;
+    }
+    return len;
+}
+
+/* ------------------------------------------------------------------------------------------
  * detect.cpp:684-727 human-readable record
  * ---------------------------------------------------------------------------------------- */
 static char comp(char c) {                                               /* common.h:91 (ACGT subset) */

@@ -141,6 +141,32 @@ typedef struct {
 int  dno_eventalign(const dno_model *m, const dno_read *r, const dno_norm *n, dno_align *out);
 void dno_align_free(dno_align *a);
 
+/* ---- detect.cpp:235-378 sequenceProbability (forward algorithm, --HMM) ----
+ * fit models: (mean, std) per 9-mer in kmer2index order (config.h:53-54, data_IO.cpp:192-240).
+ * seq: 2*window + 9 bases; obs: raw event means.  Returns the forward log-probability (NaN = log 0); *neg is set when an
+ * eln of a negative number would have thrown (probability.cpp:45). */
+typedef struct {
+    const double *unl_mean, *unl_std;      /* Pore_Substrate_Config.unlabelled_model */
+    const double *ana_mean, *ana_std;      /* Pore_Substrate_Config.analogue_model */
+} dno_fit_models;
+double dno_sequence_probability(const dno_fit_models *fm, const double *obs, size_t T, const char *seq, size_t window,
+                                int use_analogue, double shift, double scale, double events_per_base,
+                                size_t brdu_start, size_t brdu_end, int *neg);
+
+/* ---- detect.cpp:381-574 getPOIs + llAcrossRead (window 12, detect.cpp:885) ----
+ * One entry per emitted line, in emission order. */
+typedef struct {
+    size_t n;
+    uint32_t *pos_on_ref, *pos_on_query;   /* strand coordinates of the call */
+    int32_t *global_pos;                   /* :531-541 */
+    uint32_t *n_events;                    /* eventSnippet.size() */
+    double *log_analogue, *log_thymidine, *llr;
+} dno_hmm;
+int  dno_ll_across_read(const dno_fit_models *fm, const dno_read *r, const dno_norm *n, unsigned window, dno_hmm *out);
+void dno_hmm_free(dno_hmm *h);
+/* text of the read's record in --HMM mode (:414, :571): ">id contig start end strand" + "pos\tllr\tkmerRef\tkmerQuery" lines */
+size_t dno_format_hmm(const char *read_id, const char *contig, const dno_read *r, const dno_hmm *h, char *buf, size_t cap);
+
 /* ---- detect.cpp:684-731 human-readable record from CNN outputs ---- */
 /* probs: n_pos*3 (class0 thymidine, class1 BrdU, class2 EdU). Writes text to buf, returns length
  * (or required length if > cap). */

@@ -47,6 +47,16 @@ class Align(C.Structure):
                 ("win_ref", u32p), ("win_len", u32p), ("win_T", u32p), ("win_score", f64p)]
 
 
+class FitModels(C.Structure):
+    _fields_ = [("unl_mean", C.c_void_p), ("unl_std", C.c_void_p), ("ana_mean", C.c_void_p), ("ana_std", C.c_void_p)]
+
+
+class Hmm(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("pos_on_ref", C.POINTER(C.c_uint32)), ("pos_on_query", C.POINTER(C.c_uint32)),
+                ("global_pos", C.POINTER(C.c_int32)), ("n_events", C.POINTER(C.c_uint32)), ("log_analogue", C.POINTER(C.c_double)),
+                ("log_thymidine", C.POINTER(C.c_double)), ("llr", C.POINTER(C.c_double))]
+
+
 class SEvent(C.Structure):
     _fields_ = [("start", C.c_uint64), ("length", C.c_float), ("mean", C.c_float), ("stdv", C.c_float)]
 
@@ -92,6 +102,14 @@ def oracle():
         L.dno_eventalign.restype = C.c_int
         L.dno_eventalign.argtypes = [C.POINTER(Model), C.POINTER(Read), C.POINTER(Norm), C.POINTER(Align)]
         L.dno_align_free.argtypes = [C.POINTER(Align)]
+        L.dno_sequence_probability.restype = C.c_double
+        L.dno_sequence_probability.argtypes = [C.POINTER(FitModels), C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_double,
+                                               C.c_double, C.c_double, C.c_size_t, C.c_size_t, C.POINTER(C.c_int)]
+        L.dno_ll_across_read.restype = C.c_int
+        L.dno_ll_across_read.argtypes = [C.POINTER(FitModels), C.POINTER(Read), C.POINTER(Norm), C.c_uint, C.POINTER(Hmm)]
+        L.dno_hmm_free.argtypes = [C.POINTER(Hmm)]
+        L.dno_format_hmm.restype = C.c_size_t
+        L.dno_format_hmm.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Read), C.POINTER(Hmm), C.c_void_p, C.c_size_t]
         L.dno_modbam_tags.restype = C.c_size_t
         L.dno_modbam_tags.argtypes = [C.POINTER(Read), C.POINTER(Align), C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.dno_format_detect.restype = C.c_size_t
@@ -247,6 +265,27 @@ class OracleRead:
         assert n <= cap
         return buf.raw[:n]
 
+    def hmm(self, fit, window=12):
+        """llAcrossRead (detect.cpp:393): dict of per-call arrays, in emission order."""
+        um, us, am, as_ = (np.ascontiguousarray(a, np.float64) for a in fit)
+        self._fit = (um, us, am, as_)
+        fm = FitModels(um.ctypes.data, us.ctypes.data, am.ctypes.data, as_.ctypes.data)
+        self.hmm_c = Hmm()
+        rc = oracle().dno_ll_across_read(C.byref(fm), C.byref(self.c), C.byref(self.norm), window, C.byref(self.hmm_c))
+        assert rc == 0
+        h = self.hmm_c; n = h.n
+        return dict(pos_on_ref=self._arr(h.pos_on_ref, n, np.uint32), pos_on_query=self._arr(h.pos_on_query, n, np.uint32),
+                    global_pos=self._arr(h.global_pos, n, np.int32), n_events=self._arr(h.n_events, n, np.uint32),
+                    log_analogue=self._arr(h.log_analogue, n, np.float64), log_thymidine=self._arr(h.log_thymidine, n, np.float64),
+                    llr=self._arr(h.llr, n, np.float64))
+
+    def format_hmm(self):
+        cap = 128 + 64 * max(1, self.hmm_c.n)
+        buf = C.create_string_buffer(cap)
+        n = oracle().dno_format_hmm(self.sr.read_id.encode(), self.sr.contig.encode(), C.byref(self.c), C.byref(self.hmm_c), buf, cap)
+        assert n <= cap
+        return buf.raw[:n]
+
     def modbam(self, probs):
         probs = np.ascontiguousarray(probs, np.float32)
         mm = C.create_string_buffer(16 * int(self.align.n_pos) + 64)
@@ -259,6 +298,8 @@ class OracleRead:
             oracle().dno_norm_free(C.byref(self.norm)); self.norm = None
         if self.align is not None:
             oracle().dno_align_free(C.byref(self.align)); self.align = None
+        if getattr(self, "hmm_c", None) is not None:
+            oracle().dno_hmm_free(C.byref(self.hmm_c)); self.hmm_c = None
 
 
 def viterbi(model_mean, obs, seq, shift, scale, epb, sigma=0.14):
