@@ -201,6 +201,48 @@ int runCNN(dn_ctx *ctx, ReadBatch &batch, bool humanReadable, std::vector<ReadCa
     return DN_OK;
 }
 
+std::string formatHmmRecord(const std::string &readID, const std::string &contig, int refStart, int refEnd, bool isReverse,
+                            const std::string &basecall, const std::string &refseq, size_t n, const uint32_t *posOnRef,
+                            const uint32_t *posOnQuery, const int32_t *globalPos, const double *llr) {
+    std::string out = ">" + readID + " " + contig + " " + std::to_string(refStart) + " " + std::to_string(refEnd) + " " +
+                      (isReverse ? "rev" : "fwd") + "\n";
+    auto kmerAt = [&](const std::string &s, uint32_t pos) {            // s.substr(pos - k/2, k) (:534-536); out-of-range bases print N
+        std::string k(9, 'N');
+        for (int z = 0; z < 9; z++) { const long i = (long)pos - 4 + z; if (i >= 0 && (size_t)i < s.size()) k[z] = s[(size_t)i]; }
+        return isReverse ? reverseComplement(k) : k;                    // :540-541
+    };
+    char num[64];
+    for (size_t i = 0; i < n; i++) {
+        const int len = snprintf(num, sizeof num, "%d\t%f\t", globalPos[i], llr[i]);                  // std::to_string: "%d", "%f"
+        out.append(num, (size_t)len);
+        out += kmerAt(refseq, posOnRef[i]); out += '\t'; out += kmerAt(basecall, posOnQuery[i]); out += '\n';
+    }
+    return out;
+}
+
+int llAcrossRead(dn_ctx *ctx, ReadBatch &batch, std::vector<ReadCalls> &calls) {
+    int rc = dn_run_hmm(ctx);
+    if (rc) return rc;
+    const size_t n = batch.size();
+    batch.summary.resize(n);
+    if ((rc = dn_get_summaries(ctx, batch.summary.data()))) return rc;
+    calls.assign(n, ReadCalls());
+    std::vector<uint32_t> pr, pq; std::vector<int32_t> gp; std::vector<double> llr;
+    for (size_t r = 0; r < n; r++) {
+        const dn_read_summary &s = batch.summary[r];
+        if (s.status != DN_READ_OK) continue;                            // detect.cpp:879-883
+        const size_t k = s.n_hmm_calls;
+        pr.resize(k); pq.resize(k); gp.resize(k); llr.resize(k);
+        if ((rc = dn_get_hmm_calls(ctx, (uint32_t)r, pr.data(), pq.data(), gp.data(), nullptr, nullptr, nullptr, llr.data()))) return rc;
+        const std::string bc(batch.basecall.data() + batch.basecall_off[r], batch.basecall.data() + batch.basecall_off[r + 1]);
+        const std::string rf(batch.refseq.data() + batch.refseq_off[r], batch.refseq.data() + batch.refseq_off[r + 1]);
+        calls[r].humanReadable_detectOut = formatHmmRecord(batch.readID[r], batch.contig[r], batch.ref_start[r], batch.ref_end[r],
+                                                           batch.is_reverse[r] != 0, bc, rf, k, pr.data(), pq.data(), gp.data(), llr.data());
+        calls[r].nCalls = (uint32_t)k;
+    }
+    return DN_OK;
+}
+
 std::string writeDetectHeader(const std::string &alignmentFilename, const std::string &refFilename, const std::string &indexFn,
                               int threads, unsigned quality, unsigned length, bool useGPU, const std::string &startTime,
                               const std::string &software, const std::string &version, const std::string &commit) {
@@ -296,6 +338,22 @@ int dnh_detect_write(void *ctx, void *b, const char *path, const char *header) {
     if (rc) return rc;
     std::vector<DNAscent::ReadCalls> calls;
     if ((rc = DNAscent::runCNN((dn_ctx *)ctx, *B, true, calls))) return rc;
+    DNAscent::HumanReadableWriter w;
+    if (!w.open(path)) return DN_ERR_ARG;
+    if (header) w.writeHeader_HR(header);
+    int written = 0;
+    for (size_t i = 0; i < calls.size(); i++)
+        if (B->summary[i].status == DN_READ_OK) { w.write(calls[i]); written++; }
+    w.close();
+    return written;
+}
+
+// --HMM output step for an uploaded + normalised batch (detect.cpp:885 + writer); returns reads written or a negative code
+int dnh_hmm_write(void *ctx, void *b, const char *path, const char *header) {
+    ReadBatch *B = (ReadBatch *)b;
+    std::vector<DNAscent::ReadCalls> calls;
+    int rc = DNAscent::llAcrossRead((dn_ctx *)ctx, *B, calls);
+    if (rc) return rc;
     DNAscent::HumanReadableWriter w;
     if (!w.open(path)) return DN_ERR_ARG;
     if (header) w.writeHeader_HR(header);

@@ -86,6 +86,13 @@ void modBamFields(size_t n, const uint32_t *queryIdx, const uint32_t *refIdx, co
 // CNN for every read of the batch that passed eventalign, then the per-read output above; failed reads get empty calls
 int runCNN(dn_ctx *ctx, ReadBatch &batch, bool humanReadable, std::vector<ReadCalls> &calls);
 
+// `detect --HMM` (detect.cpp:885): llAcrossRead for every read that passed normaliseEvents; fills
+// calls[i].humanReadable_detectOut with ">readID contig start end strand" + "pos\tlogLR\tkmerRef\tkmerQuery" lines (:414, :571)
+int llAcrossRead(dn_ctx *ctx, ReadBatch &batch, std::vector<ReadCalls> &calls);
+std::string formatHmmRecord(const std::string &readID, const std::string &contig, int refStart, int refEnd, bool isReverse,
+                            const std::string &basecall, const std::string &refseq /* both in strand direction */, size_t n,
+                            const uint32_t *posOnRef, const uint32_t *posOnQuery, const int32_t *globalPos, const double *llr);
+
 // writeDetectHeader (detect.cpp:196-232); the time stamp / software strings are the caller's (they are not parity data)
 std::string writeDetectHeader(const std::string &alignmentFilename, const std::string &refFilename, const std::string &indexFn,
                               int threads, unsigned quality, unsigned length, bool useGPU, const std::string &startTime,

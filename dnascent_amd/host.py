@@ -38,6 +38,8 @@ def lib():
                                  C.c_void_p, C.c_uint64]
         L.dnh_detect_write.restype = C.c_int
         L.dnh_detect_write.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p]
+        L.dnh_hmm_write.restype = C.c_int
+        L.dnh_hmm_write.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p]
         L.dnh_revcomp.restype = C.c_int
         L.dnh_revcomp.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         _lib = L
@@ -122,6 +124,13 @@ class ReadBatch:
 
     def upload(self, ctx):
         ctx.upload(self.desc(), self.size(), keep=self)
+
+    def hmm_write(self, ctx, path, header=None):
+        """detect --HMM: llAcrossRead for the normalised batch + HumanReadableWriter; returns reads written."""
+        rc = lib().dnh_hmm_write(ctx.h, self.h, path.encode(), header.encode() if header is not None else None)
+        if rc < 0:
+            raise _hip.DnError("dnh_hmm_write failed (%d): %s" % (rc, _hip.lib().dn_last_error(ctx.h).decode()))
+        return rc
 
     def detect_write(self, ctx, path, header=None):
         """runCNN for the aligned batch + HumanReadableWriter: writes the .detect records; returns reads written."""

@@ -58,3 +58,36 @@ def test_hmm_calls_match_oracle(model):
     # eventalign + CNN inputs are still available after the HMM pass (same normalised batch)
     ctx.run("eventalign")
     assert (ctx.summaries()["n_positions"][[0, 1]] > 1000).all()
+
+
+def test_hmm_detect_file_matches_oracle(model, tmp_path):
+    """The `--HMM` .detect file of a buffer of reads (host C++ layer: llAcrossRead + writer) vs the oracle's records.
+    Lines are compared field by field: position and both 9-mers exact, the "%f" log-likelihood ratio within 2e-6
+    (printed with 6 decimals from values that agree to ~1e-13)."""
+    fit = synth.fit_models()
+    ctx = hip.Context(0)
+    ctx.load_pore_model(model, 0.14); ctx.load_fit_models(*fit)
+    specs = [SPECS[0], SPECS[1], SPECS[4]]
+    reads = [synth.make_read(seed, n, model=model, **kw) for seed, n, kw in specs]
+    b = host.ReadBatch()
+    for r in reads:
+        assert b.add_synth(r) >= 0
+    b.upload(ctx); ctx.run("normalise")
+    path = str(tmp_path / "hmm.detect")
+    assert b.hmm_write(ctx, path, "#Mode HMM\n") == 2
+    got = open(path).read().splitlines()
+    want = ["#Mode HMM"]
+    for r in reads:
+        o = po.OracleRead(r, model)
+        if o.normalise() == 0:
+            o.hmm(fit)
+            want += o.format_hmm().decode().splitlines()
+        o.free()
+    assert len(got) == len(want) and len(got) > 1000
+    for g, w in zip(got, want):
+        if g.startswith(">") or g.startswith("#"):
+            assert g == w
+            continue
+        gf, wf = g.split("\t"), w.split("\t")
+        assert gf[0] == wf[0] and gf[2:] == wf[2:]
+        assert abs(float(gf[1]) - float(wf[1])) <= 2e-6
