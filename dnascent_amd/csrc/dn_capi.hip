@@ -282,7 +282,7 @@ int dn_load_pore_model(dn_ctx *c, const double *mean, double sigma) {
 }
 
 int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
-    if (!c || !d || d->n_reads == 0) return DN_ERR_ARG;
+    if (!c || !d) return DN_ERR_ARG;
     if (!c->have_model) return fail(c, DN_ERR_STATE, "dn_load_pore_model must be called first");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -291,6 +291,13 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     c->dev_bytes = DN_NKMER * sizeof(double) + c->trace.cap + c->bandc.cap;
     c->have_batch = false; c->stage = 0;
     const uint32_t n = d->n_reads;
+    if (n == 0) {                                         // an empty buffer of reads is legal: every stage is a no-op
+        memset(&c->B, 0, sizeof(c->B));
+        c->h_samp_off.assign(1, 0); c->h_base_off.assign(1, 0); c->h_ref_off.assign(1, 0);
+        c->h_res.clear(); c->hmm_done = false;
+        c->have_batch = true; c->stage = 1;
+        return DN_OK;
+    }
     if (n > 65535) return fail(c, DN_ERR_ARG, "at most 65535 reads per batch (grid.y)");
     BatchDev &B = c->B;
     memset(&B, 0, sizeof(B));
@@ -372,6 +379,7 @@ static int need(dn_ctx *c, int stage, const char *what) {
 
 int dn_run_segment(dn_ctx *c) {
     int rc = need(c, 1, "dn_run_segment"); if (rc) return rc;
+    if (c->B.n_reads == 0) { c->stage = std::max(c->stage, 2); return DN_OK; }
     { Timed t(c, DN_K_SCAN);   k1_launch_scan(c->B, c->stream); }
     { Timed t(c, DN_K_TSTAT);  k1_launch_tstat(c->B, c->max_samples, c->stream); }
     { Timed t(c, DN_K_DETECT); k1_launch_detect(c->B, c->max_chunks, c->stream); }
@@ -384,6 +392,7 @@ int dn_run_segment(dn_ctx *c) {
 
 int dn_run_rough_scaling(dn_ctx *c) {
     int rc = need(c, 2, "dn_run_rough_scaling"); if (rc) return rc;
+    if (c->B.n_reads == 0) { c->stage = std::max(c->stage, 3); return DN_OK; }
     { Timed t(c, DN_K_QUANTILE); ks_launch_quantile(c->B, c->stream); }
     HIPCHK(c, hipGetLastError());
     c->stage = 3;
@@ -392,6 +401,7 @@ int dn_run_rough_scaling(dn_ctx *c) {
 
 int dn_run_banded(dn_ctx *c) {
     int rc = need(c, 3, "dn_run_banded"); if (rc) return rc;
+    if (c->B.n_reads == 0) { c->stage = std::max(c->stage, 4); return DN_OK; }
     const uint32_t n = (uint32_t)c->B.n_reads;
     // the trace size depends on the number of events found on the device: one small D2H + host-side offsets.
     HIPCHK(c, hipMemcpyAsync(c->h_res.data(), c->B.res, n * sizeof(ReadRes), hipMemcpyDeviceToHost, c->stream));
@@ -432,6 +442,7 @@ int dn_run_banded(dn_ctx *c) {
 
 int dn_run_theilsen(dn_ctx *c) {
     int rc = need(c, 4, "dn_run_theilsen"); if (rc) return rc;
+    if (c->B.n_reads == 0) { c->stage = std::max(c->stage, 5); return DN_OK; }
     { Timed t(c, DN_K_THEILSEN); ks_launch_theilsen(c->B, c->stream); }
     HIPCHK(c, hipGetLastError());
     c->stage = 5;
@@ -461,6 +472,7 @@ static double h_lnSum(double a, double b) {           // probability.cpp:50-76
 
 int dn_run_eventalign(dn_ctx *c) {
     int rc = need(c, 5, "dn_run_eventalign"); if (rc) return rc;
+    if (c->B.n_reads == 0) { c->stage = std::max(c->stage, 6); return DN_OK; }
     const uint32_t n = (uint32_t)c->B.n_reads;
     // per-read transitions depend on eventsPerBase (alignment.cpp:207-210): one small D2H, host libm, one small H2D
     HIPCHK(c, hipMemcpyAsync(c->h_res.data(), c->B.res, n * sizeof(ReadRes), hipMemcpyDeviceToHost, c->stream));
@@ -490,6 +502,7 @@ int dn_run_eventalign(dn_ctx *c) {
 
 static int fetch_res(dn_ctx *c) {
     const uint32_t n = (uint32_t)c->B.n_reads;
+    if (n == 0) return DN_OK;
     HIPCHK(c, hipMemcpyAsync(c->h_res.data(), c->B.res, n * sizeof(ReadRes), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DN_OK;
@@ -497,6 +510,7 @@ static int fetch_res(dn_ctx *c) {
 
 int dn_get_summaries(dn_ctx *c, dn_read_summary *out) {
     int rc = need(c, 1, "dn_get_summaries"); if (rc) return rc;
+    if (c->B.n_reads == 0) return DN_OK;
     if (!out) return DN_ERR_ARG;
     if ((rc = fetch_res(c))) return rc;
     for (int r = 0; r < c->B.n_reads; r++) {
@@ -733,6 +747,7 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *npos, const uint64
 
 int dn_run_cnn(dn_ctx *c) {
     int rc = need(c, 6, "dn_run_cnn"); if (rc) return rc;
+    if (c->B.n_reads == 0) { c->stage = std::max(c->stage, 7); return DN_OK; }
     const uint32_t n = (uint32_t)c->B.n_reads;
     if ((rc = fetch_res(c))) return rc;                      // rows per read = positions found by eventalign (small D2H)
     std::vector<unsigned> npos(n);
@@ -789,6 +804,7 @@ int dn_load_fit_models(dn_ctx *c, const double *um, const double *us, const doub
 
 int dn_run_hmm(dn_ctx *c) {
     int rc = need(c, 5, "dn_run_hmm"); if (rc) return rc;
+    if (c->B.n_reads == 0) { c->hmm_done = true; c->h_npoi.clear(); c->h_nhmm.clear(); return DN_OK; }
     if (!c->have_fit) return fail(c, DN_ERR_STATE, "dn_load_fit_models must be called first");
     const uint32_t n = (uint32_t)c->B.n_reads;
     const size_t NR = (size_t)c->h_ref_off[n];

@@ -1,0 +1,80 @@
+"""Edge cases of the whole path on the GPU against the oracle: the config-5 maximum read length (200 kb) next to minimum-size
+reads in one ragged batch, an empty batch, a batch in which every read fails, stages called out of order."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+from dnascent_amd import hip, host, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(ctx, reads):
+    b = host.ReadBatch()
+    for r in reads:
+        assert b.add_synth(r) >= 0
+    b.upload(ctx)
+    return b
+
+
+def test_ragged_batch_with_200kb_read(model):
+    specs = [(501, 200, dict()), (502, 200000, dict(sub_rate=0.002)), (503, 64, dict()), (504, 1200, dict(is_reverse=True)),
+             (505, 2500, dict())]
+    reads = [synth.make_read(seed, n, model=model, **kw) for seed, n, kw in specs]
+    ctx = hip.Context(0)
+    ctx.load_pore_model(model, 0.14)
+    _batch(ctx, reads)
+    ctx.run("normalise"); ctx.run("eventalign"); ctx.sync()
+    s = ctx.summaries()
+    for i, r in enumerate(reads):
+        o = po.OracleRead(r, model)
+        st = o.normalise()
+        assert (s["status"][i] != 0) == (st != 0), (i, s["status"][i], st)
+        assert s["n_scrappie"][i] == o.norm.n_scrappie and s["n_events"][i] == o.norm.n_events
+        assert s["n_aligned"][i] == o.norm.n_aln and s["n_cleaned"][i] == o.norm.n_cleaned
+        if st == 0:
+            assert s["shift"][i] == o.norm.shift and s["scale"][i] == o.norm.scale          # fp64, bit-exact
+            ae, ak = ctx.alignment(i, int(s["n_aligned"][i]))
+            we, wk = o.alignment()
+            assert np.array_equal(ae, we) and np.array_equal(ak, wk)
+            assert o.eventalign() == 0
+            n = int(s["n_positions"][i])
+            assert n == o.align.n_pos
+            got = ctx.positions(i, n); want = o.positions()
+            for k in ("coord", "query_idx", "ref_idx", "indel", "n_signal", "core", "residual", "kmer"):
+                assert np.array_equal(got[k], want[k]), (i, k)
+            assert got["signal"].tobytes() == want["signal"].tobytes()
+        o.free()
+    assert s["status"][1] == 0 and s["n_positions"][1] > 150000          # the 200 kb read went all the way through
+    ctx.close()
+
+
+def test_empty_batch_and_all_failed(model):
+    ctx = hip.Context(0)
+    ctx.load_pore_model(model, 0.14)
+    b = host.ReadBatch()
+    b.upload(ctx)                                        # zero reads: every stage is a no-op, nothing is launched out of bounds
+    ctx.run("normalise"); ctx.run("eventalign"); ctx.sync()
+    assert ctx.summaries().shape[0] == 0
+    reads = [synth.make_read(600 + i, 300, model=model) for i in range(3)]          # all too short for the QC (:438)
+    _batch(ctx, reads)
+    ctx.run("normalise"); ctx.run("eventalign"); ctx.sync()
+    s = ctx.summaries()
+    assert (s["status"] != 0).all() and (s["n_positions"] == 0).all()
+    ctx.close()
+
+
+def test_stage_order_is_enforced(model):
+    ctx = hip.Context(0)
+    ctx.load_pore_model(model, 0.14)
+    with pytest.raises(hip.DnError):
+        ctx.run("normalise")                             # nothing uploaded
+    _batch(ctx, [synth.make_read(700, 2500, model=model)])
+    with pytest.raises(hip.DnError):
+        ctx.run("eventalign")                            # normalise has not run
+    with pytest.raises(hip.DnError):
+        ctx.run("cnn")                                   # no model description loaded, eventalign has not run
+    ctx.run("normalise"); ctx.run("eventalign")
+    with pytest.raises(hip.DnError):
+        ctx.run("hmm")                                   # fit models not loaded
+    ctx.close()
