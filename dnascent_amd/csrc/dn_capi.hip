@@ -30,7 +30,7 @@ void k2_launch_post(const BatchDev &, const uint8_t *, float *, const void *, hi
 void k2b_launch(const BatchDev &, const void *, const void *, const void *, unsigned, hipStream_t);
 struct CnnRows { const unsigned *row_off; const uint8_t *valid; unsigned rows, r0, r1; const unsigned *n_pos; const uint64_t *io_off; };
 struct CnnRun { const dn_cnn_op *ops; int n_ops; const float *wts; float *buf[8]; int n_buf; CnnRows rows; uint8_t *valid;
-                 const float *core, *resid, *sig; float *probs; unsigned max_pos; };
+                 const float *core, *resid, *sig; float *probs; unsigned max_pos; const uint16_t *wts_bf16; const int64_t *wb_off; };
 int k3_run(const CnnRun &, hipStream_t);
 struct HmmConstsH { double D2D, D2M, I2M, M2D, M2I, I2I, ln025, ln05; };
 struct HmmReadH { double iM2M, eM2M, endM; };
@@ -76,6 +76,7 @@ struct dn_ctx {
     uint8_t *d_path_from = nullptr; float *d_path_lp = nullptr;
     uint64_t *d_trace_off = nullptr;
     FillConstsH fc{};
+    std::vector<int64_t> cnn_wb_off; uint16_t *d_cnn_wb = nullptr; size_t cnn_nwb = 0; int cnn_math = DN_CNN_MATH_BF16X6;
     std::vector<dn_cnn_op> cnn_ops; float *d_cnn_w = nullptr; size_t cnn_nw = 0; int cnn_nbuf = 0; DevBuf cnn_buf[8], cnn_valid, cnn_rowoff, cnn_npos, cnn_iooff, cnn_in[3], cnn_out;
     float *d_probs = nullptr;
     double4 *d_fit[2] = { nullptr, nullptr }; bool have_fit = false, hmm_done = false;
@@ -229,6 +230,7 @@ void dn_ctx_destroy(dn_ctx *c) {
     if (c->bandc.p) hipFree(c->bandc.p);
     if (c->d_model) hipFree(c->d_model);
     if (c->d_cnn_w) hipFree(c->d_cnn_w);
+    if (c->d_cnn_wb) hipFree(c->d_cnn_wb);
     for (auto *p : c->d_fit) if (p) hipFree(p);
     for (DevBuf *b : { &c->hmm_poi, &c->hmm_npoi, &c->hmm_nev, &c->hmm_ok, &c->hmm_la, &c->hmm_lt, &c->hmm_reads }) if (b->p) hipFree(b->p);
     for (auto &b : c->cnn_buf) if (b.p) hipFree(b.p);
@@ -677,6 +679,35 @@ int dn_load_cnn(dn_ctx *c, const dn_cnn_op *ops, uint32_t n_ops, const float *we
                 for (int n = 0; n < o.cout; n++)
                     dst[(((size_t)t * (o.cin / 32) + ci / 32) * o.cout + n) * 32 + (ci % 32)] = src[((size_t)t * o.cin + ci) * o.cout + n];
     }
+    // the bf16 path's weights: three exact pieces per value (round to nearest even), [step][piece][cout][32]
+    auto bf16_rne = [](float f) -> uint16_t { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
+    auto bf16_f32 = [](uint16_t b) -> float { const uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+    std::vector<uint16_t> wb; std::vector<int64_t> wb_off(n_ops, 0);
+    for (uint32_t i = 0; i < n_ops; i++) {
+        const dn_cnn_op &o = ops[i];
+        if (o.op != DN_CNN_CONV && o.op != DN_CNN_CONV_ADD) continue;
+        wb_off[i] = (int64_t)wb.size();
+        const size_t steps = (size_t)o.k * (o.cin / 32), blk = (size_t)o.cout * 32;
+        wb.resize(wb.size() + steps * 3 * blk);
+        uint16_t *dst = wb.data() + wb_off[i];
+        const float *src = wl.data() + o.w;                // [tap][channel block][cout][32]; the bf16 kernel walks [channel block][tap]
+        const size_t cbn = (size_t)(o.cin / 32);
+        for (size_t st = 0; st < steps; st++)
+            for (size_t e = 0; e < blk; e++) {
+                const size_t cb = st / (size_t)o.k, tp = st % (size_t)o.k;
+                const float x = src[(tp * cbn + cb) * blk + e];
+                const uint16_t h = bf16_rne(x); const float r1 = x - bf16_f32(h);
+                const uint16_t m = bf16_rne(r1); const float r2 = r1 - bf16_f32(m);
+                dst[(st * 3 + 0) * blk + e] = h; dst[(st * 3 + 1) * blk + e] = m; dst[(st * 3 + 2) * blk + e] = bf16_rne(r2);
+            }
+    }
+    if (c->d_cnn_wb) { hipFree(c->d_cnn_wb); c->dev_bytes -= c->cnn_nwb * 2; c->d_cnn_wb = nullptr; }
+    HIPCHK(c, hipMalloc((void **)&c->d_cnn_wb, std::max<size_t>(wb.size(), 8) * 2));
+    c->cnn_nwb = wb.size(); c->dev_bytes += wb.size() * 2;
+    HIPCHK(c, hipMemcpyAsync(c->d_cnn_wb, wb.data(), wb.size() * 2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cnn_wb_off = wb_off;
+    { const char *e = getenv("DN_CNN_MATH"); if (e) c->cnn_math = (strcmp(e, "fp32") == 0) ? DN_CNN_MATH_FP32 : DN_CNN_MATH_BF16X6; }
     weights = wl.data();
     if (c->d_cnn_w) { hipFree(c->d_cnn_w); c->dev_bytes -= c->cnn_nw * sizeof(float); c->d_cnn_w = nullptr; }
     HIPCHK(c, hipMalloc((void **)&c->d_cnn_w, n_weights * sizeof(float)));
@@ -693,6 +724,12 @@ static uint64_t cnn_row_cap() {
     const char *e = getenv("DN_CNN_ROWS");
     const uint64_t v = e ? strtoull(e, nullptr, 10) : (4ull << 20);
     return std::max<uint64_t>(v, 1024);
+}
+
+int dn_cnn_set_math(dn_ctx *c, int mode) {
+    if (!c || (mode != DN_CNN_MATH_FP32 && mode != DN_CNN_MATH_BF16X6)) return DN_ERR_ARG;
+    c->cnn_math = mode;
+    return DN_OK;
 }
 
 // the CNN over n sequences whose input tensors (core, residual, signal) are already on the device
@@ -739,6 +776,7 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *npos, const uint64
         run.rows.n_pos = (const unsigned *)c->cnn_npos.p; run.rows.io_off = (const uint64_t *)c->cnn_iooff.p;
         run.valid = (uint8_t *)c->cnn_valid.p;
         run.core = d_core; run.resid = d_resid; run.sig = d_sig; run.probs = d_probs; run.max_pos = ps.max_pos;
+        run.wts_bf16 = c->cnn_math == DN_CNN_MATH_BF16X6 ? c->d_cnn_wb : nullptr; run.wb_off = c->cnn_wb_off.data();
         if (k3_run(run, c->stream)) return fail(c, DN_ERR_ARG, "unsupported op in the CNN description");
     }
     HIPCHK(c, hipGetLastError());

@@ -125,6 +125,42 @@ __global__ __launch_bounds__(64) void k3_encode(const float *core, const float *
 #define CNN_PITCH 36
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// epilogue shared by the conv kernels: C/D layout of 32x32 tiles: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) +
+// 4 * (lane >> 5).  Row validity of the wavefront's 64 rows is one ballot; the residual values are fetched 16 at a time
+// (no load -> wait -> load chains).
+template <int BN, bool ADD>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][BN / 64], float *__restrict__ Y, const float *__restrict__ scale,
+                                              const float *__restrict__ shift, const float *__restrict__ Add,
+                                              const uint8_t *__restrict__ valid, int m0, int n0, int wm, int wn, int lane, int cout, int relu) {
+    constexpr int NJ = BN / 64;
+    const unsigned long long vmask = __ballot(valid[m0 + wm * 64 + lane] != 0);
+    const float floor_ = relu ? 0.0f : -3.402823466e38f;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+            const float sc = scale[col], sh = shift[col];
+            const int rbase = i * 32 + 4 * (lane >> 5);
+            float *yp = Y + (size_t)(m0 + wm * 64 + rbase) * cout + col;
+            float addv[16];
+            if (ADD) {
+                const float *ap = Add + (size_t)(m0 + wm * 64 + rbase) * cout + col;
+#pragma unroll
+                for (int q = 0; q < 16; q++) addv[q] = ap[(size_t)((q & 3) + 8 * (q >> 2)) * cout];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int ro = (q & 3) + 8 * (q >> 2);
+                float y = __builtin_fmaf(acc[i][j][q], sc, sh);
+                if (ADD) y += addv[q];
+                y = fmaxf(y, floor_);
+                y = ((vmask >> (rbase + ro)) & 1ull) ? y : 0.0f;
+                yp[(size_t)ro * cout] = y;
+            }
+        }
+}
+
 template <int BN, int NBUF, bool ADD>
 __global__ __launch_bounds__(256) void k3_conv(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wt,
                                                   const float *__restrict__ scale, const float *__restrict__ shift,
@@ -198,35 +234,141 @@ __global__ __launch_bounds__(256) void k3_conv(const float *__restrict__ X, floa
         lstore(nxt);
         __syncthreads();
     }
-    // epilogue: C/D layout of 32x32 tiles: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-    // Row validity of the wavefront's 64 rows is one ballot; the residual values are fetched 16 at a time (no load -> wait
-    // -> load chains).
-    const unsigned long long vmask = __ballot(valid[m0 + wm * 64 + lane] != 0);
-    const float floor_ = relu ? 0.0f : -3.402823466e38f;
+    conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, m0, n0, wm, wn, lane, cout, relu);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the same convolution on the BF16 matrix cores at fp32 accuracy: every fp32 operand is split EXACTLY into three bf16
+// pieces (x = h + m + l, 3 x 8 = the 24 significant bits), and the six products that matter are accumulated in fp32:
+//     x w  ~=  h h' + (h m' + m h') + (h l' + l h' + m m')            (dropped: m l', l m', l l' < 2^-24 |x w|)
+// v_mfma_f32_32x32x16_bf16 runs at 16x the fp32 MFMA rate, so six of them are 2.67x faster than the fp32 instruction for
+// the same product (417 vs 157 TFLOP/s peak).  Weights are split once at dn_load_cnn ([step][piece][cout][32] bf16);
+// activations stay fp32 in HBM and are split by the loader on their way into LDS (three bf16 planes, pitch 40 elements:
+// one ds_read_b128 per fragment).  tools/cnn_split_precision.py: probabilities move by 2e-6 (fp32 MFMA vs CPU: 2e-6).
+// ---------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define CNN_BP 40
+
+__device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const float x = q < 4 ? lo4[q] : hi4[q - 4];
+        const __bf16 hh = (__bf16)x;
+        const float r1 = x - (float)hh;                    // exact
+        const __bf16 mm = (__bf16)r1;
+        const float r2 = r1 - (float)mm;                   // exact
+        h[q] = hh; m[q] = mm; l[q] = (__bf16)r2;
+    }
+}
+
+// Loop order: input-channel block outermost, taps inside.  The A tile of a channel block (128 + k - 1 rows) is split and
+// staged ONCE and every tap reads it at a row offset, so a k-tap layer converts each activation once instead of k times;
+// only the B tile changes per step.  Weights are laid out [channel block][tap][piece][cout][32] to match.
+#define CNN_AROWS (CNN_BM + 16)
+template <int BN, bool ADD>
+__global__ __launch_bounds__(256) void k3_conv_bf16(const float *__restrict__ X, float *__restrict__ Y, const __bf16 *__restrict__ Wb,
+                                                    const float *__restrict__ scale, const float *__restrict__ shift,
+                                                    const float *__restrict__ Add, const uint8_t *__restrict__ valid, int rows, int k,
+                                                    int cin, int cout, int relu) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[3][CNN_AROWS * CNN_BP];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[3][BN * CNN_BP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * CNN_BM, n0 = blockIdx.y * BN;
+    constexpr int NJ = BN / 64;
+    constexpr int NBQ = BN / 64;                          // 16-byte B chunks per thread per piece
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-            const float sc = scale[col], sh = shift[col];
-            const int rbase = i * 32 + 4 * (lane >> 5);
-            float *yp = Y + (size_t)(m0 + wm * 64 + rbase) * cout + col;
-            float addv[16];
-            if (ADD) {
-                const float *ap = Add + (size_t)(m0 + wm * 64 + rbase) * cout + col;
+        for (int j = 0; j < NJ; j++)
 #pragma unroll
-                for (int q = 0; q < 16; q++) addv[q] = ap[(size_t)((q & 3) + 8 * (q >> 2)) * cout];
-            }
+            for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
+    const int half = (k - 1) / 2;
+    const int cblocks = cin >> 5;
+    const int steps = k * cblocks;
+    const int arows = CNN_BM + k - 1;
+    const int l_r = tid >> 2, l_k = (tid & 3) * 8;        // loader: 64 rows x 4 chunks of 8 elements per pass
+    f32x4 ra[3][2]; bool pin[3];
+    u32x4 rb[3][NBQ];
+    auto gloadA = [&](int cb) {
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int ro = (q & 3) + 8 * (q >> 2);
-                float y = __builtin_fmaf(acc[i][j][q], sc, sh);
-                if (ADD) y += addv[q];
-                y = fmaxf(y, floor_);
-                y = ((vmask >> (rbase + ro)) & 1ull) ? y : 0.0f;
-                yp[(size_t)ro * cout] = y;
+        for (int p = 0; p < 3; p++) {
+            const int ar = p * 64 + l_r;                   // row of the staged tile; global row = m0 - half + ar
+            const int src = m0 - half + ar;
+            const bool in = ar < arows && src >= 0 && src < rows;
+            const float *xp = X + (size_t)(in ? src : m0) * cin + (cb << 5) + l_k;
+            ra[p][0] = *reinterpret_cast<const f32x4 *>(xp); ra[p][1] = *reinterpret_cast<const f32x4 *>(xp + 4);
+            pin[p] = in;
+        }
+    };
+    auto gloadB = [&](int s) {
+#pragma unroll
+        for (int pc = 0; pc < 3; pc++) {
+            const __bf16 *wb = Wb + ((size_t)(s * 3 + pc) * cout + n0) * 32;
+#pragma unroll
+            for (int q = 0; q < NBQ; q++) rb[pc][q] = *reinterpret_cast<const u32x4 *>(wb + (size_t)(q * 64 + l_r) * 32 + l_k);
+        }
+    };
+    auto lstoreA = [&]() {
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            if (p * 64 + l_r < CNN_AROWS) {
+                bf16x8 h, m, l;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                split3(pin[p] ? ra[p][0] : z, pin[p] ? ra[p][1] : z, h, m, l);
+                const int o = (p * 64 + l_r) * CNN_BP + l_k;
+                *reinterpret_cast<bf16x8 *>(&As[0][o]) = h; *reinterpret_cast<bf16x8 *>(&As[1][o]) = m; *reinterpret_cast<bf16x8 *>(&As[2][o]) = l;
             }
         }
+    };
+    auto lstoreB = [&]() {
+#pragma unroll
+        for (int pc = 0; pc < 3; pc++)
+#pragma unroll
+            for (int q = 0; q < NBQ; q++) *reinterpret_cast<u32x4 *>(&Bs[pc][(q * 64 + l_r) * CNN_BP + l_k]) = rb[pc][q];
+    };
+    gloadA(0); gloadB(0);
+    lstoreA(); lstoreB();
+    __syncthreads();
+    const int fm = lane & 31, fk = (lane >> 5) * 8;
+    int tap = 0, cb = 0;
+    for (int s = 0; s < steps; s++) {
+        const bool lastTap = tap == k - 1;
+        gloadB(min(s + 1, steps - 1));
+        if (lastTap) gloadA(min(cb + 1, cblocks - 1));      // wave-uniform branch
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k16 = 0; k16 < 2; k16++) {
+            bf16x8 a[2][3], b[NJ][3];
+#pragma unroll
+            for (int pc = 0; pc < 3; pc++) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) a[i][pc] = *reinterpret_cast<const bf16x8 *>(&As[pc][(wm * 64 + i * 32 + fm + tap) * CNN_BP + k16 * 16 + fk]);
+#pragma unroll
+                for (int j = 0; j < NJ; j++) b[j][pc] = *reinterpret_cast<const bf16x8 *>(&Bs[pc][(wn * (BN / 2) + j * 32 + fm) * CNN_BP + k16 * 16 + fk]);
+            }
+            // smallest terms first, so the big h h' product meets an accumulator that already holds the corrections
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+                constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};      // m m', l h', h l', m h', h m', h h'
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < NJ; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        lstoreB();
+        if (lastTap) lstoreA();
+        __syncthreads();
+        tap = lastTap ? 0 : tap + 1;
+        cb += lastTap ? 1 : 0;
+    }
+    conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, m0, n0, wm, wn, lane, cout, relu);
 }
 
 // depthwise part of SeparableConv1D: each thread owns 4 channels of DW_ROWS consecutive rows and slides a register window
@@ -320,6 +462,8 @@ struct CnnRun {
     CnnRows rows; uint8_t *valid;
     const float *core, *resid, *sig; float *probs;
     unsigned max_pos;
+    const __bf16 *wts_bf16;           // device: split conv weights (null = fp32 MFMA path)
+    const int64_t *wb_off;            // host: per op offset into wts_bf16 (in elements)
 };
 
 int k3_run(const CnnRun &c, hipStream_t st) {
@@ -339,9 +483,15 @@ int k3_run(const CnnRun &c, hipStream_t st) {
                 const float *add = o.op == DN_CNN_CONV_ADD ? c.buf[o.a] : nullptr;          // fused residual join: y = act(conv + buf[a])
 #define CONV_GO(BN_, NBUF_, ADD_) hipLaunchKernelGGL((k3_conv<BN_, NBUF_, ADD_>), dim3(rows / CNN_BM, o.cout / BN_), dim3(256), 0, st, \
         c.buf[o.src], c.buf[o.dst], c.wts + o.w, c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu)
-                if (o.cout % 128 == 0) { if (add) CONV_GO(128, 2, true); else CONV_GO(128, 2, false); }
+#define CONV_GO_BF(BN_, ADD_) hipLaunchKernelGGL((k3_conv_bf16<BN_, ADD_>), dim3(rows / CNN_BM, o.cout / BN_), dim3(256), 0, st, \
+        c.buf[o.src], c.buf[o.dst], c.wts_bf16 + c.wb_off[i], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu)
+                if (c.wts_bf16) {
+                    if (o.cout % 128 == 0) { if (add) CONV_GO_BF(128, true); else CONV_GO_BF(128, false); }
+                    else { if (add) CONV_GO_BF(64, true); else CONV_GO_BF(64, false); }
+                } else if (o.cout % 128 == 0) { if (add) CONV_GO(128, 2, true); else CONV_GO(128, 2, false); }
                 else { if (add) CONV_GO(64, 1, true); else CONV_GO(64, 1, false); }
 #undef CONV_GO
+#undef CONV_GO_BF
                 break;
             }
             case DN_CNN_DWCONV: {

@@ -103,6 +103,10 @@ typedef struct {
     int64_t aux[6];             /* ENCODE_GRU: kernel/recurrent/bias offsets of the two GRUs */
 } dn_cnn_op;
 int dn_load_cnn(dn_ctx *ctx, const dn_cnn_op *ops, uint32_t n_ops, const float *weights, uint64_t n_weights, uint32_t n_buffers);
+/* how the convolutions multiply: exact fp32 MFMA, or fp32 operands split exactly into three bf16 pieces with the six
+ * significant products accumulated in fp32 on the bf16 matrix cores (fp32-equivalent: dropped terms < 2^-24; default) */
+enum { DN_CNN_MATH_FP32 = 0, DN_CNN_MATH_BF16X6 = 1 };
+int dn_cnn_set_math(dn_ctx *ctx, int mode);
 int dn_run_cnn(dn_ctx *ctx);            /* runCNN for every read that passed eventalign */
 int dn_get_probabilities(dn_ctx *ctx, uint32_t read, float *probs /* [n_positions * 3] */);
 /* the TF_SessionRun seam itself (detect.cpp:653): n_seq sequences given as the three host tensors runCNN builds --
