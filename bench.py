@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--reads", type=int, default=1000)
     ap.add_argument("--bases", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scope", choices=["banded", "full"], default="banded",
+                    help="banded = BASELINE configs[1] (the default, CNN stubbed); full = configs[2]'s pipeline at this batch size: "
+                         "normalise + eventalign + CNN, probabilities left in HBM")
     ap.add_argument("--inflight", type=int, default=4,
                     help="batches in flight per GPU (each on its own context/stream/workspace); every stage is latency-bound "
                          "at <= 1 wavefront per SIMD for a 1000-read batch, so consecutive steps are overlapped")
@@ -97,8 +100,15 @@ def main():
     nctx = max(1, min(args.inflight, args.steps))
     ctxs = [hip.Context(dev) for _ in range(nctx)]
     batch, reads = make_batch(args.reads, args.bases, 1000003 * (rank + 1), model)
+    stages = ["normalise"] if args.scope == "banded" else ["normalise", "eventalign", "cnn"]
+    cnn_desc = None
+    if args.scope == "full":
+        from dnascent_amd import cnn_model
+        cnn_desc, cnn_blob, _ = cnn_model.default_model()
     for c in ctxs:
         c.load_pore_model(model, 0.14)
+        if cnn_desc is not None:
+            c.load_cnn(cnn_desc, cnn_blob)
         batch.upload(c)                    # inputs resident in HBM before the timed region (one copy per in-flight slot)
     ctx = ctxs[0]
     samples_per_step = batch.samples()
@@ -117,14 +127,16 @@ def main():
         """k steps in total; slot j runs steps j, j+nctx, ... on its own host thread (dn_run_banded syncs its stream)."""
         if nctx == 1:
             for _ in range(k):
-                ctx.run("normalise")
+                for st in stages:
+                    ctx.run(st)
             ctx.sync()
             return
         import threading
 
         def worker(j):
             for _ in range(j, k, nctx):
-                ctxs[j].run("normalise")
+                for st in stages:
+                    ctxs[j].run(st)
             ctxs[j].sync()
         th = [threading.Thread(target=worker, args=(j,)) for j in range(nctx)]
         for t in th:
@@ -195,6 +207,21 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": fill_ms / max(fill_n, 1)},
             "kernel_ms_per_launch": {k: v[0] / v[1] for k, v in prof.items() if v[1]},
         }
+        if args.scope == "full":
+            # dominant stage = the CNN: algorithmic flops = 2 x MACs of the description x positions (3.7 MFLOP x L);
+            # peak = the 6 x bf16-MFMA rate the fp32-equivalent split runs at (2.5 PFLOP/s / 6), see DESIGN.md s4b
+            mac = sum(o["k"] * o["cin"] * o["cout"] for o in cnn_desc["ops"] if o["op"] == "conv") + 47040
+            pos = float(np.sum(summ["n_positions"][summ["status"] == 0]))
+            cnn_ms, cnn_n = prof["k3_cnn"]
+            ach = 2.0 * mac * pos / ((cnn_ms / max(cnn_n, 1)) / 1e3) / 1e12
+            out["config"]["workload"] = out["config"]["workload"].replace("banded-HMM scope (segmentation + rough scaling + adaptive banded "
+                                                                          "alignment + backtrack/QC + Theil-Sen), CNN stubbed",
+                                                                          "full pipeline (normalise + eventalign + CNN, bf16x6 math)")
+            out["config"]["cnn_positions_per_gpu_step"] = int(pos)
+            out["roofline_banded"] = out["roofline"]
+            out["roofline"] = {"bound": "mfma", "kernel": "k3_cnn (all layers of one pass)", "achieved": ach, "peak": 417.0, "unit": "TFLOP/s",
+                               "frac": ach / 417.0, "traffic": None, "mean_launch_ms": cnn_ms / max(cnn_n, 1),
+                               "algorithmic_flops_per_launch": 2.0 * mac * pos}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(reads, model)
         print(json.dumps(out), flush=True)
