@@ -28,6 +28,7 @@ void k2_launch_fill(const BatchDev &, const void *, const void *, bool, hipStrea
 void k2_launch_chase(const BatchDev &, uint8_t *, hipStream_t);
 void k2_launch_post(const BatchDev &, const uint8_t *, float *, const void *, hipStream_t);
 void k2b_launch(const BatchDev &, const void *, const void *, const void *, unsigned, hipStream_t);
+int k2_fill_variant();
 struct CnnRows { const unsigned *row_off; const uint8_t *valid; unsigned rows, r0, r1; const unsigned *n_pos; const uint64_t *io_off; };
 struct CnnRun { const dn_cnn_op *ops; int n_ops; const float *wts; float *buf[8]; int n_buf; CnnRows rows; uint8_t *valid;
                  const float *core, *resid, *sig; float *probs; unsigned max_pos; const uint16_t *wts_bf16; const int64_t *wb_off; };
@@ -614,10 +615,21 @@ int dn_get_trace(dn_ctx *c, uint32_t read, uint8_t *trace, int32_t *band_event, 
     const size_t nb = c->h_res[read].n_bands;
     std::vector<uint8_t> rows(nb * DN_TROW);
     if ((rc = d2h(c, rows.data(), c->B.trace + c->h_trace_off[read] * DN_TROW, nb * DN_TROW))) return rc;
+    const bool slot_rows = k2_fill_variant() == 6;
+    int32_t ev_prev = 48;
     for (size_t b = 0; b < nb; b++) {
         const uint8_t *p = rows.data() + b * DN_TROW;
-        if (trace) memcpy(trace + b * DN_BANDWIDTH, p, DN_BANDWIDTH);
-        int32_t ev; memcpy(&ev, p + 104, 4);          // ll.event_idx; ll.event_idx + ll.kmer_idx == band - 2 for every band
+        int32_t ev;
+        if (slot_rows) {
+            // k2_fill6 rows are indexed by event & 127 with 0xFF outside the band; the corner moves by exactly one per band:
+            // the band moved down iff the slot of event ev_prev + 1 is in the band
+            ev = (b == 0) ? 49 : ((p[(ev_prev + 1) & 127] != 0xFF) ? ev_prev + 1 : ev_prev);
+            if (trace) for (int o = 0; o < DN_BANDWIDTH; o++) trace[b * DN_BANDWIDTH + o] = p[(ev - o) & 127];
+            ev_prev = ev;
+        } else {
+            if (trace) memcpy(trace + b * DN_BANDWIDTH, p, DN_BANDWIDTH);
+            memcpy(&ev, p + 104, 4);                  // ll.event_idx; ll.event_idx + ll.kmer_idx == band - 2 for every band
+        }
         if (band_event) band_event[b] = ev;
         if (band_kmer) band_kmer[b] = (int32_t)b - 2 - ev;
     }

@@ -62,6 +62,13 @@ __device__ __forceinline__ double from_prev_d(double v, int lane) {
 }
 __device__ __forceinline__ double set_lane_d(double v, double nv, int which, int lane) { return lane == which ? nv : v; }
 
+// v_writelane_b32 with the value in an SGPR and the lane select in M0 (gfx9 allows one SGPR per VALU instruction; M0 is the
+// second scalar source the instruction accepts).  val and lane are wave-uniform.
+__device__ __forceinline__ int writelane_(int old, int val, int lane) {
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(lane) : "m0");
+    return old;
+}
+
 // self-test of the shift primitives (dn_ctx_create refuses to run if this fails)
 __global__ void k2_selftest(int *out) {
     const int lane = threadIdx.x;
@@ -76,6 +83,13 @@ __global__ void k2_selftest(int *out) {
     if (lane > 0) ok = ok && (g == h) && (c == (float)((lane - 1) * 3 + 1));
     if (lane == 63) ok = ok && (a == -7.0f);
     if (lane == 0) ok = ok && (c == -9.0f);
+    // primitives of k2_fill6: wave rotate (lane l <- lane l - 1 mod 64), a uniform mask as a lane predicate, writelane
+    const int rr = __builtin_amdgcn_update_dpp(0, lane * 5 + 2, 0x13C, 0xf, 0xf, false);
+    ok = ok && (rr == ((lane + 63) & 63) * 5 + 2);
+    const unsigned long long pat = 0x8000000000000001ull | (0x5ull << 20);
+    ok = ok && (__builtin_amdgcn_inverse_ballot_w64(pat) == (((pat >> lane) & 1ull) != 0ull));
+    const int wl = writelane_(lane, 777, 37);
+    ok = ok && (wl == (lane == 37 ? 777 : lane));
     const unsigned long long m = __ballot(ok);
     if (lane == 0) out[0] = (m == ~0ull) ? 1 : 0;
 }
@@ -1039,10 +1053,210 @@ __global__ __launch_bounds__(64) void k2_fill5(BatchDev B, const BandConsts *bc,
 }
 
 // ------------------------------------------------------------------------------------------------
+// k2_fill6: event-keyed slots.  The 100 cells of a band are the events [ev - 99, ev]; cell (event e, kmer k = b - 2 - e)
+// lives in slot e & 127 = lane (e & 127) >> 1, register e & 1 (A: even events, B: odd events) for as long as event e is in
+// the band.  Consequences, all of which remove per-band selects that k2_fill5 needs because its cells are keyed by the
+// band offset:
+//   * the scaled event level x is STATIONARY in its slot; a new event is written once (v_writelane) when it enters;
+//   * "left" (e, k - 1) is the SAME slot of the previous band; "up" (e - 1, k) is the previous slot of the previous band:
+//     upB = PA, upA = wave_ror(PB), one DPP move, independent of the band move; "diag" is the previous band's up operand;
+//   * the k-mer level mu rotates by one slot EVERY band (k grows by one per band for a fixed event), again independent of
+//     the move: MB' = MA, MA' = wave_ror(MB); the one level that enters the window is written by v_writelane;
+//   * the Suzuki move only changes WHICH slots are in the band: two uniform 64-bit masks (a 50-lane cyclic run each),
+//     built on the scalar unit, applied with one v_cndmask per register; the decision itself is integer arithmetic on the
+//     two end scores read with v_readlane.
+// Trace row b (128 B): byte s = from-code of the cell in slot s, 0xFF for the 28 slots outside the band.  The backtrack
+// indexes it with e & 127 and needs no per-band corner; a path that steps out of the band reads 0xFF.
+// ------------------------------------------------------------------------------------------------
+// every lane has a source under a rotate, so the "old" operand is dead: bound_ctrl lets the compiler drop its initialisation
+__device__ __forceinline__ float ror_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C, 0xf, 0xf, true));
+}
+__device__ __forceinline__ double ror_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x13C, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x13C, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double writelane_d(double v, double nv, int lane_sel) {      // nv and lane_sel are wave-uniform
+    const long long b = __double_as_longlong(v), n = __double_as_longlong(nv);
+    const int lo = writelane_((int)(b & 0xffffffffll), (int)(n & 0xffffffffll), lane_sel);
+    const int hi = writelane_((int)(b >> 32), (int)(n >> 32), lane_sel);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ unsigned long long rotl64_(unsigned long long m, unsigned n) {   // n in 0..63, uniform
+    return (m << n) | ((m >> 1) >> (63u - n));
+}
+__device__ __forceinline__ int ordered_f32_bits(int x) { return x ^ ((x >> 31) & 0x7fffffff); }   // a < b as floats <=> as these ints
+
+// both registers of one lane at once: A[lane_sel] = va, B[lane_sel] = vb (four v_writelane under one M0)
+__device__ __forceinline__ void writelane_pair_d(double &A, double &Bv, double va, double vb, int lane_sel) {
+    const long long a = __double_as_longlong(A), b = __double_as_longlong(Bv);
+    const long long na = __double_as_longlong(va), nb = __double_as_longlong(vb);
+    int alo = (int)(a & 0xffffffffll), ahi = (int)(a >> 32), blo = (int)(b & 0xffffffffll), bhi = (int)(b >> 32);
+    asm volatile("s_mov_b32 m0, %8\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0\n\tv_writelane_b32 %3, %7, m0"
+                 : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi)
+                 : "s"((int)(na & 0xffffffffll)), "s"((int)(na >> 32)), "s"((int)(nb & 0xffffffffll)), "s"((int)(nb >> 32)), "s"(lane_sel)
+                 : "m0");
+    A = __longlong_as_double(((long long)ahi << 32) | (unsigned)alo);
+    Bv = __longlong_as_double(((long long)bhi << 32) | (unsigned)blo);
+}
+
+struct F6State {
+    float PA, PB, DA, DB;
+    double XA, XB, MA, MB;
+    int ev, km;              // lower-left corner of the last band
+};
+struct F6In { double x0, x1, m0, m1; };   // prefetched for the next band: x of an event pair (2j, 2j + 1), mu of kmers (kA - 1, kA)
+
+template <bool FAST>
+__device__ __forceinline__ void f6_prefetch(F6In &in, int b_next, int ev, int E, int K, const cdptr_t xs_c, const cdptr_t mu_c) {
+    // band b_next writes the event pair that holds event ev + 1 and the kmer levels of the pair that holds event ev - 99
+    const int p = (ev + 1) & ~1;
+    const int q = (ev - (DN_W - 1)) & ~1;                  // two's complement: rounds down for negative events too
+    const int kA = b_next - 2 - q;                         // kmer of the even event of that pair in band b_next; the odd one has kA - 1
+    if (FAST) { in.x0 = xs_c[p]; in.x1 = xs_c[p + 1]; in.m0 = mu_c[kA - 1]; in.m1 = mu_c[kA]; }
+    else {
+        in.x0 = xs_c[max(min(p, E - 1), 0)]; in.x1 = xs_c[max(min(p + 1, E - 1), 0)];
+        in.m0 = mu_c[max(min(kA - 1, K - 1), 0)]; in.m1 = mu_c[max(min(kA, K - 1), 0)];
+    }
+}
+
+template <bool FAST>
+__device__ __forceinline__ void f6_band(F6State &st, const int b, const int E, const int K, const int lane2, const cdptr_t xs_c,
+                                        const cdptr_t mu_c, F6In &in, const FillConsts &fc, const double lp_step,
+                                        const double lp_stay, unsigned short *rows16, float &best, int &best_e, int &found) {
+    const int NINF_BITS = (int)0xff800000;
+    const float NINF = neg_inf();
+    // ---- Suzuki-Kasahara move (:237-253) from the end cells of the previous band: events ev (lower left) and ev - 99 ----
+    const int ev0 = st.ev, el0 = ev0 - (DN_W - 1);
+    const int l_lo = (ev0 & 127) >> 1, l_hi = (el0 & 127) >> 1;
+    const int loA = __builtin_amdgcn_readlane(__float_as_int(st.PA), l_lo), loB = __builtin_amdgcn_readlane(__float_as_int(st.PB), l_lo);
+    const int hiA = __builtin_amdgcn_readlane(__float_as_int(st.PA), l_hi), hiB = __builtin_amdgcn_readlane(__float_as_int(st.PB), l_hi);
+    const int lo = (ev0 & 1) ? loB : loA, hi = (el0 & 1) ? hiB : hiA;
+    // integer 0/1 arithmetic (scalar unit, no branch): both end cells out of band -> alternate by parity, else ll < ur
+    const int ob = (int)(((lo ^ NINF_BITS) | (hi ^ NINF_BITS)) == 0);
+    const int lt = (int)(ordered_f32_bits(lo) < ordered_f32_bits(hi));
+    const int right = (ob & b & 1) | ((ob ^ 1) & lt);
+    // ---- entering values, written pair-wise (both registers of a lane under one M0), independent of the move and
+    //      idempotent: the event pair that holds event ev0 + 1; after the rotation, the kmer levels of the pair that
+    //      holds event ev0 - 99.  Whatever is not needed yet lies outside the band or already has exactly that value. ----
+    writelane_pair_d(st.XA, st.XB, in.x0, in.x1, ((ev0 + 1) & 127) >> 1);
+    {
+        const double nMA = ror_d(st.MB);                   // event 2l now has the kmer event 2l - 1 had
+        st.MB = st.MA;                                     // event 2l + 1 the kmer event 2l had
+        st.MA = nMA;
+    }
+    writelane_pair_d(st.MA, st.MB, in.m1, in.m0, l_hi);
+    const int km = st.km + right, ev = ev0 + (right ^ 1);
+    st.km = km; st.ev = ev;
+    f6_prefetch<FAST>(in, b + 1, ev, E, K, xs_c, mu_c);
+    // ---- in-band slots: ((ev - event) & 127) < 100 ----
+    const unsigned tA = (unsigned)(ev - lane2) & 127u;
+    const bool actA = tA < (unsigned)DN_W, actB = (tA - 1u) < (unsigned)DN_W;
+    // ---- operands: left = same slot, up = previous slot, diag = the previous band's up ----
+    const float upA = ror_f(st.PB), upB = st.PA;
+    float SA, SB; unsigned FA, FB;
+    cell(st.DA, upA, st.PA, st.XA, st.MA, fc, lp_step, lp_stay, SA, FA);
+    cell(st.DB, upB, st.PB, st.XB, st.MB, fc, lp_step, lp_stay, SB, FB);
+    if (FAST) {
+        SA = actA ? SA : NINF; SB = actB ? SB : NINF;
+    } else {
+        const int eA = ev - (int)tA, eB = ev - (int)((tA - 1u) & 127u);
+        const int kA = b - 2 - eA, kB = b - 2 - eB;
+        const bool okA = actA && (unsigned)kA < (unsigned)K && (unsigned)eA < (unsigned)E;       // :269-278
+        const bool okB = actB && (unsigned)kB < (unsigned)K && (unsigned)eB < (unsigned)E;
+        SA = okA ? SA : NINF; FA = okA ? FA : 0u;
+        SB = okB ? SB : NINF; FB = okB ? FB : 0u;
+        if (km <= -1) {                                    // trim column kmer == -1 (:256-265)
+            if (actA && kA == -1 && (unsigned)eA < (unsigned)E) { SA = (float)(fc.lp_trim * (double)((unsigned)eA + 1u)); FA = 1; }
+            if (actB && kB == -1 && (unsigned)eB < (unsigned)E) { SB = (float)(fc.lp_trim * (double)((unsigned)eB + 1u)); FB = 1; }
+        }
+        const int ee = b - 2 - (K - 1);                    // end column kmer == K - 1 (:329-340)
+        if (ee <= ev && ee > ev - DN_W && ee >= 0 && ee < E) {
+            const int svA = __builtin_amdgcn_readlane(__float_as_int(SA), (ee & 127) >> 1), svB = __builtin_amdgcn_readlane(__float_as_int(SB), (ee & 127) >> 1);
+            const float sv = __int_as_float((ee & 1) ? svB : svA);
+            const float sc = (float)((double)sv + (double)(unsigned long long)(E - ee) * fc.lp_trim);
+            if (sc > best) { best = sc; best_e = ee; found = 1; }
+        }
+    }
+    FA = actA ? FA : 0xFFu; FB = actB ? FB : 0xFFu;
+    rows16[(size_t)b * (DN_TROW / 2) + (lane2 >> 1)] = (unsigned short)(FA | (FB << 8));
+    st.DA = upA; st.DB = upB; st.PA = SA; st.PB = SB;
+}
+
+__global__ __launch_bounds__(64) void k2_fill6(BatchDev B, const BandConsts *bc, FillConsts fc) {
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x, lane2 = 2 * lane;
+    ReadRes &R = B.res[r];
+    if (R.status != 0) return;
+    const int E = __builtin_amdgcn_readfirstlane((int)R.n_events), K = __builtin_amdgcn_readfirstlane((int)R.n_kq);   // wave-uniform: keep them scalar
+    const int n_bands = E + K + 2;
+    const double lp_stay = bc[r].lp_stay, lp_step = bc[r].lp_step;
+    const double *xs = B.ev_x + B.ev_off[r];
+    const double *mus = B.mu_q + B.base_off[r];
+    const cdptr_t xs_c = (cdptr_t)(uintptr_t)xs;
+    const cdptr_t mu_c = (cdptr_t)(uintptr_t)mus;
+    unsigned short *rows16 = reinterpret_cast<unsigned short *>(B.trace + B.trace_off[r] * DN_TROW);
+    const float NINF = neg_inf();
+    // ---- bands 0 and 1 (event_handling.cpp:213-228): corners (49, -51) and (50, -51) ----
+    F6State st;
+    st.ev = 50; st.km = -51;
+    // slot events as seen from band 1 (events -49 .. 50 are in the band; the other slots belong to the events that enter next)
+    const int eA = 50 - (int)(((unsigned)(50 - lane2)) & 127u), eB = 50 - (int)(((unsigned)(50 - lane2 - 1)) & 127u);
+    st.PA = (eA == 0) ? (float)fc.lp_trim : NINF; st.PB = NINF;          // band 1: cell (event 0, kmer -1) = lp_trim (:224-228)
+    st.DA = (lane == 0) ? 0.0f : NINF; st.DB = NINF;                     // band 0: cell (event -1, kmer -1) = 0 is the up operand of event 0
+    auto ldx = [&](int e) -> double { return (e >= 0 && e < E) ? xs[e] : 0.0; };
+    auto ldm = [&](int k) -> double { return (k >= 0 && k < K) ? mus[k] : 0.0; };
+    st.XA = ldx(eA); st.XB = ldx(eB);
+    st.MA = ldm(1 - 2 - eA); st.MB = ldm(1 - 2 - eB);                    // kmer of event e in band 1
+    {
+        // rows 0 and 1: band 0 holds events -50 .. 49 (all from-codes 0), band 1 events -49 .. 50 (event 0: from U, :226)
+        const int e0A = 49 - (int)(((unsigned)(49 - lane2)) & 127u), e0B = 49 - (int)(((unsigned)(49 - lane2 - 1)) & 127u);
+        const unsigned a0 = (e0A >= -50) ? 0u : 0xFFu, b0 = (e0B >= -50) ? 0u : 0xFFu;
+        const unsigned a1 = (eA >= -49) ? (eA == 0 ? 1u : 0u) : 0xFFu, b1 = (eB >= -49) ? 0u : 0xFFu;
+        rows16[lane] = (unsigned short)(a0 | (b0 << 8));
+        rows16[DN_TROW / 2 + lane] = (unsigned short)(a1 | (b1 << 8));
+    }
+    F6In in;
+    f6_prefetch<false>(in, 2, st.ev, E, K, xs_c, mu_c);
+    float best = NINF; int best_e = 0; int found = 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // retire the pre-loop vector loads once (not per band)
+
+    int b = 2;
+    while (b < n_bands) {
+        const int km = st.km, ev = st.ev;                  // corner of band b-1
+        // a band is "fast" when, after its move, 0 <= km', km' + 101 < K and 99 <= ev' < E - 1: all 100 cells inside the matrix,
+        // no trim / end column, every prefetch index in range.  Each band moves the corner by exactly one.
+        int run = 0;
+        if (km >= 0 && ev >= DN_W - 1) run = min(K - 102 - km, E - 3 - ev);
+        run = min(run, n_bands - b);
+        if (run > 0) {
+            const int bend = b + run;
+            for (; b + 1 < bend; b += 2) {                 // two bands per trip: the rotating state is renamed instead of moved
+                f6_band<true>(st, b, E, K, lane2, xs_c, mu_c, in, fc, lp_step, lp_stay, rows16, best, best_e, found);
+                f6_band<true>(st, b + 1, E, K, lane2, xs_c, mu_c, in, fc, lp_step, lp_stay, rows16, best, best_e, found);
+            }
+            if (b < bend) { f6_band<true>(st, b, E, K, lane2, xs_c, mu_c, in, fc, lp_step, lp_stay, rows16, best, best_e, found); b++; }
+        } else {
+            f6_band<false>(st, b, E, K, lane2, xs_c, mu_c, in, fc, lp_step, lp_stay, rows16, best, best_e, found);
+            b++;
+        }
+    }
+    if (lane == 0) {
+        R.n_bands = (unsigned)n_bands;
+        R.end_event = best_e;
+        R.end_score = best;
+        if (!found) R.status = 3;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k2_chase: record the backtrack path.  aln arrays are filled from the back so they end up in forward order.
 // ------------------------------------------------------------------------------------------------
 #define CH_ROWS 64
 
+template <bool SLOT>
 __global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[2][CH_ROWS * DN_TROW];
     const int r = blockIdx.x;
@@ -1086,7 +1300,7 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
         const uint8_t *p = tile[which] + lane * DN_TROW + 104;
         return (int)(*reinterpret_cast<const unsigned *>(p));
     };
-    int evrow = row_ev(cur);
+    int evrow = SLOT ? 0 : row_ev(cur);
 
     unsigned step = 0;
     unsigned rec_e = 0, rec_k = 0, rec_f = 0;
@@ -1100,13 +1314,19 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
             nlo = lo - CH_ROWS; if (nlo < 0) nlo = 0;
             if (lo > 0) load_tile(nlo, regs);
             __syncthreads();
-            evrow = row_ev(cur);
+            if (!SLOT) evrow = row_ev(cur);
         }
         const int bi = b - lo;
-        const int ev_b = __builtin_amdgcn_readlane(evrow, bi);
-        const int off = ev_b - e;
-        if (off < 0 || off >= DN_W || step >= cap) { bad = 1; break; }    // reference: out-of-bounds read (UB)
-        const unsigned from = tile[cur][bi * DN_TROW + off];
+        unsigned from;
+        if (SLOT) {                                        // k2_fill6 rows: byte = slot of the event, 0xFF outside the band
+            from = tile[cur][bi * DN_TROW + (e & 127)];
+            if (from == 0xFFu || step >= cap) { bad = 1; break; }            // reference: out-of-bounds read (UB)
+        } else {
+            const int ev_b = __builtin_amdgcn_readlane(evrow, bi);
+            const int off = ev_b - e;
+            if (off < 0 || off >= DN_W || step >= cap) { bad = 1; break; }    // reference: out-of-bounds read (UB)
+            from = tile[cur][bi * DN_TROW + off];
+        }
         // stash step in lane (step & 63); flush 64 steps at a time, back to front
         const int slot = step & 63;
         if (lane == slot) { rec_e = (unsigned)e; rec_k = (unsigned)k; rec_f = from; }
@@ -1254,9 +1474,14 @@ int k2_selftest_run(hipStream_t st) {
     hipFree(d);
     return h;
 }
+int k2_fill_variant() {      // 6 = event-keyed slots (slot-indexed trace rows); anything else writes offset-indexed rows
+    static const int variant = getenv("DN_FILL_VARIANT") ? atoi(getenv("DN_FILL_VARIANT")) : 6;
+    return variant;
+}
 void k2_launch_fill(const BatchDev &B, const void *bc, const void *fc, bool dpp, hipStream_t st) {
     const FillConsts f = *reinterpret_cast<const FillConsts *>(fc);
-    static const int variant = getenv("DN_FILL_VARIANT") ? atoi(getenv("DN_FILL_VARIANT")) : 5;
+    const int variant = k2_fill_variant();
+    if (variant == 6) { hipLaunchKernelGGL(k2_fill6, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f); return; }
     if (variant == 5) {
         static const int abl = getenv("DN_FILL_ABL") ? atoi(getenv("DN_FILL_ABL")) : 0;   // timing-only ablations (wrong results)
 #define L5(A) case A: hipLaunchKernelGGL(k2_fill5<A>, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f); return;
@@ -1277,7 +1502,8 @@ void k2_launch_fill(const BatchDev &B, const void *bc, const void *fc, bool dpp,
     else hipLaunchKernelGGL(k2_fill<false>, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f);
 }
 void k2_launch_chase(const BatchDev &B, uint8_t *path_from, hipStream_t st) {
-    hipLaunchKernelGGL(k2_chase, dim3(B.n_reads), dim3(64), 0, st, B, path_from);
+    if (k2_fill_variant() == 6) hipLaunchKernelGGL(k2_chase<true>, dim3(B.n_reads), dim3(64), 0, st, B, path_from);
+    else hipLaunchKernelGGL(k2_chase<false>, dim3(B.n_reads), dim3(64), 0, st, B, path_from);
 }
 void k2_launch_post(const BatchDev &B, const uint8_t *path_from, float *path_lp, const void *fc, hipStream_t st) {
     const FillConsts f = *reinterpret_cast<const FillConsts *>(fc);
