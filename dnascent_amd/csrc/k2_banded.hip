@@ -1115,7 +1115,15 @@ __device__ __forceinline__ void f6_prefetch(F6In &in, int b_next, int ev, int E,
     const int p = (ev + 1) & ~1;
     const int q = (ev - (DN_W - 1)) & ~1;                  // two's complement: rounds down for negative events too
     const int kA = b_next - 2 - q;                         // kmer of the even event of that pair in band b_next; the odd one has kA - 1
-    if (FAST) { in.x0 = xs_c[p]; in.x1 = xs_c[p + 1]; in.m0 = mu_c[kA - 1]; in.m1 = mu_c[kA]; }
+    if (FAST) {
+        // indices are in range and non-negative here: one 16-byte scalar load per pair, 32-bit byte offsets (s_load ... soffset)
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        typedef const d2_t __attribute__((address_space(4), aligned(8))) *cd2ptr_t;
+        typedef const char __attribute__((address_space(4))) *ccptr_t;
+        const d2_t xv = *(cd2ptr_t)((ccptr_t)xs_c + (unsigned)(p << 3));
+        const d2_t mv = *(cd2ptr_t)((ccptr_t)mu_c + (unsigned)((kA - 1) << 3));
+        in.x0 = xv[0]; in.x1 = xv[1]; in.m0 = mv[0]; in.m1 = mv[1];
+    }
     else {
         in.x0 = xs_c[max(min(p, E - 1), 0)]; in.x1 = xs_c[max(min(p + 1, E - 1), 0)];
         in.m0 = mu_c[max(min(kA - 1, K - 1), 0)]; in.m1 = mu_c[max(min(kA, K - 1), 0)];
@@ -1135,9 +1143,9 @@ __device__ __forceinline__ void f6_band(F6State &st, const int b, const int E, c
     const int hiA = __builtin_amdgcn_readlane(__float_as_int(st.PA), l_hi), hiB = __builtin_amdgcn_readlane(__float_as_int(st.PB), l_hi);
     const int lo = (ev0 & 1) ? loB : loA, hi = (el0 & 1) ? hiB : hiA;
     // integer 0/1 arithmetic (scalar unit, no branch): both end cells out of band -> alternate by parity, else ll < ur
-    const int ob = (int)(((lo ^ NINF_BITS) | (hi ^ NINF_BITS)) == 0);
-    const int lt = (int)(ordered_f32_bits(lo) < ordered_f32_bits(hi));
-    const int right = (ob & b & 1) | ((ob ^ 1) & lt);
+    const int ol = ordered_f32_bits(lo), oh = ordered_f32_bits(hi);
+    const int lt = (ol < oh) ? 1 : 0;
+    const int right = (max(ol, oh) == ordered_f32_bits(NINF_BITS)) ? (b & 1) : lt;
     // ---- entering values, written pair-wise (both registers of a lane under one M0), independent of the move and
     //      idempotent: the event pair that holds event ev0 + 1; after the rotation, the kmer levels of the pair that
     //      holds event ev0 - 99.  Whatever is not needed yet lies outside the band or already has exactly that value. ----
