@@ -62,8 +62,9 @@ struct dn_ctx {
     bool use_dpp = true;
     std::string err;
     size_t dev_bytes = 0;
-    std::vector<void *> allocs;
-    std::vector<std::pair<void *, size_t>> alloc_sizes;
+    // per-batch workspaces come out of grow-only slabs: after the first batches no hipMalloc / hipFree happens per upload
+    struct Slab { char *p; size_t cap, used; };
+    std::vector<Slab> slabs; size_t slab_cur = 0;
     // model
     double *d_model = nullptr; double sigma = 0.14; bool have_model = false;
     // batch
@@ -106,17 +107,32 @@ static int fail(dn_ctx *c, int code, const char *fmt, ...) {
 
 template <class T>
 static int dalloc(dn_ctx *c, T **p, size_t n) {
+    const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+    for (; c->slab_cur < c->slabs.size(); c->slab_cur++) {
+        dn_ctx::Slab &s = c->slabs[c->slab_cur];
+        if (s.used + bytes <= s.cap) { *p = (T *)(s.p + s.used); s.used += bytes; return DN_OK; }
+    }
+    // a new slab: at least 256 MiB or half of what is already held, so a handful of slabs cover any steady-state batch size
+    size_t held = 0;
+    for (const dn_ctx::Slab &s : c->slabs) held += s.cap;
+    const size_t cap = std::max(bytes, std::max<size_t>((size_t)256 << 20, held / 2));
     void *q = nullptr;
-    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
-    hipError_t e = hipMalloc(&q, bytes);
+    hipError_t e = hipMalloc(&q, cap);
+    if (e != hipSuccess && cap > bytes) e = hipMalloc(&q, bytes);          // memory is tight: exactly what is needed
     if (e != hipSuccess) return fail(c, DN_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
-    c->allocs.push_back(q); c->alloc_sizes.push_back({q, bytes}); c->dev_bytes += bytes;
+    const size_t got = (e == hipSuccess && q) ? std::max(bytes, cap) : bytes;
+    c->slabs.push_back({ (char *)q, got, bytes }); c->dev_bytes += got;
+    c->slab_cur = c->slabs.size() - 1;
     *p = (T *)q;
     return DN_OK;
 }
-static void dfree_all(dn_ctx *c) {
-    for (void *p : c->allocs) hipFree(p);
-    c->allocs.clear(); c->alloc_sizes.clear();
+static void dfree_all(dn_ctx *c) {                       // start of a new batch: every slab is reusable from its beginning
+    for (dn_ctx::Slab &s : c->slabs) s.used = 0;
+    c->slab_cur = 0;
+}
+static void dfree_slabs(dn_ctx *c) {
+    for (dn_ctx::Slab &s : c->slabs) hipFree(s.p);
+    c->slabs.clear(); c->slab_cur = 0;
 }
 static int dgrow(dn_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap) return DN_OK;
@@ -226,7 +242,7 @@ void dn_ctx_destroy(dn_ctx *c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     prof_collect(c);
-    dfree_all(c);
+    dfree_slabs(c);
     if (c->trace.p) hipFree(c->trace.p);
     if (c->bandc.p) hipFree(c->bandc.p);
     if (c->d_model) hipFree(c->d_model);
@@ -291,7 +307,6 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
     dfree_all(c);
-    c->dev_bytes = DN_NKMER * sizeof(double) + c->trace.cap + c->bandc.cap;
     c->have_batch = false; c->stage = 0;
     const uint32_t n = d->n_reads;
     if (n == 0) {                                         // an empty buffer of reads is legal: every stage is a no-op

@@ -64,3 +64,32 @@ def test_dorado_trimming(model):
     b.add_synth(r, signal_length=2000, signal_trim=10, signal_start=300, is_split=True)   # pod5.cpp:79-86
     assert b.samples() == (n - 150) + 1990
     assert b.add_synth(r, signal_length=5, signal_trim=0) == -1                 # nothing left: rejected
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """The ctypes / numpy mirrors of the header's structs have the C compiler's sizes and field offsets (plain C, the
+    header must stay includable from C)."""
+    import ctypes as C
+    import subprocess
+    src = tmp_path / "layout.c"
+    fields_summary = [n for n in hip.SUMMARY_DTYPE.names]
+    fields_op = [f[0] for f in hip.CnnOp._fields_]
+    fields_batch = [f[0] for f in hip.BatchDesc._fields_]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dnascent_hip.h"', 'int main(void) {',
+             'printf("%zu %zu %zu\\n", sizeof(dn_read_summary), sizeof(dn_cnn_op), sizeof(dn_batch_desc));']
+    for f in fields_summary:
+        lines.append('printf("%%zu\\n", offsetof(dn_read_summary, %s));' % f)
+    for f in fields_op:
+        lines.append('printf("%%zu\\n", offsetof(dn_cnn_op, %s));' % f)
+    for f in fields_batch:
+        lines.append('printf("%%zu\\n", offsetof(dn_batch_desc, %s));' % f)
+    lines += ['return 0; }']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    sizes, offs = [int(x) for x in out[:3]], [int(x) for x in out[3:]]
+    assert sizes == [hip.SUMMARY_DTYPE.itemsize, C.sizeof(hip.CnnOp), C.sizeof(hip.BatchDesc)]
+    want = [hip.SUMMARY_DTYPE.fields[f][1] for f in fields_summary] + [getattr(hip.CnnOp, f).offset for f in fields_op] + \
+           [getattr(hip.BatchDesc, f).offset for f in fields_batch]
+    assert offs == want
