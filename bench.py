@@ -38,16 +38,28 @@ def make_batch(n_reads, n_bases, seed0, model):
     return batch, reads
 
 
-def cpu_baseline(reads, model, budget_s=20.0):
-    """Oracle (CPU restatement of the reference path) on a bounded sample, one read per thread like detect.cpp:852."""
+def cpu_baseline(reads, model, budget_s=20.0, full=False):
+    """Oracle (CPU restatement of the reference path) on a bounded sample, one read per thread like detect.cpp:852.
+    full: + eventalign, and the CNN through the stock-PyTorch CPU rendering of the same model description (fp32)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     from concurrent.futures import ThreadPoolExecutor
     cores = os.cpu_count() or 1
+    cnn = None
+    if full:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import cnn_torch_ref
+        import torch
+        from dnascent_amd import cnn_model
+        torch.set_num_threads(1)                        # one read per thread, like the reference's OpenMP loop
+        cnn = (cnn_torch_ref, cnn_model.default_model()[2])
 
     def one(r):
         o = po.OracleRead(r, model)      # includes int16 -> pA and CIGAR flattening, as the GPU path does
-        o.normalise()
+        st = o.normalise()
+        if full and st == 0 and o.eventalign() == 0:
+            pos = o.positions()
+            cnn[0].run(cnn[1], pos["core"], pos["residual"], pos["signal"])
         n = r.n_samples()
         o.free()
         return n
@@ -62,8 +74,9 @@ def cpu_baseline(reads, model, budget_s=20.0):
     with ThreadPoolExecutor(cores) as ex:      # ctypes releases the GIL inside the oracle
         samples = sum(ex.map(one, sample))
     dt = time.time() - t0
+    what = "oracle normaliseEvents + eventalign + PyTorch CPU fp32 CNN" if full else "oracle normaliseEvents (CNN excluded)"
     return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%d of the %d-base reads of the workload, oracle normaliseEvents (CNN excluded), %.1f s" % (n, reads[0].refseq.shape[0], dt)}
+            "sample": "%d of the %d-base reads of the workload, %s, %.1f s" % (n, reads[0].refseq.shape[0], what, dt)}
 
 
 def main():
@@ -223,7 +236,7 @@ def main():
                                "frac": ach / 417.0, "traffic": None, "mean_launch_ms": cnn_ms / max(cnn_n, 1),
                                "algorithmic_flops_per_launch": 2.0 * mac * pos}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(reads, model)
+            out["cpu_baseline"] = cpu_baseline(reads, model, full=(args.scope == "full"))
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()
