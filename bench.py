@@ -82,8 +82,8 @@ def cpu_baseline(reads, model, budget_s=20.0, full=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--reads", type=int, default=1000)
     ap.add_argument("--bases", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
