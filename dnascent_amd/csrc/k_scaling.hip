@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_prep(BatchDev B) {
 // Theil-Sen
 // ------------------------------------------------------------------------------------------------
 #define TS_MAXP 1000
-#define TS_CAND 1024
+#define TS_CAND 2048       // candidate keys kept in LDS (also holds the 2 x 2048 second-level counters of pass 1)
 
 // visit every pair (a < b) of the np points: wave w takes rows a = w, w+4, ...; lanes stride over b
 template <class F>
@@ -181,8 +181,7 @@ __global__ __launch_bounds__(256) void k_theilsen(BatchDev B, const double *host
     __shared__ double x[TS_MAXP], y[TS_MAXP];
     __shared__ unsigned hist[2048];
     __shared__ unsigned long long cand[TS_CAND];
-    __shared__ unsigned ncand, sel_digit, sel_rank;
-    __shared__ unsigned long long icpt_key[1024];
+    __shared__ unsigned ncand, sel_digit, sel_digit2, sel_rank;
     __shared__ unsigned long long slope_key, icpt_sel;
     __shared__ unsigned cnt0;
     const int r = blockIdx.x;
@@ -213,16 +212,46 @@ __global__ __launch_bounds__(256) void k_theilsen(BatchDev B, const double *host
     }
     const unsigned long long ns = (unsigned long long)np * (np - 1) / 2ull;
     unsigned want = (unsigned)(ns / 2ull);                        // :78 slopes[size/2]
-    // ---- three 11-bit MSB histogram passes narrow the median to one value of the top 33 key bits ----
+    // ---- pass 1: 11-bit MSB histogram (sign + exponent) of every slope, and -- because x is already roughly scaled, so
+    //      the median slope is close to 1 -- a second-level histogram of the next 11 bits for the two exponent buckets that
+    //      straddle 1.0 ([0.5, 1) and [1, 2)).  When the median falls in one of them (the normal case) 22 leading bits are
+    //      known after ONE regeneration of the 499 500 slopes. ----
     unsigned long long pref = 0ull;                               // selected leading bits so far (right aligned)
-    for (int pass = 0; pass < 3; pass++) {
-        const int lo_bit = 53 - 11 * pass;                        // digit = key bits [lo_bit+10 : lo_bit]
+    int bits_done = 0;
+    const unsigned GA = (unsigned)(dkey(0.75) >> 53), GB = (unsigned)(dkey(1.5) >> 53);
+    unsigned *hist2 = reinterpret_cast<unsigned *>(cand);         // 2 x 2048 counters, dead before the candidates are collected
+    for (int j = tid; j < 2048; j += 256) { hist[j] = 0; hist2[j] = 0; hist2[2048 + j] = 0; }
+    __syncthreads();
+    for_each_slope(x, y, np, [&](unsigned long long k, bool act) {
+        const unsigned top = (unsigned)(k >> 53);
+        hist_add_agg(hist, top, act);
+        if (act && (top == GA || top == GB)) atomicAdd(&hist2[(top == GB ? 2048u : 0u) + ((unsigned)(k >> 42) & 2047u)], 1u);
+    });
+    __syncthreads();
+    if (tid == 0) {
+        unsigned cum = 0, d = 2047;
+        for (unsigned b = 0; b < 2048; b++) { if (want < cum + hist[b]) { d = b; break; } cum += hist[b]; }
+        unsigned rank = want - cum, d2 = 0xffffffffu;
+        if (d == GA || d == GB) {
+            const unsigned *h2 = hist2 + (d == GB ? 2048u : 0u);
+            unsigned c2 = 0; d2 = 2047;
+            for (unsigned b = 0; b < 2048; b++) { if (rank < c2 + h2[b]) { d2 = b; break; } c2 += h2[b]; }
+            cnt0 = h2[d2];                                        // slopes sharing the 22 leading bits
+            rank -= c2;
+        }
+        sel_digit = d; sel_digit2 = d2; sel_rank = rank;
+    }
+    __syncthreads();
+    pref = sel_digit; want = sel_rank; bits_done = 11;
+    if (sel_digit2 != 0xffffffffu) { pref = (pref << 11) | sel_digit2; bits_done = 22; }
+    const bool collect22 = bits_done == 22 && cnt0 <= TS_CAND;
+    __syncthreads();
+    // ---- further 11-bit passes until 33 bits are fixed (skipped when the 22-bit bucket already fits the candidate buffer) ----
+    while (!collect22 && bits_done < 33) {
+        const int lo_bit = 53 - bits_done;                        // digit = key bits [lo_bit+10 : lo_bit]
         for (int j = tid; j < 2048; j += 256) hist[j] = 0;
         __syncthreads();
-        if (pass == 0) {
-            // sign + exponent: a handful of bins take everything -> wave-aggregated atomics
-            for_each_slope(x, y, np, [&](unsigned long long k, bool act) { hist_add_agg(hist, (unsigned)(k >> 53), act); });
-        } else {
+        {
             const unsigned long long want_hi = pref;
             for_each_slope(x, y, np, [&](unsigned long long k, bool act) {
                 if (act && (k >> (lo_bit + 11)) == want_hi) atomicAdd(&hist[(unsigned)(k >> lo_bit) & 2047u], 1u);
@@ -237,13 +266,15 @@ __global__ __launch_bounds__(256) void k_theilsen(BatchDev B, const double *host
         __syncthreads();
         pref = (pref << 11) | sel_digit;
         want = sel_rank;
+        bits_done += 11;
         __syncthreads();
     }
-    // ---- collect the survivors (they share 33 leading bits), finish by rank counting in LDS ----
+    // ---- collect the survivors (they share bits_done leading bits), finish by rank counting in LDS ----
+    const int rest = 64 - bits_done;
     if (tid == 0) ncand = 0;
     __syncthreads();
     for_each_slope(x, y, np, [&](unsigned long long k, bool act) {
-        if (act && (k >> 31) == pref) {
+        if (act && (k >> rest) == pref) {
             const unsigned slot = atomicAdd(&ncand, 1u);
             if (slot < TS_CAND) cand[slot] = k;
         }
@@ -259,9 +290,9 @@ __global__ __launch_bounds__(256) void k_theilsen(BatchDev B, const double *host
         }
         __syncthreads();
     } else {
-        // > TS_CAND slopes share 33 leading bits (degenerate data): resolve the remaining 31 bits one per pass
-        unsigned long long full = pref << 31;
-        for (int bit = 30; bit >= 0; bit--) {
+        // > TS_CAND slopes share 33 leading bits (degenerate data): resolve the remaining bits one per pass
+        unsigned long long full = pref << rest;
+        for (int bit = rest - 1; bit >= 0; bit--) {
             if (tid == 0) cnt0 = 0;
             __syncthreads();
             unsigned local = 0;
@@ -278,6 +309,8 @@ __global__ __launch_bounds__(256) void k_theilsen(BatchDev B, const double *host
         __syncthreads();
     }
     const double slope_med = dkey_inv(slope_key);
+    unsigned long long *icpt_key = cand;                          // the candidate keys are dead: same LDS (4 blocks per CU fit)
+    __syncthreads();
     // ---- intercepts :79-87 : median of y - slope*x over <= 1000 points (rank np/2) ----
     for (unsigned j = tid; j < np; j += 256) {
         const double prod = slope_med * x[j];                     // product rounded, then subtracted (no contraction)
