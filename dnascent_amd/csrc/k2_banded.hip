@@ -1282,18 +1282,19 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
     int b = e + k + 2;
     // tile t covers bands [lo, lo + 63]; cur tile index 0/1
     int lo = b - (CH_ROWS - 1); if (lo < 0) lo = 0;
-    auto load_tile = [&](int tlo, int4 (&regs)[8]) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));        // a native vector type: the HIP int4 struct array went to scratch
+    auto load_tile = [&](int tlo, i32x4 (&regs)[8]) {
         // 64 rows * 128 B = 512 pieces of 16 B; lane handles pieces lane, lane+64, ...
-        const int4 *src = reinterpret_cast<const int4 *>(rows + (size_t)tlo * DN_TROW);
+        const i32x4 *src = reinterpret_cast<const i32x4 *>(rows + (size_t)tlo * DN_TROW);
 #pragma unroll
         for (int i = 0; i < 8; i++) regs[i] = src[lane + 64 * i];
     };
-    auto store_tile = [&](int which, const int4 (&regs)[8]) {
-        int4 *dst = reinterpret_cast<int4 *>(tile[which]);
+    auto store_tile = [&](int which, const i32x4 (&regs)[8]) {
+        i32x4 *dst = reinterpret_cast<i32x4 *>(tile[which]);
 #pragma unroll
         for (int i = 0; i < 8; i++) dst[lane + 64 * i] = regs[i];
     };
-    int4 regs[8];
+    i32x4 regs[8];
     // note: rows below band 0 do not exist; tiles are clamped at 0 and always hold 64 rows starting at `lo`
     // (rows above the read's last band are never addressed).  The trace allocation is padded by 64 rows.
     load_tile(lo, regs);

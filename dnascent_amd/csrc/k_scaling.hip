@@ -111,7 +111,7 @@ __device__ __forceinline__ void select10(F val, unsigned n, double *out10, unsig
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_quantile(BatchDev B) {
+__global__ __launch_bounds__(256, 4) void k_quantile(BatchDev B) {     // 4 waves per SIMD: a 1000-read batch must be resident at once
     __shared__ unsigned hist[10][256];
     __shared__ unsigned long long prefix[10];
     __shared__ unsigned rank_in[10];
