@@ -82,8 +82,8 @@ def cpu_baseline(reads, model, budget_s=20.0, full=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--reads", type=int, default=1000)
     ap.add_argument("--bases", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -175,6 +175,17 @@ def main():
             prof[k] = (a[0] + v[0], a[1] + v[1])
         c.profile(False)
     summ = ctx.summaries()
+    # the same kernel with the GPU to itself (not part of the timed region): one batch, nothing else in flight
+    solo_fill_ms = None
+    if nctx > 1 and rank == 0:
+        ctx.profile(True); ctx.profile_reset()
+        for _ in range(2):
+            ctx.run("normalise")
+        ctx.sync()
+        pf = ctx.profile_get().get("k2_fill")
+        if pf and pf[1]:
+            solo_fill_ms = pf[0] / pf[1]
+        ctx.profile(False)
 
     # the only collectives of the path: MAX of the elapsed time, SUM of the counters (dnascent_amd/shard.py)
     from dnascent_amd import shard
@@ -193,7 +204,7 @@ def main():
         achieved = alg_bytes / fill_s / 1e9 if fill_s > 0 else 0.0
         traffic = None
         try:   # HBM bytes per launch from the committed PMC passes (cannot be collected inside a timed run)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_k2_fill.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_k2_fill.json")))
             if pm["workload"] == {"reads": args.reads, "bases": args.bases}:
                 traffic = pm["write_bytes"] + pm["fetch_bytes_corrected"]
         except Exception:
@@ -220,6 +231,12 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": fill_ms / max(fill_n, 1)},
             "kernel_ms_per_launch": {k: v[0] / v[1] for k, v in prof.items() if v[1]},
         }
+        if solo_fill_ms:
+            # launch durations in the timed region are stretched by the other batches in flight (the kernels time-share the
+            # SIMDs); the kernel's own rate is what it reaches with one batch on the GPU
+            out["roofline_solo"] = {"bound": "hbm", "kernel": "k2_fill", "achieved": alg_bytes / (solo_fill_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": alg_bytes / (solo_fill_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "mean_launch_ms": solo_fill_ms,
+                                    "note": "one batch in flight, outside the timed region"}
         if args.scope == "full":
             # dominant stage = the CNN: algorithmic flops = 2 x MACs of the description x positions (3.7 MFLOP x L);
             # peak = the 6 x bf16-MFMA rate the fp32-equivalent split runs at (2.5 PFLOP/s / 6), see DESIGN.md s4b
