@@ -443,7 +443,7 @@ int dno_normalise(const dno_model *m, const dno_read *r, dno_norm *o) {
                 unsigned int posOnRef = (unsigned int)q2r;
                 if (posOnRef < o->n_kr) {
                     o->cleaned_rank[nc] = o->rank_r[posOnRef];
-                    o->cleaned_sig[nc] = buf_total / (double)buf_n;
+                    o->cleaned_sig[nc] = buf_total / (double)buf_n;            /* == dno_vector_mean of the buffer, pinned in tests */
                     nc++;
                 }
             }
@@ -882,6 +882,24 @@ int dno_ll_across_read(const dno_fit_models *fm, const dno_read *r, const dno_no
 void dno_hmm_free(dno_hmm *h) {
     free(h->pos_on_ref); free(h->pos_on_query); free(h->global_pos); free(h->n_events); free(h->log_analogue); free(h->log_thymidine); free(h->llr);
     memset(h, 0, sizeof(*h));
+}
+
+/* common.h:91-150 */
+static char comp_iupac(char c) {
+    switch (c) {
+        case 'A': return 'T'; case 'T': return 'A'; case 'G': return 'C'; case 'C': return 'G'; case 'U': return 'A';
+        case 'Y': return 'R'; case 'R': return 'Y'; case 'K': return 'M'; case 'M': return 'K'; case 'B': return 'V';
+        case 'D': return 'H'; case 'H': return 'D'; case 'V': return 'B'; default: return c;      /* N, W, S map to themselves */
+    }
+}
+void dno_reverse_complement(const char *in, size_t n, char *out) {
+    for (size_t i = 0; i < n; i++) out[i] = comp_iupac(in[n - 1 - i]);
+}
+/* common.h:185-195: left-to-right fp64 sum, then one division; 0 for an empty vector */
+double dno_vector_mean(const double *v, size_t n) {
+    double total = 0.0;
+    for (size_t i = 0; i < n; i++) total += v[i];
+    return n == 0 ? 0.0 : total / (double)n;
 }
 
 static char comp(char c);

@@ -167,6 +167,10 @@ void dno_hmm_free(dno_hmm *h);
 /* text of the read's record in --HMM mode (:414, :571): ">id contig start end strand" + "pos\tllr\tkmerRef\tkmerQuery" lines */
 size_t dno_format_hmm(const char *read_id, const char *contig, const dno_read *r, const dno_hmm *h, char *buf, size_t cap);
 
+/* ---- common.h:91 reverseComplement (A/C/G/T + the IUPAC codes the reference maps), common.h:185 vectorMean ---- */
+void   dno_reverse_complement(const char *in, size_t n, char *out);
+double dno_vector_mean(const double *v, size_t n);
+
 /* ---- detect.cpp:684-731 human-readable record from CNN outputs ---- */
 /* probs: n_pos*3 (class0 thymidine, class1 BrdU, class2 EdU). Writes text to buf, returns length
  * (or required length if > cap). */

@@ -110,6 +110,9 @@ def oracle():
         L.dno_hmm_free.argtypes = [C.POINTER(Hmm)]
         L.dno_format_hmm.restype = C.c_size_t
         L.dno_format_hmm.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Read), C.POINTER(Hmm), C.c_void_p, C.c_size_t]
+        L.dno_reverse_complement.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+        L.dno_vector_mean.restype = C.c_double
+        L.dno_vector_mean.argtypes = [C.c_void_p, C.c_size_t]
         L.dno_modbam_tags.restype = C.c_size_t
         L.dno_modbam_tags.argtypes = [C.POINTER(Read), C.POINTER(Align), C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.dno_format_detect.restype = C.c_size_t
@@ -142,6 +145,11 @@ def ref():
         L.ref_normalPDF.argtypes = [C.c_double] * 3
         L.ref_detect_events.restype = C.c_size_t
         L.ref_detect_events.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        if hasattr(L, "ref_reverseComplement"):
+            L.ref_reverseComplement.restype = C.c_size_t
+            L.ref_reverseComplement.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+            L.ref_vectorMean.restype = C.c_double
+            L.ref_vectorMean.argtypes = [C.c_void_p, C.c_size_t]
         _r = L
     return _r
 
@@ -149,6 +157,28 @@ def ref():
 # ---------------------------------------------------------------------------------------------
 # convenience layer over the raw structs
 # ---------------------------------------------------------------------------------------------
+def reverse_complement(seq_bytes):
+    out = C.create_string_buffer(len(seq_bytes))
+    oracle().dno_reverse_complement(seq_bytes, len(seq_bytes), out)
+    return out.raw
+
+
+def vector_mean(v):
+    v = np.ascontiguousarray(v, np.float64)
+    return float(oracle().dno_vector_mean(v.ctypes.data, v.shape[0]))
+
+
+def ref_reverse_complement(seq_bytes):
+    out = C.create_string_buffer(len(seq_bytes))
+    n = ref().ref_reverseComplement(seq_bytes, len(seq_bytes), out)
+    return out.raw[:n]
+
+
+def ref_vector_mean(v):
+    v = np.ascontiguousarray(v, np.float64)
+    return float(ref().ref_vectorMean(v.ctypes.data, v.shape[0]))
+
+
 def adc_to_pa(adc, offset, scale):
     out = np.empty(adc.shape[0], dtype=np.float64)
     a = np.ascontiguousarray(adc, dtype=np.int16)

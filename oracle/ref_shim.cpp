@@ -4,13 +4,14 @@
 // generate the golden vectors under tests/golden/ (tests/golden/make_golden.py).
 //
 // This file declares nothing the reference lacks: it only includes the reference's headers
-// (probability.h, scrappie/event_detection.h) and forwards calls.
+// (common.h, probability.h, scrappie/event_detection.h) and forwards calls.
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 
+#include "common.h"                      // /root/reference/src/common.h (reverseComplement, vectorMean; common.cpp links in)
 #include "probability.h"                 // /root/reference/src/probability.h
 #include "scrappie/event_detection.h"    // /root/reference/src/scrappie/event_detection.h
 
@@ -40,6 +41,18 @@ size_t ref_detect_events(double *raw, size_t n, uint64_t *start, float *length, 
     size_t total = et.n;
     free(et.event);
     return total;
+}
+
+// common.h:91 reverseComplement (IUPAC input only: anything else makes the reference exit); returns the length written
+size_t ref_reverseComplement(const char *in, size_t n, char *out) {
+    const std::string r = reverseComplement(std::string(in, n));
+    memcpy(out, r.data(), r.size());
+    return r.size();
+}
+// common.h:185 vectorMean<double>
+double ref_vectorMean(const double *v, size_t n) {
+    std::vector<double> x(v, v + n);
+    return vectorMean(x);
 }
 
 }  // extern "C"

@@ -1,7 +1,7 @@
 """Generate the golden vectors under tests/golden/ from the REFERENCE's own code.
 
 Runs only where /root/reference exists (this container): oracle/_ref/libref.so is the reference's
-scrappie/event_detection.c and probability.cpp compiled in place (oracle/Makefile).  The outputs are data only:
+scrappie/event_detection.c, probability.cpp and common.cpp compiled in place (oracle/Makefile).  The outputs are data only:
 inputs (seeded synthetic int16 signals + calibration) and the reference's results for them.
 
     python tests/golden/make_golden.py
@@ -9,6 +9,7 @@ inputs (seeded synthetic int16 signals + calibration) and the reference's result
 Files:
   ref_segmentation.npz   for each case: adc (int16), cal_offset, cal_scale -> reference detect_events (start, length,
                          mean, stdv) with the reference's default detector parameters (event_detection.h:19-25)
+  ref_common.npz         IUPAC sequences -> reference reverseComplement; fp64 vectors -> reference vectorMean (common.h)
   ref_logspace.npz       argument grids -> reference eexp / eln / lnSum / lnProd / lnGreaterThan / normalPDF (bit patterns)
 """
 import ctypes as C
@@ -63,7 +64,17 @@ def main():
     npdf = np.array([ref.ref_normalPDF(float(m), 0.14, float(v)) for m, v in zip(mu, x)])
     np.savez_compressed(os.path.join(HERE, "ref_logspace.npz"), xs=xs, eexp=eexp, eln=np.array(eln), eln_neg=np.array(eln_neg, np.int8),
                         a=a, b=b, lnsum=lnsum, lnprod=lnprod, lngt=lngt, mu=mu, x=x, npdf=npdf)
-    for f in ("ref_segmentation.npz", "ref_logspace.npz"):
+    # common.h: reverseComplement over the IUPAC alphabet the reference accepts, vectorMean on buffers of event means
+    alpha = np.frombuffer(b"ATGCUYRKMBDHVNWS", np.uint8)
+    seqs = [bytes(alpha[rng.integers(0, 16, n)]) for n in (0, 1, 9, 33, 250)] + [b"ATGCATGCN", b"TTTTTTTTT"]
+    rc = [po.ref_reverse_complement(q) for q in seqs]
+    vm_in = [rng.normal(95, 14, n) for n in (1, 2, 3, 7, 50)] + [np.array([1e300, 1e300, -1e300]), np.array([0.1] * 10)]
+    vm = np.array([po.ref_vector_mean(v) for v in vm_in])
+    np.savez_compressed(os.path.join(HERE, "ref_common.npz"), n_seq=np.int64(len(seqs)), n_vm=np.int64(len(vm_in)), vm=vm,
+                        **{"seq_%d" % i: np.frombuffer(q, np.uint8) for i, q in enumerate(seqs)},
+                        **{"rc_%d" % i: np.frombuffer(q, np.uint8) for i, q in enumerate(rc)},
+                        **{"vm_in_%d" % i: v for i, v in enumerate(vm_in)})
+    for f in ("ref_segmentation.npz", "ref_logspace.npz", "ref_common.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -72,3 +72,17 @@ def test_hip_segmentation_matches_reference_goldens(model):
         assert np.array_equal(_bits(ln), _bits(g["length_%d" % i]))
         assert np.array_equal(_bits(mn), _bits(g["mean_%d" % i]))
     ctx.close()
+
+
+def test_common_helpers_match_reference_goldens():
+    """common.h reverseComplement / vectorMean: the oracle's restatements and the host C++ layer's reverseComplement
+    against what the reference's own common.h returned (tests/golden/ref_common.npz)."""
+    from dnascent_amd import host
+    g = np.load(os.path.join(G, "ref_common.npz"))
+    for i in range(int(g["n_seq"])):
+        q, want = g["seq_%d" % i].tobytes(), g["rc_%d" % i].tobytes()
+        assert po.reverse_complement(q) == want
+        assert host.revcomp(np.frombuffer(q, np.uint8)).tobytes() == want
+    for i in range(int(g["n_vm"])):
+        got = po.vector_mean(g["vm_in_%d" % i])
+        assert _bits(np.float64(got)) == _bits(np.float64(g["vm"][i]))

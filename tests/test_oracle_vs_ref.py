@@ -95,3 +95,20 @@ def test_adc_conversion_is_float32(model):
     pa = po.adc_to_pa(r.adc, r.cal_offset, r.cal_scale)
     want = ((r.adc.astype(np.float32) + np.float32(r.cal_offset)) * np.float32(r.cal_scale)).astype(np.float64)
     assert np.array_equal(pa, want)
+
+
+def test_common_helpers_match_reference():
+    """reverseComplement (common.h:91) over random IUPAC strings and vectorMean (common.h:185) over random fp64 buffers:
+    oracle restatement == the reference's own code, bit for bit."""
+    if po.ref() is None or not hasattr(po.ref(), "ref_reverseComplement"):
+        pytest.skip("oracle/_ref/libref.so without common.cpp")
+    rng = np.random.default_rng(3)
+    alpha = np.frombuffer(b"ATGCUYRKMBDHVNWS", np.uint8)
+    for n in list(range(0, 40)) + [500, 5000]:
+        q = bytes(alpha[rng.integers(0, 16, n)])
+        assert po.reverse_complement(q) == po.ref_reverse_complement(q)
+    for n in (1, 2, 3, 5, 17, 1000):
+        for scale in (1.0, 1e-12, 1e12):
+            v = rng.normal(0, scale, n)
+            assert np.float64(po.vector_mean(v)).tobytes() == np.float64(po.ref_vector_mean(v)).tobytes()
+    assert po.vector_mean(np.zeros(0)) == 0.0 and po.ref_vector_mean(np.zeros(0)) == 0.0
