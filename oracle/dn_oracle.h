@@ -8,7 +8,9 @@
  * Parity pinning status (see DESIGN.md "Oracle"):
  *   PINNED    dno_detect_events          vs  oracle/_ref  (reference scrappie/event_detection.c, compiled in place)
  *   PINNED    dno_eexp/eln/lnSum/...     vs  oracle/_ref  (reference probability.cpp, compiled in place)
- *   UNPINNED  banded alignment, scaling, Viterbi, eventalign, tensor packing:
+ *   PINNED    dno_reverse_complement, dno_vector_mean  vs  oracle/_ref  (reference common.h / common.cpp)
+ *   UNPINNED  banded alignment, scaling, Viterbi, eventalign, tensor packing, the --HMM forward path,
+ *             output formatting (.detect / modbam):
  *             the reference has no tests / golden vectors for them and
  *             event_handling.cpp / alignment.cpp cannot be compiled here without
  *             stand-in htslib / TensorFlow / generated headers, which is not allowed.
