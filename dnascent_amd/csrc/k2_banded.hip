@@ -1312,9 +1312,9 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
     int evrow = SLOT ? 0 : row_ev(cur);
 
     unsigned step = 0;
-    unsigned rec_e = 0, rec_k = 0, rec_f = 0;
+    unsigned rec_e = 0, rec_k = 0;                     // rec_e carries the from-code in its top two bits until the flush
     int bad = 0;
-    while (k >= 0 && e >= 0) {
+    while ((k | e) >= 0) {
         if (b < lo) {
             // switch to the prefetched tile
             cur ^= 1;
@@ -1328,7 +1328,7 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
         const int bi = b - lo;
         unsigned from;
         if (SLOT) {                                        // k2_fill6 rows: byte = slot of the event, 0xFF outside the band
-            from = tile[cur][bi * DN_TROW + (e & 127)];
+            from = (unsigned)__builtin_amdgcn_readfirstlane((int)tile[cur][bi * DN_TROW + (e & 127)]);
             if (from == 0xFFu || step >= cap) { bad = 1; break; }            // reference: out-of-bounds read (UB)
         } else {
             const int ev_b = __builtin_amdgcn_readlane(evrow, bi);
@@ -1336,23 +1336,25 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
             if (off < 0 || off >= DN_W || step >= cap) { bad = 1; break; }    // reference: out-of-bounds read (UB)
             from = tile[cur][bi * DN_TROW + off];
         }
-        // stash step in lane (step & 63); flush 64 steps at a time, back to front
-        const int slot = step & 63;
-        if (lane == slot) { rec_e = (unsigned)e; rec_k = (unsigned)k; rec_f = from; }
+        // stash the step in lane (step & 63); flush 64 steps at a time, back to front
+        const bool mine = lane == (int)(step & 63u);
+        rec_e = mine ? ((unsigned)e | (from << 30)) : rec_e;
+        rec_k = mine ? (unsigned)k : rec_k;
         step++;
         if ((step & 63u) == 0u) {
             const unsigned idx = cap - (step - 64u) - 1u - (unsigned)lane;     // step-64+lane -> slot cap-1-(step-64+lane)
-            ae[idx] = rec_e; ak[idx] = rec_k; pf[idx] = (uint8_t)rec_f;
+            ae[idx] = rec_e & 0x3fffffffu; ak[idx] = rec_k; pf[idx] = (uint8_t)(rec_e >> 30);
         }
-        if (from == 0) { e -= 1; k -= 1; b -= 2; }
-        else if (from == 1) { e -= 1; b -= 1; }
-        else { k -= 1; b -= 1; }
+        // from 0 (diag): e-1, k-1, b-2; 1 (up): e-1, b-1; 2 (left): k-1, b-1 -- as arithmetic on the scalar unit, no branch
+        e -= (int)((from >> 1) ^ 1u);
+        k -= (int)((from & 1u) ^ 1u);
+        b -= 2 - (int)((from + 1u) >> 1);
     }
     const unsigned rem = step & 63u;
     if (!bad && rem && (unsigned)lane < rem) {
         const unsigned base = step - rem;
         const unsigned idx = cap - (base + (unsigned)lane) - 1u;
-        ae[idx] = rec_e; ak[idx] = rec_k; pf[idx] = (uint8_t)rec_f;
+        ae[idx] = rec_e & 0x3fffffffu; ak[idx] = rec_k; pf[idx] = (uint8_t)(rec_e >> 30);
     }
     if (lane == 0) {
         if (bad) { R.status = 3; R.n_aligned = 0; R.aln_begin = cap; }
