@@ -1314,28 +1314,9 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
     unsigned step = 0;
     unsigned rec_e = 0, rec_k = 0;                     // rec_e carries the from-code in its top two bits until the flush
     int bad = 0;
-    while ((k | e) >= 0) {
-        if (b < lo) {
-            // switch to the prefetched tile
-            cur ^= 1;
-            store_tile(cur, regs);
-            lo = nlo;
-            nlo = lo - CH_ROWS; if (nlo < 0) nlo = 0;
-            if (lo > 0) load_tile(nlo, regs);
-            __syncthreads();
-            if (!SLOT) evrow = row_ev(cur);
-        }
-        const int bi = b - lo;
-        unsigned from;
-        if (SLOT) {                                        // k2_fill6 rows: byte = slot of the event, 0xFF outside the band
-            from = (unsigned)__builtin_amdgcn_readfirstlane((int)tile[cur][bi * DN_TROW + (e & 127)]);
-            if (from == 0xFFu || step >= cap) { bad = 1; break; }            // reference: out-of-bounds read (UB)
-        } else {
-            const int ev_b = __builtin_amdgcn_readlane(evrow, bi);
-            const int off = ev_b - e;
-            if (off < 0 || off >= DN_W || step >= cap) { bad = 1; break; }    // reference: out-of-bounds read (UB)
-            from = tile[cur][bi * DN_TROW + off];
-        }
+    // one walk step with a known from-code; returns false when the walk is over (matrix edge reached or path invalid)
+    auto take = [&](unsigned from) -> bool {
+        if (from == 0xFFu || step >= cap) { bad = 1; return false; }        // reference: out-of-bounds read (UB)
         // stash the step in lane (step & 63); flush 64 steps at a time, back to front
         const bool mine = lane == (int)(step & 63u);
         rec_e = mine ? ((unsigned)e | (from << 30)) : rec_e;
@@ -1349,6 +1330,54 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
         e -= (int)((from >> 1) ^ 1u);
         k -= (int)((from & 1u) ^ 1u);
         b -= 2 - (int)((from + 1u) >> 1);
+        return (k | e) >= 0;
+    };
+    // four-step lookahead (slot rows): lane L < 40 stands for a prefix of up to three moves (1 + 3 + 9 + 27 nodes of the ternary
+    // tree of continuations); ONE LDS read fetches the from-codes of all 40 candidate cells, four dependent v_readlane then walk
+    // the tree -- four steps per LDS round trip instead of one.
+    int la_db = 0, la_de = 0;                          // band / event offset of this lane's node from the current cell
+    {
+        const int base[4] = {0, 1, 4, 13};
+        int lvl = lane >= 13 ? 3 : (lane >= 4 ? 2 : (lane >= 1 ? 1 : 0));
+        int code = lane - base[lvl];
+        for (int j = 0; j < lvl; j++) {                // digits, last move first
+            const int m = code % 3; code /= 3;
+            la_db += 2 - ((m + 1) >> 1); la_de += ((m >> 1) ^ 1);
+        }
+        if (lane >= 40) { la_db = 0; la_de = 0; }
+    }
+    while ((k | e) >= 0) {
+        if (b < lo) {
+            // switch to the prefetched tile
+            cur ^= 1;
+            store_tile(cur, regs);
+            lo = nlo;
+            nlo = lo - CH_ROWS; if (nlo < 0) nlo = 0;
+            if (lo > 0) load_tile(nlo, regs);
+            __syncthreads();
+            if (!SLOT) evrow = row_ev(cur);
+        }
+        const int bi = b - lo;
+        if (SLOT) {                                        // k2_fill6 rows: byte = slot of the event, 0xFF outside the band
+            if (bi >= 6) {
+                const unsigned v = tile[cur][(bi - la_db) * DN_TROW + ((e - la_de) & 127)];
+                const unsigned f0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+                if (!take(f0)) break;
+                const unsigned f1 = (unsigned)__builtin_amdgcn_readlane((int)v, 1 + (int)f0);
+                if (!take(f1)) break;
+                const unsigned f2 = (unsigned)__builtin_amdgcn_readlane((int)v, 4 + 3 * (int)f0 + (int)f1);
+                if (!take(f2)) break;
+                const unsigned f3 = (unsigned)__builtin_amdgcn_readlane((int)v, 13 + 9 * (int)f0 + 3 * (int)f1 + (int)f2);
+                if (!take(f3)) break;
+            } else {
+                if (!take((unsigned)__builtin_amdgcn_readfirstlane((int)tile[cur][bi * DN_TROW + (e & 127)]))) break;
+            }
+        } else {
+            const int ev_b = __builtin_amdgcn_readlane(evrow, bi);
+            const int off = ev_b - e;
+            if (off < 0 || off >= DN_W) { bad = 1; break; }                   // reference: out-of-bounds read (UB)
+            if (!take(tile[cur][bi * DN_TROW + off])) break;
+        }
     }
     const unsigned rem = step & 63u;
     if (!bad && rem && (unsigned)lane < rem) {
