@@ -1,20 +1,19 @@
 // k2_banded.hip -- K2: adaptive banded event-to-9mer alignment (event_handling.cpp:148-448) on gfx950.
 //
-//   k2_fill   one wavefront per read.  A band is 100 cells; lane l (l < 50) owns cells 2l and 2l+1, so a band is
-//             two VGPRs of scores and the whole recurrence lives in registers: the three neighbours of a cell sit
-//             in the same lane or one lane away (wave-shift DPP), depending on the last two Suzuki moves.  The
-//             event value x_e and the k-mer level mu_k of a cell also stay in registers and are shifted by one
-//             cell per band (only ONE of them moves per band: x on a "down" move, mu on a "right" move); the one
-//             new value per band is wave-uniform and is fetched one band ahead through the scalar unit (s_load),
-//             so the loop body holds no vector load and never waits on vmcnt.  Per band the kernel stores one
-//             128-byte row: 100 trace bytes + the band's lower-left event index, i.e. one full cache line per
-//             wavefront store.  No LDS, no atomics.
-//             Arithmetic is the reference's, cast by cast (float scores, candidates evaluated in fp64 and
+//   k2_fill6  (default) one wavefront per read, EVENT-KEYED slots: the cell of event e lives in slot e & 127 for as long as
+//             e is in the band, so x is stationary, the neighbours sit at fixed offsets, the k-mer level rotates by one
+//             slot every band regardless of the Suzuki move, and the move only changes which slots are active (see the
+//             comment above the kernel).  The whole recurrence lives in registers; the value that enters a band is
+//             wave-uniform and fetched one band ahead through the scalar unit (s_load), so the loop holds no vector load
+//             and never waits on vmcnt.  Per band one 128-byte row is stored: the from-codes by slot, 0xFF outside the band.
+//   k2_fill5  (DN_FILL_VARIANT=5) the offset-keyed predecessor, kept for A/B measurements: cells keyed by band offset,
+//             both moves' operands formed with DPP and picked with v_cndmask; rows hold 100 from-codes + the band corner.
+//             Arithmetic of both is the reference's, cast by cast (float scores, candidates evaluated in fp64 and
 //             rounded back; event_handling.cpp:116-137, :296-306); the fp64 division by sigma is done exactly
 //             with an FMA-corrected reciprocal (3 ops, brute-force verified against IEEE division).
 //   k2_chase  backtrack (event_handling.cpp:356-412), one wavefront per read: trace rows are staged through a
-//             double-buffered 8-KB LDS tile (coalesced 16-B loads), the walk itself is wave-uniform and touches
-//             LDS once per step.  It only records the path.
+//             double-buffered LDS tile (coalesced 16-B loads); with slot rows one LDS read fetches the from-codes of the
+//             40 cells reachable in the next three moves and four dependent v_readlane walk that tree.
 //   k2_post   per-read block: emission log-probabilities of the path, the QC triple (:420-441), and the
 //             cleaned (signal, rank) pairs for Theil-Sen, with every order-dependent fp64 sum accumulated in the
 //             reference's order.
@@ -133,770 +132,6 @@ __device__ __forceinline__ void cell(float diag, float up, float left, double x,
 // the in-order vmcnt on gfx950).  The arrays were written by earlier kernels and are read-only here, which is what
 // the constant address space promises.
 typedef const double __attribute__((address_space(4))) *cdptr_t;
-
-template <bool DPP>
-__global__ __launch_bounds__(64) void k2_fill(BatchDev B, const BandConsts *bc, FillConsts fc) {
-    const int r = blockIdx.x;
-    const int lane = threadIdx.x;
-    ReadRes &R = B.res[r];
-    if (R.status != 0) return;
-    const int E = (int)R.n_events, K = (int)R.n_kq;
-    const int n_bands = E + K + 2;
-    const double lp_stay = bc[r].lp_stay, lp_step = bc[r].lp_step;
-    const double *xs = B.ev_x + B.ev_off[r];
-    const double *mus = B.mu_q + B.base_off[r];
-    const cdptr_t xs_c = (cdptr_t)(uintptr_t)xs;
-    const cdptr_t mu_c = (cdptr_t)(uintptr_t)mus;
-    uint8_t *rows = B.trace + B.trace_off[r] * DN_TROW;
-    const float NINF = neg_inf();
-    const bool inb = lane < 50;
-    // cell offsets of this lane; lanes >= 50 hold no cell: an offset that fails every range test
-    const unsigned o0 = inb ? (unsigned)(2 * lane) : 0x40000000u, o1 = inb ? (unsigned)(2 * lane + 1) : 0x40000000u;
-    // row bytes 104..107 carry the band's lower-left event index (lanes 52, 53 hold its two halves)
-    const unsigned meta_shift = (lane == 53) ? 16u : 0u;
-    const unsigned meta_mask = (lane == 52 || lane == 53) ? 0xffffu : 0u;
-
-    // ---- bands 0 and 1 (event_handling.cpp:213-228) ----
-    int ev = 50, km = -51;                                // lower-left of band 1; band 0 is (49, -51)
-    float Q0 = (o0 == 50u) ? 0.0f : NINF, Q1 = NINF;      // band 0: score 0 at the cell with kmer == -1 (offset 50)
-    float P0 = (o0 == 50u) ? (float)fc.lp_trim : NINF, P1 = NINF;   // band 1: first event trimmed (offset 50)
-    {
-        const unsigned short w1 = (o0 == 50u) ? 1u : 0u;  // trace[1][50] = FROM_U
-        reinterpret_cast<unsigned short *>(rows)[lane] = inb ? (unsigned short)0 : (unsigned short)((49u >> meta_shift) & meta_mask);
-        reinterpret_cast<unsigned short *>(rows + DN_TROW)[lane] = inb ? w1 : (unsigned short)((50u >> meta_shift) & meta_mask);
-    }
-    // x / mu of this lane's two cells in band 1: event index ev - o, kmer index km + o
-    auto ldx = [&](int e) -> double { return (e >= 0 && e < E) ? xs[e] : 0.0; };
-    auto ldm = [&](int k) -> double { return (k >= 0 && k < K) ? mus[k] : 0.0; };
-    double X0 = ldx(ev - (int)o0), X1 = ldx(ev - (int)o1);
-    double M0 = ldm(km + (int)o0), M1 = ldm(km + (int)o1);
-    // value entering the band on the next "down" (x[ev+1] -> cell 0) / "right" (mu[km+100] -> cell 99) move
-    double nx = xs_c[min(ev + 1, E - 1)];
-    double nm = mu_c[max(min(km + 100, K - 1), 0)];
-
-    float best = NINF; int best_e = 0; int found = 0;
-    int prev_right = 0;                                   // band 0 -> 1 was a "down" move
-
-    for (int b = 2; b < n_bands; b++) {
-        // ---- Suzuki-Kasahara move (:237-253) ----
-        const float lo = bcast_f(P0, 0), hi = bcast_f(P1, 49);
-        int right;
-        if (lo == NINF && hi == NINF) right = (b & 1);
-        else right = lo < hi;
-
-        float up0, up1, lf0, lf1, dg0, dg1;
-        if (right) {
-            km += 1;
-            const double t = from_next_d<DPP>(M0, lane);
-            M0 = M1; M1 = (lane == 49) ? nm : t;
-            const float nq = from_next<DPP>(Q0, NINF, lane);
-            up0 = P1; lf0 = P0; up1 = from_next<DPP>(P0, NINF, lane); lf1 = P1;
-            dg0 = prev_right ? Q1 : Q0; dg1 = prev_right ? nq : Q1;
-        } else {
-            ev += 1;
-            const double t = from_prev_d<DPP>(X1, lane);
-            X1 = X0; X0 = (lane == 0) ? nx : t;
-            const float pq = from_prev<DPP>(Q1, NINF, lane);
-            up0 = P0; lf0 = from_prev<DPP>(P1, NINF, lane); up1 = P1; lf1 = P0;
-            dg0 = prev_right ? Q0 : pq; dg1 = prev_right ? Q1 : Q0;
-        }
-        // prefetch for the next band (consumed one iteration later)
-        nx = xs_c[min(ev + 1, E - 1)];
-        nm = mu_c[max(min(km + 100, K - 1), 0)];
-
-        // ---- the two cells of this lane ----
-        float S0, S1; unsigned F0, F1;
-        cell(dg0, up0, lf0, X0, M0, fc, lp_step, lp_stay, S0, F0);
-        cell(dg1, up1, lf1, X1, M1, fc, lp_step, lp_stay, S1, F1);
-        if (km >= 0 && km + (DN_W - 1) < K && ev >= DN_W - 1 && ev < E) {
-            // interior band (almost all of them): every cell 0..99 is inside the matrix; only the 14 idle lanes are masked
-            S0 = inb ? S0 : NINF; S1 = inb ? S1 : NINF;
-        } else {
-            // in range: 0 <= kmer < K and 0 <= event < E (:269-278), one unsigned compare each
-            const unsigned e0 = (unsigned)ev - o0, e1 = (unsigned)ev - o1;
-            const bool ok0 = ((unsigned)km + o0 < (unsigned)K) && (e0 < (unsigned)E);
-            const bool ok1 = ((unsigned)km + o1 < (unsigned)K) && (e1 < (unsigned)E);
-            S0 = ok0 ? S0 : NINF; F0 = ok0 ? F0 : 0u;
-            S1 = ok1 ? S1 : NINF; F1 = ok1 ? F1 : 0u;
-            if (km <= -1) {
-                // trim column kmer == -1 is still inside the band (:256-265); only the first ~100 bands get here
-                const bool t0 = ((unsigned)km + o0 == 0xffffffffu) && (e0 < (unsigned)E);
-                const bool t1 = ((unsigned)km + o1 == 0xffffffffu) && (e1 < (unsigned)E);
-                if (t0) { S0 = (float)(fc.lp_trim * (double)(e0 + 1u)); F0 = 1; }
-                if (t1) { S1 = (float)(fc.lp_trim * (double)(e1 + 1u)); F1 = 1; }
-            }
-        }
-
-        // ---- one 128-byte row: 100 trace bytes (lanes 0..49) + the band's lower-left event index ----
-        const unsigned meta = ((unsigned)ev >> meta_shift) & meta_mask;
-        const unsigned short w = (unsigned short)(inb ? (F0 | (F1 << 8)) : meta);
-        reinterpret_cast<unsigned short *>(rows + (size_t)b * DN_TROW)[lane] = w;
-
-        // ---- end cell: best score on the last k-mer column after trimming the remaining events (:329-340) ----
-        const int oe = K - 1 - km;
-        if (oe >= 0 && oe < DN_W) {
-            const int ee = ev - oe;
-            if (ee >= 0 && ee < E) {
-                const float sv = bcast_f((oe & 1) ? S1 : S0, oe >> 1);
-                const float s = (float)((double)sv + (double)(unsigned long long)(E - ee) * fc.lp_trim);
-                if (s > best) { best = s; best_e = ee; found = 1; }
-            }
-        }
-        Q0 = P0; Q1 = P1; P0 = S0; P1 = S1;
-        prev_right = right;
-    }
-    if (lane == 0) {
-        R.n_bands = (unsigned)n_bands;
-        R.end_event = best_e;
-        R.end_score = best;
-        if (!found) R.status = 3;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k2_fill2: TWO wavefronts per read, one band cell per lane (100 of 128 lanes).
-//
-// A single wavefront issues one VALU instruction every ~5 cycles at best (measured, profiles/r01_valu_issue_microbench.txt)
-// and a 1 000-read batch gives the chip only 1 000 of them, one per SIMD.  Splitting a read over two wavefronts halves the
-// per-band instruction stream of each and puts two wavefronts on every SIMD, which the SIMD interleaves for free.  The
-// price is one workgroup barrier per band, so the band state moves to LDS:
-//   * the scores of the last three bands live in a 3-slot LDS ring; the neighbours of cell o are plain LDS reads at
-//     o-1, o, o+1 (both Suzuki moves are read at once, then selected: one LDS round trip per band, no dependent second read);
-//   * x_e and mu_k are served from two 512-entry LDS rings refilled 128 entries at a time, the global load for the next
-//     refill being issued one refill (>= 128 bands) ahead;
-//   * trace: one byte per lane into the same 128-byte row layout as before.
-// ------------------------------------------------------------------------------------------------
-#define F2_RING 512
-#define F2_PW 136
-
-__global__ __launch_bounds__(128) void k2_fill2(BatchDev B, const BandConsts *bc, FillConsts fc) {
-    __shared__ float Pb[3][F2_PW];                        // [band % 3][cell offset + 1]; [0] and [101..] stay -inf
-    __shared__ double rx[F2_RING], rm[F2_RING];           // x[e] at e & 511, mu[k] at k & 511
-    __shared__ float red_s[128]; __shared__ int red_e[128];
-    const int r = blockIdx.x;
-    const int tid = threadIdx.x;
-    ReadRes &R = B.res[r];
-    if (R.status != 0) return;
-    const int E = (int)R.n_events, K = (int)R.n_kq;
-    const int n_bands = E + K + 2;
-    const double lp_stay = bc[r].lp_stay, lp_step = bc[r].lp_step;
-    const double *xs = B.ev_x + B.ev_off[r];
-    const double *mus = B.mu_q + B.base_off[r];
-    uint8_t *rows = B.trace + B.trace_off[r] * DN_TROW;
-    const float NINF = neg_inf();
-    const int o = tid;                                    // cell offset of this lane
-    const bool inb = o < DN_W;
-    auto ldx = [&](int e) -> double { return (e >= 0 && e < E) ? xs[e] : 0.0; };
-    auto ldm = [&](int k) -> double { return (k >= 0 && k < K) ? mus[k] : 0.0; };
-
-    // ---- bands 0 and 1 (event_handling.cpp:213-228) ----
-    for (int i = tid; i < 3 * F2_PW; i += 128) (&Pb[0][0])[i] = NINF;
-    for (int i = tid; i < 384; i += 128) { rx[i] = ldx(i); rm[i] = ldm(i); }
-    int xhi = 384, mhi = 384;                             // rings hold [.., xhi) / [.., mhi)
-    double pendx = ldx(xhi + tid), pendm = ldm(mhi + tid);
-    __syncthreads();
-    if (tid == 0) { Pb[0][50 + 1] = 0.0f; Pb[1][50 + 1] = (float)fc.lp_trim; }
-    int ev = 50, km = -51;                                // lower-left of band 1; band 0 is (49, -51)
-    {
-        uint8_t b0 = 0, b1 = (o == 50) ? 1 : 0;           // trace[1][50] = FROM_U
-        if (tid >= 104 && tid < 108) { b0 = (uint8_t)((49u >> (8 * (tid - 104))) & 0xff); b1 = (uint8_t)((50u >> (8 * (tid - 104))) & 0xff); }
-        rows[tid] = b0; rows[DN_TROW + tid] = b1;
-    }
-    double x = ldx(ev - o), mu = ldm(km + o);
-    float best = NINF; int best_e = 0x7fffffff;
-    int prev_right = 0;
-    __syncthreads();
-    // retire the pre-loop global loads HERE (vmcnt(0), builtin form so the compiler's scoreboard sees it): otherwise
-    // the first use of x / mu inside the loop carries a vmcnt(0) on every iteration and each band waits for its own store
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-
-    for (int b = 2; b < n_bands; b++) {
-        const int sp = (b + 2) % 3, sq = (b + 1) % 3, sc = b % 3;
-        const float *Pp = Pb[sp], *Qq = Pb[sq];
-        // ---- one LDS round trip: everything either move can need ----
-        const float lo = Pp[1], hi = Pp[DN_W];
-        const float pm1 = Pp[o], p0 = Pp[o + 1], pp1 = Pp[o + 2];            // P[o-1], P[o], P[o+1]
-        const float qa = Qq[o + prev_right], qb = Qq[o + 1 + prev_right];    // diag for a down / right move
-        const double xn = rx[(ev + 1 - o) & (F2_RING - 1)];                  // x of this cell after a down move
-        const double mn = rm[(km + 1 + o) & (F2_RING - 1)];                  // mu of this cell after a right move
-        // ---- Suzuki-Kasahara move (:237-253) ----
-        const bool vright = (lo == NINF && hi == NINF) ? ((b & 1) != 0) : (lo < hi);
-        const float up = vright ? pp1 : p0, left = vright ? p0 : pm1, diag = vright ? qb : qa;
-        x = vright ? x : xn;
-        mu = vright ? mn : mu;
-        const int right = __builtin_amdgcn_readfirstlane((int)vright);
-        ev += 1 - right; km += right;
-
-        float S; unsigned F;
-        cell(diag, up, left, x, mu, fc, lp_step, lp_stay, S, F);
-        if (km >= 0 && km + (DN_W - 1) < K && ev >= DN_W - 1 && ev < E) {
-            S = inb ? S : NINF;                           // interior band: every cell 0..99 is inside the matrix
-        } else {
-            const unsigned e_u = (unsigned)ev - (unsigned)o;
-            const bool ok = inb && ((unsigned)(km + o) < (unsigned)K) && (e_u < (unsigned)E);   // :269-278
-            S = ok ? S : NINF; F = ok ? F : 0u;
-            if (inb && km + o == -1 && e_u < (unsigned)E) { S = (float)(fc.lp_trim * (double)(e_u + 1u)); F = 1; }   // :256-265
-        }
-        Pb[sc][o + 1] = S;                                // lanes >= 100 rewrite -inf into the sentinel cells
-        // ---- trace row: byte per cell + the band's lower-left event index in bytes 104..107 ----
-        uint8_t tb = (uint8_t)F;
-        if (tid >= 104 && tid < 108) tb = (uint8_t)(((unsigned)ev >> (8 * (tid - 104))) & 0xffu);
-        rows[(size_t)b * DN_TROW + tid] = tb;
-        // ---- end cell (:329-340): the lane that holds column K-1 keeps its best; reduced after the loop ----
-        const int oe = K - 1 - km;
-        if (oe >= 0 && oe < DN_W) {
-            const int ee = ev - o;
-            if (o == oe && ee >= 0 && ee < E) {
-                const float sv = (float)((double)S + (double)(unsigned long long)(E - ee) * fc.lp_trim);
-                if (sv > best) { best = sv; best_e = ee; }
-            }
-        }
-        // ---- ring refills (uniform, rare) ----
-        if (ev + 130 >= xhi) { rx[(xhi + tid) & (F2_RING - 1)] = pendx; xhi += 128; pendx = ldx(xhi + tid); }
-        if (km + 230 >= mhi) { rm[(mhi + tid) & (F2_RING - 1)] = pendm; mhi += 128; pendm = ldm(mhi + tid); }
-        prev_right = right;
-        // LDS-only barrier: __syncthreads() would also wait vmcnt(0), i.e. for this band's trace store to be acknowledged
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    // first maximum in increasing event order == maximum score, smallest event on ties
-    red_s[tid] = best; red_e[tid] = best_e;
-    __syncthreads();
-    if (tid == 0) {
-        float bs = NINF; int be = 0x7fffffff;
-        for (int i = 0; i < DN_W; i++)
-            if (red_e[i] != 0x7fffffff && (red_s[i] > bs || (red_s[i] == bs && red_e[i] < be))) { bs = red_s[i]; be = red_e[i]; }
-        const int found = (be != 0x7fffffff) && (bs > NINF);
-        R.n_bands = (unsigned)n_bands;
-        R.end_event = found ? be : 0;
-        R.end_score = bs;
-        if (!found) R.status = 3;
-    }
-}
-
-// diagnostic build of k2_fill2 with s_memtime stamps per phase (DN_FILL_VARIANT=22); never used for results or timing
-__global__ __launch_bounds__(128) void k2_fill2p(BatchDev B, const BandConsts *bc, FillConsts fc) {
-    __shared__ float Pb[3][F2_PW];                        // [band % 3][cell offset + 1]; [0] and [101..] stay -inf
-    __shared__ double rx[F2_RING], rm[F2_RING];           // x[e] at e & 511, mu[k] at k & 511
-    __shared__ float red_s[128]; __shared__ int red_e[128];
-    const int r = blockIdx.x;
-    const int tid = threadIdx.x;
-    ReadRes &R = B.res[r];
-    if (R.status != 0) return;
-    const int E = (int)R.n_events, K = (int)R.n_kq;
-    const int n_bands = E + K + 2;
-    const double lp_stay = bc[r].lp_stay, lp_step = bc[r].lp_step;
-    const double *xs = B.ev_x + B.ev_off[r];
-    const double *mus = B.mu_q + B.base_off[r];
-    uint8_t *rows = B.trace + B.trace_off[r] * DN_TROW;
-    const float NINF = neg_inf();
-    const int o = tid;                                    // cell offset of this lane
-    const bool inb = o < DN_W;
-    auto ldx = [&](int e) -> double { return (e >= 0 && e < E) ? xs[e] : 0.0; };
-    auto ldm = [&](int k) -> double { return (k >= 0 && k < K) ? mus[k] : 0.0; };
-
-    // ---- bands 0 and 1 (event_handling.cpp:213-228) ----
-    for (int i = tid; i < 3 * F2_PW; i += 128) (&Pb[0][0])[i] = NINF;
-    for (int i = tid; i < 384; i += 128) { rx[i] = ldx(i); rm[i] = ldm(i); }
-    int xhi = 384, mhi = 384;                             // rings hold [.., xhi) / [.., mhi)
-    double pendx = ldx(xhi + tid), pendm = ldm(mhi + tid);
-    __syncthreads();
-    if (tid == 0) { Pb[0][50 + 1] = 0.0f; Pb[1][50 + 1] = (float)fc.lp_trim; }
-    int ev = 50, km = -51;                                // lower-left of band 1; band 0 is (49, -51)
-    {
-        uint8_t b0 = 0, b1 = (o == 50) ? 1 : 0;           // trace[1][50] = FROM_U
-        if (tid >= 104 && tid < 108) { b0 = (uint8_t)((49u >> (8 * (tid - 104))) & 0xff); b1 = (uint8_t)((50u >> (8 * (tid - 104))) & 0xff); }
-        rows[tid] = b0; rows[DN_TROW + tid] = b1;
-    }
-    double x = ldx(ev - o), mu = ldm(km + o);
-    float best = NINF; int best_e = 0x7fffffff;
-    int prev_right = 0;
-    __syncthreads();
-    // retire the pre-loop global loads HERE (vmcnt(0), builtin form so the compiler's scoreboard sees it): otherwise
-    // the first use of x / mu inside the loop carries a vmcnt(0) on every iteration and each band waits for its own store
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-
-    unsigned long long T[6] = {0,0,0,0,0,0};
-#define STAMP(i) { unsigned long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); T[i] += t_ - tl; tl = t_; }
-    unsigned long long tl; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl) :: "memory");
-    for (int b = 2; b < n_bands; b++) {
-        const int sp = (b + 2) % 3, sq = (b + 1) % 3, sc = b % 3;
-        const float *Pp = Pb[sp], *Qq = Pb[sq];
-        // ---- one LDS round trip: everything either move can need ----
-        const float lo = Pp[1], hi = Pp[DN_W];
-        const float pm1 = Pp[o], p0 = Pp[o + 1], pp1 = Pp[o + 2];            // P[o-1], P[o], P[o+1]
-        const float qa = Qq[o + prev_right], qb = Qq[o + 1 + prev_right];    // diag for a down / right move
-        const double xn = rx[(ev + 1 - o) & (F2_RING - 1)];                  // x of this cell after a down move
-        const double mn = rm[(km + 1 + o) & (F2_RING - 1)];                  // mu of this cell after a right move
-        asm volatile("" :: "v"(lo), "v"(hi), "v"(pm1), "v"(p0), "v"(pp1), "v"(qa), "v"(qb), "v"(xn), "v"(mn));
-        STAMP(0)
-        // ---- Suzuki-Kasahara move (:237-253) ----
-        const bool vright = (lo == NINF && hi == NINF) ? ((b & 1) != 0) : (lo < hi);
-        const float up = vright ? pp1 : p0, left = vright ? p0 : pm1, diag = vright ? qb : qa;
-        x = vright ? x : xn;
-        mu = vright ? mn : mu;
-        const int right = __builtin_amdgcn_readfirstlane((int)vright);
-        ev += 1 - right; km += right;
-
-        asm volatile("" :: "v"(up), "v"(left), "v"(diag), "v"(x), "v"(mu));
-        STAMP(1)
-        float S; unsigned F;
-        cell(diag, up, left, x, mu, fc, lp_step, lp_stay, S, F);
-        if (km >= 0 && km + (DN_W - 1) < K && ev >= DN_W - 1 && ev < E) {
-            S = inb ? S : NINF;                           // interior band: every cell 0..99 is inside the matrix
-        } else {
-            const unsigned e_u = (unsigned)ev - (unsigned)o;
-            const bool ok = inb && ((unsigned)(km + o) < (unsigned)K) && (e_u < (unsigned)E);   // :269-278
-            S = ok ? S : NINF; F = ok ? F : 0u;
-            if (inb && km + o == -1 && e_u < (unsigned)E) { S = (float)(fc.lp_trim * (double)(e_u + 1u)); F = 1; }   // :256-265
-        }
-        asm volatile("" :: "v"(S), "v"(F));
-        STAMP(2)
-        Pb[sc][o + 1] = S;                                // lanes >= 100 rewrite -inf into the sentinel cells
-        // ---- trace row: byte per cell + the band's lower-left event index in bytes 104..107 ----
-        uint8_t tb = (uint8_t)F;
-        if (tid >= 104 && tid < 108) tb = (uint8_t)(((unsigned)ev >> (8 * (tid - 104))) & 0xffu);
-        rows[(size_t)b * DN_TROW + tid] = tb;
-        // ---- end cell (:329-340): the lane that holds column K-1 keeps its best; reduced after the loop ----
-        const int oe = K - 1 - km;
-        if (oe >= 0 && oe < DN_W) {
-            const int ee = ev - o;
-            if (o == oe && ee >= 0 && ee < E) {
-                const float sv = (float)((double)S + (double)(unsigned long long)(E - ee) * fc.lp_trim);
-                if (sv > best) { best = sv; best_e = ee; }
-            }
-        }
-        // ---- ring refills (uniform, rare) ----
-        if (ev + 130 >= xhi) { rx[(xhi + tid) & (F2_RING - 1)] = pendx; xhi += 128; pendx = ldx(xhi + tid); }
-        if (km + 230 >= mhi) { rm[(mhi + tid) & (F2_RING - 1)] = pendm; mhi += 128; pendm = ldm(mhi + tid); }
-        prev_right = right;
-        STAMP(3)
-        // LDS-only barrier: __syncthreads() would also wait vmcnt(0), i.e. for this band's trace store to be acknowledged
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        STAMP(4)
-    }
-    if (blockIdx.x == 0 && (tid == 0 || tid == 64))
-        printf("fill2p wave %d: bands %d  cycles/band: lds-reads %.1f  move+select %.1f  cell+mask %.1f  write+store+endcell+refill %.1f  barrier %.1f  total %.1f\n",
-               tid / 64, n_bands, (double)T[0] / n_bands, (double)T[1] / n_bands, (double)T[2] / n_bands, (double)T[3] / n_bands, (double)T[4] / n_bands,
-               (double)(T[0] + T[1] + T[2] + T[3] + T[4]) / n_bands);
-    // first maximum in increasing event order == maximum score, smallest event on ties
-    red_s[tid] = best; red_e[tid] = best_e;
-    __syncthreads();
-    if (tid == 0) {
-        float bs = NINF; int be = 0x7fffffff;
-        for (int i = 0; i < DN_W; i++)
-            if (red_e[i] != 0x7fffffff && (red_s[i] > bs || (red_s[i] == bs && red_e[i] < be))) { bs = red_s[i]; be = red_e[i]; }
-        const int found = (be != 0x7fffffff) && (bs > NINF);
-        R.n_bands = (unsigned)n_bands;
-        R.end_event = found ? be : 0;
-        R.end_score = bs;
-        if (!found) R.status = 3;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k2_fill3<NR>: the two-wavefront LDS design of k2_fill2 with NR reads interleaved per workgroup.
-//
-// One band cell is ONE long dependency chain (x-mu -> /sigma -> -a*a/2 -> +C -> three candidates -> max), and a
-// lone wavefront issues a dependent instruction only every ~8 cycles (4 independent chains: ~5).  Giving every lane
-// one cell of each of NR different reads puts NR independent chains into the same instruction stream, and the NR reads
-// share the one barrier per band.  The code is written phase by phase (all LDS reads, all selects, all cells, all
-// writes) and branch-free inside a phase so the scheduler can interleave the reads.
-// ------------------------------------------------------------------------------------------------
-template <int NR>
-__global__ __launch_bounds__(128) void k2_fill3(BatchDev B, const BandConsts *bc, FillConsts fc) {
-    __shared__ float Pb[NR][3][F2_PW];
-    __shared__ double rx[NR][F2_RING], rm[NR][F2_RING];
-    __shared__ float red_s[NR][128]; __shared__ int red_e[NR][128];
-    const int tid = threadIdx.x;
-    const int o = tid;
-    const bool inb = o < DN_W;
-    const float NINF = neg_inf();
-    int E[NR], K[NR], nb[NR], ev[NR], km[NR], prev_right[NR], xhi[NR], mhi[NR];
-    double lp_stay[NR], lp_step[NR], x[NR], mu[NR], pendx[NR], pendm[NR];
-    const double *xs[NR], *mus[NR];
-    uint8_t *rows[NR];
-    float best[NR]; int best_e[NR];
-    int max_nb = 0;
-#pragma unroll
-    for (int q = 0; q < NR; q++) {
-        const int r = blockIdx.x * NR + q;
-        const bool live = r < B.n_reads && B.res[r < B.n_reads ? r : 0].status == 0;
-        const int rr = r < B.n_reads ? r : 0;
-        E[q] = live ? (int)B.res[rr].n_events : 0; K[q] = live ? (int)B.res[rr].n_kq : 0;
-        nb[q] = live ? E[q] + K[q] + 2 : 0;
-        max_nb = max(max_nb, nb[q]);
-        lp_stay[q] = bc[rr].lp_stay; lp_step[q] = bc[rr].lp_step;
-        xs[q] = B.ev_x + B.ev_off[rr]; mus[q] = B.mu_q + B.base_off[rr];
-        rows[q] = B.trace + B.trace_off[rr] * DN_TROW;
-        best[q] = NINF; best_e[q] = 0x7fffffff; prev_right[q] = 0;
-        ev[q] = 50; km[q] = -51; xhi[q] = 384; mhi[q] = 384;
-    }
-    if (max_nb == 0) return;
-#define LDX(q, e) (((e) >= 0 && (e) < E[q]) ? xs[q][e] : 0.0)
-#define LDM(q, k) (((k) >= 0 && (k) < K[q]) ? mus[q][k] : 0.0)
-    // ---- bands 0 and 1 (event_handling.cpp:213-228) ----
-#pragma unroll
-    for (int q = 0; q < NR; q++) {
-        for (int i = tid; i < 3 * F2_PW; i += 128) (&Pb[q][0][0])[i] = NINF;
-        for (int i = tid; i < 384; i += 128) { rx[q][i] = LDX(q, i); rm[q][i] = LDM(q, i); }
-        pendx[q] = LDX(q, xhi[q] + tid); pendm[q] = LDM(q, mhi[q] + tid);
-        x[q] = LDX(q, ev[q] - o); mu[q] = LDM(q, km[q] + o);
-        if (nb[q]) {
-            uint8_t b0 = 0, b1 = (o == 50) ? 1 : 0;       // trace[1][50] = FROM_U
-            if (tid >= 104 && tid < 108) { b0 = (uint8_t)((49u >> (8 * (tid - 104))) & 0xff); b1 = (uint8_t)((50u >> (8 * (tid - 104))) & 0xff); }
-            rows[q][tid] = b0; rows[q][DN_TROW + tid] = b1;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-#pragma unroll
-        for (int q = 0; q < NR; q++) { Pb[q][0][50 + 1] = 0.0f; Pb[q][1][50 + 1] = (float)fc.lp_trim; }
-    }
-    __syncthreads();
-    __builtin_amdgcn_s_waitcnt(0x0F70);                   // retire the pre-loop global loads (see k2_fill2)
-
-    for (int b = 2; b < max_nb; b++) {
-        const int sp = (b + 2) % 3, sq = (b + 1) % 3, sc = b % 3;
-        float lo[NR], hi[NR], pm1[NR], p0[NR], pp1[NR], qa[NR], qb[NR];
-        double xn[NR], mn[NR];
-        // ---- phase 1: one LDS round trip for everything either move can need ----
-#pragma unroll
-        for (int q = 0; q < NR; q++) {
-            const float *Pp = Pb[q][sp], *Qq = Pb[q][sq];
-            lo[q] = Pp[1]; hi[q] = Pp[DN_W];
-            pm1[q] = Pp[o]; p0[q] = Pp[o + 1]; pp1[q] = Pp[o + 2];
-            qa[q] = Qq[o + prev_right[q]]; qb[q] = Qq[o + 1 + prev_right[q]];
-            xn[q] = rx[q][(ev[q] + 1 - o) & (F2_RING - 1)];
-            mn[q] = rm[q][(km[q] + 1 + o) & (F2_RING - 1)];
-        }
-        // ---- phase 2: Suzuki-Kasahara move (:237-253) and neighbour selection, branch-free ----
-        float up[NR], left[NR], diag[NR];
-        bool all_interior = true, any_end = false;
-#pragma unroll
-        for (int q = 0; q < NR; q++) {
-            const bool both_ob = (lo[q] == NINF) & (hi[q] == NINF);
-            const bool vright = both_ob ? ((b & 1) != 0) : (lo[q] < hi[q]);
-            up[q] = vright ? pp1[q] : p0[q]; left[q] = vright ? p0[q] : pm1[q]; diag[q] = vright ? qb[q] : qa[q];
-            x[q] = vright ? x[q] : xn[q];
-            mu[q] = vright ? mn[q] : mu[q];
-            const int right = __builtin_amdgcn_readfirstlane((int)vright);
-            ev[q] += 1 - right; km[q] += right; prev_right[q] = right;
-            all_interior = all_interior && (km[q] >= 0 && km[q] + (DN_W - 1) < K[q] && ev[q] >= DN_W - 1 && ev[q] < E[q] && b < nb[q]);
-            any_end = any_end || (K[q] - 1 - km[q] < DN_W);
-        }
-        // ---- phase 3: the cells ----
-        float S[NR]; unsigned F[NR];
-#pragma unroll
-        for (int q = 0; q < NR; q++) cell(diag[q], up[q], left[q], x[q], mu[q], fc, lp_step[q], lp_stay[q], S[q], F[q]);
-        if (all_interior) {
-#pragma unroll
-            for (int q = 0; q < NR; q++) S[q] = inb ? S[q] : NINF;
-        } else {
-#pragma unroll
-            for (int q = 0; q < NR; q++) {
-                const unsigned e_u = (unsigned)ev[q] - (unsigned)o;
-                const bool ok = inb && ((unsigned)(km[q] + o) < (unsigned)K[q]) && (e_u < (unsigned)E[q]);   // :269-278
-                S[q] = ok ? S[q] : NINF; F[q] = ok ? F[q] : 0u;
-                if (inb && km[q] + o == -1 && e_u < (unsigned)E[q]) { S[q] = (float)(fc.lp_trim * (double)(e_u + 1u)); F[q] = 1; }   // :256-265
-            }
-        }
-        // ---- phase 4: scores to LDS, trace row to HBM ----
-#pragma unroll
-        for (int q = 0; q < NR; q++) {
-            Pb[q][sc][o + 1] = S[q];
-            uint8_t tb = (uint8_t)F[q];
-            if (tid >= 104 && tid < 108) tb = (uint8_t)(((unsigned)ev[q] >> (8 * (tid - 104))) & 0xffu);
-            if (b < nb[q]) rows[q][(size_t)b * DN_TROW + tid] = tb;
-        }
-        // ---- end cell (:329-340) and ring refills: uniform, rare ----
-        if (any_end) {
-#pragma unroll
-            for (int q = 0; q < NR; q++) {
-                const int oe = K[q] - 1 - km[q];
-                const int ee = ev[q] - o;
-                if (b < nb[q] && oe >= 0 && o == oe && ee >= 0 && ee < E[q]) {
-                    const float sv = (float)((double)S[q] + (double)(unsigned long long)(E[q] - ee) * fc.lp_trim);
-                    if (sv > best[q]) { best[q] = sv; best_e[q] = ee; }
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NR; q++) {
-            if (ev[q] + 130 >= xhi[q]) { rx[q][(xhi[q] + tid) & (F2_RING - 1)] = pendx[q]; xhi[q] += 128; pendx[q] = LDX(q, xhi[q] + tid); }
-            if (km[q] + 230 >= mhi[q]) { rm[q][(mhi[q] + tid) & (F2_RING - 1)] = pendm[q]; mhi[q] += 128; pendm[q] = LDM(q, mhi[q] + tid); }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier (no vmcnt: stores stay in flight)
-    }
-#undef LDX
-#undef LDM
-#pragma unroll
-    for (int q = 0; q < NR; q++) { red_s[q][tid] = best[q]; red_e[q][tid] = best_e[q]; }
-    __syncthreads();
-    if (tid < NR) {
-        const int q = tid;
-        const int r = blockIdx.x * NR + q;
-        bool live = false; int nbq = 0;
-#pragma unroll
-        for (int z = 0; z < NR; z++) if (z == q) { live = nb[z] > 0; nbq = nb[z]; }
-        if (live) {
-            float bs = NINF; int be = 0x7fffffff;
-            for (int i = 0; i < DN_W; i++) {
-                const float si = red_s[q][i]; const int ei = red_e[q][i];
-                if (ei != 0x7fffffff && (si > bs || (si == bs && ei < be))) { bs = si; be = ei; }   // first maximum in event order
-            }
-            const int found = (be != 0x7fffffff) && (bs > NINF);
-            ReadRes &R = B.res[r];
-            R.n_bands = (unsigned)nbq;
-            R.end_event = found ? be : 0;
-            R.end_score = bs;
-            if (!found) R.status = 3;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k2_fill4: the single-wavefront register/DPP design (k2_fill) rewritten around the measured costs of a lone
-// wavefront on a SIMD: ~8 cycles per VALU instruction, and ~40+ cycles for every VALU->SALU hop or VALU-dependent
-// branch (profiles/r01_valu_issue_microbench.txt, stamped phases of k2_fill2p):
-//   * the Suzuki move is decided on the SCALAR unit with integer arithmetic on the two broadcast edge scores
-//     (float order == signed order of sign-magnitude keys), so the loop has one VALU->SALU hop (two v_readlane) and
-//     no VALU-dependent branch;
-//   * every rare condition (band touching a matrix edge, trim column, end column) is one merged scalar test and one
-//     branch to a general slow path; the fast path has no other branch than the move itself;
-//   * idle lanes are kept at -inf with a single select (only cell 100 can leak into the band).
-// ------------------------------------------------------------------------------------------------
-template <bool DPP>
-__global__ __launch_bounds__(64) void k2_fill4(BatchDev B, const BandConsts *bc, FillConsts fc) {
-    const int r = blockIdx.x;
-    const int lane = threadIdx.x;
-    ReadRes &R = B.res[r];
-    if (R.status != 0) return;
-    const int E = (int)R.n_events, K = (int)R.n_kq;
-    const int n_bands = E + K + 2;
-    const double lp_stay = bc[r].lp_stay, lp_step = bc[r].lp_step;
-    const double *xs = B.ev_x + B.ev_off[r];
-    const double *mus = B.mu_q + B.base_off[r];
-    const cdptr_t xs_c = (cdptr_t)(uintptr_t)xs;
-    const cdptr_t mu_c = (cdptr_t)(uintptr_t)mus;
-    uint8_t *rows = B.trace + B.trace_off[r] * DN_TROW;
-    const float NINF = neg_inf();
-    const bool inb = lane < 50;
-    const unsigned o0 = inb ? (unsigned)(2 * lane) : 0x40000000u, o1 = inb ? (unsigned)(2 * lane + 1) : 0x40000000u;
-    const unsigned meta_shift = (lane == 53) ? 16u : 0u;
-    const unsigned meta_mask = (lane == 52 || lane == 53) ? 0xffffu : 0u;
-
-    // ---- bands 0 and 1 (event_handling.cpp:213-228) ----
-    int ev = 50, km = -51;
-    float Q0 = (o0 == 50u) ? 0.0f : NINF, Q1 = NINF;
-    float P0 = (o0 == 50u) ? (float)fc.lp_trim : NINF, P1 = NINF;
-    {
-        const unsigned short w1 = (o0 == 50u) ? 1u : 0u;
-        reinterpret_cast<unsigned short *>(rows)[lane] = inb ? (unsigned short)0 : (unsigned short)((49u >> meta_shift) & meta_mask);
-        reinterpret_cast<unsigned short *>(rows + DN_TROW)[lane] = inb ? w1 : (unsigned short)((50u >> meta_shift) & meta_mask);
-    }
-    auto ldx = [&](int e) -> double { return (e >= 0 && e < E) ? xs[e] : 0.0; };
-    auto ldm = [&](int k) -> double { return (k >= 0 && k < K) ? mus[k] : 0.0; };
-    double X0 = ldx(ev - (int)o0), X1 = ldx(ev - (int)o1);
-    double M0 = ldm(km + (int)o0), M1 = ldm(km + (int)o1);
-    double nx = xs_c[min(ev + 1, E - 1)];
-    double nm = mu_c[max(min(km + 100, K - 1), 0)];
-    float best = NINF; int best_e = 0; int found = 0;
-    int prev_right = 0;
-    unsigned short *wrow = reinterpret_cast<unsigned short *>(rows) + lane;      // + 64 shorts per band
-    __builtin_amdgcn_s_waitcnt(0x0F70);                   // retire the pre-loop vector loads once (not per band)
-
-    for (int b = 2; b < n_bands; b++) {
-        // ---- Suzuki-Kasahara move (:237-253), on the scalar unit ----
-        const int lo_i = __builtin_amdgcn_readlane(__float_as_int(P0), 0);
-        const int hi_i = __builtin_amdgcn_readlane(__float_as_int(P1), 49);
-        const int klo = lo_i ^ ((lo_i >> 31) & 0x7fffffff), khi = hi_i ^ ((hi_i >> 31) & 0x7fffffff);
-        int right = klo < khi;                                            // lo < hi for non-NaN floats ...
-        if ((((unsigned)lo_i | (unsigned)hi_i) & 0x7fffffffu) == 0u) right = 0;   // ... except -0 vs +0, which compare equal
-        if (lo_i == (int)0xff800000 && hi_i == (int)0xff800000) right = b & 1;   // both edges out of band: alternate
-
-        float up0, up1, lf0, lf1, dg0, dg1;
-        if (right) {
-            km += 1;
-            const double t = from_next_d<DPP>(M0, lane);
-            M0 = M1; M1 = (lane == 49) ? nm : t;
-            const float nq = from_next<DPP>(Q0, NINF, lane);
-            up0 = P1; lf0 = P0; up1 = from_next<DPP>(P0, NINF, lane); lf1 = P1;
-            dg0 = prev_right ? Q1 : Q0; dg1 = prev_right ? nq : Q1;
-        } else {
-            ev += 1;
-            const double t = from_prev_d<DPP>(X1, lane);
-            X1 = X0; X0 = (lane == 0) ? nx : t;
-            const float pq = from_prev<DPP>(Q1, NINF, lane);
-            up0 = P0; lf0 = from_prev<DPP>(P1, NINF, lane); up1 = P1; lf1 = P0;
-            dg0 = prev_right ? Q0 : pq; dg1 = prev_right ? Q1 : Q0;
-        }
-        nx = xs_c[min(ev + 1, E - 1)];                    // scalar prefetch for the next band
-        nm = mu_c[max(min(km + 100, K - 1), 0)];
-
-        float S0, S1; unsigned F0, F1;
-        cell(dg0, up0, lf0, X0, M0, fc, lp_step, lp_stay, S0, F0);
-        cell(dg1, up1, lf1, X1, M1, fc, lp_step, lp_stay, S1, F1);
-        S0 = inb ? S0 : NINF;                             // cell 100 (lane 50) is the only idle cell a band cell can read
-        if (__builtin_expect(!(km >= 0 && km + DN_W < K && ev >= DN_W - 1 && ev < E), 0)) {
-            // ---- slow path: the band touches a matrix edge, the trim column or the end column ----
-            const unsigned e0 = (unsigned)ev - o0, e1 = (unsigned)ev - o1;
-            const bool ok0 = ((unsigned)km + o0 < (unsigned)K) && (e0 < (unsigned)E);    // :269-278
-            const bool ok1 = ((unsigned)km + o1 < (unsigned)K) && (e1 < (unsigned)E);
-            S0 = ok0 ? S0 : NINF; F0 = ok0 ? F0 : 0u;
-            S1 = ok1 ? S1 : NINF; F1 = ok1 ? F1 : 0u;
-            if (km <= -1) {                               // trim column kmer == -1 (:256-265)
-                const bool t0 = ((unsigned)km + o0 == 0xffffffffu) && (e0 < (unsigned)E);
-                const bool t1 = ((unsigned)km + o1 == 0xffffffffu) && (e1 < (unsigned)E);
-                if (t0) { S0 = (float)(fc.lp_trim * (double)(e0 + 1u)); F0 = 1; }
-                if (t1) { S1 = (float)(fc.lp_trim * (double)(e1 + 1u)); F1 = 1; }
-            }
-            const int oe = K - 1 - km;                    // end column (:329-340)
-            if (oe >= 0 && oe < DN_W) {
-                const int ee = ev - oe;
-                if (ee >= 0 && ee < E) {
-                    const float sv = bcast_f((oe & 1) ? S1 : S0, oe >> 1);
-                    const float sc = (float)((double)sv + (double)(unsigned long long)(E - ee) * fc.lp_trim);
-                    if (sc > best) { best = sc; best_e = ee; found = 1; }
-                }
-            }
-        }
-        // ---- one 128-byte row: 100 trace bytes (lanes 0..49) + the band's lower-left event index (lanes 52, 53) ----
-        const unsigned meta = ((unsigned)ev >> meta_shift) & meta_mask;
-        wrow += DN_TROW / 2;
-        *wrow = (unsigned short)(inb ? (F0 | (F1 << 8)) : meta);
-        Q0 = P0; Q1 = P1; P0 = S0; P1 = S1;
-        prev_right = right;
-    }
-    if (lane == 0) {
-        R.n_bands = (unsigned)n_bands;
-        R.end_event = best_e;
-        R.end_score = best;
-        if (!found) R.status = 3;
-    }
-}
-
-// diagnostic build of k2_fill4 with s_memtime stamps (DN_FILL_VARIANT=44); never used for results or timing
-__global__ __launch_bounds__(64) void k2_fill4p(BatchDev B, const BandConsts *bc, FillConsts fc) {
-    const int r = blockIdx.x;
-    const int lane = threadIdx.x;
-    ReadRes &R = B.res[r];
-    if (R.status != 0) return;
-    const int E = (int)R.n_events, K = (int)R.n_kq;
-    const int n_bands = E + K + 2;
-    const double lp_stay = bc[r].lp_stay, lp_step = bc[r].lp_step;
-    const double *xs = B.ev_x + B.ev_off[r];
-    const double *mus = B.mu_q + B.base_off[r];
-    const cdptr_t xs_c = (cdptr_t)(uintptr_t)xs;
-    const cdptr_t mu_c = (cdptr_t)(uintptr_t)mus;
-    uint8_t *rows = B.trace + B.trace_off[r] * DN_TROW;
-    const float NINF = neg_inf();
-    const bool inb = lane < 50;
-    const unsigned o0 = inb ? (unsigned)(2 * lane) : 0x40000000u, o1 = inb ? (unsigned)(2 * lane + 1) : 0x40000000u;
-    const unsigned meta_shift = (lane == 53) ? 16u : 0u;
-    const unsigned meta_mask = (lane == 52 || lane == 53) ? 0xffffu : 0u;
-
-    // ---- bands 0 and 1 (event_handling.cpp:213-228) ----
-    int ev = 50, km = -51;
-    float Q0 = (o0 == 50u) ? 0.0f : NINF, Q1 = NINF;
-    float P0 = (o0 == 50u) ? (float)fc.lp_trim : NINF, P1 = NINF;
-    {
-        const unsigned short w1 = (o0 == 50u) ? 1u : 0u;
-        reinterpret_cast<unsigned short *>(rows)[lane] = inb ? (unsigned short)0 : (unsigned short)((49u >> meta_shift) & meta_mask);
-        reinterpret_cast<unsigned short *>(rows + DN_TROW)[lane] = inb ? w1 : (unsigned short)((50u >> meta_shift) & meta_mask);
-    }
-    auto ldx = [&](int e) -> double { return (e >= 0 && e < E) ? xs[e] : 0.0; };
-    auto ldm = [&](int k) -> double { return (k >= 0 && k < K) ? mus[k] : 0.0; };
-    double X0 = ldx(ev - (int)o0), X1 = ldx(ev - (int)o1);
-    double M0 = ldm(km + (int)o0), M1 = ldm(km + (int)o1);
-    double nx = xs_c[min(ev + 1, E - 1)];
-    double nm = mu_c[max(min(km + 100, K - 1), 0)];
-    float best = NINF; int best_e = 0; int found = 0;
-    int prev_right = 0;
-    unsigned short *wrow = reinterpret_cast<unsigned short *>(rows) + lane;      // + 64 shorts per band
-    __builtin_amdgcn_s_waitcnt(0x0F70);                   // retire the pre-loop vector loads once (not per band)
-
-    unsigned long long T[6] = {0,0,0,0,0,0};
-#define STAMP4(i) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); T[i] += t_ - tl; tl = t_; }
-    unsigned long long tl; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl) :: "memory");
-    for (int b = 2; b < n_bands; b++) {
-        // ---- Suzuki-Kasahara move (:237-253), on the scalar unit ----
-        const int lo_i = __builtin_amdgcn_readlane(__float_as_int(P0), 0);
-        const int hi_i = __builtin_amdgcn_readlane(__float_as_int(P1), 49);
-        const int klo = lo_i ^ ((lo_i >> 31) & 0x7fffffff), khi = hi_i ^ ((hi_i >> 31) & 0x7fffffff);
-        int right = klo < khi;                                            // lo < hi for non-NaN floats ...
-        if ((((unsigned)lo_i | (unsigned)hi_i) & 0x7fffffffu) == 0u) right = 0;   // ... except -0 vs +0, which compare equal
-        if (lo_i == (int)0xff800000 && hi_i == (int)0xff800000) right = b & 1;   // both edges out of band: alternate
-
-        asm volatile("" :: "s"(right));
-        STAMP4(0)
-        float up0, up1, lf0, lf1, dg0, dg1;
-        if (right) {
-            km += 1;
-            const double t = from_next_d<true>(M0, lane);
-            M0 = M1; M1 = (lane == 49) ? nm : t;
-            const float nq = from_next<true>(Q0, NINF, lane);
-            up0 = P1; lf0 = P0; up1 = from_next<true>(P0, NINF, lane); lf1 = P1;
-            dg0 = prev_right ? Q1 : Q0; dg1 = prev_right ? nq : Q1;
-        } else {
-            ev += 1;
-            const double t = from_prev_d<true>(X1, lane);
-            X1 = X0; X0 = (lane == 0) ? nx : t;
-            const float pq = from_prev<true>(Q1, NINF, lane);
-            up0 = P0; lf0 = from_prev<true>(P1, NINF, lane); up1 = P1; lf1 = P0;
-            dg0 = prev_right ? Q0 : pq; dg1 = prev_right ? Q1 : Q0;
-        }
-        asm volatile("" :: "v"(up0), "v"(up1), "v"(lf0), "v"(lf1), "v"(dg0), "v"(dg1), "v"(X0), "v"(X1), "v"(M0), "v"(M1));
-        STAMP4(1)
-        nx = xs_c[min(ev + 1, E - 1)];                    // scalar prefetch for the next band
-        nm = mu_c[max(min(km + 100, K - 1), 0)];
-
-        float S0, S1; unsigned F0, F1;
-        cell(dg0, up0, lf0, X0, M0, fc, lp_step, lp_stay, S0, F0);
-        cell(dg1, up1, lf1, X1, M1, fc, lp_step, lp_stay, S1, F1);
-        asm volatile("" :: "v"(S0), "v"(S1), "v"(F0), "v"(F1));
-        STAMP4(2)
-        S0 = inb ? S0 : NINF;                             // cell 100 (lane 50) is the only idle cell a band cell can read
-        if (__builtin_expect(!(km >= 0 && km + DN_W < K && ev >= DN_W - 1 && ev < E), 0)) {
-            // ---- slow path: the band touches a matrix edge, the trim column or the end column ----
-            const unsigned e0 = (unsigned)ev - o0, e1 = (unsigned)ev - o1;
-            const bool ok0 = ((unsigned)km + o0 < (unsigned)K) && (e0 < (unsigned)E);    // :269-278
-            const bool ok1 = ((unsigned)km + o1 < (unsigned)K) && (e1 < (unsigned)E);
-            S0 = ok0 ? S0 : NINF; F0 = ok0 ? F0 : 0u;
-            S1 = ok1 ? S1 : NINF; F1 = ok1 ? F1 : 0u;
-            if (km <= -1) {                               // trim column kmer == -1 (:256-265)
-                const bool t0 = ((unsigned)km + o0 == 0xffffffffu) && (e0 < (unsigned)E);
-                const bool t1 = ((unsigned)km + o1 == 0xffffffffu) && (e1 < (unsigned)E);
-                if (t0) { S0 = (float)(fc.lp_trim * (double)(e0 + 1u)); F0 = 1; }
-                if (t1) { S1 = (float)(fc.lp_trim * (double)(e1 + 1u)); F1 = 1; }
-            }
-            const int oe = K - 1 - km;                    // end column (:329-340)
-            if (oe >= 0 && oe < DN_W) {
-                const int ee = ev - oe;
-                if (ee >= 0 && ee < E) {
-                    const float sv = bcast_f((oe & 1) ? S1 : S0, oe >> 1);
-                    const float sc = (float)((double)sv + (double)(unsigned long long)(E - ee) * fc.lp_trim);
-                    if (sc > best) { best = sc; best_e = ee; found = 1; }
-                }
-            }
-        }
-        // ---- one 128-byte row: 100 trace bytes (lanes 0..49) + the band's lower-left event index (lanes 52, 53) ----
-        const unsigned meta = ((unsigned)ev >> meta_shift) & meta_mask;
-        wrow += DN_TROW / 2;
-        *wrow = (unsigned short)(inb ? (F0 | (F1 << 8)) : meta);
-        Q0 = P0; Q1 = P1; P0 = S0; P1 = S1;
-        prev_right = right;
-        STAMP4(3)
-    }
-    if (blockIdx.x == 0 && lane == 0)
-        printf("fill4p: bands %d cycles/band: decide %.1f  shift %.1f  sload+cells %.1f  mask+slow+store %.1f  total %.1f\n", n_bands,
-               (double)T[0] / n_bands, (double)T[1] / n_bands, (double)T[2] / n_bands, (double)T[3] / n_bands, (double)(T[0] + T[1] + T[2] + T[3]) / n_bands);
-    if (lane == 0) {
-        R.n_bands = (unsigned)n_bands;
-        R.end_event = best_e;
-        R.end_score = best;
-        if (!found) R.status = 3;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // k2_fill5: single wavefront per read, 2 cells per lane, written for what the stamped builds measured on a lone
@@ -1519,27 +754,10 @@ int k2_fill_variant() {      // 6 = event-keyed slots (slot-indexed trace rows);
     return variant;
 }
 void k2_launch_fill(const BatchDev &B, const void *bc, const void *fc, bool dpp, hipStream_t st) {
+    (void)dpp;
     const FillConsts f = *reinterpret_cast<const FillConsts *>(fc);
-    const int variant = k2_fill_variant();
-    if (variant == 6) { hipLaunchKernelGGL(k2_fill6, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f); return; }
-    if (variant == 5) {
-        static const int abl = getenv("DN_FILL_ABL") ? atoi(getenv("DN_FILL_ABL")) : 0;   // timing-only ablations (wrong results)
-#define L5(A) case A: hipLaunchKernelGGL(k2_fill5<A>, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f); return;
-        switch (abl) { L5(0) L5(1) L5(2) L5(4) L5(8) L5(16) L5(31) default: break; }
-#undef L5
-    }
-    if (variant == 44) { hipLaunchKernelGGL(k2_fill4p, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f); return; }
-    if (variant == 4) {
-        if (dpp) hipLaunchKernelGGL(k2_fill4<true>, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f);
-        else hipLaunchKernelGGL(k2_fill4<false>, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f);
-        return;
-    }
-    if (variant == 3) { hipLaunchKernelGGL(k2_fill3<2>, dim3((B.n_reads + 1) / 2), dim3(128), 0, st, B, (const BandConsts *)bc, f); return; }
-    if (variant == 31) { hipLaunchKernelGGL(k2_fill3<1>, dim3(B.n_reads), dim3(128), 0, st, B, (const BandConsts *)bc, f); return; }
-    if (variant == 22) { hipLaunchKernelGGL(k2_fill2p, dim3(B.n_reads), dim3(128), 0, st, B, (const BandConsts *)bc, f); return; }
-    if (variant == 2) { hipLaunchKernelGGL(k2_fill2, dim3(B.n_reads), dim3(128), 0, st, B, (const BandConsts *)bc, f); return; }
-    if (dpp) hipLaunchKernelGGL(k2_fill<true>, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f);
-    else hipLaunchKernelGGL(k2_fill<false>, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f);
+    if (k2_fill_variant() == 6) { hipLaunchKernelGGL(k2_fill6, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f); return; }
+    hipLaunchKernelGGL(k2_fill5<0>, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f);
 }
 void k2_launch_chase(const BatchDev &B, uint8_t *path_from, hipStream_t st) {
     if (k2_fill_variant() == 6) hipLaunchKernelGGL(k2_chase<true>, dim3(B.n_reads), dim3(64), 0, st, B, path_from);
