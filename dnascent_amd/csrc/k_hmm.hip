@@ -7,11 +7,9 @@
 // T-containing k-mers within +-4 of the centre, once without; the call is the difference of the two log-likelihoods.
 //
 //   k_hmm_pois     wavefront per read: ordered compaction of the POIs (ascending strand coordinate).
-//   k_hmm_forward  THREAD per (POI, pass): the recursion is a serial chain in t and the D states chain in i, so the
-//                  work-efficient mapping is one lane per chain; a 20 kb read has ~5 k POIs x 2 passes, a batch millions.
-//                  One ascending sweep over i per observation updates I, M and D in place (the previous column's values
-//                  at i - 1 are carried in registers), state lives in LDS ([array][i][lane]: conflict-free), the loop over i
-//                  is rolled so the ~200 transcendental call sites of an unrolled version do not blow the instruction cache.
+//   k_hmm_forward  four lanes per (POI, pass) chain, six states each, skewed in time (see the comment above the kernel);
+//                  a 20 kb read has ~5 k POIs x 2 passes, a batch ten million chains.  One ascending sweep over the states per
+//                  observation updates I, M and D in place (the previous column's values at i - 1 are carried along).
 //
 // log(0) is NaN in the reference (probability.cpp:35-77); here it is -inf: lnProd is a plain add (x + -inf = -inf) and
 // lnSum(a, b) = max + log(1 + exp(min - max)) with min == -inf short-circuited, which is the reference's case split.
@@ -68,41 +66,55 @@ __device__ __forceinline__ double emission_(double x, const double4 p) {      //
     return e;
 }
 
-__global__ __launch_bounds__(64) void k_hmm_forward(BatchDev B, HmmDev H, const HmmRead *hr, HmmConsts hc) {
-    __shared__ double S[3][HMM_N][64];                    // I, M, D of the previous / current column (updated in place)
-    __shared__ unsigned KI[HMM_N][64];                    // k-mer rank of state i; bit 31: analogue model applies in pass 0
+// ------------------------------------------------------------------------------------------------
+// k_hmm_forward: FOUR lanes per (POI, pass) chain, six states each, skewed in time (a systolic pipeline): lane g works on
+// observation t = step - g, so that when it starts a column its left neighbour has just finished the same column.  What
+// crosses a lane boundary per step is five doubles (the neighbour's last state: previous-column I, M, D and current-column
+// M, D), moved with DPP row_shr:1.  The state of a lane is 18 doubles in REGISTERS (no LDS), so four wavefronts per SIMD are
+// resident where the LDS-resident one-lane-per-chain version had one: the kernel turns from latency-bound to bound by
+// the fp64 exp / log of the log-sum-exp (30 per lane and observation).  The order of every lnSum / lnProd is unchanged.
+// ------------------------------------------------------------------------------------------------
+#define HMM_G 4                  // lanes per chain
+#define HMM_S (HMM_N / HMM_G)    // states per lane
+
+__device__ __forceinline__ double shr1_d(double v) {       // lane l <- lane l - 1 within a row of 16 (lane 0 of a row keeps 0)
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x111, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x111, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+__global__ __launch_bounds__(64, 3) void k_hmm_forward(BatchDev B, HmmDev H, const HmmRead *hr, HmmConsts hc) {
     const int r = blockIdx.y, lane = threadIdx.x;
     const ReadRes &R = B.res[r];
     if (R.status != 0) return;
-    const unsigned idx = blockIdx.x * 64 + lane;
+    const int g = lane & (HMM_G - 1);                      // state group of this lane: states [6 g, 6 g + 6)
+    const unsigned idx = blockIdx.x * (64 / HMM_G) + (lane >> 2);
     const unsigned k = idx >> 1, pass = idx & 1u;         // pass 0: analogue, 1: thymidine
     const unsigned npoi = H.n_poi[r];
-    if (k >= npoi) return;
+    const bool chain = k < npoi;
     const uint64_t f0 = B.ref_off[r];
-    const unsigned pos = H.poi[f0 + k];
+    const unsigned pos = chain ? H.poi[f0 + k] : (unsigned)(2 * HMM_W);
     const char *ref = B.refseq + f0;
-    // ---- readSnippet fully A/T/G/C (:423-442) + k-mer ranks of the 2 W states ----
+    // ---- readSnippet fully A/T/G/C (:423-442) + k-mer ranks of this lane's six states ----
     const char *snip = ref + pos - HMM_W;
     bool acgt = true;
-    unsigned code[HMM_SNIP];
-#pragma unroll
-    for (int z = 0; z < HMM_SNIP; z++) {
-        const char c = snip[z];
-        acgt = acgt && (c == 'A' || c == 'T' || c == 'G' || c == 'C');
-        code[z] = base_code(c);
-    }
-    if (!acgt) { if (pass == 0) { H.ok[f0 + k] = 0; H.n_ev[f0 + k] = 0; } return; }
+    unsigned ki[HMM_S];
     {
         unsigned rank = 0, tmask = 0;                     // rolling 18-bit rank; tmask: which of the 9 bases are T
 #pragma unroll
         for (int z = 0; z < HMM_SNIP; z++) {
-            rank = ((rank << 2) | code[z]) & 0x3ffffu;
-            tmask = ((tmask << 1) | (code[z] == 1u ? 1u : 0u)) & 0x1ffu;
+            const char c = snip[z];
+            acgt = acgt && (c == 'A' || c == 'T' || c == 'G' || c == 'C');
+            const unsigned code = base_code(c);
+            rank = ((rank << 2) | code) & 0x3ffffu;
+            tmask = ((tmask << 1) | (code == 1u ? 1u : 0u)) & 0x1ffu;
             if (z >= 8) {
                 const int i = z - 8;
                 if (i < HMM_N) {
-                    const bool an = i >= HMM_W - 4 && i <= HMM_W + 4 && tmask != 0u;       // :319, BrdUStart/End :544-545 (i >= 1 holds)
-                    KI[i][lane] = rank | (an ? 0x80000000u : 0u);
+                    const bool an = pass == 0 && i >= HMM_W - 4 && i <= HMM_W + 4 && tmask != 0u;   // :319, BrdUStart/End :544-545
+#pragma unroll
+                    for (int q = 0; q < HMM_S; q++) if (i == g * HMM_S + q) ki[q] = rank | (an ? 0x80000000u : 0u);
                 }
             }
         }
@@ -119,60 +131,84 @@ __global__ __launch_bounds__(64) void k_hmm_forward(BatchDev B, HmmDev H, const 
     const double *evm = B.ev_mean + B.ev_off[r];
     unsigned ns = 0;
     for (int j = j0; j < j1; j++) { const double ev = evm[ae[j]]; ns += (ev > 0. && ev < 250.0) ? 1u : 0u; }
-    if (ns < 2 * HMM_W - 9) { if (pass == 0) { H.ok[f0 + k] = 0; H.n_ev[f0 + k] = 0; } return; }   // :510
+    const bool go = chain && acgt && ns >= 2 * HMM_W - 9;                                       // :442, :510
+    if (chain && !go && g == 0 && pass == 0) { H.ok[f0 + k] = 0; H.n_ev[f0 + k] = 0; }
+    // the four lanes of a chain agree on `go`; a wavefront leaves only when none of its chains runs
+    if (__ballot(go) == 0ull) return;
     // a reverse-strand snippet is only put back in forward order when the scan leaves through the break at :476-480,
     // i.e. when some aligned pair lies below the window; otherwise it stays in descending order
     const bool descending = B.is_rev[r] != 0 && j0 == 0;
     const double shift = R.shift, scale = R.scale;
     const double iM2M = hr[r].iM2M, eM2M = hr[r].eM2M;
     const double NI = neg_inf_d();
-    // ---- initialisation (:257-271) ----
+    const bool first = g == 0;
+    // ---- initialisation (:257-271): D_prev[i] = ln 0.25 + i * D2D accumulated left to right ----
+    double SI[HMM_S], SM[HMM_S], SD[HMM_S];
     {
-        double d = hc.ln025;                               // lnProd(start_prev = 0, eln(0.25))
-        for (int i = 0; i < HMM_N; i++) { S[0][i][lane] = NI; S[1][i][lane] = NI; S[2][i][lane] = d; d = d + hc.D2D; }
+        double d = hc.ln025;
+        for (int i = 0; i < HMM_N; i++) {
+#pragma unroll
+            for (int q = 0; q < HMM_S; q++) if (i == g * HMM_S + q) { SI[q] = NI; SM[q] = NI; SD[q] = d; }
+            d = d + hc.D2D;
+        }
     }
     double firstI_prev = NI, start_prev = 0.0;
-    const bool use_an = pass == 0;
-    // ---- recursion (:277-358) ----
-    for (int jj = 0; jj < j1 - j0; jj++) {
-        const int j = descending ? (j1 - 1 - jj) : (j0 + jj);
-        const double ev = evm[ae[j]];
-        if (!(ev > 0. && ev < 250.0)) continue;
-        const double x = (ev - shift) / scale;
-        // position 0 (:286-311): always the unlabelled model
-        unsigned ki = KI[0][lane];
-        double match = emission_(x, H.unl[ki & 0x3ffffu]);
-        const double firstI_curr = lnsum_(start_prev + hc.ln025, firstI_prev + hc.ln025);            // :297-298 (insProb = 0)
-        double oI = S[0][0][lane], oM = S[1][0][lane], oD = S[2][0][lane];
-        double nI = lnsum_(oI + hc.I2I, oM + hc.M2I);                                                // :301-302
-        double nM = lnsum_(lnsum_((firstI_prev + hc.ln05) + match, (oM + iM2M) + match), (start_prev + hc.ln05) + match);   // :305-307
-        double nD = firstI_curr + hc.ln025;                                                          // :310-311 (start -> D is log 0)
-        S[0][0][lane] = nI; S[1][0][lane] = nM; S[2][0][lane] = nD;
-        double pI = oI, pM = oM, pD = oD, cM = nM, cD = nD;
-        for (int i = 1; i < HMM_N; i++) {
-            ki = KI[i][lane];
-            const double4 prm = (use_an && (ki & 0x80000000u)) ? H.ana[ki & 0x3ffffu] : H.unl[ki & 0x3ffffu];
-            match = emission_(x, prm);
-            oI = S[0][i][lane]; oM = S[1][i][lane]; oD = S[2][i][lane];
-            nI = lnsum_(oI + hc.I2I, oM + hc.M2I);                                                   // :336-337
-            nM = lnsum_(lnsum_(lnsum_((pI + hc.I2M) + match, (pM + eM2M) + match), (oM + iM2M) + match), (pD + hc.D2M) + match);   // :340-343
-            nD = lnsum_(cM + hc.M2D, cD + hc.D2D);                                                   // :349-350
-            S[0][i][lane] = nI; S[1][i][lane] = nM; S[2][i][lane] = nD;
-            pI = oI; pM = oM; pD = oD; cM = nM; cD = nD;
-        }
-        firstI_prev = firstI_curr;
-        start_prev = NI;                                   // start_curr is log 0 (:261, :357)
+    // boundary handed to the next lane: this lane's LAST state, previous column (I, M, D) and current column (M, D)
+    double bI = NI, bM = NI, bD = SD[HMM_S - 1], bcM = NI, bcD = NI;
+    {
+        // before any observation the "previous column" of the neighbour's last state is its initial state
+        // (I, M = log 0, D = its initial D), and there is no current column yet
     }
-    // ---- termination (:362-367) ----
-    const double fwd = lnsum_(lnsum_(S[2][HMM_N - 1][lane] + 0.0, S[1][HMM_N - 1][lane] + hr[r].endM), S[0][HMM_N - 1][lane] + hc.I2M);
-    if (pass == 0) { H.la[f0 + k] = fwd; H.ok[f0 + k] = 1; H.n_ev[f0 + k] = ns; }
-    else H.lt[f0 + k] = fwd;
+    int cur = descending ? j1 - 1 : j0;                    // this lane's cursor over the aligned pairs
+    const int dir = descending ? -1 : 1;
+    const int T = (int)ns;
+    for (int step = 0; step < T + HMM_G - 1; step++) {
+        // what the left neighbour left behind in the step before (for g == 0 the values are not used)
+        const double pI0 = shr1_d(bI), pM0 = shr1_d(bM), pD0 = shr1_d(bD), cM0 = shr1_d(bcM), cD0 = shr1_d(bcD);
+        const int t = step - g;
+        const bool act = go && t >= 0 && t < T;
+        if (act) {
+            double ev = evm[ae[cur]];
+            while (!(ev > 0. && ev < 250.0)) { cur += dir; ev = evm[ae[cur]]; }      // events outside (0, 250) are not observations (:466)
+            cur += dir;
+            const double x = (ev - shift) / scale;
+            const double firstI_curr = lnsum_(start_prev + hc.ln025, firstI_prev + hc.ln025);       // :297-298 (insProb = 0)
+            // incoming edge of this lane's first state: for position 0 the start / first-insertion states take the place of
+            // the (i - 1) states (:305-311); everything else is the generic recursion (:336-350)
+            double pI = first ? firstI_prev : pI0, pM = first ? NI : pM0, pD = first ? start_prev : pD0;
+            double cM = first ? NI : cM0, cD = first ? firstI_curr : cD0;
+            double tI = first ? hc.ln05 : hc.I2M, tD = first ? hc.ln05 : hc.D2M, tcD = first ? hc.ln025 : hc.D2D;
+            const double oI5 = SI[HMM_S - 1], oM5 = SM[HMM_S - 1], oD5 = SD[HMM_S - 1];
+#pragma unroll
+            for (int q = 0; q < HMM_S; q++) {
+                const unsigned kk = ki[q];
+                const double4 prm = (kk & 0x80000000u) ? H.ana[kk & 0x3ffffu] : H.unl[kk & 0x3ffffu];
+                const double match = emission_(x, prm);
+                const double oI = SI[q], oM = SM[q], oD = SD[q];
+                const double nI = lnsum_(oI + hc.I2I, oM + hc.M2I);                                  // :301-302 / :336-337
+                const double nM = lnsum_(lnsum_(lnsum_((pI + tI) + match, (pM + eM2M) + match), (oM + iM2M) + match), (pD + tD) + match);   // :305-307 / :340-343
+                const double nD = lnsum_(cM + hc.M2D, cD + tcD);                                     // :310-311 / :349-350
+                SI[q] = nI; SM[q] = nM; SD[q] = nD;
+                pI = oI; pM = oM; pD = oD; cM = nM; cD = nD;
+                tI = hc.I2M; tD = hc.D2M; tcD = hc.D2D;
+            }
+            bI = oI5; bM = oM5; bD = oD5; bcM = SM[HMM_S - 1]; bcD = SD[HMM_S - 1];
+            firstI_prev = firstI_curr;
+            start_prev = NI;                               // start_curr is log 0 (:261, :357)
+        }
+    }
+    // ---- termination (:362-367): the last state lives in the last lane of the chain ----
+    if (go && g == HMM_G - 1) {
+        const double fwd = lnsum_(lnsum_(SD[HMM_S - 1] + 0.0, SM[HMM_S - 1] + hr[r].endM), SI[HMM_S - 1] + hc.I2M);
+        if (pass == 0) { H.la[f0 + k] = fwd; H.ok[f0 + k] = 1; H.n_ev[f0 + k] = ns; }
+        else H.lt[f0 + k] = fwd;
+    }
 }
 
 void k_hmm_launch(const BatchDev &B, const void *hdev, const void *hreads, const void *hconsts, unsigned max_ref, hipStream_t st) {
     const HmmDev &H = *(const HmmDev *)hdev;
     hipLaunchKernelGGL(k_hmm_pois, dim3(B.n_reads), dim3(64), 0, st, B, H);
     // upper bound on POIs per read = reference length; blocks beyond a read's POI count exit at once
-    hipLaunchKernelGGL(k_hmm_forward, dim3((2 * max_ref + 63) / 64, B.n_reads), dim3(64), 0, st, B, H, (const HmmRead *)hreads,
+    hipLaunchKernelGGL(k_hmm_forward, dim3((2 * max_ref + 15) / 16, B.n_reads), dim3(64), 0, st, B, H, (const HmmRead *)hreads,
                        *(const HmmConsts *)hconsts);
 }
