@@ -67,6 +67,7 @@ struct dn_ctx {
     std::vector<Slab> slabs; size_t slab_cur = 0;
     // model
     double *d_model = nullptr; double sigma = 0.14; bool have_model = false;
+    unsigned *d_model_pos = nullptr; double *d_model_sorted = nullptr;
     // batch
     BatchDev B{};
     bool have_batch = false;
@@ -246,6 +247,8 @@ void dn_ctx_destroy(dn_ctx *c) {
     if (c->trace.p) hipFree(c->trace.p);
     if (c->bandc.p) hipFree(c->bandc.p);
     if (c->d_model) hipFree(c->d_model);
+    if (c->d_model_pos) hipFree(c->d_model_pos);
+    if (c->d_model_sorted) hipFree(c->d_model_sorted);
     if (c->d_cnn_w) hipFree(c->d_cnn_w);
     if (c->d_cnn_wb) hipFree(c->d_cnn_wb);
     for (auto *p : c->d_fit) if (p) hipFree(p);
@@ -275,6 +278,23 @@ int dn_load_pore_model(dn_ctx *c, const double *mean, double sigma) {
         c->dev_bytes += DN_NKMER * sizeof(double);
     }
     HIPCHK(c, hipMemcpyAsync(c->d_model, mean, DN_NKMER * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    {
+        // the sorted table + each k-mer's position in it: order statistics of model levels (estimateScaling_quantiles,
+        // event_handling.cpp:533) become order statistics of 18-bit integers on the device
+        std::vector<unsigned> order(DN_NKMER), pos(DN_NKMER);
+        for (unsigned k = 0; k < DN_NKMER; k++) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return mean[a] < mean[b]; });
+        std::vector<double> sorted(DN_NKMER);
+        for (unsigned i = 0; i < DN_NKMER; i++) { pos[order[i]] = i; sorted[i] = mean[order[i]]; }
+        if (!c->d_model_pos) {
+            HIPCHK(c, hipMalloc((void **)&c->d_model_pos, DN_NKMER * sizeof(unsigned)));
+            HIPCHK(c, hipMalloc((void **)&c->d_model_sorted, DN_NKMER * sizeof(double)));
+            c->dev_bytes += DN_NKMER * (sizeof(unsigned) + sizeof(double));
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_model_pos, pos.data(), DN_NKMER * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_model_sorted, sorted.data(), DN_NKMER * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));          // the vectors are locals
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->sigma = sigma;
     c->have_model = true;
@@ -321,6 +341,7 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     memset(&B, 0, sizeof(B));
     B.n_reads = (int)n;
     B.model_mean = c->d_model; B.sigma = c->sigma;
+    B.model_pos = c->d_model_pos; B.model_sorted = c->d_model_sorted;
     c->h_samp_off.assign(d->adc_off, d->adc_off + n + 1);
     c->h_base_off.assign(d->basecall_off, d->basecall_off + n + 1);
     c->h_ref_off.assign(d->refseq_off, d->refseq_off + n + 1);

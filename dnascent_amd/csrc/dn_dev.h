@@ -48,6 +48,8 @@ struct BatchDev {
     const int32_t *ref_start, *ref_end;
     const uint8_t *is_rev;
     const double *model_mean; double sigma;
+    const unsigned *model_pos;     // [4^9] position of each 9-mer's level in the sorted table (ties: any order, equal values)
+    const double *model_sorted;    // [4^9] the levels in ascending order
     // ---- K1 workspace ----
     double2 *psum;           // [samples]  psum[i] = {sum[i+1], sumsq[i+1]}  (sum[0] = 0 is implicit)
     float *t1, *t2;          // [samples]

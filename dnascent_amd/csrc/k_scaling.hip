@@ -60,40 +60,51 @@ __device__ __forceinline__ void hist_add_agg(unsigned *hist, unsigned bin, bool 
 }
 
 // ------------------------------------------------------------------------------------------------
-// 10-target radix select.  val(i) is supplied by a functor so the model means are gathered on the fly.
+// 10-target radix select over 32-bit keys (NBITS significant), 8 bits per pass from the top.  key(i) is supplied by a
+// functor; out[t] receives the selected KEY of target t (rank ((t m + (t + 1) m) / 2, quantileMedians :467-470).
+// Both inputs of estimateScaling_quantiles reduce to 32-bit keys without changing any order statistic:
+//   * event means are floats widened to double (event_handling.cpp:549-575 copies event_t.mean), so the order-preserving
+//     map of their FLOAT bits orders them exactly like the doubles;
+//   * model levels are looked up in a 4^9 table: their position in the sorted table (computed once at load) is an 18-bit key.
 // ------------------------------------------------------------------------------------------------
-template <class F>
-__device__ __forceinline__ void select10(F val, unsigned n, double *out10, unsigned (*hist)[256], unsigned long long *prefix,
-                                         unsigned *rank_in) {
+__device__ __forceinline__ unsigned fkey(float x) {                // order-preserving float -> u32 (-0 sorts just below +0)
+    const unsigned u = (unsigned)__float_as_int(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) { return __int_as_float((int)((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k)); }
+
+template <int NBITS, class F>
+__device__ __forceinline__ void select10(F key, unsigned n, unsigned *out10, unsigned (*hist)[256], unsigned *prefix, unsigned *rank_in) {
     const int tid = threadIdx.x;
     const unsigned m = n / 10u;                                   // quantileMedians :467
     if (tid < 10) {
-        prefix[tid] = 0ull;
+        prefix[tid] = 0u;
         rank_in[tid] = ((unsigned)tid * m + (unsigned)(tid + 1) * m) / 2u;   // :470
     }
     __syncthreads();
-    for (int pass = 7; pass >= 0; pass--) {
+    constexpr int NPASS = (NBITS + 7) / 8;
+    for (int pass = NPASS - 1; pass >= 0; pass--) {
         for (int j = tid; j < 10 * 256; j += 256) (&hist[0][0])[j] = 0u;
         __syncthreads();
         // targets are in rank order, so equal prefixes are adjacent: one histogram per distinct prefix (group).
         // In the leading passes every target shares one prefix and the element loop does a single compare + atomic.
         const int sh = 8 * (pass + 1);
-        unsigned long long gp[10]; int ng = 0;
+        unsigned gp[10]; int ng = 0;
 #pragma unroll
         for (int t = 0; t < 10; t++) {
-            const unsigned long long ph = (pass == 7) ? 0ull : (prefix[t] >> sh);
+            const unsigned ph = (pass == NPASS - 1) ? 0u : (prefix[t] >> sh);
             if (ng == 0 || gp[ng - 1] != ph) gp[ng++] = ph;
         }
         for (unsigned i = tid; i < n; i += 256) {
-            const unsigned long long key = dkey(val(i));
-            const unsigned digit = (unsigned)(key >> (8 * pass)) & 255u;
-            const unsigned long long hi = (pass == 7) ? 0ull : (key >> sh);
+            const unsigned k = key(i);
+            const unsigned digit = (k >> (8 * pass)) & 255u;
+            const unsigned hi = (pass == NPASS - 1) ? 0u : (k >> sh);
             for (int g = 0; g < ng; g++)
                 if (hi == gp[g]) { atomicAdd(&hist[g][digit], 1u); break; }
         }
         __syncthreads();
         if (tid < 10) {
-            const unsigned long long ph = (pass == 7) ? 0ull : (prefix[tid] >> sh);
+            const unsigned ph = (pass == NPASS - 1) ? 0u : (prefix[tid] >> sh);
             int g = 0;
             for (int q = 0; q < ng; q++) if (gp[q] == ph) g = q;
             unsigned want = rank_in[tid], cum = 0; unsigned d = 255;
@@ -103,18 +114,19 @@ __device__ __forceinline__ void select10(F val, unsigned n, double *out10, unsig
                 cum += h;
             }
             rank_in[tid] = want - cum;
-            prefix[tid] |= ((unsigned long long)d) << (8 * pass);
+            prefix[tid] |= d << (8 * pass);
         }
         __syncthreads();
     }
-    if (tid < 10) out10[tid] = dkey_inv(prefix[tid]);
+    if (tid < 10) out10[tid] = prefix[tid];
     __syncthreads();
 }
 
 __global__ __launch_bounds__(256, 4) void k_quantile(BatchDev B) {     // 4 waves per SIMD: a 1000-read batch must be resident at once
     __shared__ unsigned hist[10][256];
-    __shared__ unsigned long long prefix[10];
+    __shared__ unsigned prefix[10];
     __shared__ unsigned rank_in[10];
+    __shared__ unsigned skey[10], mkey[10];
     __shared__ double sq[10], mq[10];
     const int r = blockIdx.x;
     ReadRes &R = B.res[r];
@@ -125,9 +137,11 @@ __global__ __launch_bounds__(256, 4) void k_quantile(BatchDev B) {     // 4 wave
     }
     const double *em = B.ev_mean + B.ev_off[r];
     const unsigned *rr = B.rank_r + B.ref_off[r];
-    const double *model = B.model_mean;
-    select10([=](unsigned i) { return em[i]; }, ne, sq, hist, prefix, rank_in);           // signal quantiles :532
-    select10([=](unsigned i) { return model[rr[i]]; }, nr, mq, hist, prefix, rank_in);    // model quantiles  :533
+    const unsigned *mpos = B.model_pos;
+    select10<32>([=](unsigned i) { return fkey((float)em[i]); }, ne, skey, hist, prefix, rank_in);     // signal quantiles :532
+    select10<18>([=](unsigned i) { return mpos[rr[i]]; }, nr, mkey, hist, prefix, rank_in);            // model quantiles  :533
+    if (threadIdx.x < 10) { sq[threadIdx.x] = (double)fkey_inv(skey[threadIdx.x]); mq[threadIdx.x] = B.model_sorted[mkey[threadIdx.x]]; }
+    __syncthreads();
     if (threadIdx.x == 0) {
         // linear_regression(x = model quantiles, y = signal quantiles) :478-507, :535
         double sx = 0., sx2 = 0., sy = 0., sxy = 0.;
