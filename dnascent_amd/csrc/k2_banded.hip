@@ -547,12 +547,76 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
     int evrow = SLOT ? 0 : row_ev(cur);
 
     unsigned step = 0;
-    unsigned rec_e = 0, rec_k = 0;                     // rec_e carries the from-code in its top two bits until the flush
     int bad = 0;
-    // one walk step with a known from-code; returns false when the walk is over (matrix edge reached or path invalid)
+    if (SLOT) {
+        // ---- slot rows: the walk records ONLY the from-codes, 2 bits per step, 32 steps per 64-bit word (written by lane 0
+        //      into the still-unused cleaned-signal workspace); k2_expand turns the code stream into (event, kmer) pairs with a
+        //      parallel scan.  Four-step lookahead: lane L < 40 stands for a prefix of up to three moves (1 + 3 + 9 + 27 nodes
+        //      of the ternary tree of continuations); ONE LDS read fetches the from-codes of all 40 candidate cells and four
+        //      dependent v_readlane walk the tree.  Away from the matrix edge a group of four steps needs no per-step test:
+        //      the position update is two popcounts of the packed codes (diag: e-1 k-1 b-2, up: e-1 b-1, left: k-1 b-1). ----
+        unsigned long long *words = reinterpret_cast<unsigned long long *>(B.cl_sig + a0);
+        unsigned long long acc = 0ull; unsigned nacc = 0, nword = 0;
+        int la_db = 0, la_de = 0;                          // band / event offset of this lane's node from the current cell
+        {
+            const int base[4] = {0, 1, 4, 13};
+            const int lvl = lane >= 13 ? 3 : (lane >= 4 ? 2 : (lane >= 1 ? 1 : 0));
+            int code = lane - base[lvl];
+            for (int j = 0; j < lvl; j++) {
+                const int m = code % 3; code /= 3;
+                la_db += 2 - ((m + 1) >> 1); la_de += ((m >> 1) ^ 1);
+            }
+            if (lane >= 40) { la_db = 0; la_de = 0; }
+        }
+        auto push = [&](unsigned codes, unsigned cnt) {     // cnt codes of 2 bits, oldest in the low bits; cnt <= 4
+            acc |= (unsigned long long)codes << (2u * nacc);
+            const unsigned room = 32u - nacc;
+            if (cnt >= room) {
+                if (lane == 0) words[nword] = acc;
+                nword++;
+                acc = (cnt > room) ? ((unsigned long long)codes >> (2u * room)) : 0ull;
+                nacc = cnt - room;
+            } else nacc += cnt;
+        };
+        while ((k | e) >= 0) {
+            if (b < lo) {
+                cur ^= 1;
+                store_tile(cur, regs);
+                lo = nlo;
+                nlo = lo - CH_ROWS; if (nlo < 0) nlo = 0;
+                if (lo > 0) load_tile(nlo, regs);
+                __syncthreads();
+            }
+            const int bi = b - lo;
+            if (bi >= 6 && e >= 4 && k >= 4 && step + 4u <= cap) {
+                const unsigned v = tile[cur][(bi - la_db) * DN_TROW + ((e - la_de) & 127)];
+                const unsigned f0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+                const unsigned f1 = (unsigned)__builtin_amdgcn_readlane((int)v, 1 + (int)(f0 & 3u));
+                const unsigned f2 = (unsigned)__builtin_amdgcn_readlane((int)v, 4 + 3 * (int)(f0 & 3u) + (int)(f1 & 3u));
+                const unsigned f3 = (unsigned)__builtin_amdgcn_readlane((int)v, 13 + 9 * (int)(f0 & 3u) + 3 * (int)(f1 & 3u) + (int)(f2 & 3u));
+                if (((f0 | f1 | f2 | f3) & 0xFCu) == 0u && f0 != 3u && f1 != 3u && f2 != 3u && f3 != 3u) {
+                    const unsigned p = f0 | (f1 << 2) | (f2 << 4) | (f3 << 6);
+                    push(p, 4u);
+                    const int de = 4 - __builtin_popcount(p & 0xAAu), dk = 4 - __builtin_popcount(p & 0x55u);
+                    e -= de; k -= dk; b -= de + dk;
+                    step += 4u;
+                    continue;
+                }
+            }
+            // single step (matrix edge, tile seam, or an invalid code ahead)
+            const unsigned from = (unsigned)__builtin_amdgcn_readfirstlane((int)tile[cur][bi * DN_TROW + (e & 127)]);
+            if (from > 2u || step >= cap) { bad = 1; break; }                  // reference: out-of-bounds read (UB)
+            push(from, 1u);
+            step++;
+            e -= (int)((from >> 1) ^ 1u);
+            k -= (int)((from & 1u) ^ 1u);
+            b -= 2 - (int)((from + 1u) >> 1);
+        }
+        if (nacc && lane == 0) words[nword] = acc;
+    } else {
+    unsigned rec_e = 0, rec_k = 0;                     // rec_e carries the from-code in its top two bits until the flush
     auto take = [&](unsigned from) -> bool {
         if (from == 0xFFu || step >= cap) { bad = 1; return false; }        // reference: out-of-bounds read (UB)
-        // stash the step in lane (step & 63); flush 64 steps at a time, back to front
         const bool mine = lane == (int)(step & 63u);
         rec_e = mine ? ((unsigned)e | (from << 30)) : rec_e;
         rec_k = mine ? (unsigned)k : rec_k;
@@ -561,58 +625,26 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
             const unsigned idx = cap - (step - 64u) - 1u - (unsigned)lane;     // step-64+lane -> slot cap-1-(step-64+lane)
             ae[idx] = rec_e & 0x3fffffffu; ak[idx] = rec_k; pf[idx] = (uint8_t)(rec_e >> 30);
         }
-        // from 0 (diag): e-1, k-1, b-2; 1 (up): e-1, b-1; 2 (left): k-1, b-1 -- as arithmetic on the scalar unit, no branch
         e -= (int)((from >> 1) ^ 1u);
         k -= (int)((from & 1u) ^ 1u);
         b -= 2 - (int)((from + 1u) >> 1);
         return (k | e) >= 0;
     };
-    // four-step lookahead (slot rows): lane L < 40 stands for a prefix of up to three moves (1 + 3 + 9 + 27 nodes of the ternary
-    // tree of continuations); ONE LDS read fetches the from-codes of all 40 candidate cells, four dependent v_readlane then walk
-    // the tree -- four steps per LDS round trip instead of one.
-    int la_db = 0, la_de = 0;                          // band / event offset of this lane's node from the current cell
-    {
-        const int base[4] = {0, 1, 4, 13};
-        int lvl = lane >= 13 ? 3 : (lane >= 4 ? 2 : (lane >= 1 ? 1 : 0));
-        int code = lane - base[lvl];
-        for (int j = 0; j < lvl; j++) {                // digits, last move first
-            const int m = code % 3; code /= 3;
-            la_db += 2 - ((m + 1) >> 1); la_de += ((m >> 1) ^ 1);
-        }
-        if (lane >= 40) { la_db = 0; la_de = 0; }
-    }
     while ((k | e) >= 0) {
         if (b < lo) {
-            // switch to the prefetched tile
             cur ^= 1;
             store_tile(cur, regs);
             lo = nlo;
             nlo = lo - CH_ROWS; if (nlo < 0) nlo = 0;
             if (lo > 0) load_tile(nlo, regs);
             __syncthreads();
-            if (!SLOT) evrow = row_ev(cur);
+            evrow = row_ev(cur);
         }
         const int bi = b - lo;
-        if (SLOT) {                                        // k2_fill6 rows: byte = slot of the event, 0xFF outside the band
-            if (bi >= 6) {
-                const unsigned v = tile[cur][(bi - la_db) * DN_TROW + ((e - la_de) & 127)];
-                const unsigned f0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
-                if (!take(f0)) break;
-                const unsigned f1 = (unsigned)__builtin_amdgcn_readlane((int)v, 1 + (int)f0);
-                if (!take(f1)) break;
-                const unsigned f2 = (unsigned)__builtin_amdgcn_readlane((int)v, 4 + 3 * (int)f0 + (int)f1);
-                if (!take(f2)) break;
-                const unsigned f3 = (unsigned)__builtin_amdgcn_readlane((int)v, 13 + 9 * (int)f0 + 3 * (int)f1 + (int)f2);
-                if (!take(f3)) break;
-            } else {
-                if (!take((unsigned)__builtin_amdgcn_readfirstlane((int)tile[cur][bi * DN_TROW + (e & 127)]))) break;
-            }
-        } else {
-            const int ev_b = __builtin_amdgcn_readlane(evrow, bi);
-            const int off = ev_b - e;
-            if (off < 0 || off >= DN_W) { bad = 1; break; }                   // reference: out-of-bounds read (UB)
-            if (!take(tile[cur][bi * DN_TROW + off])) break;
-        }
+        const int ev_b = __builtin_amdgcn_readlane(evrow, bi);
+        const int off = ev_b - e;
+        if (off < 0 || off >= DN_W) { bad = 1; break; }                   // reference: out-of-bounds read (UB)
+        if (!take(tile[cur][bi * DN_TROW + off])) break;
     }
     const unsigned rem = step & 63u;
     if (!bad && rem && (unsigned)lane < rem) {
@@ -620,9 +652,60 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
         const unsigned idx = cap - (base + (unsigned)lane) - 1u;
         ae[idx] = rec_e & 0x3fffffffu; ak[idx] = rec_k; pf[idx] = (uint8_t)(rec_e >> 30);
     }
+    }
     if (lane == 0) {
         if (bad) { R.status = 3; R.n_aligned = 0; R.aln_begin = cap; }
         else { R.n_aligned = step; R.aln_begin = cap - step; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k2_expand: the from-code stream of k2_chase<true> (2 bits per walk step, step 0 = the end cell) -> alignment pairs.
+// The event / kmer of step i is the end cell minus the number of earlier steps that moved in that dimension: an exclusive
+// prefix sum over the codes (per 32-step word: two popcounts), done per read by one block.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k2_expand(BatchDev B, uint8_t *path_from) {
+    __shared__ unsigned s_e[256], s_k[256];
+    __shared__ unsigned base_e, base_k;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const ReadRes &R = B.res[r];
+    if (R.status != 0) return;
+    const unsigned n = R.n_aligned;
+    const uint64_t a0 = B.aln_off[r];
+    const unsigned cap = (unsigned)(B.aln_off[r + 1] - a0);
+    const unsigned long long *words = reinterpret_cast<const unsigned long long *>(B.cl_sig + a0);
+    unsigned *ae = B.aln_event + a0, *ak = B.aln_kmer + a0;
+    uint8_t *pf = path_from + a0;
+    const unsigned nw = (n + 31u) / 32u;
+    if (tid == 0) { base_e = 0; base_k = 0; }
+    __syncthreads();
+    const unsigned e_end = (unsigned)R.end_event, k_end = R.n_kq - 1u;
+    for (unsigned w0 = 0; w0 < nw; w0 += 256) {
+        const unsigned w = w0 + tid;
+        unsigned long long word = 0ull; unsigned cnt = 0;
+        if (w < nw) { word = words[w]; cnt = min(32u, n - w * 32u); }
+        const unsigned long long live = cnt >= 32u ? ~0ull : ((1ull << (2u * cnt)) - 1ull);
+        // steps that decrement e have code 0 or 1 (high bit clear), steps that decrement k have code 0 or 2 (low bit clear)
+        const unsigned de = cnt - (unsigned)__popcll(word & live & 0xAAAAAAAAAAAAAAAAull);
+        const unsigned dk = cnt - (unsigned)__popcll(word & live & 0x5555555555555555ull);
+        s_e[tid] = de; s_k[tid] = dk;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const unsigned te = tid >= d ? s_e[tid - d] : 0u, tk = tid >= d ? s_k[tid - d] : 0u;
+            __syncthreads();
+            s_e[tid] += te; s_k[tid] += tk;
+            __syncthreads();
+        }
+        unsigned e = e_end - (base_e + s_e[tid] - de), k = k_end - (base_k + s_k[tid] - dk);
+        for (unsigned j = 0; j < cnt; j++) {
+            const unsigned from = (unsigned)(word >> (2u * j)) & 3u;
+            const unsigned idx = cap - 1u - (w * 32u + j);              // walk step -> slot: the arrays end up in forward order
+            ae[idx] = e; ak[idx] = k; pf[idx] = (uint8_t)from;
+            e -= (from >> 1) ^ 1u; k -= (from & 1u) ^ 1u;
+        }
+        __syncthreads();
+        if (tid == 255) { base_e += s_e[255]; base_k += s_k[255]; }
+        __syncthreads();
     }
 }
 
@@ -760,8 +843,10 @@ void k2_launch_fill(const BatchDev &B, const void *bc, const void *fc, bool dpp,
     hipLaunchKernelGGL(k2_fill5<0>, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f);
 }
 void k2_launch_chase(const BatchDev &B, uint8_t *path_from, hipStream_t st) {
-    if (k2_fill_variant() == 6) hipLaunchKernelGGL(k2_chase<true>, dim3(B.n_reads), dim3(64), 0, st, B, path_from);
-    else hipLaunchKernelGGL(k2_chase<false>, dim3(B.n_reads), dim3(64), 0, st, B, path_from);
+    if (k2_fill_variant() == 6) {
+        hipLaunchKernelGGL(k2_chase<true>, dim3(B.n_reads), dim3(64), 0, st, B, path_from);
+        hipLaunchKernelGGL(k2_expand, dim3(B.n_reads), dim3(256), 0, st, B, path_from);
+    } else hipLaunchKernelGGL(k2_chase<false>, dim3(B.n_reads), dim3(64), 0, st, B, path_from);
 }
 void k2_launch_post(const BatchDev &B, const uint8_t *path_from, float *path_lp, const void *fc, hipStream_t st) {
     const FillConsts f = *reinterpret_cast<const FillConsts *>(fc);
