@@ -724,8 +724,7 @@ __device__ __forceinline__ float lp_match_dev(double x, double mu, const FillCon
 }
 
 __global__ __launch_bounds__(256) void k2_post(BatchDev B, const uint8_t *path_from, float *path_lp, FillConsts fc) {
-    __shared__ int redi[256];
-    __shared__ unsigned s_base;
+    __shared__ int redi[4];
     const int r = blockIdx.x;
     const int tid = threadIdx.x;
     ReadRes &R = B.res[r];
@@ -776,24 +775,22 @@ __global__ __launch_bounds__(256) void k2_post(BatchDev B, const uint8_t *path_f
                 }
             }
         }
-        // block exclusive scan of flags
-        redi[tid] = flag;
+        // ordered compaction: ballot + popcount inside a wavefront, one LDS hop for the four wavefront totals
+        const unsigned long long bm = __ballot(flag != 0);
+        const unsigned within = (unsigned)__popcll(bm & ((1ull << (tid & 63)) - 1ull));
+        if ((tid & 63) == 0) redi[tid >> 6] = (int)__popcll(bm);
         __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {
-            int t = (tid >= d) ? redi[tid - d] : 0;
-            __syncthreads();
-            redi[tid] += t;
-            __syncthreads();
-        }
-        const unsigned pos = out_base + (unsigned)redi[tid] - (unsigned)flag;
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const unsigned c = (unsigned)redi[q]; before += (q < (tid >> 6)) ? c : 0u; total += c; }
+        const unsigned pos = out_base + before + within;
         if (flag) { cl_sig[pos] = sig; cl_rank[pos] = rk; }
-        if (tid == 255) s_base = out_base + (unsigned)redi[255];
-        __syncthreads();
-        out_base = s_base;
+        out_base += total;
         __syncthreads();
     }
 
-    // 3. ordered fp64 sum of the emissions and the gap statistic: one wavefront, walk order, staged through LDS
+    // 3. ordered fp64 sum of the emissions (:364, walk order: one dependent add per step, nothing else in the chain) and the
+    //    longest run of FROM_L steps (:399-410) from 64-step ballots with scalar bit arithmetic
     if (tid < 64) {
         double sum_em = 0.; int gap = 0, max_gap = 0;
         for (unsigned wb = 0; wb < n; wb += 64) {
@@ -801,12 +798,23 @@ __global__ __launch_bounds__(256) void k2_post(BatchDev B, const uint8_t *path_f
             float v = 0.f; unsigned f = 1;
             if (w < n) { v = lp[n - 1 - w]; f = pf[n - 1 - w]; }
             const unsigned lim = min(64u, n - wb);
-            for (unsigned i = 0; i < lim; i++) {
-                const float vi = bcast_f(v, (int)i);
-                const unsigned fi = (unsigned)__builtin_amdgcn_readlane((int)f, (int)i);
-                sum_em += (double)vi;                                         // :364
-                if (fi == 2) { gap += 1; max_gap = max(max_gap, gap); } else gap = 0;   // :399-410
+            unsigned long long m2 = __ballot(f == 2u);                        // bit i: walk step wb + i came from the left
+            if (lim == 64u) {
+#pragma unroll 16
+                for (unsigned i = 0; i < 64u; i++) sum_em += (double)bcast_f(v, (int)i);
+            } else {
+                for (unsigned i = 0; i < lim; i++) sum_em += (double)bcast_f(v, (int)i);
             }
+            if (m2 == 0ull) { gap = 0; continue; }
+            const unsigned long long valid = lim == 64u ? ~0ull : ((1ull << lim) - 1ull);
+            const unsigned long long inv = (~m2) & valid;                     // the steps of the chunk that are NOT from the left
+            const unsigned lead = inv ? (unsigned)__builtin_ctzll(inv) : lim; // run that continues the previous chunk's
+            max_gap = max(max_gap, gap + (int)lead);
+            unsigned long long x = m2; int longest = 0;
+            while (x) { x &= x << 1; longest++; }                             // longest run inside the chunk
+            max_gap = max(max_gap, longest);
+            // run that reaches the end of the chunk (carried into the next one)
+            gap = inv ? (int)(lim - 1u - (63u - (unsigned)__builtin_clzll(inv))) : gap + (int)lim;
         }
         if (tid == 0) {
             R.avg_log_emission = sum_em / (double)n;                          // :420 (n_aligned_events is a double count)
