@@ -62,28 +62,30 @@ __global__ __launch_bounds__(64) void k1_scan(BatchDev B) {
             for (int j = 0; j < 4; j++) { const unsigned i = nb + (unsigned)lane * 4u + j; nxt[j] = i < n ? a[i] : (int16_t)0; }
         }
         LDS_FENCE();
-        // ---- serial, order-exact (event_detection.c:45-46), in lane 0 only: every LDS access then moves 16 bytes, not
-        //      64 x 16; reads are issued 16 at a time ----
-        if (lane == 0) {
+        // ---- serial, order-exact (event_detection.c:45-46).  A single-lane ds_write_b128 costs ~50 cycles, so the chain is
+        //      run REDUNDANTLY by 16 lanes (broadcast LDS reads; same instruction count as one lane): lane j keeps the
+        //      running sums after sample g + j, and one 16-lane store puts 16 results back. ----
+        if (lane < 16) {
             const unsigned full = cnt & ~15u;
             for (unsigned g = 0; g < full; g += 16) {
                 double2 v[16];
 #pragma unroll
                 for (int j = 0; j < 16; j++) v[j] = buf[g + j];
+                double ks = 0.0, kq = 0.0;
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
                     s = s + v[j].x;
                     q = q + v[j].y;
-                    v[j] = make_double2(s, q);
+                    ks = (lane == j) ? s : ks;
+                    kq = (lane == j) ? q : kq;
                 }
-#pragma unroll
-                for (int j = 0; j < 16; j++) buf[g + j] = v[j];
+                buf[g + lane] = make_double2(ks, kq);
             }
             for (unsigned i = full; i < cnt; i++) {
                 const double2 v = buf[i];
                 s = s + v.x;
                 q = q + v.y;
-                buf[i] = make_double2(s, q);
+                if (lane == 0) buf[i] = make_double2(s, q);
             }
         }
         LDS_FENCE();
