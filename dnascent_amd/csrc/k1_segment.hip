@@ -31,6 +31,26 @@
 // ------------------------------------------------------------------------------------------------
 #define SCAN_CHUNK 256
 
+// eight order-exact steps s += x, q += y of k1_scan with EXEC = lanes j..15 for step j (lanes 0..15 are active on entry)
+#define SCAN_ADD8(v, o, m0, m1, m2, m3, m4, m5, m6, m7)                                                                          \
+    {                                                                                                                             \
+        unsigned long long sv_;                                                                                                   \
+        asm volatile("s_mov_b64 %2, exec\n\t"                                                                                     \
+                     "s_mov_b64 exec, " m0 "\n\tv_add_f64 %0, %0, %3\n\tv_add_f64 %1, %1, %4\n\t"                                \
+                     "s_mov_b64 exec, " m1 "\n\tv_add_f64 %0, %0, %5\n\tv_add_f64 %1, %1, %6\n\t"                                \
+                     "s_mov_b64 exec, " m2 "\n\tv_add_f64 %0, %0, %7\n\tv_add_f64 %1, %1, %8\n\t"                                \
+                     "s_mov_b64 exec, " m3 "\n\tv_add_f64 %0, %0, %9\n\tv_add_f64 %1, %1, %10\n\t"                               \
+                     "s_mov_b64 exec, " m4 "\n\tv_add_f64 %0, %0, %11\n\tv_add_f64 %1, %1, %12\n\t"                              \
+                     "s_mov_b64 exec, " m5 "\n\tv_add_f64 %0, %0, %13\n\tv_add_f64 %1, %1, %14\n\t"                              \
+                     "s_mov_b64 exec, " m6 "\n\tv_add_f64 %0, %0, %15\n\tv_add_f64 %1, %1, %16\n\t"                              \
+                     "s_mov_b64 exec, " m7 "\n\tv_add_f64 %0, %0, %17\n\tv_add_f64 %1, %1, %18\n\t"                              \
+                     "s_mov_b64 exec, %2"                                                                                         \
+                     : "+v"(s), "+v"(q), "=&s"(sv_)                                                                               \
+                     : "v"(v[o + 0].x), "v"(v[o + 0].y), "v"(v[o + 1].x), "v"(v[o + 1].y), "v"(v[o + 2].x), "v"(v[o + 2].y),        \
+                       "v"(v[o + 3].x), "v"(v[o + 3].y), "v"(v[o + 4].x), "v"(v[o + 4].y), "v"(v[o + 5].x), "v"(v[o + 5].y),        \
+                       "v"(v[o + 6].x), "v"(v[o + 6].y), "v"(v[o + 7].x), "v"(v[o + 7].y));                                        \
+    }
+
 #define LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")   /* one wavefront per block: LDS ops are in order */
 
 __global__ __launch_bounds__(64) void k1_scan(BatchDev B) {
@@ -63,23 +83,21 @@ __global__ __launch_bounds__(64) void k1_scan(BatchDev B) {
         }
         LDS_FENCE();
         // ---- serial, order-exact (event_detection.c:45-46).  A single-lane ds_write_b128 costs ~50 cycles, so the chain is
-        //      run REDUNDANTLY by 16 lanes (broadcast LDS reads; same instruction count as one lane): lane j keeps the
-        //      running sums after sample g + j, and one 16-lane store puts 16 results back. ----
+        //      run by 16 lanes at once (broadcast LDS reads; same instruction count as one lane): lane j stops adding after
+        //      sample g + j (the adds of sample i execute only on lanes >= i), so it ends the group holding the running
+        //      sums after ITS sample; one 16-lane store puts the 16 results back and lane 15's sums carry on. ----
         if (lane < 16) {
             const unsigned full = cnt & ~15u;
             for (unsigned g = 0; g < full; g += 16) {
                 double2 v[16];
 #pragma unroll
                 for (int j = 0; j < 16; j++) v[j] = buf[g + j];
-                double ks = 0.0, kq = 0.0;
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    s = s + v[j].x;
-                    q = q + v[j].y;
-                    ks = (lane == j) ? s : ks;
-                    kq = (lane == j) ? q : kq;
-                }
-                buf[g + lane] = make_double2(ks, kq);
+                // the adds of sample j run on lanes j..15 only: EXEC is narrowed by hand (the compiler would turn an `if` into
+                // four v_cndmask per sample inside the dependency chain); both blocks restore it before they end
+                SCAN_ADD8(v, 0, "0xffff", "0xfffe", "0xfffc", "0xfff8", "0xfff0", "0xffe0", "0xffc0", "0xff80")
+                SCAN_ADD8(v, 8, "0xff00", "0xfe00", "0xfc00", "0xf800", "0xf000", "0xe000", "0xc000", "0x8000")
+                buf[g + lane] = make_double2(s, q);
+                s = bcast_d(s, 15); q = bcast_d(q, 15);
             }
             for (unsigned i = full; i < cnt; i++) {
                 const double2 v = buf[i];
