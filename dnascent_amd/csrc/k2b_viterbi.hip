@@ -225,6 +225,9 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             int i = N - 1, col = T;
             bool done = false;
             int guard = 3 * N * (T + 1) + 8;
+            // labels are parked in registers (lane = observation & 63) and leave through ONE 64-lane LDS store per 64
+            // observations: a single-lane LDS store per step costs ~50 cycles in this wave-uniform walk
+            unsigned lab = 0u; int last_ob = -1;
             while (!done && guard-- > 0) {
                 const unsigned code = (col > 0) ? bt[col * VT_NS + i] : 0u;
                 if (st == 0) {
@@ -233,7 +236,12 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
                 } else if (col <= 0) {
                     done = true;                             // only reachable in an all-log(0) lattice
                 } else {
-                    if (lane == 0) evlab[col - 1] = (unsigned short)((st << 8) | i);
+                    {
+                        const int ob = col - 1;
+                        lab = (lane == (ob & 63)) ? (unsigned)((st << 8) | i) : lab;
+                        if ((ob & 63) == 0) evlab[ob + lane] = (unsigned short)lab;       // observations ob .. ob + 63 are complete
+                        last_ob = ob;
+                    }
                     if (st == 1) {
                         unsigned cmx = (code >> 2) & 7u;
                         if (i == 0) cmx = (cmx == 3u) ? 4u : 2u;                 // position 0: {M_0, START}
@@ -247,6 +255,8 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
                 }
                 if (col < 0 || i < 0) done = true;          // cannot happen for a finite score; guards all-log(0) lattices
             }
+            // a walk that stopped inside a group of 64 (only in an all-log(0) lattice) still leaves what it labelled
+            if (last_ob > 0 && (last_ob & 63) != 0 && lane >= (last_ob & 63)) evlab[(last_ob & ~63) + lane] = (unsigned short)lab;
         }
         __syncthreads();
         // ---- window log ----
