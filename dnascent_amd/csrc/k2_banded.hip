@@ -371,16 +371,13 @@ __device__ __forceinline__ void f6_band(F6State &st, const int b, const int E, c
                                         const double lp_stay, unsigned short *rows16, float &best, int &best_e, int &found) {
     const int NINF_BITS = (int)0xff800000;
     const float NINF = neg_inf();
-    // ---- Suzuki-Kasahara move (:237-253) from the end cells of the previous band: events ev (lower left) and ev - 99 ----
+    // Program order is chosen for a lone wavefront (in-order issue): the end scores of the previous band are read first,
+    // the cell arithmetic -- which needs neither the move nor the masks -- follows, and only then comes the scalar chain of
+    // the Suzuki move, so that its VALU -> SALU hazard and dependent scalar instructions hide behind the cell work.
     const int ev0 = st.ev, el0 = ev0 - (DN_W - 1);
     const int l_lo = (ev0 & 127) >> 1, l_hi = (el0 & 127) >> 1;
     const int loA = __builtin_amdgcn_readlane(__float_as_int(st.PA), l_lo), loB = __builtin_amdgcn_readlane(__float_as_int(st.PB), l_lo);
     const int hiA = __builtin_amdgcn_readlane(__float_as_int(st.PA), l_hi), hiB = __builtin_amdgcn_readlane(__float_as_int(st.PB), l_hi);
-    const int lo = (ev0 & 1) ? loB : loA, hi = (el0 & 1) ? hiB : hiA;
-    // integer 0/1 arithmetic (scalar unit, no branch): both end cells out of band -> alternate by parity, else ll < ur
-    const int ol = ordered_f32_bits(lo), oh = ordered_f32_bits(hi);
-    const int lt = (ol < oh) ? 1 : 0;
-    const int right = (max(ol, oh) == ordered_f32_bits(NINF_BITS)) ? (b & 1) : lt;
     // ---- entering values, written pair-wise (both registers of a lane under one M0), independent of the move and
     //      idempotent: the event pair that holds event ev0 + 1; after the rotation, the kmer levels of the pair that
     //      holds event ev0 - 99.  Whatever is not needed yet lies outside the band or already has exactly that value. ----
@@ -391,17 +388,23 @@ __device__ __forceinline__ void f6_band(F6State &st, const int b, const int E, c
         st.MA = nMA;
     }
     writelane_pair_d(st.MA, st.MB, in.m1, in.m0, l_hi);
+    // ---- operands: left = same slot, up = previous slot, diag = the previous band's up ----
+    const float upA = ror_f(st.PB), upB = st.PA;
+    float SA, SB; unsigned FA, FB;
+    cell(st.DA, upA, st.PA, st.XA, st.MA, fc, lp_step, lp_stay, SA, FA);
+    cell(st.DB, upB, st.PB, st.XB, st.MB, fc, lp_step, lp_stay, SB, FB);
+    // ---- Suzuki-Kasahara move (:237-253) from the end cells of the previous band: events ev (lower left) and ev - 99 ----
+    const int lo = (ev0 & 1) ? loB : loA, hi = (el0 & 1) ? hiB : hiA;
+    // integer 0/1 arithmetic (scalar unit, no branch): both end cells out of band -> alternate by parity, else ll < ur
+    const int ol = ordered_f32_bits(lo), oh = ordered_f32_bits(hi);
+    const int lt = (ol < oh) ? 1 : 0;
+    const int right = (max(ol, oh) == ordered_f32_bits(NINF_BITS)) ? (b & 1) : lt;
     const int km = st.km + right, ev = ev0 + (right ^ 1);
     st.km = km; st.ev = ev;
     f6_prefetch<FAST>(in, b + 1, ev, E, K, xs_c, mu_c);
     // ---- in-band slots: ((ev - event) & 127) < 100 ----
     const unsigned tA = (unsigned)(ev - lane2) & 127u;
     const bool actA = tA < (unsigned)DN_W, actB = (tA - 1u) < (unsigned)DN_W;
-    // ---- operands: left = same slot, up = previous slot, diag = the previous band's up ----
-    const float upA = ror_f(st.PB), upB = st.PA;
-    float SA, SB; unsigned FA, FB;
-    cell(st.DA, upA, st.PA, st.XA, st.MA, fc, lp_step, lp_stay, SA, FA);
-    cell(st.DB, upB, st.PB, st.XB, st.MB, fc, lp_step, lp_stay, SB, FB);
     if (FAST) {
         SA = actA ? SA : NINF; SB = actB ? SB : NINF;
     } else {
