@@ -20,6 +20,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Every in-flight batch has its own HIP stream; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and
+# streams that share a queue serialise.  Must be set before the HIP runtime initialises (torch or libdnascent_hip).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 
@@ -90,7 +93,7 @@ def main():
     ap.add_argument("--scope", choices=["banded", "full"], default="banded",
                     help="banded = BASELINE configs[1] (the default, CNN stubbed); full = configs[2]'s pipeline at this batch size: "
                          "normalise + eventalign + CNN, probabilities left in HBM")
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=8,
                     help="batches in flight per GPU (each on its own context/stream/workspace); every stage is latency-bound "
                          "at <= 1 wavefront per SIMD for a 1000-read batch, so consecutive steps are overlapped")
     args = ap.parse_args()
@@ -104,12 +107,17 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # DN_BENCH_BACKEND=gloo (+ ranks sharing a device) exists only to exercise the N > 1 code path on a 1-GPU box
+        backend = os.environ.get("DN_BENCH_BACKEND", "nccl")
+        ndev = max(1, torch.cuda.device_count())
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank % ndev)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     from dnascent_amd import hip, synth
     model = synth.pore_model()
-    dev = local_rank if world > 1 else 0
+    dev = (local_rank % max(1, hip.lib().dn_device_count())) if world > 1 else 0
+    red_dev = "cuda" if (dist is not None and os.environ.get("DN_BENCH_BACKEND", "nccl") == "nccl") else "cpu"
     nctx = max(1, min(args.inflight, args.steps))
     ctxs = [hip.Context(dev) for _ in range(nctx)]
     batch, reads = make_batch(args.reads, args.bases, 1000003 * (rank + 1), model)
@@ -146,16 +154,23 @@ def main():
             return
         import threading
 
+        errors = []
+
         def worker(j):
-            for _ in range(j, k, nctx):
-                for st in stages:
-                    ctxs[j].run(st)
-            ctxs[j].sync()
+            try:
+                for _ in range(j, k, nctx):
+                    for st in stages:
+                        ctxs[j].run(st)
+                ctxs[j].sync()
+            except BaseException as e:          # a failed step must fail the run, not shorten it
+                errors.append(e)
         th = [threading.Thread(target=worker, args=(j,)) for j in range(nctx)]
         for t in th:
             t.start()
         for t in th:
             t.join()
+        if errors:
+            raise errors[0]
 
     run_steps(max(args.warmup, nctx if args.warmup else 0))
     barrier()
@@ -191,8 +206,8 @@ def main():
     from dnascent_amd import shard
     total_samples = float(samples_per_step)
     if dist is not None:
-        dt = shard.reduce_max(dist, dt, device="cuda")
-        total_samples = shard.reduce_counters(dist, [total_samples], device="cuda")[0]
+        dt = shard.reduce_max(dist, dt, device=red_dev)
+        total_samples = shard.reduce_counters(dist, [total_samples], device=red_dev)[0]
 
     if rank == 0:
         fill_ms, fill_n = prof["k2_fill"]

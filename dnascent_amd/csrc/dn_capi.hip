@@ -94,6 +94,11 @@ struct dn_ctx {
     uint32_t prof_n[DN_K_COUNT] = {0};
 };
 
+// Contexts are meant to be used several at a time (one per in-flight batch); their streams only run concurrently when the
+// runtime has that many hardware queues (ROCm default: 4).  Effective when this library is loaded before the HIP runtime
+// initialises; a host that initialises HIP first sets GPU_MAX_HW_QUEUES itself.
+__attribute__((constructor)) static void dn_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 static int fail(dn_ctx *c, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
