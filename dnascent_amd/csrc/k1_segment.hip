@@ -124,22 +124,41 @@ __device__ __forceinline__ double2 prefix_at(const double2 *P, unsigned j) {   /
     return j == 0 ? make_double2(0.0, 0.0) : P[j - 1];
 }
 
-__device__ __forceinline__ float tstat_at(const double2 *P, unsigned n, unsigned i, unsigned w) {
+// Division by the window length (3 or 6) as multiply + FMA correction: q = a r; q' = fma(fma(-q, d, a), r, q) with r = RN(1 / d)
+// is the correctly rounded a / d (Markstein).  Checked against IEEE division for d = 3 and 6: fp32 EXHAUSTIVELY (every finite
+// input; the only mismatches have |a / d| < 4 FLT_MIN, hence the guard), fp64 on 6.4e9 random + mantissa-edge cases with
+// exponents within 2^+-200 (guarded likewise).  The guards fall back to the hardware division sequence.
+__device__ __forceinline__ float div_w(float a, float d, float r) {
+    if (!(fabsf(a) >= 1e-30f)) return a / d;              // tiny, zero, NaN: literal division
+    const float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, d, a), r, q);
+}
+__device__ __forceinline__ double div_w(double a, double d, double r) {
+    if (!(fabs(a) >= 1e-60 && fabs(a) <= 1e60)) return a / d;
+    const double q = a * r;
+    return fma(fma(-q, d, a), r, q);
+}
+
+template <unsigned W>
+__device__ __forceinline__ float tstat_at(const double2 *P, unsigned n, unsigned i) {
+    constexpr unsigned w = W;
     if (n < 2 * w) return 0.0f;                                  // :76-81
     if (i < w || i > n - w) return 0.0f;                         // :83-86, loop bound :89 is inclusive
-    const float wf = (float)w;
+    constexpr float wf = (float)W;
+    constexpr float rwf = 1.0f / wf;                             // RN(1 / w), folded by the compiler exactly as IEEE division
+    constexpr double wd = (double)wf, rwd = 1.0 / wd;
     const double2 a = prefix_at(P, i - w), b = prefix_at(P, i), c = prefix_at(P, i + w);
     const double sum1 = b.x - a.x, sumsq1 = b.y - a.y;           // :90-95 (sum[0] == 0, so i == w is the same expression)
     const float sum2 = (float)(c.x - b.x);                       // :96
     const float sumsq2 = (float)(c.y - b.y);                     // :97
-    const float mean1 = (float)(sum1 / (double)wf);              // :98
-    const float mean2 = sum2 / wf;                               // :99
+    const float mean1 = (float)div_w(sum1, wd, rwd);             // :98
+    const float mean2 = div_w(sum2, wf, rwf);                    // :99
     const float m1sq = mean1 * mean1, m2sq = mean2 * mean2;
-    const float s2w = sumsq2 / wf;
-    float var = (float)(((sumsq1 / (double)wf - (double)m1sq) + (double)s2w) - (double)m2sq);   // :100-101
+    const float s2w = div_w(sumsq2, wf, rwf);
+    float var = (float)(((div_w(sumsq1, wd, rwd) - (double)m1sq) + (double)s2w) - (double)m2sq);   // :100-101
     var = fmaxf(var, FLT_MIN);                                   // :104
     const float dm = mean2 - mean1;                              // :110
-    const float vw = var / wf;
+    const float vw = div_w(var, wf, rwf);
     return (float)(fabs((double)dm) / sqrt((double)vw));         // :111
 }
 
@@ -150,8 +169,8 @@ __global__ __launch_bounds__(256) void k1_tstat(BatchDev B) {
     const unsigned i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const double2 *P = B.psum + s0;
-    B.t1[s0 + i] = tstat_at(P, n, i, 3);                          // event_detection.h:19-25
-    B.t2[s0 + i] = tstat_at(P, n, i, 6);
+    B.t1[s0 + i] = tstat_at<3>(P, n, i);                          // event_detection.h:19-25
+    B.t2[s0 + i] = tstat_at<6>(P, n, i);
 }
 
 // ------------------------------------------------------------------------------------------------
