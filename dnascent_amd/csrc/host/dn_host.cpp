@@ -364,6 +364,16 @@ int dnh_hmm_write(void *ctx, void *b, const char *path, const char *header) {
     return written;
 }
 
+// writeDetectHeader into a caller buffer; returns the length (the required size if > cap)
+uint64_t dnh_detect_header(const char *alignment, const char *genome, const char *index, int threads, unsigned quality, unsigned length,
+                           int use_gpu, const char *start_time, const char *software, const char *version, const char *commit,
+                           char *buf, uint64_t cap) {
+    const std::string s = DNAscent::writeDetectHeader(alignment, genome, index, threads, quality, length, use_gpu != 0, start_time, software,
+                                                      version, commit);
+    if (s.size() <= cap) memcpy(buf, s.data(), s.size());
+    return s.size();
+}
+
 int dnh_revcomp(const char *in, uint32_t n, char *out) {
     const std::string r = DNAscent::reverseComplement(std::string(in, n));
     memcpy(out, r.data(), r.size());

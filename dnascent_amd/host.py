@@ -40,6 +40,9 @@ def lib():
         L.dnh_detect_write.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p]
         L.dnh_hmm_write.restype = C.c_int
         L.dnh_hmm_write.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p]
+        L.dnh_detect_header.restype = C.c_uint64
+        L.dnh_detect_header.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_char_p, C.c_char_p,
+                                        C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64]
         L.dnh_revcomp.restype = C.c_int
         L.dnh_revcomp.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         _lib = L
@@ -51,6 +54,14 @@ def revcomp(seq_u8):
     out = np.zeros_like(s)
     lib().dnh_revcomp(s.ctypes.data, s.shape[0], out.ctypes.data)
     return out
+
+
+def detect_header(alignment, genome, index, threads, quality, length, use_gpu, start_time, software, version, commit):
+    """DNAscent::writeDetectHeader (detect.cpp:196-232) -> bytes."""
+    buf = C.create_string_buffer(4096)
+    n = lib().dnh_detect_header(alignment.encode(), genome.encode(), index.encode(), threads, quality, length, int(use_gpu),
+                                start_time.encode(), software.encode(), version.encode(), commit.encode(), buf, len(buf))
+    return buf.raw[:n]
 
 
 def format_detect(read_id, contig, ref_start, ref_end, is_reverse, coord, kmer_s9, probs):

@@ -70,3 +70,21 @@ def test_empty_read():
     assert got == b">r chr 5 9 fwd\n"
     n, mm, ml = host.modbam(np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, "S9"), np.zeros((0, 3), np.float32), np.zeros(1, np.uint8))
     assert n == 0 and mm == "N+b?;N+e?;" and ml.shape[0] == 0
+
+
+def test_header_matches_the_documented_example():
+    """docs/source/detect.rst:44-57 of the reference prints a complete .detect header; our writeDetectHeader, fed the values
+    of that example, reproduces it byte for byte (tests/golden/doc_detect_header.txt holds the documented lines)."""
+    import os
+    want = open(os.path.join(os.path.dirname(__file__), "golden", "doc_detect_header.txt"), "rb").read()
+    got = host.detect_header("/path/to/alignment.bam", "/path/to/reference.fasta", "/path/to/index.dnascent", 1, 20, 5000, False,
+                             "09/02/2024 12:45:29", "/path/to/DNAscent", "4.0.3", "4cf80a7b89bdf510a91b54572f8f94d3daf9b167")
+    assert got == want
+    # the documented record lines: ">readID contig start end strand", then "coord<TAB>p<TAB>p" with six decimals (:88-97);
+    # the code adds the strand 9-mer as a fourth column (detect.cpp:698-701)
+    import re
+    rec = host.format_detect("a4ea2872-9cb6-4218-afad-905f79204eb1", "14", 992440, 996846, True, np.array([992448], np.uint32),
+                             np.array([b"ACGTTCGTA"], "S9"), np.array([[0.7, 0.131483, 0.125751]], np.float32))
+    lines = rec.decode().splitlines()
+    assert lines[0] == ">a4ea2872-9cb6-4218-afad-905f79204eb1 14 992440 996846 rev"
+    assert re.fullmatch(r"992448\t0\.125751\t0\.131483\t[ACGT]{9}", lines[1])
