@@ -402,9 +402,13 @@ __device__ __forceinline__ void f6_band(F6State &st, const int b, const int E, c
     const int km = st.km + right, ev = ev0 + (right ^ 1);
     st.km = km; st.ev = ev;
     f6_prefetch<FAST>(in, b + 1, ev, E, K, xs_c, mu_c);
-    // ---- in-band slots: ((ev - event) & 127) < 100 ----
-    const unsigned tA = (unsigned)(ev - lane2) & 127u;
-    const bool actA = tA < (unsigned)DN_W, actB = (tA - 1u) < (unsigned)DN_W;
+    // ---- in-band slots: ((ev - event) & 127) < 100, a cyclic run of 50 lanes in each register.  With several batches in
+    //      flight the vector unit is the scarce one, so the two masks are built on the scalar unit (rotate a 50-bit run) ----
+    const unsigned tA = (unsigned)(ev - lane2) & 127u;     // only the edge path below needs the per-lane distance
+    const unsigned p0 = (unsigned)(ev - (DN_W - 1)) & 127u;
+    const unsigned long long FIFTY = (1ull << 50) - 1ull;
+    const bool actA = __builtin_amdgcn_inverse_ballot_w64(rotl64_(FIFTY, ((p0 + 1u) >> 1) & 63u));
+    const bool actB = __builtin_amdgcn_inverse_ballot_w64(rotl64_(FIFTY, p0 >> 1));
     if (FAST) {
         SA = actA ? SA : NINF; SB = actB ? SB : NINF;
     } else {
