@@ -1,0 +1,75 @@
+"""Randomised parity sweep: 48 seeded synthetic reads with random length, strand, noise, substitution / indel rates, soft
+clips and unknown bases, in ONE ragged batch, through normaliseEvents + eventalign + the --HMM path on the GPU, against the
+oracle.  Everything compared here is index / bit-exact work (status, counts, scalings, alignment pairs, positions, tensors,
+HMM calls); the point is breadth of input shapes, not new tolerances."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+from dnascent_amd import hip, host, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _specs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        nb = int(rng.choice([300, 800, 1300, 2200, 3100, 4700, 8000]))
+        kw = dict(is_reverse=bool(rng.integers(0, 2)), noise_pa=float(rng.choice([1.0, 1.6, 2.5, 4.0, 6.5])),
+                  sub_rate=float(rng.choice([0.0, 0.002, 0.01])), ins_rate=float(rng.choice([0.0, 0.001, 0.004])),
+                  del_rate=float(rng.choice([0.0, 0.001, 0.004])), mean_dwell=float(rng.choice([8.0, 11.5, 15.0])))
+        if rng.random() < 0.3:
+            kw.update(soft_clip_head=int(rng.integers(1, 60)), soft_clip_tail=int(rng.integers(1, 60)))
+        if rng.random() < 0.2:
+            kw.update(n_unknown=int(rng.integers(1, 5)))
+        out.append((7000 + i, nb, kw))
+    return out
+
+
+def test_random_batch_matches_oracle(model):
+    specs = _specs(48, 20251002)
+    reads = [synth.make_read(seed, nb, model=model, **kw) for seed, nb, kw in specs]
+    fit = synth.fit_models()
+    ctx = hip.Context(0)
+    ctx.load_pore_model(model, 0.14); ctx.load_fit_models(*fit)
+    b = host.ReadBatch()
+    for r in reads:
+        assert b.add_synth(r) >= 0
+    b.upload(ctx)
+    ctx.run("normalise"); ctx.run("hmm"); ctx.run("eventalign"); ctx.sync()
+    s = ctx.summaries()
+    n_ok = n_fail = 0
+    for i, r in enumerate(reads):
+        o = po.OracleRead(r, model)
+        st = o.normalise()
+        tag = (i, specs[i])
+        assert (s["status"][i] != 0) == (st != 0), tag
+        assert s["n_scrappie"][i] == o.norm.n_scrappie and s["n_events"][i] == o.norm.n_events, tag
+        assert s["n_aligned"][i] == o.norm.n_aln and s["n_cleaned"][i] == o.norm.n_cleaned, tag
+        assert s["max_gap"][i] == o.norm.max_gap and s["spanned"][i] == o.norm.spanned, tag
+        if o.norm.n_aln:
+            assert np.float64(s["avg_log_emission"][i]).tobytes() == np.float64(o.norm.avg_log_emission).tobytes(), tag
+        if st != 0:
+            n_fail += 1
+            assert s["n_positions"][i] == 0 and s["n_hmm_calls"][i] == 0
+            o.free(); continue
+        n_ok += 1
+        assert np.float64(s["shift"][i]).tobytes() == np.float64(o.norm.shift).tobytes(), tag
+        assert np.float64(s["scale"][i]).tobytes() == np.float64(o.norm.scale).tobytes(), tag
+        ae, ak = ctx.alignment(i, int(s["n_aligned"][i])); we, wk = o.alignment()
+        assert np.array_equal(ae, we) and np.array_equal(ak, wk), tag
+        h = o.hmm(fit)
+        assert int(s["n_hmm_calls"][i]) == h["llr"].shape[0], tag
+        g = ctx.hmm_calls(i, int(s["n_hmm_calls"][i]))
+        assert np.array_equal(g["pos_on_ref"], h["pos_on_ref"]) and np.array_equal(g["n_events"], h["n_events"]), tag
+        assert np.allclose(g["llr"], h["llr"], rtol=1e-9, atol=1e-9, equal_nan=True), tag
+        assert o.eventalign() == 0
+        assert int(s["n_positions"][i]) == o.align.n_pos, tag
+        got, want = ctx.positions(i, int(s["n_positions"][i])), o.positions()
+        for k in ("coord", "query_idx", "ref_idx", "indel", "n_signal", "core", "residual", "kmer"):
+            assert np.array_equal(got[k], want[k]), (tag, k)
+        assert got["signal"].tobytes() == want["signal"].tobytes(), tag
+        o.free()
+    assert n_ok >= 15 and n_fail >= 8          # the sweep covers both outcomes
+    ctx.close()
