@@ -883,7 +883,7 @@ int dn_load_fit_models(dn_ctx *c, const double *um, const double *us, const doub
             if (!(sd[k] > 0.)) return fail(c, DN_ERR_ARG, "fit model %d: std of k-mer %zu is not positive", m, k);
             const double s2 = sd[k] * sd[k], d2 = 2.0 * s2;
             const double cc = 1.0 / sqrt(d2 * M_PI);
-            t[k] = make_double4(mu[k], d2, log(cc), cc);
+            t[k] = make_double4(mu[k], d2, -1.0 / d2, cc);
         }
         if (!c->d_fit[m]) { HIPCHK(c, hipMalloc((void **)&c->d_fit[m], DN_NKMER * sizeof(double4))); c->dev_bytes += DN_NKMER * sizeof(double4); }
         HIPCHK(c, hipMemcpyAsync(c->d_fit[m], t.data(), DN_NKMER * sizeof(double4), hipMemcpyHostToDevice, c->stream));
@@ -904,16 +904,20 @@ int dn_run_hmm(dn_ctx *c) {
         (rc = dgrow(c, c->hmm_reads, n * sizeof(HmmReadH)))) return rc;
     if ((rc = fetch_res(c))) return rc;
     HmmConstsH hc;
-    hc.D2D = log(0.3); hc.D2M = log(0.7); hc.I2M = log(0.999); hc.M2D = log(0.0025); hc.M2I = log(0.001); hc.I2I = log(0.001);   // :245-250, config.h:42
-    hc.ln025 = log(0.25); hc.ln05 = log(0.5);
+    // the reference's transitions are eln() of the config.h:42 probabilities; the kernel multiplies probabilities, so it gets
+    // exp(eln(p)) -- the value the log-space arithmetic effectively uses -- computed with the host libm
+    const double lD2D = log(0.3), lD2M = log(0.7), lI2M = log(0.999), lM2D = log(0.0025), lM2I = log(0.001), lI2I = log(0.001);   // :245-250
+    hc.D2D = exp(lD2D); hc.D2M = exp(lD2M); hc.I2M = exp(lI2M); hc.M2D = exp(lM2D); hc.M2I = exp(lM2I); hc.I2I = exp(lI2I);
+    hc.ln025 = exp(log(0.25)); hc.ln05 = exp(log(0.5));
     std::vector<HmmReadH> hr(n);
     std::vector<int> newstat(n, -1);
     for (uint32_t r = 0; r < n; r++) {
         const ReadRes &R = c->h_res[r];
         int neg = 0;
-        hr[r].iM2M = h_eln(1. - (1. / R.events_per_base), &neg);                         // :253
-        hr[r].eM2M = h_eln(1.0 - hc.M2D - hc.M2I - hr[r].iM2M, &neg);                     // :254 (sic: log values)
-        hr[r].endM = h_lnSum(hr[r].eM2M, hc.M2D);                                         // :366
+        const double liM2M = h_eln(1. - (1. / R.events_per_base), &neg);                  // :253
+        const double leM2M = h_eln(1.0 - lM2D - lM2I - liM2M, &neg);                      // :254 (sic: log values inside)
+        hr[r].iM2M = exp(liM2M); hr[r].eM2M = exp(leM2M);
+        hr[r].endM = exp(h_lnSum(leM2M, lM2D));                                           // :366
         if (R.status == 0 && neg) newstat[r] = DN_READ_FAIL_NEGATIVE_LOG;                 // the reference throws NegativeLog
     }
     for (uint32_t r = 0; r < n; r++)

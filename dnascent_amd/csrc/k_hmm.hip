@@ -11,20 +11,19 @@
 //                  a 20 kb read has ~5 k POIs x 2 passes, a batch ten million chains.  One ascending sweep over the states per
 //                  observation updates I, M and D in place (the previous column's values at i - 1 are carried along).
 //
-// log(0) is NaN in the reference (probability.cpp:35-77); here it is -inf: lnProd is a plain add (x + -inf = -inf) and
-// lnSum(a, b) = max + log(1 + exp(min - max)) with min == -inf short-circuited, which is the reference's case split.
-// Arithmetic order (lnProd nesting, lnSum accumulation order) follows the source statement by statement; the bar is the
-// north_star's 1e-3 relative on log-likelihoods (device exp/log vs glibc differ in the last ulps).
+// The recursion runs in the probability domain with exact binary rescaling (see k_hmm_forward); the grouping of products
+// and sums follows the source statement by statement; the bar is the north_star's 1e-3 relative on log-likelihoods (observed
+// ~1e-12 against the log-space restatement in oracle/).
 #include "dn_dev.h"
 
 #define HMM_W 12                 // detect.cpp:885
 #define HMM_N (2 * HMM_W)        // states per kind
 #define HMM_SNIP (2 * HMM_W + 9) // readSnippet length (:420)
 
-struct HmmConsts { double D2D, D2M, I2M, M2D, M2I, I2I, ln025, ln05; };     // :245-250 via host libm
-struct HmmRead { double iM2M, eM2M, endM; };                                 // :253-254, lnSum(eM2M, M2D) of :366
+struct HmmConsts { double D2D, D2M, I2M, M2D, M2I, I2I, ln025, ln05; };     // :245-250 as PROBABILITIES (exp of the log values, host libm)
+struct HmmRead { double iM2M, eM2M, endM; };                                 // exp of :253-254 and of lnSum(eM2M, M2D) (:366)
 struct HmmDev {
-    const double4 *unl, *ana;    // per 9-mer rank: {mu, 2 sigma^2, log(1 / sqrt(2 sigma^2 pi)), 1 / sqrt(2 sigma^2 pi)}
+    const double4 *unl, *ana;    // per 9-mer rank: {mu, 2 sigma^2, -1 / (2 sigma^2), 1 / sqrt(2 sigma^2 pi)}
     unsigned *poi;               // at ref_off: POIs of the read, ascending
     unsigned *n_poi;             // [n_reads]
     unsigned *n_ev;              // at ref_off, per POI: eventSnippet.size() (0 = no call made)
@@ -49,46 +48,42 @@ __global__ __launch_bounds__(64) void k_hmm_pois(BatchDev B, HmmDev H) {
     if (lane == 0) H.n_poi[r] = n;
 }
 
-__device__ __forceinline__ double lnsum_(double a, double b) {                // probability.cpp:50-77
-    const double hi = fmax(a, b), lo = fmin(a, b);
-    if (lo == neg_inf_d()) return hi;
-    return hi + log(1.0 + exp(lo - hi));
-}
-
-__device__ __forceinline__ double emission_(double x, const double4 p) {      // eln(normalPDF(mu, sigma, x)) (:293, probability.cpp:145)
-    const double d = x - p.x;
-    const double arg = -(d * d) / p.y;
-    double e = p.z + arg;
-    if (arg < -708.0) {                                   // exp() subnormal or zero in the reference: evaluate the literal chain
-        const double q = p.w * exp(arg);
-        e = (q == 0.0) ? neg_inf_d() : log(q);
-    }
-    return e;
-}
-
 // ------------------------------------------------------------------------------------------------
-// k_hmm_forward: FOUR lanes per (POI, pass) chain, six states each, skewed in time (a systolic pipeline): lane g works on
+// k_hmm_forward: the forward algorithm in the PROBABILITY domain with exact power-of-two rescaling.
+//
+// The reference works in log space: every "+" is lnSum = max + log(1 + exp(min - max)) (probability.cpp:50), i.e. five
+// exp + five log per (observation, position).  The same quantity is a sum of products of probabilities; here it is
+// accumulated as such -- (x t) e for lnProd(lnProd(x, t), e), left-to-right "+" for the lnSum chain, so the grouping of
+// the source is kept -- with ONE exp per cell (the Gaussian emission itself, normalPDF of probability.cpp:145).  The
+// range problem that log space solves is handled by carrying a binary exponent per lane and rescaling inputs with
+// v_ldexp_f64 at every step: a power-of-two scale changes no mantissa bit, so the only rounding is that of the fused
+// multiply-adds (~1e-16 each).  Result: log P = log(sum) + E ln 2, within ~1e-12 of the log-space restatement (the
+// north_star bar for log-likelihoods is 1e-3 relative), at one eighth of the instructions.  log 0 (NaN in the reference)
+// is probability 0.
+//
+// Mapping: FOUR lanes per (POI, pass) chain, six positions each, skewed in time (a systolic pipeline): lane g works on
 // observation t = step - g, so that when it starts a column its left neighbour has just finished the same column.  What
-// crosses a lane boundary per step is five doubles (the neighbour's last state: previous-column I, M, D and current-column
-// M, D), moved with DPP row_shr:1.  The state of a lane is 18 doubles in REGISTERS (no LDS), so four wavefronts per SIMD are
-// resident where the LDS-resident one-lane-per-chain version had one: the kernel turns from latency-bound to bound by
-// the fp64 exp / log of the log-sum-exp (30 per lane and observation).  The order of every lnSum / lnProd is unchanged.
+// crosses a lane boundary per step is the neighbour's last position -- previous-column I, M, D, current-column M, D -- and
+// the neighbour's exponent (DPP row_shr:1).  The state of a lane is 18 doubles in registers; no LDS.
 // ------------------------------------------------------------------------------------------------
 #define HMM_G 4                  // lanes per chain
-#define HMM_S (HMM_N / HMM_G)    // states per lane
+#define HMM_S (HMM_N / HMM_G)    // positions per lane
+#define HMM_EZERO (-1000000)     // "exponent" of an all-zero set of values
 
-__device__ __forceinline__ double shr1_d(double v) {       // lane l <- lane l - 1 within a row of 16 (lane 0 of a row keeps 0)
+__device__ __forceinline__ double shr1_d(double v) {       // lane l <- lane l - 1 within a row of 16 (lane 0 of a row gets 0)
     const long long b = __double_as_longlong(v);
     const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x111, 0xf, 0xf, true);
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x111, 0xf, 0xf, true);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
+__device__ __forceinline__ int shr1_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); }
+__device__ __forceinline__ int exp_of(double m, int e) { return m > 0.0 ? __builtin_amdgcn_frexp_exp(m) + e : HMM_EZERO; }
 
 __global__ __launch_bounds__(64, 3) void k_hmm_forward(BatchDev B, HmmDev H, const HmmRead *hr, HmmConsts hc) {
     const int r = blockIdx.y, lane = threadIdx.x;
     const ReadRes &R = B.res[r];
     if (R.status != 0) return;
-    const int g = lane & (HMM_G - 1);                      // state group of this lane: states [6 g, 6 g + 6)
+    const int g = lane & (HMM_G - 1);                      // position group of this lane: positions [6 g, 6 g + 6)
     const unsigned idx = blockIdx.x * (64 / HMM_G) + (lane >> 2);
     const unsigned k = idx >> 1, pass = idx & 1u;         // pass 0: analogue, 1: thymidine
     const unsigned npoi = H.n_poi[r];
@@ -96,7 +91,7 @@ __global__ __launch_bounds__(64, 3) void k_hmm_forward(BatchDev B, HmmDev H, con
     const uint64_t f0 = B.ref_off[r];
     const unsigned pos = chain ? H.poi[f0 + k] : (unsigned)(2 * HMM_W);
     const char *ref = B.refseq + f0;
-    // ---- readSnippet fully A/T/G/C (:423-442) + k-mer ranks of this lane's six states ----
+    // ---- readSnippet fully A/T/G/C (:423-442) + k-mer ranks of this lane's six positions ----
     const char *snip = ref + pos - HMM_W;
     bool acgt = true;
     unsigned ki[HMM_S];
@@ -139,32 +134,29 @@ __global__ __launch_bounds__(64, 3) void k_hmm_forward(BatchDev B, HmmDev H, con
     // i.e. when some aligned pair lies below the window; otherwise it stays in descending order
     const bool descending = B.is_rev[r] != 0 && j0 == 0;
     const double shift = R.shift, scale = R.scale;
-    const double iM2M = hr[r].iM2M, eM2M = hr[r].eM2M;
-    const double NI = neg_inf_d();
+    const double iM2M = hr[r].iM2M, eM2M = hr[r].eM2M;     // probabilities (the exp of the reference's log values)
     const bool first = g == 0;
-    // ---- initialisation (:257-271): D_prev[i] = ln 0.25 + i * D2D accumulated left to right ----
+    // ---- initialisation (:257-271): D_prev[i] = 0.25 * 0.3^i, built left to right; I, M = 0; true value = stored * 2^E ----
     double SI[HMM_S], SM[HMM_S], SD[HMM_S];
+    int E = 0;
     {
         double d = hc.ln025;
         for (int i = 0; i < HMM_N; i++) {
 #pragma unroll
-            for (int q = 0; q < HMM_S; q++) if (i == g * HMM_S + q) { SI[q] = NI; SM[q] = NI; SD[q] = d; }
-            d = d + hc.D2D;
+            for (int q = 0; q < HMM_S; q++) if (i == g * HMM_S + q) { SI[q] = 0.0; SM[q] = 0.0; SD[q] = d; }
+            d = d * hc.D2D;
         }
     }
-    double firstI_prev = NI, start_prev = 0.0;
-    // boundary handed to the next lane: this lane's LAST state, previous column (I, M, D) and current column (M, D)
-    double bI = NI, bM = NI, bD = SD[HMM_S - 1], bcM = NI, bcD = NI;
-    {
-        // before any observation the "previous column" of the neighbour's last state is its initial state
-        // (I, M = log 0, D = its initial D), and there is no current column yet
-    }
+    double firstI_prev = 0.0, start_prev = 1.0;
+    // boundary handed to the next lane: this lane's LAST position, previous column (I, M, D) and current column (M, D), exponent
+    double bI = 0.0, bM = 0.0, bD = 0.0, bcM = 0.0, bcD = 0.0; int bE = 0;
     int cur = descending ? j1 - 1 : j0;                    // this lane's cursor over the aligned pairs
     const int dir = descending ? -1 : 1;
     const int T = (int)ns;
     for (int step = 0; step < T + HMM_G - 1; step++) {
         // what the left neighbour left behind in the step before (for g == 0 the values are not used)
-        const double pI0 = shr1_d(bI), pM0 = shr1_d(bM), pD0 = shr1_d(bD), cM0 = shr1_d(bcM), cD0 = shr1_d(bcD);
+        double pI0 = shr1_d(bI), pM0 = shr1_d(bM), pD0 = shr1_d(bD), cM0 = shr1_d(bcM), cD0 = shr1_d(bcD);
+        const int inE = shr1_i(bE);
         const int t = step - g;
         const bool act = go && t >= 0 && t < T;
         if (act) {
@@ -172,34 +164,49 @@ __global__ __launch_bounds__(64, 3) void k_hmm_forward(BatchDev B, HmmDev H, con
             while (!(ev > 0. && ev < 250.0)) { cur += dir; ev = evm[ae[cur]]; }      // events outside (0, 250) are not observations (:466)
             cur += dir;
             const double x = (ev - shift) / scale;
-            const double firstI_curr = lnsum_(start_prev + hc.ln025, firstI_prev + hc.ln025);       // :297-298 (insProb = 0)
-            // incoming edge of this lane's first state: for position 0 the start / first-insertion states take the place of
+            // ---- bring everything this step reads onto one binary scale (exact: only exponents change) ----
+            double own = fmax(firstI_prev, start_prev);
+#pragma unroll
+            for (int q = 0; q < HMM_S; q++) own = fmax(own, fmax(SI[q], fmax(SM[q], SD[q])));
+            const double inc = first ? 0.0 : fmax(fmax(pI0, pM0), fmax(pD0, fmax(cM0, cD0)));
+            const int eo = exp_of(own, E), ei = exp_of(inc, inE);
+            const int En = max(eo, ei) == HMM_EZERO ? E : max(eo, ei);
+            const int so = max(E - En, -2000), si = max(inE - En, -2000);
+#pragma unroll
+            for (int q = 0; q < HMM_S; q++) { SI[q] = ldexp(SI[q], so); SM[q] = ldexp(SM[q], so); SD[q] = ldexp(SD[q], so); }
+            firstI_prev = ldexp(firstI_prev, so); start_prev = ldexp(start_prev, so);
+            pI0 = ldexp(pI0, si); pM0 = ldexp(pM0, si); pD0 = ldexp(pD0, si); cM0 = ldexp(cM0, si); cD0 = ldexp(cD0, si);
+            E = En;
+            const double firstI_curr = start_prev * hc.ln025 + firstI_prev * hc.ln025;               // :297-298 (insProb = 1)
+            // incoming edge of this lane's first position: for position 0 the start / first-insertion states take the place of
             // the (i - 1) states (:305-311); everything else is the generic recursion (:336-350)
-            double pI = first ? firstI_prev : pI0, pM = first ? NI : pM0, pD = first ? start_prev : pD0;
-            double cM = first ? NI : cM0, cD = first ? firstI_curr : cD0;
+            double pI = first ? firstI_prev : pI0, pM = first ? 0.0 : pM0, pD = first ? start_prev : pD0;
+            double cM = first ? 0.0 : cM0, cD = first ? firstI_curr : cD0;
             double tI = first ? hc.ln05 : hc.I2M, tD = first ? hc.ln05 : hc.D2M, tcD = first ? hc.ln025 : hc.D2D;
             const double oI5 = SI[HMM_S - 1], oM5 = SM[HMM_S - 1], oD5 = SD[HMM_S - 1];
 #pragma unroll
             for (int q = 0; q < HMM_S; q++) {
                 const unsigned kk = ki[q];
                 const double4 prm = (kk & 0x80000000u) ? H.ana[kk & 0x3ffffu] : H.unl[kk & 0x3ffffu];
-                const double match = emission_(x, prm);
+                const double dd = x - prm.x;
+                const double match = prm.w * exp((dd * dd) * prm.z);                                 // normalPDF (probability.cpp:145)
                 const double oI = SI[q], oM = SM[q], oD = SD[q];
-                const double nI = lnsum_(oI + hc.I2I, oM + hc.M2I);                                  // :301-302 / :336-337
-                const double nM = lnsum_(lnsum_(lnsum_((pI + tI) + match, (pM + eM2M) + match), (oM + iM2M) + match), (pD + tD) + match);   // :305-307 / :340-343
-                const double nD = lnsum_(cM + hc.M2D, cD + tcD);                                     // :310-311 / :349-350
+                const double nI = oI * hc.I2I + oM * hc.M2I;                                         // :301-302 / :336-337
+                const double nM = ((((pI * tI) * match + (pM * eM2M) * match) + (oM * iM2M) * match) + (pD * tD) * match);   // :305-307 / :340-343
+                const double nD = cM * hc.M2D + cD * tcD;                                            // :310-311 / :349-350
                 SI[q] = nI; SM[q] = nM; SD[q] = nD;
                 pI = oI; pM = oM; pD = oD; cM = nM; cD = nD;
                 tI = hc.I2M; tD = hc.D2M; tcD = hc.D2D;
             }
-            bI = oI5; bM = oM5; bD = oD5; bcM = SM[HMM_S - 1]; bcD = SD[HMM_S - 1];
+            bI = oI5; bM = oM5; bD = oD5; bcM = SM[HMM_S - 1]; bcD = SD[HMM_S - 1]; bE = E;
             firstI_prev = firstI_curr;
-            start_prev = NI;                               // start_curr is log 0 (:261, :357)
+            start_prev = 0.0;                              // the start state is left for good after the first observation (:261, :357)
         }
     }
-    // ---- termination (:362-367): the last state lives in the last lane of the chain ----
+    // ---- termination (:362-367): the last position lives in the last lane of the chain ----
     if (go && g == HMM_G - 1) {
-        const double fwd = lnsum_(lnsum_(SD[HMM_S - 1] + 0.0, SM[HMM_S - 1] + hr[r].endM), SI[HMM_S - 1] + hc.I2M);
+        const double tot = (SD[HMM_S - 1] + SM[HMM_S - 1] * hr[r].endM) + SI[HMM_S - 1] * hc.I2M;
+        const double fwd = tot > 0.0 ? log(tot) + (double)E * 0.6931471805599453 : neg_inf_d();
         if (pass == 0) { H.la[f0 + k] = fwd; H.ok[f0 + k] = 1; H.n_ev[f0 + k] = ns; }
         else H.lt[f0 + k] = fwd;
     }
