@@ -254,18 +254,21 @@ def main():
                                     "note": "one batch in flight, outside the timed region"}
         if args.scope == "full":
             # dominant stage = the CNN: algorithmic flops = 2 x MACs of the description x positions (3.7 MFLOP x L);
-            # peak = the 6 x bf16-MFMA rate the fp32-equivalent split runs at (2.5 PFLOP/s / 6), see DESIGN.md s4b
+            # peak = the dense 16-bit MFMA rate (2.5 PFLOP/s) / the products per fp32 product of the split in use: 3 for the two-piece
+            # fp16 split (default), 6 for the three-piece bf16 split; 157 for exact fp32 MFMA.  See DESIGN.md s4b
+            cnn_math = os.environ.get("DN_CNN_MATH", "f16x3")
+            cnn_peak = {"f16x3": 2500.0 / 3, "bf16x6": 2500.0 / 6, "fp32": 157.0}[cnn_math]
             mac = sum(o["k"] * o["cin"] * o["cout"] for o in cnn_desc["ops"] if o["op"] == "conv") + 47040
             pos = float(np.sum(summ["n_positions"][summ["status"] == 0]))
             cnn_ms, cnn_n = prof["k3_cnn"]
             ach = 2.0 * mac * pos / ((cnn_ms / max(cnn_n, 1)) / 1e3) / 1e12
             out["config"]["workload"] = out["config"]["workload"].replace("banded-HMM scope (segmentation + rough scaling + adaptive banded "
                                                                           "alignment + backtrack/QC + Theil-Sen), CNN stubbed",
-                                                                          "full pipeline (normalise + eventalign + CNN, bf16x6 math)")
+                                                                          "full pipeline (normalise + eventalign + CNN, %s math)" % cnn_math)
             out["config"]["cnn_positions_per_gpu_step"] = int(pos)
             out["roofline_banded"] = out["roofline"]
-            out["roofline"] = {"bound": "mfma", "kernel": "k3_cnn (all layers of one pass)", "achieved": ach, "peak": 417.0, "unit": "TFLOP/s",
-                               "frac": ach / 417.0, "traffic": None, "mean_launch_ms": cnn_ms / max(cnn_n, 1),
+            out["roofline"] = {"bound": "mfma", "kernel": "k3_cnn (all layers of one pass)", "achieved": ach, "peak": cnn_peak, "unit": "TFLOP/s",
+                               "frac": ach / cnn_peak, "traffic": None, "mean_launch_ms": cnn_ms / max(cnn_n, 1),
                                "algorithmic_flops_per_launch": 2.0 * mac * pos}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(reads, model, full=(args.scope == "full"))

@@ -31,7 +31,8 @@ void k2b_launch(const BatchDev &, const void *, const void *, const void *, unsi
 int k2_fill_variant();
 struct CnnRows { const unsigned *row_off; const uint8_t *valid; unsigned rows, r0, r1; const unsigned *n_pos; const uint64_t *io_off; };
 struct CnnRun { const dn_cnn_op *ops; int n_ops; const float *wts; float *buf[8]; int n_buf; CnnRows rows; uint8_t *valid;
-                 const float *core, *resid, *sig; float *probs; unsigned max_pos; const uint16_t *wts_bf16; const int64_t *wb_off; };
+                 const float *core, *resid, *sig; float *probs; unsigned max_pos; const uint16_t *wts_split; const int64_t *wb_off;
+                 int pieces; const float *post; unsigned *range_flag; };
 int k3_run(const CnnRun &, hipStream_t);
 struct HmmConstsH { double D2D, D2M, I2M, M2D, M2I, I2I, ln025, ln05; };
 struct HmmReadH { double iM2M, eM2M, endM; };
@@ -79,7 +80,8 @@ struct dn_ctx {
     uint8_t *d_path_from = nullptr; float *d_path_lp = nullptr;
     uint64_t *d_trace_off = nullptr;
     FillConstsH fc{};
-    std::vector<int64_t> cnn_wb_off; uint16_t *d_cnn_wb = nullptr; size_t cnn_nwb = 0; int cnn_math = DN_CNN_MATH_BF16X6;
+    std::vector<int64_t> cnn_wb_off, cnn_wh_off; uint16_t *d_cnn_wb = nullptr, *d_cnn_wh = nullptr; size_t cnn_nwb = 0, cnn_nwh = 0; int cnn_math = DN_CNN_MATH_F16X3;
+    std::vector<float> cnn_post, cnn_one; unsigned *d_cnn_flag = nullptr; uint64_t cnn_escalations = 0; bool cnn_f16_off = false;
     std::vector<dn_cnn_op> cnn_ops; float *d_cnn_w = nullptr; size_t cnn_nw = 0; int cnn_nbuf = 0; DevBuf cnn_buf[8], cnn_valid, cnn_rowoff, cnn_npos, cnn_iooff, cnn_in[3], cnn_out;
     float *d_probs = nullptr;
     double4 *d_fit[2] = { nullptr, nullptr }; bool have_fit = false, hmm_done = false;
@@ -256,6 +258,8 @@ void dn_ctx_destroy(dn_ctx *c) {
     if (c->d_model_sorted) hipFree(c->d_model_sorted);
     if (c->d_cnn_w) hipFree(c->d_cnn_w);
     if (c->d_cnn_wb) hipFree(c->d_cnn_wb);
+    if (c->d_cnn_wh) hipFree(c->d_cnn_wh);
+    if (c->d_cnn_flag) hipFree(c->d_cnn_flag);
     for (auto *p : c->d_fit) if (p) hipFree(p);
     for (DevBuf *b : { &c->hmm_poi, &c->hmm_npoi, &c->hmm_nev, &c->hmm_ok, &c->hmm_la, &c->hmm_lt, &c->hmm_reads }) if (b->p) hipFree(b->p);
     for (auto &b : c->cnn_buf) if (b.p) hipFree(b.p);
@@ -760,7 +764,44 @@ int dn_load_cnn(dn_ctx *c, const dn_cnn_op *ops, uint32_t n_ops, const float *we
     HIPCHK(c, hipMemcpyAsync(c->d_cnn_wb, wb.data(), wb.size() * 2, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cnn_wb_off = wb_off;
-    { const char *e = getenv("DN_CNN_MATH"); if (e) c->cnn_math = (strcmp(e, "fp32") == 0) ? DN_CNN_MATH_FP32 : DN_CNN_MATH_BF16X6; }
+    // the fp16 path's weights: scaled per layer by a power of two into [2^13, 2^14) (so that the low pieces of all but the
+    // tiniest weights are normal fp16 numbers), then two pieces per value (round to nearest even), same layout
+    auto f16_bits = [](float f) -> uint16_t { const _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; };
+    auto f16_f32 = [](uint16_t b) -> float { _Float16 h; memcpy(&h, &b, 2); return (float)h; };
+    std::vector<uint16_t> wh; std::vector<int64_t> wh_off(n_ops, 0); std::vector<float> post(n_ops, 1.0f);
+    for (uint32_t i = 0; i < n_ops; i++) {
+        const dn_cnn_op &o = ops[i];
+        if (o.op != DN_CNN_CONV && o.op != DN_CNN_CONV_ADD) continue;
+        wh_off[i] = (int64_t)wh.size();
+        const size_t steps = (size_t)o.k * (o.cin / 32), blk = (size_t)o.cout * 32;
+        wh.resize(wh.size() + steps * 2 * blk);
+        uint16_t *dst = wh.data() + wh_off[i];
+        const float *src = wl.data() + o.w;
+        float wmax = 0.0f;
+        for (size_t e = 0; e < steps * blk; e++) wmax = std::max(wmax, fabsf(src[e]));
+        const int up = (wmax > 0.0f && std::isfinite(wmax)) ? 13 - ilogbf(wmax) : 0;
+        const float mul = ldexpf(1.0f, up);
+        post[i] = ldexpf(1.0f, -up);
+        const size_t cbn = (size_t)(o.cin / 32);
+        for (size_t st = 0; st < steps; st++)
+            for (size_t e = 0; e < blk; e++) {
+                const size_t cb = st / (size_t)o.k, tp = st % (size_t)o.k;
+                const float x = src[(tp * cbn + cb) * blk + e] * mul;      // exact
+                const uint16_t h = f16_bits(x);
+                dst[(st * 2 + 0) * blk + e] = h; dst[(st * 2 + 1) * blk + e] = f16_bits(x - f16_f32(h));
+            }
+    }
+    if (c->d_cnn_wh) { hipFree(c->d_cnn_wh); c->dev_bytes -= c->cnn_nwh * 2; c->d_cnn_wh = nullptr; }
+    HIPCHK(c, hipMalloc((void **)&c->d_cnn_wh, std::max<size_t>(wh.size(), 8) * 2));
+    c->cnn_nwh = wh.size(); c->dev_bytes += wh.size() * 2;
+    HIPCHK(c, hipMemcpyAsync(c->d_cnn_wh, wh.data(), wh.size() * 2, hipMemcpyHostToDevice, c->stream));
+    if (!c->d_cnn_flag) HIPCHK(c, hipMalloc((void **)&c->d_cnn_flag, sizeof(unsigned)));
+    HIPCHK(c, hipMemsetAsync(c->d_cnn_flag, 0, sizeof(unsigned), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cnn_wh_off = wh_off; c->cnn_post = post; c->cnn_one.assign(n_ops, 1.0f);
+    { const char *e = getenv("DN_CNN_MATH");
+      if (e) c->cnn_math = strcmp(e, "fp32") == 0 ? DN_CNN_MATH_FP32 : strcmp(e, "bf16x6") == 0 ? DN_CNN_MATH_BF16X6 : DN_CNN_MATH_F16X3; }
+    c->cnn_f16_off = false;
     weights = wl.data();
     if (c->d_cnn_w) { hipFree(c->d_cnn_w); c->dev_bytes -= c->cnn_nw * sizeof(float); c->d_cnn_w = nullptr; }
     HIPCHK(c, hipMalloc((void **)&c->d_cnn_w, n_weights * sizeof(float)));
@@ -780,8 +821,8 @@ static uint64_t cnn_row_cap() {
 }
 
 int dn_cnn_set_math(dn_ctx *c, int mode) {
-    if (!c || (mode != DN_CNN_MATH_FP32 && mode != DN_CNN_MATH_BF16X6)) return DN_ERR_ARG;
-    c->cnn_math = mode;
+    if (!c || (mode != DN_CNN_MATH_FP32 && mode != DN_CNN_MATH_BF16X6 && mode != DN_CNN_MATH_F16X3)) return DN_ERR_ARG;
+    c->cnn_math = mode; c->cnn_f16_off = false;
     return DN_OK;
 }
 
@@ -829,12 +870,31 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *npos, const uint64
         run.rows.n_pos = (const unsigned *)c->cnn_npos.p; run.rows.io_off = (const uint64_t *)c->cnn_iooff.p;
         run.valid = (uint8_t *)c->cnn_valid.p;
         run.core = d_core; run.resid = d_resid; run.sig = d_sig; run.probs = d_probs; run.max_pos = ps.max_pos;
-        run.wts_bf16 = c->cnn_math == DN_CNN_MATH_BF16X6 ? c->d_cnn_wb : nullptr; run.wb_off = c->cnn_wb_off.data();
-        if (k3_run(run, c->stream)) return fail(c, DN_ERR_ARG, "unsupported op in the CNN description");
+        // fp16 pieces are only valid while every activation fits fp16: the kernels raise range_flag otherwise and the pass is
+        // repeated with bf16 pieces (same result contract, 2x the matrix work) -- never a silently wrong answer
+        for (int math = (c->cnn_math == DN_CNN_MATH_F16X3 && c->cnn_f16_off) ? DN_CNN_MATH_BF16X6 : c->cnn_math;;) {
+            run.wts_split = math == DN_CNN_MATH_BF16X6 ? c->d_cnn_wb : math == DN_CNN_MATH_F16X3 ? c->d_cnn_wh : nullptr;
+            run.wb_off = math == DN_CNN_MATH_F16X3 ? c->cnn_wh_off.data() : c->cnn_wb_off.data();
+            run.pieces = math == DN_CNN_MATH_F16X3 ? 2 : 3;
+            run.post = math == DN_CNN_MATH_F16X3 ? c->cnn_post.data() : c->cnn_one.data();
+            run.range_flag = c->d_cnn_flag;
+            if (k3_run(run, c->stream)) return fail(c, DN_ERR_ARG, "unsupported op in the CNN description");
+            if (math != DN_CNN_MATH_F16X3) break;
+            unsigned flag = 0;
+            HIPCHK(c, hipMemcpyAsync(&flag, c->d_cnn_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (!flag) break;
+            HIPCHK(c, hipMemsetAsync(c->d_cnn_flag, 0, sizeof(unsigned), c->stream));
+            c->cnn_escalations++;
+            c->cnn_f16_off = true;                          // this model's activations do not fit: stay on bf16 pieces from now on
+            math = DN_CNN_MATH_BF16X6;
+        }
     }
     HIPCHK(c, hipGetLastError());
     return DN_OK;
 }
+
+uint64_t dn_cnn_range_escalations(dn_ctx *c) { return c ? c->cnn_escalations : 0; }
 
 int dn_run_cnn(dn_ctx *c) {
     int rc = need(c, 6, "dn_run_cnn"); if (rc) return rc;

@@ -131,7 +131,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int BN, bool ADD>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][BN / 64], float *__restrict__ Y, const float *__restrict__ scale,
                                               const float *__restrict__ shift, const float *__restrict__ Add,
-                                              const uint8_t *__restrict__ valid, int m0, int n0, int wm, int wn, int lane, int cout, int relu) {
+                                              const uint8_t *__restrict__ valid, int m0, int n0, int wm, int wn, int lane, int cout, int relu,
+                                              float post = 1.0f) {
     constexpr int NJ = BN / 64;
     const unsigned long long vmask = __ballot(valid[m0 + wm * 64 + lane] != 0);
     const float floor_ = relu ? 0.0f : -3.402823466e38f;
@@ -140,7 +141,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][BN / 64], float *
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-            const float sc = scale[col], sh = shift[col];
+            const float sc = scale[col] * post, sh = shift[col];     // post: a power of two (exact), 1 except on the fp16 path
             const int rbase = i * 32 + 4 * (lane >> 5);
             float *yp = Y + (size_t)(m0 + wm * 64 + rbase) * cout + col;
             float addv[16];
@@ -238,15 +239,28 @@ __global__ __launch_bounds__(256) void k3_conv(const float *__restrict__ X, floa
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// the same convolution on the BF16 matrix cores at fp32 accuracy: every fp32 operand is split EXACTLY into three bf16
-// pieces (x = h + m + l, 3 x 8 = the 24 significant bits), and the six products that matter are accumulated in fp32:
-//     x w  ~=  h h' + (h m' + m h') + (h l' + l h' + m m')            (dropped: m l', l m', l l' < 2^-24 |x w|)
-// v_mfma_f32_32x32x16_bf16 runs at 16x the fp32 MFMA rate, so six of them are 2.67x faster than the fp32 instruction for
-// the same product (417 vs 157 TFLOP/s peak).  Weights are split once at dn_load_cnn ([step][piece][cout][32] bf16);
-// activations stay fp32 in HBM and are split by the loader on their way into LDS (three bf16 planes, pitch 40 elements:
-// one ds_read_b128 per fragment).  tools/cnn_split_precision.py: probabilities move by 2e-6 (fp32 MFMA vs CPU: 2e-6).
+// the same convolution on the 16-bit matrix cores at fp32-level accuracy: every fp32 operand is split into 16-bit pieces and
+// the products that matter are accumulated in fp32.  Two splits are built (template parameter NP = pieces per operand):
+//
+//   NP = 3, bf16 ("bf16x6"): x = h + m + l EXACTLY (3 x 8 = the 24 significant bits); six products
+//       x w ~= h h' + (h m' + m h') + (h l' + l h' + m m')                 (dropped: m l', l m', l l' < 2^-24 |x w|)
+//     v_mfma_f32_32x32x16_bf16 runs at 16x the fp32 MFMA rate, so six of them are 2.67x faster than the fp32 instruction
+//     (417 vs 157 TFLOP/s peak).  bf16 has the fp32 exponent range: no range caveat at all.
+//   NP = 2, fp16 ("f16x3"): x = h + l + O(2^-22 |x|) (2 x 11 bits); three products h h' + h l' + l h' -- HALF the matrix work
+//     of bf16x6 (peak 834 TFLOP/s of fp32-equivalent work) and two planes instead of three through LDS.  The price is fp16's
+//     exponent range: (a) |x| > 65504 does not convert -- the loader tracks max |x| and raises a device flag, and the host then
+//     repeats the pass in bf16x6 (dn_capi.hip: cnn_execute), so the result is never silently wrong; (b) below 2^-3 the low piece
+//     is subnormal and the split keeps an ABSOLUTE 2^-25 instead of a relative 2^-22 -- the matrix cores honour fp16 subnormals
+//     (tools/ubench_f16_denorm.hip, measured), and 3e-8 absolute on an activation is below fp32 rounding of the O(1) sums it
+//     feeds.  Weights are pre-scaled per layer by a power of two into [2^13, 2^14) so their low pieces stay normal; the
+//     epilogue multiplies the folded BatchNorm scale by the inverse power (exact).
+//
+// Weights are split once at dn_load_cnn ([channel block][tap][piece][cout][32]); activations stay fp32 in HBM and are split by
+// the loader on their way into LDS (NP planes, pitch 40 elements: one ds_read_b128 per fragment).
+// tools/cnn_split_precision.py: probabilities move by 2e-6 for bf16x6 (fp32 MFMA vs CPU: 2e-6).
 // ---------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define CNN_BP 40
 
@@ -261,18 +275,31 @@ __device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, bf16x8 
         h[q] = hh; m[q] = mm; l[q] = (__bf16)r2;
     }
 }
+__device__ __forceinline__ void split2(const f32x4 lo4, const f32x4 hi4, f16x8 &h, f16x8 &l, float &amax) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const float x = q < 4 ? lo4[q] : hi4[q - 4];
+        amax = fmaxf(amax, fabsf(x));
+        const _Float16 hh = (_Float16)x;
+        h[q] = hh; l[q] = (_Float16)(x - (float)hh);       // the difference is exact while |x| <= 65504
+    }
+}
+template <int NP> __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    if (NP == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 
 // Loop order: input-channel block outermost, taps inside.  The A tile of a channel block (128 + k - 1 rows) is split and
 // staged ONCE and every tap reads it at a row offset, so a k-tap layer converts each activation once instead of k times;
 // only the B tile changes per step.  Weights are laid out [channel block][tap][piece][cout][32] to match.
 #define CNN_AROWS (CNN_BM + 16)
-template <int BN, bool ADD>
-__global__ __launch_bounds__(256) void k3_conv_bf16(const float *__restrict__ X, float *__restrict__ Y, const __bf16 *__restrict__ Wb,
-                                                    const float *__restrict__ scale, const float *__restrict__ shift,
-                                                    const float *__restrict__ Add, const uint8_t *__restrict__ valid, int rows, int k,
-                                                    int cin, int cout, int relu) {
-    __shared__ __attribute__((aligned(16))) __bf16 As[3][CNN_AROWS * CNN_BP];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[3][BN * CNN_BP];
+template <int BN, bool ADD, int NP>
+__global__ __launch_bounds__(256) void k3_conv_split(const float *__restrict__ X, float *__restrict__ Y, const uint16_t *__restrict__ Wb,
+                                                     const float *__restrict__ scale, const float *__restrict__ shift,
+                                                     const float *__restrict__ Add, const uint8_t *__restrict__ valid, int rows, int k,
+                                                     int cin, int cout, int relu, float post, unsigned *range_flag) {
+    __shared__ __attribute__((aligned(16))) uint16_t As[NP][CNN_AROWS * CNN_BP];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[NP][BN * CNN_BP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * CNN_BM, n0 = blockIdx.y * BN;
@@ -291,7 +318,8 @@ __global__ __launch_bounds__(256) void k3_conv_bf16(const float *__restrict__ X,
     const int arows = CNN_BM + k - 1;
     const int l_r = tid >> 2, l_k = (tid & 3) * 8;        // loader: 64 rows x 4 chunks of 8 elements per pass
     f32x4 ra[3][2]; bool pin[3];
-    u32x4 rb[3][NBQ];
+    u32x4 rb[NP][NBQ];
+    float amax = 0.0f;                                     // NP == 2: largest |activation| this thread has split
     auto gloadA = [&](int cb) {
 #pragma unroll
         for (int p = 0; p < 3; p++) {
@@ -305,8 +333,8 @@ __global__ __launch_bounds__(256) void k3_conv_bf16(const float *__restrict__ X,
     };
     auto gloadB = [&](int s) {
 #pragma unroll
-        for (int pc = 0; pc < 3; pc++) {
-            const __bf16 *wb = Wb + ((size_t)(s * 3 + pc) * cout + n0) * 32;
+        for (int pc = 0; pc < NP; pc++) {
+            const uint16_t *wb = Wb + ((size_t)(s * NP + pc) * cout + n0) * 32;
 #pragma unroll
             for (int q = 0; q < NBQ; q++) rb[pc][q] = *reinterpret_cast<const u32x4 *>(wb + (size_t)(q * 64 + l_r) * 32 + l_k);
         }
@@ -315,17 +343,23 @@ __global__ __launch_bounds__(256) void k3_conv_bf16(const float *__restrict__ X,
 #pragma unroll
         for (int p = 0; p < 3; p++) {
             if (p * 64 + l_r < CNN_AROWS) {
-                bf16x8 h, m, l;
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                split3(pin[p] ? ra[p][0] : z, pin[p] ? ra[p][1] : z, h, m, l);
                 const int o = (p * 64 + l_r) * CNN_BP + l_k;
-                *reinterpret_cast<bf16x8 *>(&As[0][o]) = h; *reinterpret_cast<bf16x8 *>(&As[1][o]) = m; *reinterpret_cast<bf16x8 *>(&As[2][o]) = l;
+                if (NP == 3) {
+                    bf16x8 h, m, l;
+                    split3(pin[p] ? ra[p][0] : z, pin[p] ? ra[p][1] : z, h, m, l);
+                    *reinterpret_cast<bf16x8 *>(&As[0][o]) = h; *reinterpret_cast<bf16x8 *>(&As[1][o]) = m; *reinterpret_cast<bf16x8 *>(&As[NP - 1][o]) = l;
+                } else {
+                    f16x8 h, l;
+                    split2(pin[p] ? ra[p][0] : z, pin[p] ? ra[p][1] : z, h, l, amax);
+                    *reinterpret_cast<f16x8 *>(&As[0][o]) = h; *reinterpret_cast<f16x8 *>(&As[1][o]) = l;
+                }
             }
         }
     };
     auto lstoreB = [&]() {
 #pragma unroll
-        for (int pc = 0; pc < 3; pc++)
+        for (int pc = 0; pc < NP; pc++)
 #pragma unroll
             for (int q = 0; q < NBQ; q++) *reinterpret_cast<u32x4 *>(&Bs[pc][(q * 64 + l_r) * CNN_BP + l_k]) = rb[pc][q];
     };
@@ -341,23 +375,26 @@ __global__ __launch_bounds__(256) void k3_conv_bf16(const float *__restrict__ X,
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k16 = 0; k16 < 2; k16++) {
-            bf16x8 a[2][3], b[NJ][3];
+            u32x4 a[2][NP], b[NJ][NP];
 #pragma unroll
-            for (int pc = 0; pc < 3; pc++) {
+            for (int pc = 0; pc < NP; pc++) {
 #pragma unroll
-                for (int i = 0; i < 2; i++) a[i][pc] = *reinterpret_cast<const bf16x8 *>(&As[pc][(wm * 64 + i * 32 + fm + tap) * CNN_BP + k16 * 16 + fk]);
+                for (int i = 0; i < 2; i++) a[i][pc] = *reinterpret_cast<const u32x4 *>(&As[pc][(wm * 64 + i * 32 + fm + tap) * CNN_BP + k16 * 16 + fk]);
 #pragma unroll
-                for (int j = 0; j < NJ; j++) b[j][pc] = *reinterpret_cast<const bf16x8 *>(&Bs[pc][(wn * (BN / 2) + j * 32 + fm) * CNN_BP + k16 * 16 + fk]);
+                for (int j = 0; j < NJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(&Bs[pc][(wn * (BN / 2) + j * 32 + fm) * CNN_BP + k16 * 16 + fk]);
             }
             // smallest terms first, so the big h h' product meets an accumulator that already holds the corrections
+            constexpr int NT = NP == 3 ? 6 : 3;
 #pragma unroll
-            for (int t = 0; t < 6; t++) {
-                constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};      // m m', l h', h l', m h', h m', h h'
+            for (int t = 0; t < NT; t++) {
+                constexpr int PA3[6] = {1, 2, 0, 1, 0, 0}, PB3[6] = {1, 0, 2, 0, 1, 0};    // m m', l h', h l', m h', h m', h h'
+                constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};                      // l h', h l', h h'
+                const int pa = NP == 3 ? PA3[t] : PA2[t % 3], pb = NP == 3 ? PB3[t] : PB2[t % 3];
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
                     for (int j = 0; j < NJ; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16<NP>(a[i][pa], b[j][pb], acc[i][j]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -368,7 +405,8 @@ __global__ __launch_bounds__(256) void k3_conv_bf16(const float *__restrict__ X,
         tap = lastTap ? 0 : tap + 1;
         cb += lastTap ? 1 : 0;
     }
-    conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, m0, n0, wm, wn, lane, cout, relu);
+    if (NP == 2 && __any(amax > 65504.0f) && lane == 0) atomicOr(range_flag, 1u);    // out of fp16 range: the host repeats the pass in bf16x6
+    conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, m0, n0, wm, wn, lane, cout, relu, post);
 }
 
 // depthwise part of SeparableConv1D: each thread owns 4 channels of DW_ROWS consecutive rows and slides a register window
@@ -462,8 +500,11 @@ struct CnnRun {
     CnnRows rows; uint8_t *valid;
     const float *core, *resid, *sig; float *probs;
     unsigned max_pos;
-    const __bf16 *wts_bf16;           // device: split conv weights (null = fp32 MFMA path)
-    const int64_t *wb_off;            // host: per op offset into wts_bf16 (in elements)
+    const uint16_t *wts_split;        // device: split conv weights (null = fp32 MFMA path)
+    const int64_t *wb_off;            // host: per op offset into wts_split (in elements)
+    int pieces;                       // 3: bf16x6, 2: f16x3
+    const float *post;                // host, per op: inverse of the power of two the fp16 weights were scaled by (1 for bf16)
+    unsigned *range_flag;             // device: set by the fp16 path when an activation does not fit fp16
 };
 
 int k3_run(const CnnRun &c, hipStream_t st) {
@@ -483,15 +524,18 @@ int k3_run(const CnnRun &c, hipStream_t st) {
                 const float *add = o.op == DN_CNN_CONV_ADD ? c.buf[o.a] : nullptr;          // fused residual join: y = act(conv + buf[a])
 #define CONV_GO(BN_, NBUF_, ADD_) hipLaunchKernelGGL((k3_conv<BN_, NBUF_, ADD_>), dim3(rows / CNN_BM, o.cout / BN_), dim3(256), 0, st, \
         c.buf[o.src], c.buf[o.dst], c.wts + o.w, c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu)
-#define CONV_GO_BF(BN_, ADD_) hipLaunchKernelGGL((k3_conv_bf16<BN_, ADD_>), dim3(rows / CNN_BM, o.cout / BN_), dim3(256), 0, st, \
-        c.buf[o.src], c.buf[o.dst], c.wts_bf16 + c.wb_off[i], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu)
-                if (c.wts_bf16) {
+#define CONV_GO_SP(BN_, ADD_, NP_) hipLaunchKernelGGL((k3_conv_split<BN_, ADD_, NP_>), dim3(rows / CNN_BM, o.cout / BN_), dim3(256), 0, st, \
+        c.buf[o.src], c.buf[o.dst], c.wts_split + c.wb_off[i], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu, \
+        c.post[i], c.range_flag)
+#define CONV_GO_BF(BN_, ADD_) do { if (c.pieces == 3) CONV_GO_SP(BN_, ADD_, 3); else CONV_GO_SP(BN_, ADD_, 2); } while (0)
+                if (c.wts_split) {
                     if (o.cout % 128 == 0) { if (add) CONV_GO_BF(128, true); else CONV_GO_BF(128, false); }
                     else { if (add) CONV_GO_BF(64, true); else CONV_GO_BF(64, false); }
                 } else if (o.cout % 128 == 0) { if (add) CONV_GO(128, 2, true); else CONV_GO(128, 2, false); }
                 else { if (add) CONV_GO(64, 1, true); else CONV_GO(64, 1, false); }
 #undef CONV_GO
 #undef CONV_GO_BF
+#undef CONV_GO_SP
                 break;
             }
             case DN_CNN_DWCONV: {

@@ -19,7 +19,7 @@ for _i, _n in enumerate(K_NAMES):
 # every symbol include/dnascent_hip.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = ["dn_abi_version", "dn_device_count", "dn_ctx_create", "dn_ctx_destroy", "dn_last_error", "dn_sync",
            "dn_load_pore_model", "dn_batch_upload", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded",
-           "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_load_cnn", "dn_cnn_set_math", "dn_run_cnn", "dn_get_probabilities", "dn_cnn_infer", "dn_load_fit_models", "dn_run_hmm", "dn_get_hmm_calls", "dn_get_summaries", "dn_get_prefix_sums",
+           "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_load_cnn", "dn_cnn_set_math", "dn_cnn_range_escalations", "dn_run_cnn", "dn_get_probabilities", "dn_cnn_infer", "dn_load_fit_models", "dn_run_hmm", "dn_get_hmm_calls", "dn_get_summaries", "dn_get_prefix_sums",
            "dn_get_tstats", "dn_get_scrappie_events", "dn_get_events", "dn_get_kmer_ranks", "dn_get_alignment",
            "dn_get_cleaned", "dn_get_trace", "dn_get_positions", "dn_get_windows", "dn_profile_enable", "dn_profile_get",
            "dn_profile_reset", "dn_kernel_name", "dn_device_bytes"]
@@ -96,6 +96,7 @@ def lib():
         L.dn_load_cnn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32]
         L.dn_run_cnn.argtypes = [C.c_void_p]
         L.dn_cnn_set_math.argtypes = [C.c_void_p, C.c_int]
+        L.dn_cnn_range_escalations.argtypes = [C.c_void_p]; L.dn_cnn_range_escalations.restype = C.c_uint64
         L.dn_load_fit_models.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.dn_run_hmm.argtypes = [C.c_void_p]
         L.dn_get_hmm_calls.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 7
@@ -163,8 +164,12 @@ class Context:
         self._chk(lib().dn_load_cnn(self.h, ops, len(desc["ops"]), w.ctypes.data, w.shape[0], desc["n_buffers"]), "dn_load_cnn")
 
     def cnn_set_math(self, mode):
-        """'fp32' (exact fp32 MFMA) or 'bf16x6' (three-piece bf16 split on the bf16 matrix cores, default)."""
-        self._chk(lib().dn_cnn_set_math(self.h, {"fp32": 0, "bf16x6": 1}[mode]), "dn_cnn_set_math")
+        """'fp32' (exact fp32 MFMA), 'bf16x6' (three-piece bf16 split on the bf16 matrix cores) or 'f16x3' (default: two-piece fp16
+        split, half the matrix work; a pass with an activation outside fp16's range is repeated in bf16x6 automatically)."""
+        self._chk(lib().dn_cnn_set_math(self.h, {"fp32": 0, "bf16x6": 1, "f16x3": 2}[mode]), "dn_cnn_set_math")
+
+    def cnn_range_escalations(self):
+        return int(lib().dn_cnn_range_escalations(self.h))
 
     def load_fit_models(self, unl_mean, unl_std, ana_mean, ana_std):
         a = [np.ascontiguousarray(x, np.float64) for x in (unl_mean, unl_std, ana_mean, ana_std)]

@@ -103,10 +103,17 @@ typedef struct {
     int64_t aux[6];             /* ENCODE_GRU: kernel/recurrent/bias offsets of the two GRUs */
 } dn_cnn_op;
 int dn_load_cnn(dn_ctx *ctx, const dn_cnn_op *ops, uint32_t n_ops, const float *weights, uint64_t n_weights, uint32_t n_buffers);
-/* how the convolutions multiply: exact fp32 MFMA, or fp32 operands split exactly into three bf16 pieces with the six
- * significant products accumulated in fp32 on the bf16 matrix cores (fp32-equivalent: dropped terms < 2^-24; default) */
-enum { DN_CNN_MATH_FP32 = 0, DN_CNN_MATH_BF16X6 = 1 };
+/* how the convolutions multiply:
+ *   FP32    exact fp32 MFMA;
+ *   BF16X6  fp32 operands split exactly into three bf16 pieces, the six significant products accumulated in fp32 on the
+ *           bf16 matrix cores (fp32-equivalent: dropped terms < 2^-24);
+ *   F16X3   (default) two fp16 pieces, three products (dropped terms < 2^-22; half the matrix work of BF16X6).  fp16 has a
+ *           narrow exponent range: a pass in which some activation exceeds 65504 is detected on the device and repeated in
+ *           BF16X6 automatically, and the context then stays on BF16X6 until the next dn_load_cnn / dn_cnn_set_math;
+ *           dn_cnn_range_escalations counts those repeats. */
+enum { DN_CNN_MATH_FP32 = 0, DN_CNN_MATH_BF16X6 = 1, DN_CNN_MATH_F16X3 = 2 };
 int dn_cnn_set_math(dn_ctx *ctx, int mode);
+uint64_t dn_cnn_range_escalations(dn_ctx *ctx);
 int dn_run_cnn(dn_ctx *ctx);            /* runCNN for every read that passed eventalign */
 int dn_get_probabilities(dn_ctx *ctx, uint32_t read, float *probs /* [n_positions * 3] */);
 /* the TF_SessionRun seam itself (detect.cpp:653): n_seq sequences given as the three host tensors runCNN builds --

@@ -92,11 +92,11 @@ def test_detect_file_matches_oracle_records(model, tmp_path):
     assert open(path, "rb").read() == want
 
 
-@pytest.mark.parametrize("math", ["bf16x6", "fp32"])
+@pytest.mark.parametrize("math", ["bf16x6", "fp32", "f16x3"])
 def test_cnn_infer_matches_golden_vectors(math):
     """dn_cnn_infer (the TF_SessionRun seam: three host tensors in, probabilities out) against the committed vectors;
-    ragged lengths incl. a 1-position sequence and positions with no signal at all.  Both ways of multiplying: exact fp32
-    MFMA and the three-piece bf16 split on the bf16 matrix cores (the default)."""
+    ragged lengths incl. a 1-position sequence and positions with no signal at all.  All three ways of multiplying: exact fp32
+    MFMA, the three-piece bf16 split on the bf16 matrix cores (the default), the two-piece fp16 split."""
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cnn_default_model.npz"))
     desc, blob, _ = cnn_model.default_model()
@@ -112,3 +112,25 @@ def test_cnn_infer_matches_golden_vectors(math):
     alone = ctx.cnn_infer(g["lens"][:1], g["core"][:n0], g["resid"][:n0], g["signal"][:n0])
     assert np.array_equal(alone, got[:n0])
     assert ctx.cnn_infer(np.zeros(0, np.uint32), np.zeros(0), np.zeros(0), np.zeros((0, 20))).shape == (0, 3)
+    assert ctx.cnn_range_escalations() == 0
+
+
+def test_f16_split_escalates_when_an_activation_leaves_fp16_range():
+    """The two-piece fp16 split cannot represent |x| > 65504.  A model whose first convolution is blown up by 2^20 makes the
+    second one see such inputs: the device flags it and the pass is repeated with bf16 pieces -- the answer is then bit-identical
+    to asking for bf16x6 in the first place, and the repeat is counted."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cnn_default_model.npz"))
+    desc, blob, _ = cnn_model.default_model()
+    blob = blob.copy()
+    first = next(o for o in desc["ops"] if o["op"] == "conv")
+    blob[first["scale"]:first["scale"] + first["cout"]] *= 2.0 ** 20
+    ctx = hip.Context(0)
+    ctx.load_cnn(desc, blob)
+    ctx.cnn_set_math("bf16x6")
+    want = ctx.cnn_infer(g["lens"], g["core"], g["resid"], g["signal"])
+    assert ctx.cnn_range_escalations() == 0
+    ctx.cnn_set_math("f16x3")
+    got = ctx.cnn_infer(g["lens"], g["core"], g["resid"], g["signal"])
+    assert ctx.cnn_range_escalations() == 1
+    assert np.array_equal(got, want, equal_nan=True)

@@ -19,11 +19,11 @@ ctx.run("normalise"); ctx.run("eventalign"); ctx.sync()
 s = ctx.summaries()
 npos = int(s["n_positions"].sum())
 mac = sum(o["k"] * o["cin"] * o["cout"] for o in desc["ops"] if o["op"] == "conv")
-for math in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["bf16x6"]):
+for math in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["f16x3"]):
     ctx.cnn_set_math(math)
     ctx.run("cnn"); ctx.sync()
     best = 1e9
     for _ in range(3):
         t0 = time.perf_counter(); ctx.run("cnn"); ctx.sync(); best = min(best, time.perf_counter() - t0)
-    print("math %s reads %d positions %d  cnn %.2f ms  %.2f Mpos/s  network %.2f TFLOP/s algorithmic (fp32 MFMA peak 157, 6 x bf16 peak 417)" %
+    print("math %s reads %d positions %d  cnn %.2f ms  %.2f Mpos/s  network %.2f TFLOP/s algorithmic (peaks: fp32 MFMA 157, 6 x bf16 417, 3 x fp16 833)" %
           (math, n_reads, npos, best * 1e3, npos / best / 1e6, 2.0 * mac * npos / best / 1e12))
