@@ -162,6 +162,17 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][BN / 64], float *
         }
 }
 
+// Workgroup numbering of the conv kernels (1-D grid): consecutive workgroup ids go round-robin to the 8 XCDs, each with its own
+// L2.  Id L runs on XCD L % 8; on one XCD consecutive ids walk the COLUMN tiles of one row tile before moving to the next row
+// tile, so the second (third, fourth) read of the same activation rows hits that XCD's L2 instead of HBM.
+__device__ __forceinline__ bool conv_tile(int cout, int BN, int rows, int &m0, int &n0) {
+    const int nct = cout / BN;
+    const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+    m0 = ((slot / nct) * 8 + xcd) * CNN_BM; n0 = (slot % nct) * BN;
+    return m0 < rows;
+}
+static inline unsigned conv_grid(unsigned rows, int cout, int BN) { return ((rows / CNN_BM + 7) / 8) * 8 * (unsigned)(cout / BN); }
+
 template <int BN, int NBUF, bool ADD>
 __global__ __launch_bounds__(256) void k3_conv(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wt,
                                                   const float *__restrict__ scale, const float *__restrict__ shift,
@@ -171,7 +182,8 @@ __global__ __launch_bounds__(256) void k3_conv(const float *__restrict__ X, floa
     __shared__ __attribute__((aligned(16))) float Bs[NBUF][BN * CNN_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;              // each wavefront: 64 rows x BN/2 columns
-    const int m0 = blockIdx.x * CNN_BM, n0 = blockIdx.y * BN;
+    int m0, n0;
+    if (!conv_tile(cout, BN, rows, m0, n0)) return;
     constexpr int NJ = BN / 64;                           // 32-wide column tiles per wavefront
     constexpr int NB = BN / 32;                           // float4 B loads per thread per step
     f32x16 acc[2][NJ];
@@ -302,7 +314,8 @@ __global__ __launch_bounds__(256) void k3_conv_split(const float *__restrict__ X
     __shared__ __attribute__((aligned(16))) uint16_t Bs[NP][BN * CNN_BP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * CNN_BM, n0 = blockIdx.y * BN;
+    int m0, n0;
+    if (!conv_tile(cout, BN, rows, m0, n0)) return;
     constexpr int NJ = BN / 64;
     constexpr int NBQ = BN / 64;                          // 16-byte B chunks per thread per piece
     f32x16 acc[2][NJ];
@@ -409,6 +422,365 @@ __global__ __launch_bounds__(256) void k3_conv_split(const float *__restrict__ X
     conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, m0, n0, wm, wn, lane, cout, relu, post);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k3_sep_split: SeparableConv1D in ONE kernel -- the depthwise filter is applied while the A tile of the pointwise GEMM is
+// staged, so its output never goes to HBM (as two kernels the pair moves 4 x rows x C x 4 bytes, fused 2 x; the 29 separable
+// layers are memory-side, so that is most of their time).
+//   per channel block (32 channels):
+//     raw tile   (128 + KW - 1) rows x 32 channels of fp32 input, global -> registers (one step ahead) -> LDS, pitch 40 floats
+//     depthwise  thread = 4 consecutive rows x 4 channels: a register window slides over KW + 3 input rows (each read once
+//                from LDS), taps accumulate in ascending order with fmaf -- bit-identical to k3_dwconv -- and the four results
+//                are split into 16-bit pieces and written to the A planes
+//     pointwise  the 1-tap step of k3_conv_split on those planes
+//   Two barriers per block: [A planes complete / raw tile free] -> next raw tile + taps to LDS, MFMAs -> [planes and B free] ->
+//   next B tile to LDS, next depthwise.  A workgroup does not overlap its own depthwise with its own MFMAs; the 2 workgroups of a CU do.
+// The raw-tile pitch (160 B) makes 4 rows advance the bank window by half (640 mod 256 = 128): the four 16-lane groups of a
+// ds_read_b128 (MI355X_MICROARCH.md, LDS) then cover all 64 banks once.
+// ---------------------------------------------------------------------------------------------------------
+#define SEP_XP 40                                           // floats per raw-tile row
+template <int BN, int KW, bool ADD, int NP>
+__global__ __launch_bounds__(256) void k3_sep_split(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wd,
+                                                    const uint16_t *__restrict__ Wb, const float *__restrict__ scale,
+                                                    const float *__restrict__ shift, const float *__restrict__ Add,
+                                                    const uint8_t *__restrict__ valid, int rows, int cin, int cout, int relu, float post,
+                                                    unsigned *range_flag) {
+    constexpr int XROWS = CNN_BM + KW - 1;
+    constexpr int NLD = (XROWS * 8 + 255) / 256;           // float4 loads per thread for one raw tile
+    __shared__ __attribute__((aligned(16))) float Xr[XROWS * SEP_XP];
+    __shared__ __attribute__((aligned(16))) float Wl[KW * 32];
+    __shared__ __attribute__((aligned(16))) uint16_t As[NP][CNN_BM * CNN_BP];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[NP][BN * CNN_BP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int m0, n0;
+    if (!conv_tile(cout, BN, rows, m0, n0)) return;
+    constexpr int NJ = BN / 64;
+    constexpr int NBQ = BN / 64;
+    constexpr int half = (KW - 1) / 2;
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
+    const int cblocks = cin >> 5;
+    const int l_r = tid >> 2, l_k = (tid & 3) * 8;        // B loader: 64 rows x 4 chunks of 8 elements per pass
+    const int dq = tid & 7, dr = (tid >> 3) * 4;          // depthwise: channels 4 dq .. 4 dq + 3, output rows dr .. dr + 3
+    f32x4 rx[NLD]; bool pin[NLD];
+    u32x4 rb[NP][NBQ];
+    f32x4 rw = {0.f, 0.f, 0.f, 0.f};
+    float amax = 0.0f;
+    auto gloadX = [&](int cb) {
+#pragma unroll
+        for (int p = 0; p < NLD; p++) {
+            const int f = tid + 256 * p, rr = f >> 3, q = f & 7;
+            const int src = m0 - half + rr;
+            const bool in = rr < XROWS && src >= 0 && src < rows;
+            rx[p] = *reinterpret_cast<const f32x4 *>(X + (size_t)(in ? src : m0) * cin + (cb << 5) + q * 4);
+            pin[p] = in;
+        }
+        if (tid < KW * 8) rw = *reinterpret_cast<const f32x4 *>(Wd + (size_t)(tid >> 3) * cin + (cb << 5) + (tid & 7) * 4);
+    };
+    auto lstoreX = [&]() {                                  // raw tile + the depthwise taps of the same channel block
+#pragma unroll
+        for (int p = 0; p < NLD; p++) {
+            const int f = tid + 256 * p, rr = f >> 3, q = f & 7;
+            if (rr < XROWS) *reinterpret_cast<f32x4 *>(&Xr[rr * SEP_XP + q * 4]) = pin[p] ? rx[p] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (tid < KW * 8) *reinterpret_cast<f32x4 *>(&Wl[(tid >> 3) * 32 + (tid & 7) * 4]) = rw;
+    };
+    auto gloadB = [&](int cb) {
+#pragma unroll
+        for (int pc = 0; pc < NP; pc++) {
+            const uint16_t *wb = Wb + ((size_t)(cb * NP + pc) * cout + n0) * 32;
+#pragma unroll
+            for (int q = 0; q < NBQ; q++) rb[pc][q] = *reinterpret_cast<const u32x4 *>(wb + (size_t)(q * 64 + l_r) * 32 + l_k);
+        }
+    };
+    auto lstoreB = [&]() {
+#pragma unroll
+        for (int pc = 0; pc < NP; pc++)
+#pragma unroll
+            for (int q = 0; q < NBQ; q++) *reinterpret_cast<u32x4 *>(&Bs[pc][(q * 64 + l_r) * CNN_BP + l_k]) = rb[pc][q];
+    };
+    auto depthwise = [&]() {
+        f32x4 o[4], w[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KW + 3; j++) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(&Xr[(dr + j) * SEP_XP + dq * 4]);
+            if (j < KW) w[j & 3] = *reinterpret_cast<const f32x4 *>(&Wl[j * 32 + dq * 4]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int t = j - i;                       // tap of output row dr + i that input row dr + j meets
+                if (t >= 0 && t < KW) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) o[i][e] = __builtin_fmaf(x[e], w[t & 3][e], o[i][e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int off = (dr + i) * CNN_BP + dq * 4;
+            if (NP == 3) {
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                bf16x4 h, m, l;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float x = o[i][e];
+                    const __bf16 hh = (__bf16)x; const float r1 = x - (float)hh;
+                    const __bf16 mm = (__bf16)r1; const float r2 = r1 - (float)mm;
+                    h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
+                }
+                *reinterpret_cast<bf16x4 *>(&As[0][off]) = h; *reinterpret_cast<bf16x4 *>(&As[1][off]) = m; *reinterpret_cast<bf16x4 *>(&As[NP - 1][off]) = l;
+            } else {
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                f16x4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float x = o[i][e];
+                    amax = fmaxf(amax, fabsf(x));
+                    const _Float16 hh = (_Float16)x;
+                    h[e] = hh; l[e] = (_Float16)(x - (float)hh);
+                }
+                *reinterpret_cast<f16x4 *>(&As[0][off]) = h; *reinterpret_cast<f16x4 *>(&As[1][off]) = l;
+            }
+        }
+    };
+    gloadX(0); gloadB(0);
+    lstoreX(); lstoreB();
+    __syncthreads();
+    gloadX(min(1, cblocks - 1)); gloadB(min(1, cblocks - 1));
+    depthwise();
+    const int fm = lane & 31, fk = (lane >> 5) * 8;
+    for (int cb = 0; cb < cblocks; cb++) {
+        __syncthreads();                                   // A planes of cb complete; the raw tile is free
+        lstoreX();                                         // raw tile of cb + 1 (loaded during the previous block)
+        gloadX(min(cb + 2, cblocks - 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k16 = 0; k16 < 2; k16++) {
+            u32x4 a[2][NP], b[NJ][NP];
+#pragma unroll
+            for (int pc = 0; pc < NP; pc++) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) a[i][pc] = *reinterpret_cast<const u32x4 *>(&As[pc][(wm * 64 + i * 32 + fm) * CNN_BP + k16 * 16 + fk]);
+#pragma unroll
+                for (int j = 0; j < NJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(&Bs[pc][(wn * (BN / 2) + j * 32 + fm) * CNN_BP + k16 * 16 + fk]);
+            }
+            constexpr int NT = NP == 3 ? 6 : 3;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                constexpr int PA3[6] = {1, 2, 0, 1, 0, 0}, PB3[6] = {1, 0, 2, 0, 1, 0};
+                constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
+                const int pa = NP == 3 ? PA3[t] : PA2[t % 3], pb = NP == 3 ? PB3[t] : PB2[t % 3];
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < NJ; j++)
+                        acc[i][j] = mfma16<NP>(a[i][pa], b[j][pb], acc[i][j]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (cb + 1 < cblocks) {                            // wave-uniform
+            __syncthreads();                               // every wavefront is done with the planes and the B tile; raw tile of cb + 1 visible
+            lstoreB();
+            gloadB(min(cb + 2, cblocks - 1));
+            depthwise();
+        }
+    }
+    if (NP == 2 && __any(amax > 65504.0f) && lane == 0) atomicOr(range_flag, 1u);
+    conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, m0, n0, wm, wn, lane, cout, relu, post);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k3_sep_ws: the fused SeparableConv1D with WAVE SPECIALISATION.  In k3_sep_split a workgroup alternates between its
+// depthwise phase (vector unit + LDS) and its pointwise phase (matrix cores); the two never overlap inside the workgroup, and
+// the measured time is close to the sum of both (17-tap layers: slower than the two-kernel path).  Here a workgroup has 8
+// wavefronts with fixed roles, two per SIMD:
+//     producers (4)  raw rows global -> registers -> their own slice of LDS (32 + KW - 1 rows each: no cross-wave dependency),
+//                    depthwise filter out of that slice, 16-bit pieces into the A planes of the NEXT channel block
+//     consumers (4)  the MFMAs of the CURRENT channel block on its A planes and B tile; B tile of the next block to LDS
+// A planes, B tile and tap table are double-buffered: ONE barrier per channel block, and the vector work of block cb + 1 runs
+// beside the matrix work of block cb on every SIMD (the matrix pipe and the vector pipe issue from different wavefronts).
+// ---------------------------------------------------------------------------------------------------------
+template <int BN, int KW, bool ADD, int NP>
+__global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wd,
+                                                 const uint16_t *__restrict__ Wb, const float *__restrict__ scale,
+                                                 const float *__restrict__ shift, const float *__restrict__ Add,
+                                                 const uint8_t *__restrict__ valid, int rows, int cin, int cout, int relu, float post,
+                                                 unsigned *range_flag) {
+    constexpr int SROWS = 32 + KW - 1;                     // raw rows a producer wave needs for its 32 output rows
+    constexpr int NLD = (SROWS * 8 + 63) / 64;             // float4 loads per lane for one raw slice
+    __shared__ __attribute__((aligned(16))) float Xr[4][SROWS * SEP_XP];
+    __shared__ __attribute__((aligned(16))) float Wl[2][KW * 32];
+    __shared__ __attribute__((aligned(16))) uint16_t As[2][NP][CNN_BM * CNN_BP];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NP][BN * CNN_BP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;                       // wave-uniform
+    int m0, n0;
+    if (!conv_tile(cout, BN, rows, m0, n0)) return;
+    constexpr int NJ = BN / 64;
+    constexpr int NBQ = BN / 64;
+    constexpr int half = (KW - 1) / 2;
+    const int cblocks = cin >> 5;
+    // ---- consumer state ----
+    const int cw = wave & 3, wm = cw >> 1, wn = cw & 1;
+    const int ct = tid & 255;
+    const int l_r = ct >> 2, l_k = (ct & 3) * 8;          // B loader (consumer threads): 64 rows x 4 chunks of 8 elements per pass
+    u32x4 rb[NP][NBQ];
+    // ---- producer state ----
+    const int pw = wave & 3;                               // slice: output rows 32 pw .. 32 pw + 31 of the tile
+    const int dq = lane & 7, dr = (lane >> 3) * 4;         // channels 4 dq .. 4 dq + 3, rows dr .. dr + 3 of the slice
+    f32x4 rx[NLD]; bool pin[NLD];
+    f32x4 rw = {0.f, 0.f, 0.f, 0.f};
+    float amax = 0.0f;
+    float *Xs = Xr[pw];
+    auto gloadX = [&](int cb) {
+#pragma unroll
+        for (int p = 0; p < NLD; p++) {
+            const int f = lane + 64 * p, rr = f >> 3, q = f & 7;
+            const int src = m0 + 32 * pw - half + rr;
+            const bool in = rr < SROWS && src >= 0 && src < rows;
+            rx[p] = *reinterpret_cast<const f32x4 *>(X + (size_t)(in ? src : m0) * cin + (cb << 5) + q * 4);
+            pin[p] = in;
+        }
+        const int wt = ct;                                 // taps: KW x 8 float4, spread over the 256 producer threads
+        if (wt < KW * 8) rw = *reinterpret_cast<const f32x4 *>(Wd + (size_t)(wt >> 3) * cin + (cb << 5) + (wt & 7) * 4);
+    };
+    auto lstoreX = [&](int wbuf) {
+#pragma unroll
+        for (int p = 0; p < NLD; p++) {
+            const int f = lane + 64 * p, rr = f >> 3, q = f & 7;
+            if (rr < SROWS) *reinterpret_cast<f32x4 *>(&Xs[rr * SEP_XP + q * 4]) = pin[p] ? rx[p] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (ct < KW * 8) *reinterpret_cast<f32x4 *>(&Wl[wbuf][(ct >> 3) * 32 + (ct & 7) * 4]) = rw;
+    };
+    auto gloadB = [&](int cb) {
+#pragma unroll
+        for (int pc = 0; pc < NP; pc++) {
+            const uint16_t *wb = Wb + ((size_t)(cb * NP + pc) * cout + n0) * 32;
+#pragma unroll
+            for (int q = 0; q < NBQ; q++) rb[pc][q] = *reinterpret_cast<const u32x4 *>(wb + (size_t)(q * 64 + l_r) * 32 + l_k);
+        }
+    };
+    auto lstoreB = [&](int buf) {
+#pragma unroll
+        for (int pc = 0; pc < NP; pc++)
+#pragma unroll
+            for (int q = 0; q < NBQ; q++) *reinterpret_cast<u32x4 *>(&Bs[buf][pc][(q * 64 + l_r) * CNN_BP + l_k]) = rb[pc][q];
+    };
+    auto depthwise = [&](int abuf, int wbuf) {
+        f32x4 o[4], w[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KW + 3; j++) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(&Xs[(dr + j) * SEP_XP + dq * 4]);
+            if (j < KW) w[j & 3] = *reinterpret_cast<const f32x4 *>(&Wl[wbuf][j * 32 + dq * 4]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int t = j - i;                       // tap of output row dr + i that input row dr + j meets
+                if (t >= 0 && t < KW) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) o[i][e] = __builtin_fmaf(x[e], w[t & 3][e], o[i][e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int off = (32 * pw + dr + i) * CNN_BP + dq * 4;
+            if (NP == 3) {
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                bf16x4 h, m, l;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float x = o[i][e];
+                    const __bf16 hh = (__bf16)x; const float r1 = x - (float)hh;
+                    const __bf16 mm = (__bf16)r1; const float r2 = r1 - (float)mm;
+                    h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
+                }
+                *reinterpret_cast<bf16x4 *>(&As[abuf][0][off]) = h; *reinterpret_cast<bf16x4 *>(&As[abuf][1][off]) = m;
+                *reinterpret_cast<bf16x4 *>(&As[abuf][NP - 1][off]) = l;
+            } else {
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                f16x4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float x = o[i][e];
+                    amax = fmaxf(amax, fabsf(x));
+                    const _Float16 hh = (_Float16)x;
+                    h[e] = hh; l[e] = (_Float16)(x - (float)hh);
+                }
+                *reinterpret_cast<f16x4 *>(&As[abuf][0][off]) = h; *reinterpret_cast<f16x4 *>(&As[abuf][1][off]) = l;
+            }
+        }
+    };
+    // The two roles run their own loops (the accumulators exist only on the consumer side, the filter window only on the producer
+    // side: the register allocation is the larger of the two, not the sum).  Every wavefront executes the same number of barriers.
+    if (producer) {
+        gloadX(0); lstoreX(0); gloadX(min(1, cblocks - 1));
+        __syncthreads();
+        depthwise(0, 0); lstoreX(1); gloadX(min(2, cblocks - 1));
+        __syncthreads();
+        for (int cb = 0; cb < cblocks; cb++) {
+            const int cur = cb & 1, nxt = cur ^ 1;
+            if (cb + 1 < cblocks) {
+                depthwise(nxt, nxt);                       // block cb + 1: its raw slice and taps were stored during block cb - 1
+                lstoreX(cur);                              // raw slice + taps of block cb + 2 (this wave is done reading its slice)
+                gloadX(min(cb + 3, cblocks - 1));
+            }
+            __syncthreads();
+        }
+        if (NP == 2 && __any(amax > 65504.0f) && lane == 0) atomicOr(range_flag, 1u);
+        return;
+    }
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
+    gloadB(0); lstoreB(0); gloadB(min(1, cblocks - 1));
+    __syncthreads();
+    __syncthreads();
+    const int fm = lane & 31, fk = (lane >> 5) * 8;
+    for (int cb = 0; cb < cblocks; cb++) {
+        const int cur = cb & 1, nxt = cur ^ 1;
+        lstoreB(nxt);                                      // B tile of block cb + 1 (registers loaded during block cb - 1)
+        gloadB(min(cb + 2, cblocks - 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k16 = 0; k16 < 2; k16++) {
+            u32x4 a[2][NP], b[NJ][NP];
+#pragma unroll
+            for (int pc = 0; pc < NP; pc++) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) a[i][pc] = *reinterpret_cast<const u32x4 *>(&As[cur][pc][(wm * 64 + i * 32 + fm) * CNN_BP + k16 * 16 + fk]);
+#pragma unroll
+                for (int j = 0; j < NJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(&Bs[cur][pc][(wn * (BN / 2) + j * 32 + fm) * CNN_BP + k16 * 16 + fk]);
+            }
+            constexpr int NT = NP == 3 ? 6 : 3;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                constexpr int PA3[6] = {1, 2, 0, 1, 0, 0}, PB3[6] = {1, 0, 2, 0, 1, 0};
+                constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
+                const int pa = NP == 3 ? PA3[t] : PA2[t % 3], pb = NP == 3 ? PB3[t] : PB2[t % 3];
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < NJ; j++)
+                        acc[i][j] = mfma16<NP>(a[i][pa], b[j][pb], acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+    conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, m0, n0, wm, wn, lane, cout, relu, post);
+}
+
 // depthwise part of SeparableConv1D: each thread owns 4 channels of DW_ROWS consecutive rows and slides a register window
 // over them, so every input row is read once per thread instead of k times
 #define DW_ROWS 16
@@ -507,10 +879,65 @@ struct CnnRun {
     unsigned *range_flag;             // device: set by the fp16 path when an activation does not fit fp16
 };
 
+static bool k3_sep_ws_enabled() { static const bool on = !(getenv("DN_CNN_SEP_WS") && atoi(getenv("DN_CNN_SEP_WS")) == 0); return on; }
+static bool k3_fuse_enabled() { static const bool on = !(getenv("DN_CNN_FUSE") && atoi(getenv("DN_CNN_FUSE")) == 0); return on; }
+
+// a depthwise op can be folded into the pointwise convolution that follows it when nothing else reads its output
+static bool k3_can_fuse(const CnnRun &c, int i) {
+    if (!c.wts_split || !k3_fuse_enabled() || i + 1 >= c.n_ops) return false;
+    const dn_cnn_op &d = c.ops[i], &p = c.ops[i + 1];
+    if (d.op != DN_CNN_DWCONV || (p.op != DN_CNN_CONV && p.op != DN_CNN_CONV_ADD) || p.k != 1 || p.src != d.dst || p.cin != d.cin) return false;
+    if (p.op == DN_CNN_CONV_ADD && p.a == d.dst) return false;
+    if (d.cin % 32 || p.cout % 64 || (d.k != 3 && d.k != 5 && d.k != 9 && d.k != 17)) return false;
+    for (int j = i + 2; j < c.n_ops; j++) {                // is the depthwise output read again before it is overwritten?
+        const dn_cnn_op &o = c.ops[j];
+        const bool reads = (o.op != DN_CNN_ENCODE_GRU && o.src == d.dst) || ((o.op == DN_CNN_ADD_RELU || o.op == DN_CNN_CONV_ADD) && o.a == d.dst) ||
+                           (o.op == DN_CNN_ADD_RELU && o.b == d.dst);
+        if (reads) return false;
+        if (o.dst == d.dst) break;
+    }
+    return true;
+}
+
+// Which fused kernel: the wave-specialised one pays off where the depthwise filter is long and the layer wide (17 taps, 256
+// output channels: one workgroup covers ALL 256 columns, so the filter is applied once per row tile); the short filters of the
+// narrow layers are memory-side and run better as k3_sep_split with 2-3 workgroups per CU.
+template <int BN, bool ADD, int NP>
+static int k3_launch_sep(const CnnRun &c, int i, const float *add, hipStream_t st) {
+    const dn_cnn_op &d = c.ops[i], &o = c.ops[i + 1];
+    const unsigned rows = c.rows.rows;
+#define SEP_ARGS c.buf[d.src], c.buf[o.dst], c.wts + d.w, c.wts_split + c.wb_off[i + 1], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, \
+        o.cin, o.cout, o.relu, c.post[i + 1], c.range_flag
+#define SEP_GO(KW_) hipLaunchKernelGGL((k3_sep_split<BN, KW_, ADD, NP>), dim3(conv_grid(rows, o.cout, BN)), dim3(256), 0, st, SEP_ARGS)
+    if (NP == 2 && d.k == 17 && o.cout % 256 == 0 && k3_sep_ws_enabled()) {
+        hipLaunchKernelGGL((k3_sep_ws<256, 17, ADD, 2>), dim3(conv_grid(rows, o.cout, 256)), dim3(512), 0, st, SEP_ARGS);
+        return 0;
+    }
+    switch (d.k) { case 3: SEP_GO(3); break; case 5: SEP_GO(5); break; case 9: SEP_GO(9); break; case 17: SEP_GO(17); break; default: return -1; }
+#undef SEP_GO
+#undef SEP_ARGS
+    return 0;
+}
+
 int k3_run(const CnnRun &c, hipStream_t st) {
     const unsigned rows = c.rows.rows;
     for (int i = 0; i < c.n_ops; i++) {
         const dn_cnn_op &o = c.ops[i];
+        if (k3_can_fuse(c, i)) {
+            const dn_cnn_op &pw = c.ops[i + 1];
+            const float *add = pw.op == DN_CNN_CONV_ADD ? c.buf[pw.a] : nullptr;
+            int rc;
+            if (c.pieces == 3) {
+                if (pw.cout % 128 == 0) rc = add ? k3_launch_sep<128, true, 3>(c, i, add, st) : k3_launch_sep<128, false, 3>(c, i, add, st);
+                else rc = add ? k3_launch_sep<64, true, 3>(c, i, add, st) : k3_launch_sep<64, false, 3>(c, i, add, st);
+            } else {
+                if (pw.cout % 128 == 0) rc = add ? k3_launch_sep<128, true, 2>(c, i, add, st) : k3_launch_sep<128, false, 2>(c, i, add, st);
+                else rc = add ? k3_launch_sep<64, true, 2>(c, i, add, st) : k3_launch_sep<64, false, 2>(c, i, add, st);
+            }
+            if (rc) return rc;
+            i++;                                           // the pointwise op is done too
+            continue;
+        }
         switch (o.op) {
             case DN_CNN_ENCODE_GRU:
                 hipMemsetAsync(c.buf[o.dst], 0, (size_t)rows * 64 * sizeof(float), st);
@@ -522,9 +949,9 @@ int k3_run(const CnnRun &c, hipStream_t st) {
                 if (o.cin % 32 || o.cout % 64) return -1;
             {
                 const float *add = o.op == DN_CNN_CONV_ADD ? c.buf[o.a] : nullptr;          // fused residual join: y = act(conv + buf[a])
-#define CONV_GO(BN_, NBUF_, ADD_) hipLaunchKernelGGL((k3_conv<BN_, NBUF_, ADD_>), dim3(rows / CNN_BM, o.cout / BN_), dim3(256), 0, st, \
+#define CONV_GO(BN_, NBUF_, ADD_) hipLaunchKernelGGL((k3_conv<BN_, NBUF_, ADD_>), dim3(conv_grid(rows, o.cout, BN_)), dim3(256), 0, st, \
         c.buf[o.src], c.buf[o.dst], c.wts + o.w, c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu)
-#define CONV_GO_SP(BN_, ADD_, NP_) hipLaunchKernelGGL((k3_conv_split<BN_, ADD_, NP_>), dim3(rows / CNN_BM, o.cout / BN_), dim3(256), 0, st, \
+#define CONV_GO_SP(BN_, ADD_, NP_) hipLaunchKernelGGL((k3_conv_split<BN_, ADD_, NP_>), dim3(conv_grid(rows, o.cout, BN_)), dim3(256), 0, st, \
         c.buf[o.src], c.buf[o.dst], c.wts_split + c.wb_off[i], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu, \
         c.post[i], c.range_flag)
 #define CONV_GO_BF(BN_, ADD_) do { if (c.pieces == 3) CONV_GO_SP(BN_, ADD_, 3); else CONV_GO_SP(BN_, ADD_, 2); } while (0)

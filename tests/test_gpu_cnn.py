@@ -134,3 +134,15 @@ def test_f16_split_escalates_when_an_activation_leaves_fp16_range():
     got = ctx.cnn_infer(g["lens"], g["core"], g["resid"], g["signal"])
     assert ctx.cnn_range_escalations() == 1
     assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_fused_separable_conv_is_bit_identical_to_two_kernels():
+    """SeparableConv1D runs as one kernel (depthwise filter applied while the pointwise GEMM's A tile is staged; the 17-tap
+    256-channel layers in the wave-specialised variant).  Same taps in the same order, same pieces, same MFMA order: the
+    probabilities must be bit-identical to the depthwise + pointwise kernel pair (DN_CNN_FUSE=0), in both split modes."""
+    import os, subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "cnn_fuse_check.py")
+    out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if "fused == unfused" in l]
+    assert len(lines) == 2 and all("True" in l for l in lines), out.stdout
