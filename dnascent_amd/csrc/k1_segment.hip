@@ -139,6 +139,24 @@ __device__ __forceinline__ double div_w(double a, double d, double r) {
     return fma(fma(-q, d, a), r, q);
 }
 
+// (float)(fabs((double)dm) / sqrt((double)vw)) of event_detection.c:111 -- an IEEE fp64 sqrt and an IEEE fp64 division (~55
+// instructions) whose result is immediately rounded to fp32.  Fast path: y = |dm| * rsqrt(vw) from v_rsq_f64 + two Newton steps
+// is within ~2^-50 relative (< 10 ulp64) of the reference's double q; (float)y == (float)q unless a rounding boundary of fp32
+// (a midpoint between two floats: low 29 mantissa bits == 0x10000000) lies between them.  y within 1024 ulp64 of such a
+// midpoint (64 would do for a 2^-26 v_rsq_f64; 1024 = 2^-43 relative is kept as slack) -- 4e-6 of all inputs -- or outside the
+// normal fp32 range takes the exact path; everything else is bit-identical by construction.
+__device__ __forceinline__ float tstat_ratio(float dm, float vw) {
+    const double a = fabs((double)dm), v = (double)vw;
+    double s = __builtin_amdgcn_rsq(v);
+    s = s * fma(-0.5 * v * s, s, 1.5);
+    s = s * fma(-0.5 * v * s, s, 1.5);
+    const double y = a * s;
+    const unsigned lo = (unsigned)__double_as_longlong(y) & 0x1FFFFFFFu;
+    const bool risky = (lo - 0x0FFFFC00u) <= 0x800u || !((y > 0x1p-100 && y < 0x1p100) || y == 0.0);
+    if (__builtin_expect(__any(risky), 0)) return (float)(a / sqrt(v));
+    return (float)y;
+}
+
 template <unsigned W>
 __device__ __forceinline__ float tstat_at(const double2 *P, unsigned n, unsigned i) {
     constexpr unsigned w = W;
@@ -159,7 +177,7 @@ __device__ __forceinline__ float tstat_at(const double2 *P, unsigned n, unsigned
     var = fmaxf(var, FLT_MIN);                                   // :104
     const float dm = mean2 - mean1;                              // :110
     const float vw = div_w(var, wf, rwf);
-    return (float)(fabs((double)dm) / sqrt((double)vw));         // :111
+    return tstat_ratio(dm, vw);                                  // :111
 }
 
 __global__ __launch_bounds__(256) void k1_tstat(BatchDev B) {

@@ -127,6 +127,30 @@ __device__ __forceinline__ void cell(float diag, float up, float left, double x,
     score = mx; from = f;
 }
 
+// the same cell with the diagonal operand already widened: "diag" of band b is "up" of band b - 1, whose (double) conversion
+// band b - 1 computed anyway -- k2_fill6 carries it over instead of converting the same float twice
+__device__ __forceinline__ void cell_d(double ddiag, float up, float left, double x, double mu, const FillConsts &fc,
+                                       double lp_step, double lp_stay, float &score, unsigned &from, double &dup) {
+    const double d = x - mu;
+    const double q = d * fc.rsigma;
+    const double rem = fma(-q, fc.sigma, d);
+    const double ad = fma(rem, fc.rsigma, q);
+    const float a = (float)ad;                            // :133
+    float t = -0.5f * a;                                  // :135
+    t = t * a;
+    const float em = (float)(fc.C + (double)t);           // :135-136
+    const double emd = (double)em;
+    dup = (double)up;
+    const float sd = (float)((ddiag + lp_step) + emd);          // :296
+    const float su = (float)((dup + lp_stay) + emd);            // :297
+    const float sl = (float)((double)left + fc.lp_skip);        // :298
+    float mx;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(sd), "v"(su), "v"(sl));
+    unsigned f = (su == mx) ? 1u : 0u;
+    f = (sl == mx) ? 2u : f;
+    score = mx; from = f;
+}
+
 // uniform (wave-wide) loads of the one new x / mu value a band needs go through the scalar unit (s_load, counted
 // on lgkmcnt): the loop then holds no vector load, so its trace stores are never waited for (loads and stores share
 // the in-order vmcnt on gfx950).  The arrays were written by earlier kernels and are read-only here, which is what
@@ -338,7 +362,8 @@ __device__ __forceinline__ void writelane_pair_d(double &A, double &Bv, double v
 }
 
 struct F6State {
-    float PA, PB, DA, DB;
+    float PA, PB;
+    double DA, DB;           // the diagonal operands, kept widened (see cell_d)
     double XA, XB, MA, MB;
     int ev, km;              // lower-left corner of the last band
 };
@@ -390,9 +415,9 @@ __device__ __forceinline__ void f6_band(F6State &st, const int b, const int E, c
     writelane_pair_d(st.MA, st.MB, in.m1, in.m0, l_hi);
     // ---- operands: left = same slot, up = previous slot, diag = the previous band's up ----
     const float upA = ror_f(st.PB), upB = st.PA;
-    float SA, SB; unsigned FA, FB;
-    cell(st.DA, upA, st.PA, st.XA, st.MA, fc, lp_step, lp_stay, SA, FA);
-    cell(st.DB, upB, st.PB, st.XB, st.MB, fc, lp_step, lp_stay, SB, FB);
+    float SA, SB; unsigned FA, FB; double dupA, dupB;
+    cell_d(st.DA, upA, st.PA, st.XA, st.MA, fc, lp_step, lp_stay, SA, FA, dupA);
+    cell_d(st.DB, upB, st.PB, st.XB, st.MB, fc, lp_step, lp_stay, SB, FB, dupB);
     // ---- Suzuki-Kasahara move (:237-253) from the end cells of the previous band: events ev (lower left) and ev - 99 ----
     const int lo = (ev0 & 1) ? loB : loA, hi = (el0 & 1) ? hiB : hiA;
     // integer 0/1 arithmetic (scalar unit, no branch): both end cells out of band -> alternate by parity, else ll < ur
@@ -432,7 +457,7 @@ __device__ __forceinline__ void f6_band(F6State &st, const int b, const int E, c
     }
     FA = actA ? FA : 0xFFu; FB = actB ? FB : 0xFFu;
     rows16[(size_t)b * (DN_TROW / 2) + (lane2 >> 1)] = (unsigned short)(FA | (FB << 8));
-    st.DA = upA; st.DB = upB; st.PA = SA; st.PB = SB;
+    st.DA = dupA; st.DB = dupB; st.PA = SA; st.PB = SB;
 }
 
 __global__ __launch_bounds__(64) void k2_fill6(BatchDev B, const BandConsts *bc, FillConsts fc) {
@@ -455,7 +480,7 @@ __global__ __launch_bounds__(64) void k2_fill6(BatchDev B, const BandConsts *bc,
     // slot events as seen from band 1 (events -49 .. 50 are in the band; the other slots belong to the events that enter next)
     const int eA = 50 - (int)(((unsigned)(50 - lane2)) & 127u), eB = 50 - (int)(((unsigned)(50 - lane2 - 1)) & 127u);
     st.PA = (eA == 0) ? (float)fc.lp_trim : NINF; st.PB = NINF;          // band 1: cell (event 0, kmer -1) = lp_trim (:224-228)
-    st.DA = (lane == 0) ? 0.0f : NINF; st.DB = NINF;                     // band 0: cell (event -1, kmer -1) = 0 is the up operand of event 0
+    st.DA = (lane == 0) ? 0.0 : (double)NINF; st.DB = (double)NINF;      // band 0: cell (event -1, kmer -1) = 0 is the up operand of event 0
     auto ldx = [&](int e) -> double { return (e >= 0 && e < E) ? xs[e] : 0.0; };
     auto ldm = [&](int k) -> double { return (k >= 0 && k < K) ? mus[k] : 0.0; };
     st.XA = ldx(eA); st.XB = ldx(eB);

@@ -1,21 +1,39 @@
-"""Per-layer table of the last CNN run in a rocprofv3 kernel trace: python tools/cnn_layers.py <trace.csv> <n_positions>"""
+"""Per-layer table of the last CNN run in a rocprofv3 kernel trace: python tools/cnn_layers.py <trace.csv> <n_positions>
+A fused SeparableConv1D (k3_sep_*) covers a depthwise op and the pointwise conv after it."""
 import csv, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dnascent_amd import cnn_model
 desc, _, _ = cnn_model.default_model()
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k3_" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-npos = int(sys.argv[2]); n = len(desc["ops"]); tot = 0; agg = {}
-for o, r in zip(desc["ops"], rows[-n:]):
+npos = int(sys.argv[2]); ops = desc["ops"]
+# kernels of one run: walk the op list backwards from the end of the trace
+n_fused = sum(1 for r in rows if "k3_sep" in r["Kernel_Name"])
+runs = max(1, sum(1 for r in rows if "k3_encode" in r["Kernel_Name"]))
+per_run = len(rows) // runs
+last = rows[-per_run:]
+tot = 0; agg = {}; i = 0
+for r in last:
+    o = ops[i]
     dt = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; tot += dt
+    if "k3_sep" in r["Kernel_Name"]:
+        pw = ops[i + 1]
+        kind = "ws" if "k3_sep_ws" in r["Kernel_Name"] else "  "
+        key = "sep%s k%-2d %3d->%3d" % (kind, o["k"], pw["cin"], pw["cout"]); fl = 2 * (pw["cin"] * pw["cout"] + o["k"] * o["c"]) * npos
+        a = agg.setdefault(key, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += dt; a[2] += fl; a[3] += npos * (pw["cin"] + pw["cout"]) * 4
+        i += 2; continue
     if o["op"] == "conv":
-        key = "conv k%-2d %3d->%3d" % (o["k"], o["cin"], o["cout"]); fl = 2 * o["k"] * o["cin"] * o["cout"] * npos
-        a = agg.setdefault(key, [0, 0.0, 0.0]); a[0] += 1; a[1] += dt; a[2] += fl
+        key = "conv  k%-2d %3d->%3d" % (o["k"], o["cin"], o["cout"]); fl = 2 * o["k"] * o["cin"] * o["cout"] * npos
+        a = agg.setdefault(key, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += dt; a[2] += fl; a[3] += npos * (o["cin"] + o["cout"]) * 4
     elif o["op"] == "dwconv":
-        key = "dw   k%-2d %3d     " % (o["k"], o["c"]); a = agg.setdefault(key, [0, 0.0, 0.0]); a[0] += 1; a[1] += dt; a[2] += npos * o["c"] * 8
+        key = "dw    k%-2d %3d     " % (o["k"], o["c"]); a = agg.setdefault(key, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += dt; a[3] += npos * o["c"] * 8
     else:
-        a = agg.setdefault(o["op"], [0, 0.0, 0.0]); a[0] += 1; a[1] += dt
-for k, (c, dt, w) in agg.items():
-    extra = ("%7.1f TFLOP/s" % (w / dt / 1e6)) if k.startswith("conv") else (("%7.0f GB/s" % (w / dt / 1e3)) if k.startswith("dw") else "")
-    print("%-18s x%-2d %9.1f us %s" % (k, c, dt, extra))
+        a = agg.setdefault(o["op"], [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += dt
+    i += 1
+assert i == len(ops), (i, len(ops))
+for k, (c, dt, fl, by) in agg.items():
+    extra = ""
+    if fl: extra += "%7.1f TFLOP/s" % (fl / dt / 1e6)
+    if by: extra += "  %5.0f GB/s of layer I/O" % (by / dt / 1e3)
+    print("%-20s x%-2d %9.1f us %s" % (k, c, dt, extra))
 print("total %.2f ms" % (tot / 1e3))
