@@ -32,7 +32,8 @@ int k2_fill_variant();
 struct CnnRows { const unsigned *row_off; const uint8_t *valid; unsigned rows, r0, r1; const unsigned *n_pos; const uint64_t *io_off; };
 struct CnnRun { const dn_cnn_op *ops; int n_ops; const float *wts; float *buf[8]; int n_buf; CnnRows rows; uint8_t *valid;
                  const float *core, *resid, *sig; float *probs; unsigned max_pos; const uint16_t *wts_split; const int64_t *wb_off;
-                 int pieces; const float *post; unsigned *range_flag; };
+                 int pieces; const float *post; unsigned *range_flag;
+                 unsigned n_pass_pos; uint8_t *enc_len; unsigned *enc_hist; uint64_t *perm_src; unsigned *perm_row; };
 int k3_run(const CnnRun &, hipStream_t);
 struct HmmConstsH { double D2D, D2M, I2M, M2D, M2I, I2I, ln025, ln05; };
 struct HmmReadH { double iM2M, eM2M, endM; };
@@ -82,7 +83,7 @@ struct dn_ctx {
     FillConstsH fc{};
     std::vector<int64_t> cnn_wb_off, cnn_wh_off; uint16_t *d_cnn_wb = nullptr, *d_cnn_wh = nullptr; size_t cnn_nwb = 0, cnn_nwh = 0; int cnn_math = DN_CNN_MATH_F16X3;
     std::vector<float> cnn_post, cnn_one; unsigned *d_cnn_flag = nullptr; uint64_t cnn_escalations = 0; bool cnn_f16_off = false;
-    std::vector<dn_cnn_op> cnn_ops; float *d_cnn_w = nullptr; size_t cnn_nw = 0; int cnn_nbuf = 0; DevBuf cnn_buf[8], cnn_valid, cnn_rowoff, cnn_npos, cnn_iooff, cnn_in[3], cnn_out;
+    std::vector<dn_cnn_op> cnn_ops; float *d_cnn_w = nullptr; size_t cnn_nw = 0; int cnn_nbuf = 0; DevBuf cnn_buf[8], cnn_valid, cnn_rowoff, cnn_npos, cnn_iooff, cnn_in[3], cnn_out, cnn_enclen, cnn_enchist, cnn_permsrc, cnn_permrow;
     float *d_probs = nullptr;
     double4 *d_fit[2] = { nullptr, nullptr }; bool have_fit = false, hmm_done = false;
     DevBuf hmm_poi, hmm_npoi, hmm_nev, hmm_ok, hmm_la, hmm_lt, hmm_reads;
@@ -264,7 +265,8 @@ void dn_ctx_destroy(dn_ctx *c) {
     for (DevBuf *b : { &c->hmm_poi, &c->hmm_npoi, &c->hmm_nev, &c->hmm_ok, &c->hmm_la, &c->hmm_lt, &c->hmm_reads }) if (b->p) hipFree(b->p);
     for (auto &b : c->cnn_buf) if (b.p) hipFree(b.p);
     if (c->cnn_valid.p) hipFree(c->cnn_valid.p);
-    for (DevBuf *b : { &c->cnn_rowoff, &c->cnn_npos, &c->cnn_iooff, &c->cnn_in[0], &c->cnn_in[1], &c->cnn_in[2], &c->cnn_out }) if (b->p) hipFree(b->p);
+    for (DevBuf *b : { &c->cnn_rowoff, &c->cnn_npos, &c->cnn_iooff, &c->cnn_in[0], &c->cnn_in[1], &c->cnn_in[2], &c->cnn_out, &c->cnn_enclen,
+                       &c->cnn_enchist, &c->cnn_permsrc, &c->cnn_permrow }) if (b->p) hipFree(b->p);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -833,25 +835,27 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *npos, const uint64
     // sequences are packed end to end, CNN_PAD (8) zero rows around each; passes of at most cnn_row_cap() rows
     const uint64_t cap = cnn_row_cap();
     std::vector<unsigned> row_off(n, 0u);
-    struct Pass { uint32_t r0, r1; unsigned rows, max_pos; };
+    struct Pass { uint32_t r0, r1; unsigned rows, max_pos, n_pos; };
     std::vector<Pass> passes;
-    uint64_t rows = 8; unsigned max_pos = 1; uint32_t r0 = 0; uint64_t max_rows = 0;
+    uint64_t rows = 8; unsigned max_pos = 1, pass_pos = 0; uint32_t r0 = 0; uint64_t max_rows = 0;
     for (uint32_t r = 0; r < n; r++) {
         const unsigned np = npos[r];
         if (rows + np + 8 > cap && r > r0) {
             const uint64_t rr = (rows + 127) / 128 * 128;
-            passes.push_back({ r0, r, (unsigned)rr, max_pos }); max_rows = std::max(max_rows, rr);
-            r0 = r; rows = 8; max_pos = 1;
+            passes.push_back({ r0, r, (unsigned)rr, max_pos, pass_pos }); max_rows = std::max(max_rows, rr);
+            r0 = r; rows = 8; max_pos = 1; pass_pos = 0;
         }
         row_off[r] = (unsigned)rows;
-        rows += np + 8;
+        rows += np + 8; pass_pos += np;
         if (rows >= (1ull << 31)) return fail(c, DN_ERR_OVERFLOW, "sequence %u has too many positions for one CNN pass", r);
         max_pos = std::max(max_pos, np);
     }
-    { const uint64_t rr = (rows + 127) / 128 * 128; passes.push_back({ r0, n, (unsigned)rr, max_pos }); max_rows = std::max(max_rows, rr); }
+    { const uint64_t rr = (rows + 127) / 128 * 128; passes.push_back({ r0, n, (unsigned)rr, max_pos, pass_pos }); max_rows = std::max(max_rows, rr); }
     int rc;
     for (int b = 0; b < c->cnn_nbuf; b++)
         if ((rc = dgrow(c, c->cnn_buf[b], (size_t)max_rows * 256 * sizeof(float)))) return rc;
+    if ((rc = dgrow(c, c->cnn_enclen, (size_t)max_rows)) || (rc = dgrow(c, c->cnn_enchist, 64 * sizeof(unsigned))) ||
+        (rc = dgrow(c, c->cnn_permsrc, (size_t)max_rows * sizeof(uint64_t))) || (rc = dgrow(c, c->cnn_permrow, (size_t)max_rows * sizeof(unsigned)))) return rc;
     if ((rc = dgrow(c, c->cnn_valid, (size_t)max_rows)) || (rc = dgrow(c, c->cnn_rowoff, n * sizeof(unsigned))) ||
         (rc = dgrow(c, c->cnn_npos, n * sizeof(unsigned))) || (rc = dgrow(c, c->cnn_iooff, n * sizeof(uint64_t)))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->cnn_rowoff.p, row_off.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
@@ -869,6 +873,8 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *npos, const uint64
         run.rows.r0 = ps.r0; run.rows.r1 = ps.r1;
         run.rows.n_pos = (const unsigned *)c->cnn_npos.p; run.rows.io_off = (const uint64_t *)c->cnn_iooff.p;
         run.valid = (uint8_t *)c->cnn_valid.p;
+        run.n_pass_pos = ps.n_pos; run.enc_len = (uint8_t *)c->cnn_enclen.p; run.enc_hist = (unsigned *)c->cnn_enchist.p;
+        run.perm_src = (uint64_t *)c->cnn_permsrc.p; run.perm_row = (unsigned *)c->cnn_permrow.p;
         run.core = d_core; run.resid = d_resid; run.sig = d_sig; run.probs = d_probs; run.max_pos = ps.max_pos;
         // fp16 pieces are only valid while every activation fits fp16: the kernels raise range_flag otherwise and the pass is
         // repeated with bf16 pieces (same result contract, 2x the matrix work) -- never a silently wrong answer

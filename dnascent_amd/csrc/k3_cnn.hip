@@ -52,15 +52,17 @@ __device__ __forceinline__ void gru_matvec(const float (&h)[16], cfptr_t W, floa
     }
 }
 
-__global__ __launch_bounds__(64) void k3_encode(const float *core, const float *resid, const float *sig, CnnRows R,
-                                                uint8_t *valid_out, float *out, const float *wts, dn_cnn_op op) {
-    const int r = R.r0 + blockIdx.y;
-    const unsigned p = blockIdx.x * 64 + threadIdx.x;
-    const bool live = p < R.n_pos[r];
-    if (__ballot(live) == 0) return;
+// Positions are visited in order of DESCENDING signal length (k3_encode_len / k3_encode_perm below): a wavefront runs as many
+// time steps as its longest position, and the lengths are spread from 3 to the cap of 20 (mean ~10), so sorted wavefronts run
+// half the steps of wavefronts of 64 consecutive positions.  Any order gives the same numbers: positions are independent.
+__global__ __launch_bounds__(64) void k3_encode(const float *core, const float *resid, const float *sig, const uint64_t *perm_src,
+                                                const unsigned *perm_row, unsigned n_total, uint8_t *valid_out, float *out,
+                                                const float *wts, dn_cnn_op op) {
+    const unsigned i = blockIdx.x * 64 + threadIdx.x;
+    const bool live = i < n_total;
     cfptr_t K1 = (cfptr_t)(wts + op.aux[0]), R1 = (cfptr_t)(wts + op.aux[1]), b1 = (cfptr_t)(wts + op.aux[2]);
     cfptr_t K2 = (cfptr_t)(wts + op.aux[3]), R2 = (cfptr_t)(wts + op.aux[4]), b2 = (cfptr_t)(wts + op.aux[5]);
-    const uint64_t src = R.io_off[r] + (live ? p : 0);
+    const uint64_t src = perm_src[live ? i : 0];
     float h1[16], h2[16];
 #pragma unroll
     for (int u = 0; u < 16; u++) { h1[u] = 0.f; h2[u] = 0.f; }
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(64) void k3_encode(const float *core, const float *
         }
     }
     if (!live) return;
-    const unsigned row = R.row_off[r] + p;
+    const unsigned row = perm_row[i];
     float4 *o = reinterpret_cast<float4 *>(out + (size_t)row * 64);
 #pragma unroll
     for (int q = 0; q < 4; q++) o[q] = make_float4(h2[q * 4], h2[q * 4 + 1], h2[q * 4 + 2], h2[q * 4 + 3]);
@@ -110,6 +112,54 @@ __global__ __launch_bounds__(64) void k3_encode(const float *core, const float *
 #pragma unroll
     for (int q = 13; q < 16; q++) o[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     valid_out[row] = 1;
+}
+
+// signal length of a position = index of its last non-zero sample + 1 (reads.h:147 pads with zeros; a masked step is x == 0)
+#define ENC_BINS (DN_RAWDEPTH_DEV + 1)
+__global__ __launch_bounds__(256) void k3_encode_len(const float *sig, CnnRows R, uint8_t *len_by_row, unsigned *hist) {
+    __shared__ unsigned h[ENC_BINS];
+    const int r = R.r0 + blockIdx.y;
+    const unsigned p = blockIdx.x * 256 + threadIdx.x;
+    const bool live = p < R.n_pos[r];
+    if (threadIdx.x < ENC_BINS) h[threadIdx.x] = 0;
+    __syncthreads();
+    if (live) {
+        const float4 *x = reinterpret_cast<const float4 *>(sig + (R.io_off[r] + p) * DN_RAWDEPTH_DEV);   // 80-byte rows: 16-byte aligned
+        unsigned len = 0;
+#pragma unroll
+        for (int q = 0; q < DN_RAWDEPTH_DEV / 4; q++) {
+            const float4 v = x[q];
+            if (v.x != 0.0f) len = 4 * q + 1;
+            if (v.y != 0.0f) len = 4 * q + 2;
+            if (v.z != 0.0f) len = 4 * q + 3;
+            if (v.w != 0.0f) len = 4 * q + 4;
+        }
+        len_by_row[R.row_off[r] + p] = (uint8_t)len;
+        atomicAdd(&h[len], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < ENC_BINS && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// counting sort, longest first: slot = (positions with a longer signal) + rank inside the bin (workgroup-aggregated cursors)
+__global__ __launch_bounds__(256) void k3_encode_perm(CnnRows R, const uint8_t *len_by_row, const unsigned *hist, unsigned *cursor,
+                                                      uint64_t *perm_src, unsigned *perm_row) {
+    __shared__ unsigned h[ENC_BINS], base[ENC_BINS];
+    const int r = R.r0 + blockIdx.y;
+    const unsigned p = blockIdx.x * 256 + threadIdx.x;
+    const bool live = p < R.n_pos[r];
+    if (threadIdx.x < ENC_BINS) h[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned len = 0, rank = 0, row = 0;
+    if (live) { row = R.row_off[r] + p; len = len_by_row[row]; rank = atomicAdd(&h[len], 1u); }
+    __syncthreads();
+    if (threadIdx.x < ENC_BINS && h[threadIdx.x]) {
+        unsigned longer = 0;
+        for (int b = threadIdx.x + 1; b < ENC_BINS; b++) longer += hist[b];
+        base[threadIdx.x] = longer + atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]);
+    }
+    __syncthreads();
+    if (live) { const unsigned slot = base[len] + rank; perm_src[slot] = R.io_off[r] + p; perm_row[slot] = row; }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -877,6 +927,8 @@ struct CnnRun {
     int pieces;                       // 3: bf16x6, 2: f16x3
     const float *post;                // host, per op: inverse of the power of two the fp16 weights were scaled by (1 for bf16)
     unsigned *range_flag;             // device: set by the fp16 path when an activation does not fit fp16
+    unsigned n_pass_pos;              // positions of the sequences [r0, r1)
+    uint8_t *enc_len; unsigned *enc_hist; uint64_t *perm_src; unsigned *perm_row;   // device scratch of the encoder's counting sort
 };
 
 static bool k3_sep_ws_enabled() { static const bool on = !(getenv("DN_CNN_SEP_WS") && atoi(getenv("DN_CNN_SEP_WS")) == 0); return on; }
@@ -941,8 +993,13 @@ int k3_run(const CnnRun &c, hipStream_t st) {
         switch (o.op) {
             case DN_CNN_ENCODE_GRU:
                 hipMemsetAsync(c.buf[o.dst], 0, (size_t)rows * 64 * sizeof(float), st);
-                hipLaunchKernelGGL(k3_encode, dim3((c.max_pos + 63) / 64, c.rows.r1 - c.rows.r0), dim3(64), 0, st, c.core, c.resid, c.sig, c.rows,
-                                   c.valid, c.buf[o.dst], c.wts, o);
+                hipMemsetAsync(c.enc_hist, 0, 2 * ENC_BINS * sizeof(unsigned), st);
+                hipLaunchKernelGGL(k3_encode_len, dim3((c.max_pos + 255) / 256, c.rows.r1 - c.rows.r0), dim3(256), 0, st, c.sig, c.rows, c.enc_len, c.enc_hist);
+                hipLaunchKernelGGL(k3_encode_perm, dim3((c.max_pos + 255) / 256, c.rows.r1 - c.rows.r0), dim3(256), 0, st, c.rows, c.enc_len, c.enc_hist,
+                                   c.enc_hist + ENC_BINS, c.perm_src, c.perm_row);
+                if (c.n_pass_pos)
+                    hipLaunchKernelGGL(k3_encode, dim3((c.n_pass_pos + 63) / 64), dim3(64), 0, st, c.core, c.resid, c.sig, c.perm_src, c.perm_row, c.n_pass_pos,
+                                       c.valid, c.buf[o.dst], c.wts, o);
                 break;
             case DN_CNN_CONV:
             case DN_CNN_CONV_ADD:
