@@ -219,7 +219,7 @@ def main():
         achieved = alg_bytes / fill_s / 1e9 if fill_s > 0 else 0.0
         traffic = None
         try:   # HBM bytes per launch from the committed PMC passes (cannot be collected inside a timed run)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_k2_fill.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_k2_fill.json")))
             if pm["workload"] == {"reads": args.reads, "bases": args.bases}:
                 traffic = pm["write_bytes"] + pm["fetch_bytes_corrected"]
         except Exception:
