@@ -539,6 +539,7 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
     ReadRes &R = B.res[r];
     if (R.status != 0) return;
     const int E = (int)R.n_events, K = (int)R.n_kq;
+    (void)E;                                              // only the offset-keyed (SLOT == false) walk needs it
     const uint8_t *rows = B.trace + B.trace_off[r] * DN_TROW;
     const uint64_t a0 = B.aln_off[r];
     const unsigned cap = (unsigned)(B.aln_off[r + 1] - a0);
