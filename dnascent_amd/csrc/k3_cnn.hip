@@ -955,10 +955,10 @@ static bool k3_can_fuse(const CnnRun &c, int i) {
 // output channels: one workgroup covers ALL 256 columns, so the filter is applied once per row tile); the short filters of the
 // narrow layers are memory-side and run better as k3_sep_split with 2-3 workgroups per CU.
 template <int BN, bool ADD, int NP>
-static int k3_launch_sep(const CnnRun &c, int i, const float *add, hipStream_t st) {
+static int k3_launch_sep(const CnnRun &c, int i, const float *in, float *out, const float *add, hipStream_t st) {
     const dn_cnn_op &d = c.ops[i], &o = c.ops[i + 1];
     const unsigned rows = c.rows.rows;
-#define SEP_ARGS c.buf[d.src], c.buf[o.dst], c.wts + d.w, c.wts_split + c.wb_off[i + 1], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, \
+#define SEP_ARGS in, out, c.wts + d.w, c.wts_split + c.wb_off[i + 1], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, \
         o.cin, o.cout, o.relu, c.post[i + 1], c.range_flag
 #define SEP_GO(KW_) hipLaunchKernelGGL((k3_sep_split<BN, KW_, ADD, NP>), dim3(conv_grid(rows, o.cout, BN)), dim3(256), 0, st, SEP_ARGS)
     if (NP == 2 && d.k == 17 && o.cout % 256 == 0 && k3_sep_ws_enabled()) {
@@ -973,43 +973,52 @@ static int k3_launch_sep(const CnnRun &c, int i, const float *add, hipStream_t s
 
 int k3_run(const CnnRun &c, hipStream_t st) {
     const unsigned rows = c.rows.rows;
+    // logical buffer index -> device pointer.  A fused separable layer reads the depthwise INPUT while it writes the pointwise
+    // OUTPUT; model descriptions ping-pong (pointwise dst == depthwise src), and a workgroup's halo rows belong to its
+    // neighbours' tiles, so writing in place would race.  The fused kernel therefore writes into the (dead) buffer the
+    // depthwise op would have written, and the two logical buffers swap their pointers.
+    float *pb[8];
+    for (int b = 0; b < 8; b++) pb[b] = c.buf[b];
     for (int i = 0; i < c.n_ops; i++) {
         const dn_cnn_op &o = c.ops[i];
         if (k3_can_fuse(c, i)) {
             const dn_cnn_op &pw = c.ops[i + 1];
-            const float *add = pw.op == DN_CNN_CONV_ADD ? c.buf[pw.a] : nullptr;
+            const float *add = pw.op == DN_CNN_CONV_ADD ? pb[pw.a] : nullptr;
+            const float *in = pb[o.src];
+            float *out = pb[o.dst];                        // the depthwise op's own destination: never an input of this layer
             int rc;
             if (c.pieces == 3) {
-                if (pw.cout % 128 == 0) rc = add ? k3_launch_sep<128, true, 3>(c, i, add, st) : k3_launch_sep<128, false, 3>(c, i, add, st);
-                else rc = add ? k3_launch_sep<64, true, 3>(c, i, add, st) : k3_launch_sep<64, false, 3>(c, i, add, st);
+                if (pw.cout % 128 == 0) rc = add ? k3_launch_sep<128, true, 3>(c, i, in, out, add, st) : k3_launch_sep<128, false, 3>(c, i, in, out, add, st);
+                else rc = add ? k3_launch_sep<64, true, 3>(c, i, in, out, add, st) : k3_launch_sep<64, false, 3>(c, i, in, out, add, st);
             } else {
-                if (pw.cout % 128 == 0) rc = add ? k3_launch_sep<128, true, 2>(c, i, add, st) : k3_launch_sep<128, false, 2>(c, i, add, st);
-                else rc = add ? k3_launch_sep<64, true, 2>(c, i, add, st) : k3_launch_sep<64, false, 2>(c, i, add, st);
+                if (pw.cout % 128 == 0) rc = add ? k3_launch_sep<128, true, 2>(c, i, in, out, add, st) : k3_launch_sep<128, false, 2>(c, i, in, out, add, st);
+                else rc = add ? k3_launch_sep<64, true, 2>(c, i, in, out, add, st) : k3_launch_sep<64, false, 2>(c, i, in, out, add, st);
             }
             if (rc) return rc;
+            { float *t = pb[pw.dst]; pb[pw.dst] = pb[o.dst]; pb[o.dst] = t; }     // the result now IS the pointwise op's destination
             i++;                                           // the pointwise op is done too
             continue;
         }
         switch (o.op) {
             case DN_CNN_ENCODE_GRU:
-                hipMemsetAsync(c.buf[o.dst], 0, (size_t)rows * 64 * sizeof(float), st);
+                hipMemsetAsync(pb[o.dst], 0, (size_t)rows * 64 * sizeof(float), st);
                 hipMemsetAsync(c.enc_hist, 0, 2 * ENC_BINS * sizeof(unsigned), st);
                 hipLaunchKernelGGL(k3_encode_len, dim3((c.max_pos + 255) / 256, c.rows.r1 - c.rows.r0), dim3(256), 0, st, c.sig, c.rows, c.enc_len, c.enc_hist);
                 hipLaunchKernelGGL(k3_encode_perm, dim3((c.max_pos + 255) / 256, c.rows.r1 - c.rows.r0), dim3(256), 0, st, c.rows, c.enc_len, c.enc_hist,
                                    c.enc_hist + ENC_BINS, c.perm_src, c.perm_row);
                 if (c.n_pass_pos)
                     hipLaunchKernelGGL(k3_encode, dim3((c.n_pass_pos + 63) / 64), dim3(64), 0, st, c.core, c.resid, c.sig, c.perm_src, c.perm_row, c.n_pass_pos,
-                                       c.valid, c.buf[o.dst], c.wts, o);
+                                       c.valid, pb[o.dst], c.wts, o);
                 break;
             case DN_CNN_CONV:
             case DN_CNN_CONV_ADD:
                 if (o.cin % 32 || o.cout % 64) return -1;
             {
-                const float *add = o.op == DN_CNN_CONV_ADD ? c.buf[o.a] : nullptr;          // fused residual join: y = act(conv + buf[a])
+                const float *add = o.op == DN_CNN_CONV_ADD ? pb[o.a] : nullptr;          // fused residual join: y = act(conv + buf[a])
 #define CONV_GO(BN_, NBUF_, ADD_) hipLaunchKernelGGL((k3_conv<BN_, NBUF_, ADD_>), dim3(conv_grid(rows, o.cout, BN_)), dim3(256), 0, st, \
-        c.buf[o.src], c.buf[o.dst], c.wts + o.w, c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu)
+        pb[o.src], pb[o.dst], c.wts + o.w, c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu)
 #define CONV_GO_SP(BN_, ADD_, NP_) hipLaunchKernelGGL((k3_conv_split<BN_, ADD_, NP_>), dim3(conv_grid(rows, o.cout, BN_)), dim3(256), 0, st, \
-        c.buf[o.src], c.buf[o.dst], c.wts_split + c.wb_off[i], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu, \
+        pb[o.src], pb[o.dst], c.wts_split + c.wb_off[i], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu, \
         c.post[i], c.range_flag)
 #define CONV_GO_BF(BN_, ADD_) do { if (c.pieces == 3) CONV_GO_SP(BN_, ADD_, 3); else CONV_GO_SP(BN_, ADD_, 2); } while (0)
                 if (c.wts_split) {
@@ -1025,19 +1034,19 @@ int k3_run(const CnnRun &c, hipStream_t st) {
             case DN_CNN_DWCONV: {
                 const size_t n = (size_t)((rows + DW_ROWS - 1) / DW_ROWS) * (o.cin / 4);
                 const dim3 g((unsigned)((n + 255) / 256));
-#define DW_CASE(KW) case KW: hipLaunchKernelGGL(k3_dwconv<KW>, g, dim3(256), 0, st, c.buf[o.src], c.buf[o.dst], c.wts + o.w, c.valid, (int)rows, o.cin); break;
+#define DW_CASE(KW) case KW: hipLaunchKernelGGL(k3_dwconv<KW>, g, dim3(256), 0, st, pb[o.src], pb[o.dst], c.wts + o.w, c.valid, (int)rows, o.cin); break;
                 switch (o.k) { DW_CASE(3) DW_CASE(5) DW_CASE(7) DW_CASE(9) DW_CASE(17) default: return -1; }
 #undef DW_CASE
                 break;
             }
             case DN_CNN_ADD_RELU: {
                 const size_t n4 = (size_t)rows * o.cin / 4;
-                hipLaunchKernelGGL(k3_add_relu, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, c.buf[o.a], c.buf[o.b], c.buf[o.dst], n4);
+                hipLaunchKernelGGL(k3_add_relu, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, pb[o.a], pb[o.b], pb[o.dst], n4);
                 break;
             }
             case DN_CNN_DENSE_SOFTMAX:
                 if (o.cout != 3) return -1;
-                hipLaunchKernelGGL(k3_dense_softmax, dim3((c.max_pos + 63) / 64, c.rows.r1 - c.rows.r0), dim3(256), 0, st, c.buf[o.src], c.wts + o.w,
+                hipLaunchKernelGGL(k3_dense_softmax, dim3((c.max_pos + 63) / 64, c.rows.r1 - c.rows.r0), dim3(256), 0, st, pb[o.src], c.wts + o.w,
                                    c.wts + o.shift, c.rows, o.cin, c.probs);
                 break;
             default: return -1;
