@@ -7,8 +7,9 @@ running the oracle over everything would take minutes.  Size-independent propert
   * monotonicity     the rough alignment of every passing read is a monotone path (event and k-mer indices never decrease,
                      consecutive pairs differ by one of the three moves), event spans ascend without overlap;
   * spot parity      a sample of the reads -- both strands, first / middle / last of the batch -- against the oracle, bit-exact;
-  * the CNN at full size (20 M positions, several passes): every probability row sums to 1, and a read's probabilities are
-                     bit-identical whatever its place in the batch (other pass, other neighbours, other rows).
+  * eventalign, --HMM and the CNN at full size (20 M positions, several CNN passes): every probability row sums to 1, and a
+                     read's tensors, HMM calls and probabilities are bit-identical whatever its place in the batch (other
+                     pass, other neighbours, other rows).
 """
 import hashlib
 
@@ -41,6 +42,18 @@ def _per_read_digest(s, i):
     h = hashlib.sha256()
     for k in FIELDS:
         h.update(np.asarray(s[k][i]).tobytes())
+    return h.hexdigest()
+
+
+def _aux_digest(ctx, s, i):
+    """eventalign tensors and --HMM calls of read i (bit patterns)"""
+    h = hashlib.sha256()
+    pos = ctx.positions(i, int(s["n_positions"][i]))
+    for k in ("coord", "query_idx", "ref_idx", "indel", "n_signal", "core", "residual", "signal"):
+        h.update(np.ascontiguousarray(pos[k]).tobytes())
+    calls = ctx.hmm_calls(i, int(s["n_hmm_calls"][i]))
+    for k in ("pos_on_ref", "n_events", "llr"):
+        h.update(np.ascontiguousarray(calls[k]).tobytes())
     return h.hexdigest()
 
 
@@ -82,27 +95,27 @@ def test_full_size_batch_properties(model):
         o.free()
     d_fwd = [_per_read_digest(s1, i) for i in range(N_READS)]
     desc, blob, _ = cnn_model.default_model()
-    ctx.load_cnn(desc, blob)
-    ctx.run("eventalign"); ctx.run("cnn"); ctx.sync()
+    ctx.load_cnn(desc, blob); ctx.load_fit_models(*synth.fit_models())
+    ctx.run("hmm"); ctx.run("eventalign"); ctx.run("cnn"); ctx.sync()
     sp = ctx.summaries().copy()
     probe = [i for i in range(0, N_READS, 10) if sp["status"][i] == 0]
     p_fwd = {}
     for i in probe:
         p = ctx.probabilities(i, int(sp["n_positions"][i]))
         assert p.shape[0] > 15000 and np.allclose(p.sum(1), 1.0, atol=1e-5) and (p >= 0).all(), i
-        p_fwd[i] = hashlib.sha256(p.tobytes()).hexdigest()
+        p_fwd[i] = hashlib.sha256(p.tobytes()).hexdigest() + _aux_digest(ctx, sp, i)
     # ---- permutation invariance: reversed batch order, same per-read digests ----
     rev = fwd[::-1]
     _run(ctx, reads, rev)
     s3 = ctx.summaries()
     d_rev = [_per_read_digest(s3, j) for j in range(N_READS)]
     assert d_rev == d_fwd[::-1]
-    ctx.run("eventalign"); ctx.run("cnn"); ctx.sync()
+    ctx.run("hmm"); ctx.run("eventalign"); ctx.run("cnn"); ctx.sync()
     sq = ctx.summaries()
     for i in probe:
         j = N_READS - 1 - i
         assert int(sq["n_positions"][j]) == int(sp["n_positions"][i])
-        assert hashlib.sha256(ctx.probabilities(j, int(sq["n_positions"][j])).tobytes()).hexdigest() == p_fwd[i], i
+        assert hashlib.sha256(ctx.probabilities(j, int(sq["n_positions"][j])).tobytes()).hexdigest() + _aux_digest(ctx, sq, j) == p_fwd[i], i
     assert ctx.cnn_range_escalations() == 0
     # checksum of checksums, for the log
     print("full-size digest", hashlib.sha256("".join(d_fwd).encode()).hexdigest()[:16], "passing", int((s1["status"] == 0).sum()))
