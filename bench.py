@@ -190,6 +190,11 @@ def main():
             prof[k] = (a[0] + v[0], a[1] + v[1])
         c.profile(False)
     summ = ctx.summaries()
+    # every in-flight slot ran the same batch concurrently with the others: their per-read results must be identical bit for bit
+    # (outside the timed region; a disagreement fails the run instead of reporting a number)
+    for j, c in enumerate(ctxs[1:], 1):
+        if c.summaries().tobytes() != summ.tobytes():
+            raise SystemExit("bench: in-flight slot %d disagrees with slot 0 on the per-read results" % j)
     # the same kernel with the GPU to itself (not part of the timed region): one batch, nothing else in flight
     solo_fill_ms = None
     if nctx > 1 and rank == 0:
