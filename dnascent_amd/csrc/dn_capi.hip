@@ -725,6 +725,8 @@ int dn_load_cnn(dn_ctx *c, const dn_cnn_op *ops, uint32_t n_ops, const float *we
         if ((o.op == DN_CNN_CONV || o.op == DN_CNN_CONV_ADD) && (o.cin % 32 || o.cout % 64 || !(o.k & 1) || o.k > 17)) return fail(c, DN_ERR_ARG, "cnn op %u: conv shape not supported", i);
         if (o.op == DN_CNN_DWCONV && (o.cin % 4 || (o.k != 3 && o.k != 5 && o.k != 7 && o.k != 9 && o.k != 17)))
             return fail(c, DN_ERR_ARG, "cnn op %u: depthwise shape not supported", i);
+        // a convolution reads rows (halo) and channels that other workgroups of the same launch write: never in place
+        if ((o.op == DN_CNN_CONV || o.op == DN_CNN_CONV_ADD || o.op == DN_CNN_DWCONV) && o.src == o.dst) return fail(c, DN_ERR_ARG, "cnn op %u: convolution in place (src == dst)", i);
         if ((o.op == DN_CNN_CONV || o.op == DN_CNN_CONV_ADD) && (o.w < 0 || (uint64_t)o.w + (uint64_t)o.k * o.cin * o.cout > n_weights)) return fail(c, DN_ERR_ARG, "cnn op %u: weights out of range", i);
     }
     // conv kernels [k][cin][cout] (Keras order) -> [k][cin / 32][cout][32]: the B tile of k3_conv is then a straight copy

@@ -146,3 +146,17 @@ def test_fused_separable_conv_is_bit_identical_to_two_kernels():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if "fused == unfused" in l]
     assert len(lines) == 2 and all("True" in l for l in lines), out.stdout
+
+
+def test_in_place_convolution_is_rejected():
+    """Workgroups of one launch read rows / channels that others write: a description with src == dst on a convolution is an error,
+    not a silent race."""
+    import copy
+    desc, blob, _ = cnn_model.default_model()
+    d = copy.deepcopy(desc)
+    first = next(o for o in d["ops"] if o["op"] == "conv")
+    first["dst"] = first["src"]
+    ctx = hip.Context(0)
+    with pytest.raises(Exception, match="in place"):
+        ctx.load_cnn(d, blob)
+    ctx.load_cnn(desc, blob)                                # the context is still usable
