@@ -45,7 +45,9 @@ struct FillConstsH { double lp_skip, lp_trim, C, sigma, rsigma; };
 struct VitConstsH { double D2D, D2M, I2M, M2D, M2I, I2I; double c, d2, rd2, logc; double initD[66]; };
 struct VitReadH { double iM2M, eM2M, eM2MorD, eOrI; };
 struct EaDevH { unsigned *coord, *qidx, *ridx; int *indel; unsigned *nsig; float *sig, *core, *resid;
-                unsigned *win_ref, *win_len, *win_T; double *win_score; };
+                unsigned *win_ref, *win_len, *win_T; double *win_score;
+                unsigned *al_coord, *al_rpos; double *al_val; unsigned char *al_kind; const unsigned long long *al_off; unsigned *al_n; };
+void k2b_rowcap_launch(const BatchDev &, unsigned long long *, hipStream_t);
 
 namespace {
 
@@ -87,6 +89,7 @@ struct dn_ctx {
     float *d_probs = nullptr;
     double4 *d_fit[2] = { nullptr, nullptr }; bool have_fit = false, hmm_done = false;
     DevBuf hmm_poi, hmm_npoi, hmm_nev, hmm_ok, hmm_la, hmm_lt, hmm_reads;
+    bool want_align = false, have_align = false; DevBuf al_coord, al_rpos, al_val, al_kind, al_off, al_n; std::vector<unsigned long long> h_al_off; std::vector<unsigned> h_al_n;
     std::vector<unsigned> h_npoi, h_nhmm;
     std::vector<int32_t> h_ref_start, h_ref_end; std::vector<uint8_t> h_is_rev;
     VitConstsH vc{}; EaDevH ea{}; VitReadH *d_vitread = nullptr; unsigned max_ref = 0;
@@ -262,7 +265,8 @@ void dn_ctx_destroy(dn_ctx *c) {
     if (c->d_cnn_wh) hipFree(c->d_cnn_wh);
     if (c->d_cnn_flag) hipFree(c->d_cnn_flag);
     for (auto *p : c->d_fit) if (p) hipFree(p);
-    for (DevBuf *b : { &c->hmm_poi, &c->hmm_npoi, &c->hmm_nev, &c->hmm_ok, &c->hmm_la, &c->hmm_lt, &c->hmm_reads }) if (b->p) hipFree(b->p);
+    for (DevBuf *b : { &c->hmm_poi, &c->hmm_npoi, &c->hmm_nev, &c->hmm_ok, &c->hmm_la, &c->hmm_lt, &c->hmm_reads, &c->al_coord, &c->al_rpos,
+                       &c->al_val, &c->al_kind, &c->al_off, &c->al_n }) if (b->p) hipFree(b->p);
     for (auto &b : c->cnn_buf) if (b.p) hipFree(b.p);
     if (c->cnn_valid.p) hipFree(c->cnn_valid.p);
     for (DevBuf *b : { &c->cnn_rowoff, &c->cnn_npos, &c->cnn_iooff, &c->cnn_in[0], &c->cnn_in[1], &c->cnn_in[2], &c->cnn_out, &c->cnn_enclen,
@@ -544,9 +548,62 @@ int dn_run_eventalign(dn_ctx *c) {
     HIPCHK(c, hipMemcpyAsync(c->d_vitread, vr.data(), n * sizeof(VitReadH), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->ea.sig, 0, (size_t)c->h_ref_off[n] * DN_RAWDEPTH * sizeof(float), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // vr / newstat are locals
+    c->ea.al_coord = nullptr; c->ea.al_rpos = nullptr; c->ea.al_val = nullptr; c->ea.al_kind = nullptr; c->ea.al_off = nullptr; c->ea.al_n = nullptr;
+    c->have_align = false;
+    if (c->want_align) {
+        // rows per read are bounded by sum over its rough-alignment pairs of the event length: size the table exactly for that
+        if ((rc = dgrow(c, c->al_off, (n + 1) * sizeof(unsigned long long))) || (rc = dgrow(c, c->al_n, n * sizeof(unsigned)))) return rc;
+        k2b_rowcap_launch(c->B, (unsigned long long *)c->al_off.p, c->stream);
+        c->h_al_off.assign(n + 1, 0ull);
+        HIPCHK(c, hipMemcpyAsync(c->h_al_off.data() + 1, c->al_off.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (uint32_t r = 0; r < n; r++) c->h_al_off[r + 1] += c->h_al_off[r];
+        const size_t rows = std::max<size_t>((size_t)c->h_al_off[n], 1);
+        if ((rc = dgrow(c, c->al_coord, rows * 4)) || (rc = dgrow(c, c->al_rpos, rows * 4)) || (rc = dgrow(c, c->al_val, rows * 8)) ||
+            (rc = dgrow(c, c->al_kind, rows))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->al_off.p, c->h_al_off.data(), (n + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->al_n.p, 0, n * sizeof(unsigned), c->stream));
+        c->ea.al_coord = (unsigned *)c->al_coord.p; c->ea.al_rpos = (unsigned *)c->al_rpos.p; c->ea.al_val = (double *)c->al_val.p;
+        c->ea.al_kind = (unsigned char *)c->al_kind.p; c->ea.al_off = (const unsigned long long *)c->al_off.p; c->ea.al_n = (unsigned *)c->al_n.p;
+        c->have_align = true;
+    }
     { Timed t(c, DN_K_VITERBI); k2b_launch(c->B, &c->ea, c->d_vitread, &c->vc, c->max_ref, c->stream); }
     HIPCHK(c, hipGetLastError());
     c->stage = 6;
+    return DN_OK;
+}
+
+int dn_set_align_table(dn_ctx *c, int on) {
+    if (!c) return DN_ERR_ARG;
+    c->want_align = on != 0;
+    return DN_OK;
+}
+
+int dn_get_align_rows(dn_ctx *c, uint32_t *n_rows) {
+    int rc = need(c, 6, "dn_get_align_rows"); if (rc) return rc;
+    if (!n_rows) return DN_ERR_ARG;
+    if (c->B.n_reads == 0) return DN_OK;
+    if (!c->have_align) return fail(c, DN_ERR_STATE, "dn_set_align_table(ctx, 1) must precede dn_run_eventalign");
+    const uint32_t n = (uint32_t)c->B.n_reads;
+    c->h_al_n.resize(n);
+    HIPCHK(c, hipMemcpyAsync(c->h_al_n.data(), c->al_n.p, n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(n_rows, c->h_al_n.data(), n * sizeof(unsigned));
+    return DN_OK;
+}
+
+int dn_get_align_table(dn_ctx *c, uint32_t read, uint32_t n_rows, uint32_t *coord, uint32_t *ref_pos, double *value, uint8_t *kind) {
+    int rc = need(c, 6, "dn_get_align_table"); if (rc) return rc;
+    if (read >= (uint32_t)c->B.n_reads) return DN_ERR_ARG;
+    if (!c->have_align) return fail(c, DN_ERR_STATE, "dn_set_align_table(ctx, 1) must precede dn_run_eventalign");
+    const unsigned long long a0 = c->h_al_off[read];
+    if (a0 + n_rows > c->h_al_off[read + 1]) return fail(c, DN_ERR_ARG, "dn_get_align_table: read %u has at most %llu rows", read, c->h_al_off[read + 1] - a0);
+    if (n_rows == 0) return DN_OK;
+    if (coord) HIPCHK(c, hipMemcpyAsync(coord, (unsigned *)c->al_coord.p + a0, n_rows * 4ull, hipMemcpyDeviceToHost, c->stream));
+    if (ref_pos) HIPCHK(c, hipMemcpyAsync(ref_pos, (unsigned *)c->al_rpos.p + a0, n_rows * 4ull, hipMemcpyDeviceToHost, c->stream));
+    if (value) HIPCHK(c, hipMemcpyAsync(value, (double *)c->al_val.p + a0, n_rows * 8ull, hipMemcpyDeviceToHost, c->stream));
+    if (kind) HIPCHK(c, hipMemcpyAsync(kind, (unsigned char *)c->al_kind.p + a0, n_rows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return DN_OK;
 }
 

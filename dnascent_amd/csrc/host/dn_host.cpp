@@ -201,6 +201,65 @@ int runCNN(dn_ctx *ctx, ReadBatch &batch, bool humanReadable, std::vector<ReadCa
     return DN_OK;
 }
 
+static inline uint32_t kmer2index9(const char *k) {                     // data_IO.cpp:129-141: A0 T1 G2 C3, unknown -> 0
+    uint32_t r = 0;
+    for (int i = 0; i < 9; i++) { const char c = k[i]; r = r * 4u + (c == 'T' ? 1u : c == 'G' ? 2u : c == 'C' ? 3u : 0u); }
+    return r;
+}
+
+std::string formatAlignRecord(const std::string &readID, const std::string &contig, int refStart, int refEnd, bool isReverse,
+                              const std::string &refseq, const double *poreModelMean, size_t nRows, const uint32_t *coord,
+                              const uint32_t *refPos, const double *value, const uint8_t *kind) {
+    std::string out = ">" + readID + " " + contig + " " + std::to_string(refStart) + " " + std::to_string(refEnd) + " " +
+                      (isReverse ? "rev" : "fwd") + "\n";                                              // alignment.cpp:553
+    out.reserve(out.size() + nRows * 48);
+    char num[64];
+    for (size_t i = 0; i < nRows; i++) {
+        const std::string kmerStrand = refseq.substr(refPos[i], 9);                                     // :684
+        const std::string kmerRef = isReverse ? reverseComplement(kmerStrand) : kmerStrand;             // :688-695
+        int len = snprintf(num, sizeof num, "%u\t", coord[i]);
+        out.append(num, (size_t)len); out += kmerRef;
+        len = snprintf(num, sizeof num, "\t%f\t", value[i]);                                           // std::to_string(double)
+        out.append(num, (size_t)len);
+        if (kind[i] == 0) {
+            out += kmerStrand;
+            len = snprintf(num, sizeof num, "\t%f\n", poreModelMean[kmer2index9(kmerStrand.c_str())]);  // :701, :720
+            out.append(num, (size_t)len);
+        } else out += "NNNNNNNNN\t0\n";                                                                // :731
+    }
+    return out;
+}
+
+int alignWrite(dn_ctx *ctx, ReadBatch &batch, const double *poreModelMean, const std::string &path) {
+    int rc = dn_set_align_table(ctx, 1);
+    if (rc) return rc;
+    rc = dn_run_eventalign(ctx);
+    dn_set_align_table(ctx, 0);
+    if (rc) return rc;
+    const size_t n = batch.size();
+    batch.summary.resize(n);
+    if ((rc = dn_get_summaries(ctx, batch.summary.data()))) return rc;
+    std::vector<uint32_t> rows(n);
+    if (n && (rc = dn_get_align_rows(ctx, rows.data()))) return rc;
+    FILE *f = fopen(path.c_str(), "ab");
+    if (!f) return DN_ERR_ARG;
+    int written = 0;
+    std::vector<uint32_t> coord, rpos; std::vector<double> val; std::vector<uint8_t> kind;
+    for (size_t r = 0; r < n; r++) {
+        if (batch.summary[r].status != DN_READ_OK) continue;                                            // alignment.cpp:861-873
+        const size_t k = rows[r];
+        coord.resize(k); rpos.resize(k); val.resize(k); kind.resize(k);
+        if ((rc = dn_get_align_table(ctx, (uint32_t)r, (uint32_t)k, coord.data(), rpos.data(), val.data(), kind.data()))) { fclose(f); return rc; }
+        const std::string ref(batch.refseq.data() + batch.refseq_off[r], (size_t)(batch.refseq_off[r + 1] - batch.refseq_off[r]));
+        const std::string rec = formatAlignRecord(batch.readID[r], batch.contig[r], batch.ref_start[r], batch.ref_end[r], batch.is_reverse[r] != 0,
+                                                  ref, poreModelMean, k, coord.data(), rpos.data(), val.data(), kind.data());
+        fwrite(rec.data(), 1, rec.size(), f);                                                           // :876
+        written++;
+    }
+    fclose(f);
+    return written;
+}
+
 std::string formatHmmRecord(const std::string &readID, const std::string &contig, int refStart, int refEnd, bool isReverse,
                             const std::string &basecall, const std::string &refseq, size_t n, const uint32_t *posOnRef,
                             const uint32_t *posOnQuery, const int32_t *globalPos, const double *llr) {
@@ -317,6 +376,19 @@ uint64_t dnh_format_detect(const char *read_id, const char *contig, int ref_star
     const std::string s = DNAscent::formatDetectRecord(read_id, contig, ref_start, ref_end, is_reverse != 0, n, coord, kmer9, probs);
     if (s.size() <= cap) memcpy(buf, s.data(), s.size());
     return s.size();
+}
+
+uint64_t dnh_format_align(const char *read_id, const char *contig, int ref_start, int ref_end, int is_reverse, const char *refseq,
+                          uint32_t n_ref, const double *model_mean, uint32_t n_rows, const uint32_t *coord, const uint32_t *ref_pos,
+                          const double *value, const uint8_t *kind, char *buf, uint64_t cap) {
+    const std::string s = DNAscent::formatAlignRecord(read_id, contig, ref_start, ref_end, is_reverse != 0, std::string(refseq, n_ref), model_mean,
+                                                      n_rows, coord, ref_pos, value, kind);
+    if (s.size() <= cap) memcpy(buf, s.data(), s.size());
+    return s.size();
+}
+
+int dnh_align_write(void *ctx, void *b, const double *model_mean, const char *path) {
+    return DNAscent::alignWrite((dn_ctx *)ctx, *(ReadBatch *)b, model_mean, path);
 }
 
 // modBamFields; returns the number of calls, MM text into mm (NUL-terminated if it fits), ML bytes into ml (2 * calls)

@@ -93,6 +93,17 @@ std::string formatHmmRecord(const std::string &readID, const std::string &contig
                             const std::string &basecall, const std::string &refseq /* both in strand direction */, size_t n,
                             const uint32_t *posOnRef, const uint32_t *posOnQuery, const int32_t *globalPos, const double *llr);
 
+// `DNAscent align` (alignment.cpp:747-898): the record eventalign builds in r.humanReadable_eventalignOut -- header (:553) and
+// one line per raw sample (:697-733): "coord\tkmerRef\tscaled\tkmerStrand\tmodelMean" for matches,
+// "coord\tkmerRef\tscaled\tNNNNNNNNN\t0" for insertions.  refseq: referenceSeqMappedTo (strand direction);
+// poreModelMean: the 4^9 table in kmer2index order.  The rows come from dn_get_align_table.
+std::string formatAlignRecord(const std::string &readID, const std::string &contig, int refStart, int refEnd, bool isReverse,
+                              const std::string &refseq, const double *poreModelMean, size_t nRows, const uint32_t *coord,
+                              const uint32_t *refPos, const double *value, const uint8_t *kind);
+// eventalign with the table for an uploaded + normalised batch, records of the passing reads appended to `path`;
+// returns the number of reads written or a negative DN_* code
+int alignWrite(dn_ctx *ctx, ReadBatch &batch, const double *poreModelMean, const std::string &path);
+
 // writeDetectHeader (detect.cpp:196-232); the time stamp / software strings are the caller's (they are not parity data)
 std::string writeDetectHeader(const std::string &alignmentFilename, const std::string &refFilename, const std::string &indexFn,
                               int threads, unsigned quality, unsigned length, bool useGPU, const std::string &startTime,

@@ -30,6 +30,9 @@ struct VitRead { double iM2M, eM2M, eM2MorD, eOrI; };   // alignment.cpp:207-210
 struct EaDev {               // outputs, all at ref_off[r] (capacity = reference length of the read)
     unsigned *coord, *qidx, *ridx; int *indel; unsigned *nsig; float *sig /* x20 */, *core, *resid;
     unsigned *win_ref, *win_len, *win_T; double *win_score;
+    // `DNAscent align` table (alignment.cpp:697-733), optional (al_val == nullptr: not requested): one row per raw sample of
+    // every event labelled M and of every event labelled I before the window's last match; rows of read r start at al_off[r]
+    unsigned *al_coord, *al_rpos; double *al_val; unsigned char *al_kind; const unsigned long long *al_off; unsigned *al_n;
 };
 
 // log(0) is NaN in the reference (probability.cpp) and every use of it is one of: NaN + x = NaN, and lnGreaterThan
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
     __shared__ unsigned ps_p[VT_NS], ps_cnt[VT_NS];           // positions created by this window: lattice position, sample count
     __shared__ unsigned short evlab[VT_TMAX];             // label of the state that emitted observation t: state << 8 | position
     __shared__ unsigned char bt[(VT_TMAX + 1) * VT_NS];   // backtrace codes: I 2 bits | M 3 bits | D 2 bits
+    __shared__ unsigned ev_aoff[VT_TMAX];                 // align table: first row of each printed event (0xffffffff: not printed)
     const int r = blockIdx.x;
     const int lane = threadIdx.x;
     ReadRes &R = B.res[r];
@@ -122,6 +126,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
 
     unsigned readHead = 0; int ri = 0;
     unsigned npos = 0, nwin = 0;
+    unsigned al_rows = 0;                                 // rows of the align table written so far
     int fail = 0;
 
     while (ri < n_ref - (DN_K - 1)) {                     // alignment.cpp:556
@@ -345,11 +350,47 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
                 O.indel[f0 + slot] = indel; O.nsig[f0 + slot] = ps_cnt[q];
             }
         }
+        // ---- `align` table rows of this window (:697-733): events in order, each with all of its raw samples ----
+        if (O.al_val) {
+            unsigned carry = 0;
+            for (int base = 0; base < T; base += 64) {
+                const int e = base + lane;
+                const bool in = e < T;
+                const unsigned L = in ? evlab[e] : 0u;
+                const unsigned stt = L >> 8;
+                const bool emit = in && (stt == 1u || (stt == 2u && e < lastM_ev));      // :728: insertions only before the last match
+                const unsigned len = emit ? tk_len[e] : 0u;
+                unsigned run = len;
+#pragma unroll
+                for (int dlt = 1; dlt < 64; dlt <<= 1) { const unsigned up = __shfl_up(run, dlt); if (lane >= dlt) run += up; }
+                if (in) ev_aoff[e] = emit ? (al_rows + carry + run - len) : 0xffffffffu;
+                carry += __shfl(run, 63);
+            }
+            __syncthreads();
+            const unsigned long long A0 = O.al_off[r];
+            for (int e = lane; e < T; e += 64) {
+                const unsigned off = ev_aoff[e];
+                if (off == 0xffffffffu) continue;
+                const unsigned L = evlab[e];
+                const int p = (int)(L & 0xffu);
+                const unsigned char kind = ((L >> 8) == 1u) ? 0 : 1;
+                const unsigned coord = is_rev ? (unsigned)(coord0 - p - 1) : (unsigned)(coord0 + p);
+                const unsigned rs = tk_start[e], rl = tk_len[e];
+                for (unsigned j = 0; j < rl; j++) {
+                    const float v = ((float)adc[rs + j] + cal_off) * cal_sc;             // pod5.cpp:60
+                    const unsigned long long row = A0 + off + j;
+                    O.al_coord[row] = coord; O.al_rpos[row] = (unsigned)(ri + p); O.al_kind[row] = kind;
+                    O.al_val[row] = ((double)v - shift) / scale;                         // :705
+                }
+            }
+            al_rows += carry;
+        }
         readHead += (unsigned)lastM_ev + 1u;                // :739-740
         ri += lastM_ref + 1;
         __syncthreads();
     }
     if (lane == 0) {
+        if (O.al_n) O.al_n[r] = fail ? 0u : al_rows;
         R.n_positions = fail ? 0u : npos;
         R.n_windows = nwin;
         if (fail) R.status = fail;
@@ -369,6 +410,27 @@ __global__ __launch_bounds__(256) void k2b_features(BatchDev B, EaDev O) {
     res = ((base_code(km[0]) * 4u + base_code(km[1])) * 4u + base_code(km[7])) * 4u + base_code(km[8]);
     O.core[f0 + p] = (float)(core + 1u);
     O.resid[f0 + p] = (float)(res + 1u);
+}
+
+// upper bound of a read's align-table rows: an event is printed once per rough-alignment pair it is part of, with all its samples
+__global__ __launch_bounds__(256) void k2b_rowcap(BatchDev B, unsigned long long *cap) {
+    __shared__ unsigned long long part[4];
+    const int r = blockIdx.x;
+    const ReadRes &R = B.res[r];
+    unsigned long long s = 0;
+    if (R.status == 0) {
+        const uint64_t a0 = B.aln_off[r] + R.aln_begin;
+        const unsigned *len = B.ev_len + B.ev_off[r];
+        for (unsigned j = threadIdx.x; j < R.n_aligned; j += 256) s += len[B.aln_event[a0 + j]];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) cap[r] = part[0] + part[1] + part[2] + part[3];
+}
+void k2b_rowcap_launch(const BatchDev &B, unsigned long long *cap, hipStream_t st) {
+    hipLaunchKernelGGL(k2b_rowcap, dim3(B.n_reads), dim3(256), 0, st, B, cap);
 }
 
 void k2b_launch(const BatchDev &B, const void *ea, const void *vr, const void *vc, unsigned max_ref, hipStream_t st) {

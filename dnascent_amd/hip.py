@@ -19,7 +19,7 @@ for _i, _n in enumerate(K_NAMES):
 # every symbol include/dnascent_hip.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = ["dn_abi_version", "dn_device_count", "dn_ctx_create", "dn_ctx_destroy", "dn_last_error", "dn_sync",
            "dn_load_pore_model", "dn_batch_upload", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded",
-           "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_load_cnn", "dn_cnn_set_math", "dn_cnn_range_escalations", "dn_run_cnn", "dn_get_probabilities", "dn_cnn_infer", "dn_load_fit_models", "dn_run_hmm", "dn_get_hmm_calls", "dn_get_summaries", "dn_get_prefix_sums",
+           "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_set_align_table", "dn_get_align_rows", "dn_get_align_table", "dn_load_cnn", "dn_cnn_set_math", "dn_cnn_range_escalations", "dn_run_cnn", "dn_get_probabilities", "dn_cnn_infer", "dn_load_fit_models", "dn_run_hmm", "dn_get_hmm_calls", "dn_get_summaries", "dn_get_prefix_sums",
            "dn_get_tstats", "dn_get_scrappie_events", "dn_get_events", "dn_get_kmer_ranks", "dn_get_alignment",
            "dn_get_cleaned", "dn_get_trace", "dn_get_positions", "dn_get_windows", "dn_profile_enable", "dn_profile_get",
            "dn_profile_reset", "dn_kernel_name", "dn_device_bytes"]
@@ -91,7 +91,7 @@ def lib():
         L.dn_load_pore_model.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
         L.dn_batch_upload.argtypes = [C.c_void_p, C.POINTER(BatchDesc)]
         for n in ("dn_sync", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded", "dn_run_theilsen", "dn_run_normalise",
-                  "dn_run_eventalign", "dn_profile_reset"):
+                  "dn_run_eventalign", "dn_set_align_table", "dn_get_align_rows", "dn_get_align_table", "dn_profile_reset"):
             getattr(L, n).argtypes = [C.c_void_p]
         L.dn_load_cnn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32]
         L.dn_run_cnn.argtypes = [C.c_void_p]
@@ -113,6 +113,9 @@ def lib():
         L.dn_get_trace.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dn_get_positions.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 9
         L.dn_get_windows.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 4
+        L.dn_set_align_table.argtypes = [C.c_void_p, C.c_int]
+        L.dn_get_align_rows.argtypes = [C.c_void_p, C.c_void_p]
+        L.dn_get_align_table.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4
         L.dn_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.dn_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         L.dn_kernel_name.restype = C.c_char_p
@@ -265,6 +268,21 @@ class Context:
                                          d["indel"].ctypes.data, km.ctypes.data, d["n_signal"].ctypes.data, d["signal"].ctypes.data,
                                          d["core"].ctypes.data, d["residual"].ctypes.data), "dn_get_positions")
         d["kmer"] = np.frombuffer(km.tobytes(), dtype="S9").copy() if n else np.zeros(0, "S9")
+        return d
+
+    def set_align_table(self, on=True):
+        """`DNAscent align`: make the next run("eventalign") also materialise the per-sample event table."""
+        self._chk(lib().dn_set_align_table(self.h, int(on)), "dn_set_align_table")
+
+    def align_rows(self, n_reads):
+        n = np.zeros(n_reads, np.uint32)
+        self._chk(lib().dn_get_align_rows(self.h, n.ctypes.data), "dn_get_align_rows")
+        return n
+
+    def align_table(self, r, n):
+        d = dict(coord=np.zeros(n, np.uint32), ref_pos=np.zeros(n, np.uint32), value=np.zeros(n, np.float64), kind=np.zeros(n, np.uint8))
+        self._chk(lib().dn_get_align_table(self.h, r, n, d["coord"].ctypes.data, d["ref_pos"].ctypes.data, d["value"].ctypes.data,
+                                           d["kind"].ctypes.data), "dn_get_align_table")
         return d
 
     def windows(self, r, n):

@@ -38,6 +38,11 @@ def lib():
                                  C.c_void_p, C.c_uint64]
         L.dnh_detect_write.restype = C.c_int
         L.dnh_detect_write.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p]
+        L.dnh_format_align.restype = C.c_uint64
+        L.dnh_format_align.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.dnh_align_write.restype = C.c_int
+        L.dnh_align_write.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
         L.dnh_hmm_write.restype = C.c_int
         L.dnh_hmm_write.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p]
         L.dnh_detect_header.restype = C.c_uint64
@@ -62,6 +67,21 @@ def detect_header(alignment, genome, index, threads, quality, length, use_gpu, s
     n = lib().dnh_detect_header(alignment.encode(), genome.encode(), index.encode(), threads, quality, length, int(use_gpu),
                                 start_time.encode(), software.encode(), version.encode(), commit.encode(), buf, len(buf))
     return buf.raw[:n]
+
+
+def format_align(read_id, contig, ref_start, ref_end, is_reverse, refseq_strand, model_mean, table):
+    """DNAscent::formatAlignRecord -> bytes of one `DNAscent align` record (table: coord / ref_pos / value / kind arrays)."""
+    ref = bytes(refseq_strand)
+    mm = np.ascontiguousarray(model_mean, np.float64)
+    c = np.ascontiguousarray(table["coord"], np.uint32); p = np.ascontiguousarray(table["ref_pos"], np.uint32)
+    v = np.ascontiguousarray(table["value"], np.float64); k = np.ascontiguousarray(table["kind"], np.uint8)
+    n = c.shape[0]
+    cap = 256 + 80 * max(1, n)
+    buf = C.create_string_buffer(cap)
+    ln = lib().dnh_format_align(read_id.encode(), contig.encode(), ref_start, ref_end, int(is_reverse), ref, len(ref), mm.ctypes.data, n,
+                                c.ctypes.data, p.ctypes.data, v.ctypes.data, k.ctypes.data, buf, cap)
+    assert ln <= cap
+    return buf.raw[:ln]
 
 
 def format_detect(read_id, contig, ref_start, ref_end, is_reverse, coord, kmer_s9, probs):
@@ -141,6 +161,14 @@ class ReadBatch:
         rc = lib().dnh_hmm_write(ctx.h, self.h, path.encode(), header.encode() if header is not None else None)
         if rc < 0:
             raise _hip.DnError("dnh_hmm_write failed (%d): %s" % (rc, _hip.lib().dn_last_error(ctx.h).decode()))
+        return rc
+
+    def align_write(self, ctx, path, model_mean):
+        """`DNAscent align`: eventalign with the per-sample table for the normalised batch, records appended to path."""
+        mm = np.ascontiguousarray(model_mean, np.float64)
+        rc = lib().dnh_align_write(ctx.h, self.h, mm.ctypes.data, path.encode())
+        if rc < 0:
+            raise _hip.DnError("dnh_align_write failed (%d): %s" % (rc, _hip.lib().dn_last_error(ctx.h).decode()))
         return rc
 
     def detect_write(self, ctx, path, header=None):

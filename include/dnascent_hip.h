@@ -122,6 +122,15 @@ int dn_get_probabilities(dn_ctx *ctx, uint32_t read, float *probs /* [n_position
 int dn_cnn_infer(dn_ctx *ctx, uint32_t n_seq, const uint32_t *len, const float *core, const float *residual, const float *signal,
                  float *probs);
 
+/* ---- `DNAscent align` (alignment.cpp:747-898): the per-sample event table eventalign prints (alignment.cpp:697-733) ----
+ * dn_set_align_table(ctx, 1) before dn_run_eventalign makes that call also materialise, for every read that passes, one row per
+ * raw sample of every event labelled M and of every event labelled I before its window's last match, in the reference's
+ * emission order: reference coordinate of the event, start of kmerStrand in referenceSeqMappedTo (reference_index + pos),
+ * scaled sample (raw - shift) / scale, kind (0 match, 1 insertion).  The text of a record is host work (k-mers, "%f"). */
+int dn_set_align_table(dn_ctx *ctx, int on);
+int dn_get_align_rows(dn_ctx *ctx, uint32_t *n_rows /* [n_reads] */);
+int dn_get_align_table(dn_ctx *ctx, uint32_t read, uint32_t n_rows, uint32_t *coord, uint32_t *ref_pos, double *value, uint8_t *kind);
+
 /* ---- `detect --HMM` (detect.cpp:885): llAcrossRead (detect.cpp:393-574) + sequenceProbability (:235-378) ----
  * Fit models (config.h:53-54, import_poreModel_fitStdv data_IO.cpp:192): (mean, std) per 9-mer in kmer2index order.
  * dn_run_hmm needs dn_run_normalise only (the reference does not call eventalign in this mode).  Calls come back in the

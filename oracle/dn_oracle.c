@@ -620,6 +620,13 @@ int dno_eventalign(const dno_model *m, const dno_read *r, const dno_norm *nm, dn
     size_t wcap = n_ref / 8 + 16;
     o->win_ref = (uint32_t *)malloc(wcap * 4); o->win_len = (uint32_t *)malloc(wcap * 4); o->win_T = (uint32_t *)malloc(wcap * 4);
     o->win_score = (double *)malloc(wcap * 8);
+    /* an event appears once per rough-alignment pair it is part of, so the table can be longer than the signal: grow on demand */
+    size_t rcap = r->n_raw + 1024;
+    o->row_coord = (uint32_t *)malloc(rcap * 4); o->row_rpos = (uint32_t *)malloc(rcap * 4);
+    o->row_val = (double *)malloc(rcap * 8); o->row_kind = (uint8_t *)malloc(rcap);
+#define DNO_ROW_ROOM() do { if (o->n_rows == rcap) { rcap *= 2; o->row_coord = (uint32_t *)realloc(o->row_coord, rcap * 4); \
+        o->row_rpos = (uint32_t *)realloc(o->row_rpos, rcap * 4); o->row_val = (double *)realloc(o->row_val, rcap * 8); \
+        o->row_kind = (uint8_t *)realloc(o->row_kind, rcap); } } while (0)
     size_t tcap = 4096;
     uint32_t *taken = (uint32_t *)malloc(tcap * 4);
     double *tmeans = (double *)malloc(tcap * 8);
@@ -712,6 +719,18 @@ int dno_eventalign(const dno_model *m, const dno_read *r, const dno_norm *nm, dn
                     }
                     if (o->n_signal[idx] < DNO_RAWDEPTH) o->signal[idx * DNO_RAWDEPTH + o->n_signal[idx]] = (float)scaled;  /* reads.h:156 */
                     o->n_signal[idx]++;
+                    DNO_ROW_ROOM();                                      /* :717-722 (refCoordToCalls is empty in `align`) */
+                    o->row_coord[o->n_rows] = coord; o->row_rpos[o->n_rows] = ri + p; o->row_val[o->n_rows] = scaled;
+                    o->row_kind[o->n_rows] = 0; o->n_rows++;
+                }
+            }
+            else if (lst[i] == 2 && evIdx < lastM_ev) {                  /* :728-733 insertions before the last match */
+                const dno_event *ev = &nm->events[taken[evIdx]];
+                for (uint32_t s = 0; s < ev->raw_len; s++) {
+                    double scaled = (r->raw[ev->raw_start + s] - nm->shift) / nm->scale;
+                    DNO_ROW_ROOM();
+                    o->row_coord[o->n_rows] = coord; o->row_rpos[o->n_rows] = ri + p; o->row_val[o->n_rows] = scaled;
+                    o->row_kind[o->n_rows] = 1; o->n_rows++;
                 }
             }
             evIdx++;
@@ -726,6 +745,7 @@ done:
         char rs[4] = { km[0], km[1], km[7], km[8] };
         o->residual[i] = (float)(sub_index(rs, 4) + 1u);                 /* reads.h:125-138 */
     }
+#undef DNO_ROW_ROOM
     free(taken); free(tmeans); free(lst); free(lpos);
     return rc;
 }
@@ -733,7 +753,31 @@ done:
 void dno_align_free(dno_align *a) {
     free(a->coord); free(a->query_idx); free(a->ref_idx); free(a->indel_score); free(a->kmer); free(a->n_signal);
     free(a->signal); free(a->core); free(a->residual); free(a->win_ref); free(a->win_len); free(a->win_T); free(a->win_score);
+    free(a->row_coord); free(a->row_rpos); free(a->row_val); free(a->row_kind);
     memset(a, 0, sizeof(*a));
+}
+
+/* alignment.cpp:553 + :697-733.  kmerRef is the reverse complement of kmerStrand for reverse reads (:688-690). */
+size_t dno_format_align(const dno_model *m, const char *read_id, const char *contig, const dno_read *r, const dno_align *a,
+                        char *buf, size_t cap) {
+    size_t len = 0;
+    char line[160];
+    int n = snprintf(line, sizeof line, ">%s %s %d %d %s\n", read_id, contig, r->ref_start, r->ref_end, r->is_reverse ? "rev" : "fwd");
+    if (len + (size_t)n <= cap) memcpy(buf + len, line, (size_t)n);
+    len += (size_t)n;
+    for (size_t i = 0; i < a->n_rows; i++) {
+        char ks[10], kr[10];
+        memcpy(ks, r->refseq + a->row_rpos[i], 9); ks[9] = 0;
+        if (r->is_reverse) dno_reverse_complement(ks, 9, kr); else memcpy(kr, ks, 9);
+        kr[9] = 0;
+        if (a->row_kind[i] == 0)
+            n = snprintf(line, sizeof line, "%u\t%s\t%f\t%s\t%f\n", a->row_coord[i], kr, a->row_val[i], ks, m->mean[dno_kmer2index(ks, DNO_K)]);
+        else
+            n = snprintf(line, sizeof line, "%u\t%s\t%f\tNNNNNNNNN\t0\n", a->row_coord[i], kr, a->row_val[i]);
+        if (len + (size_t)n <= cap) memcpy(buf + len, line, (size_t)n);
+        len += (size_t)n;
+    }
+    return len;
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -138,10 +138,17 @@ typedef struct {
     double score_sum;      /* sum of finite window Viterbi scores (diagnostic) */
     /* per-window log for unit parity: ref_index, window_len, T */
     uint32_t *win_ref, *win_len, *win_T; double *win_score;
+    /* `DNAscent align` table (alignment.cpp:697-733): one row per raw sample of every event labelled M, and of every event
+     * labelled I before the window's last match, in emission order.  ref_pos = reference_index + pos (start of kmerStrand). */
+    size_t n_rows;
+    uint32_t *row_coord, *row_rpos; double *row_val; uint8_t *row_kind;   /* kind 0 = match, 1 = insertion */
 } dno_align;
 
 int  dno_eventalign(const dno_model *m, const dno_read *r, const dno_norm *n, dno_align *out);
 void dno_align_free(dno_align *a);
+/* text `DNAscent align` writes for the read (alignment.cpp:553 header + :697-733 rows, std::to_string = "%f") */
+size_t dno_format_align(const dno_model *m, const char *read_id, const char *contig, const dno_read *r, const dno_align *a,
+                        char *buf, size_t cap);
 
 /* ---- detect.cpp:235-378 sequenceProbability (forward algorithm, --HMM) ----
  * fit models: (mean, std) per 9-mer in kmer2index order (config.h:53-54, data_IO.cpp:192-240).

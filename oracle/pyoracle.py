@@ -44,7 +44,8 @@ class Align(C.Structure):
     _fields_ = [("n_pos", C.c_size_t), ("coord", u32p), ("query_idx", u32p), ("ref_idx", u32p), ("indel_score", i32p),
                 ("kmer", C.POINTER(C.c_char)), ("n_signal", u32p), ("signal", f32p), ("core", f32p), ("residual", f32p),
                 ("n_windows", C.c_size_t), ("sum_TN", C.c_uint64), ("score_sum", C.c_double),
-                ("win_ref", u32p), ("win_len", u32p), ("win_T", u32p), ("win_score", f64p)]
+                ("win_ref", u32p), ("win_len", u32p), ("win_T", u32p), ("win_score", f64p),
+                ("n_rows", C.c_size_t), ("row_coord", u32p), ("row_rpos", u32p), ("row_val", f64p), ("row_kind", C.POINTER(C.c_uint8))]
 
 
 class FitModels(C.Structure):
@@ -118,6 +119,8 @@ def oracle():
         L.dno_format_detect.restype = C.c_size_t
         L.dno_format_detect.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Read), C.POINTER(Align), C.c_void_p, C.c_void_p,
                                         C.c_size_t]
+        L.dno_format_align.restype = C.c_size_t
+        L.dno_format_align.argtypes = [C.POINTER(Model), C.c_char_p, C.c_char_p, C.POINTER(Read), C.POINTER(Align), C.c_void_p, C.c_size_t]
         L.dno_parse_cigar.restype = C.c_int
         L.dno_parse_cigar.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.c_size_t]
@@ -285,6 +288,21 @@ class OracleRead:
         n = a.n_windows
         return (self._arr(a.win_ref, n, np.uint32), self._arr(a.win_len, n, np.uint32), self._arr(a.win_T, n, np.uint32),
                 self._arr(a.win_score, n, np.float64))
+
+    def align_table(self):
+        """rows of the `DNAscent align` output (alignment.cpp:697-733), in emission order"""
+        a = self.align
+        n = a.n_rows
+        return dict(coord=self._arr(a.row_coord, n, np.uint32), ref_pos=self._arr(a.row_rpos, n, np.uint32),
+                    value=self._arr(a.row_val, n, np.float64), kind=self._arr(a.row_kind, n, np.uint8))
+
+    def format_align(self):
+        cap = 256 + 80 * max(1, self.align.n_rows)
+        buf = C.create_string_buffer(cap)
+        n = oracle().dno_format_align(C.byref(self.model), self.sr.read_id.encode(), self.sr.contig.encode(), C.byref(self.c),
+                                      C.byref(self.align), buf, cap)
+        assert n <= cap
+        return buf.raw[:n]
 
     def format_detect(self, probs):
         probs = np.ascontiguousarray(probs, np.float32)

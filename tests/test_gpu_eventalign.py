@@ -91,3 +91,46 @@ def test_reverse_reads_descend(run):
     assert np.all(np.diff(g["coord"].astype(np.int64)) < 0)       # creation order == sequencing direction (reads.h:321)
     g = ctx.positions(0, int(summ["n_positions"][0]))
     assert np.all(np.diff(g["coord"].astype(np.int64)) > 0)
+
+
+def test_align_table_and_record_text(run, model, tmp_path):
+    """`DNAscent align` (alignment.cpp:697-733, :747-898): the per-sample table eventalign prints.  Rows (coordinate, k-mer start,
+    kind) are index work: exact; the scaled samples are fp64 values restated cast by cast: bit-exact.  The file written by the
+    host C++ layer equals the oracle's text for the passing reads, and asking for the table does not change the positions."""
+    ctx, reads, summ, oracles = run
+    before = [ctx.positions(i, int(summ["n_positions"][i])) for i in range(len(reads))]
+    batch = host.ReadBatch()
+    for r in reads:
+        assert batch.add_synth(r) >= 0
+    batch.upload(ctx)
+    ctx.run("normalise")
+    path = str(tmp_path / "out.align")
+    written = batch.align_write(ctx, path, model)
+    s2 = ctx.summaries()
+    assert written == int((s2["status"] == 0).sum())
+    ctx.set_align_table(True); ctx.run("eventalign"); ctx.sync(); ctx.set_align_table(False)
+    rows = ctx.align_rows(len(reads))
+    want_text = b""
+    for i, (r, o) in enumerate(zip(reads, oracles)):
+        if s2["status"][i] != 0:
+            assert rows[i] == 0
+            continue
+        w = o.align_table()
+        assert int(rows[i]) == w["coord"].shape[0] > 1000, i
+        g = ctx.align_table(i, int(rows[i]))
+        for k in ("coord", "ref_pos", "kind"):
+            assert np.array_equal(g[k], w[k]), (i, k)
+        assert g["value"].tobytes() == w["value"].tobytes(), i
+        assert (w["kind"] == 1).any() or i > 0                     # the set exercises insertions
+        txt = o.format_align()
+        assert host.format_align(r.read_id, r.contig, r.ref_start, r.ref_end, r.is_reverse, r.refseq.tobytes(), model, g) == txt
+        want_text += txt
+        after = ctx.positions(i, int(s2["n_positions"][i]))
+        for k in ("coord", "n_signal", "core"):
+            assert np.array_equal(after[k], before[i][k]), (i, k)
+        assert after["signal"].tobytes() == before[i]["signal"].tobytes()
+    assert open(path, "rb").read() == want_text
+    # without the switch the getters refuse instead of returning stale rows
+    ctx.run("eventalign"); ctx.sync()
+    with pytest.raises(Exception):
+        ctx.align_rows(len(reads))

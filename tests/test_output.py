@@ -88,3 +88,19 @@ def test_header_matches_the_documented_example():
     lines = rec.decode().splitlines()
     assert lines[0] == ">a4ea2872-9cb6-4218-afad-905f79204eb1 14 992440 996846 rev"
     assert re.fullmatch(r"992448\t0\.125751\t0\.131483\t[ACGT]{9}", lines[1])
+
+
+def test_align_record_matches_oracle(aligned, model):
+    """`DNAscent align` record text (alignment.cpp:553, :697-733): host C++ formatter vs the oracle's, from the oracle's own table."""
+    for sr, o, _ in aligned:
+        t = o.align_table()
+        want = o.format_align()
+        got = host.format_align(sr.read_id, sr.contig, sr.ref_start, sr.ref_end, sr.is_reverse, sr.refseq.tobytes(), model, t)
+        assert got == want
+        lines = got.decode().splitlines()
+        assert lines[0] == ">%s %s %d %d %s" % (sr.read_id, sr.contig, sr.ref_start, sr.ref_end, "rev" if sr.is_reverse else "fwd")
+        assert len(lines) == 1 + t["coord"].shape[0]
+        f = lines[1].split("\t")
+        assert len(f) == 5 and len(f[1]) == 9 and len(f[3]) == 9 and len(f[2].split(".")[1]) == 6
+        ins = [l for l in lines[1:] if l.endswith("NNNNNNNNN\t0")]
+        assert len(ins) == int((t["kind"] == 1).sum())
