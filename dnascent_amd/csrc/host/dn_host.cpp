@@ -127,6 +127,67 @@ int eventalign(dn_ctx *ctx, ReadBatch &batch) {
     return dn_get_summaries(ctx, batch.summary.data());
 }
 
+// ---- binary read container -----------------------------------------------------------------------------------------
+namespace {
+template <typename T> bool put(FILE *f, const T &v) { return fwrite(&v, sizeof(T), 1, f) == 1; }
+template <typename T> bool get(FILE *f, T &v) { return fread(&v, sizeof(T), 1, f) == 1; }
+bool putStr(FILE *f, const std::string &s) { const uint32_t n = (uint32_t)s.size(); return put(f, n) && (n == 0 || fwrite(s.data(), 1, n, f) == n); }
+bool getStr(FILE *f, std::string &s, uint32_t limit) {
+    uint32_t n; if (!get(f, n) || n > limit) return false;
+    s.resize(n); return n == 0 || fread(&s[0], 1, n, f) == n;
+}
+}  // namespace
+
+bool ReadContainerWriter::open(const std::string &path) {
+    FILE *fp = fopen(path.c_str(), "wb"); if (!fp) return false;
+    f = fp; n = 0;
+    const uint32_t ver = 1; const uint64_t zero = 0;
+    return fwrite("DNRC", 1, 4, fp) == 4 && put(fp, ver) && put(fp, zero);
+}
+bool ReadContainerWriter::add(const ReadInput &in) {
+    FILE *fp = (FILE *)f; if (!fp || in.cigarOp.size() != in.cigarLen.size()) return false;
+    const uint8_t split = in.isSplit, rev = in.isReverse; const int32_t sl = in.signalLength, st = in.signalTrim, sc = in.signalStartCoord, rs = in.refStart;
+    const uint32_t nc = (uint32_t)in.cigarOp.size(); const uint64_t na = in.n_adc;
+    bool ok = putStr(fp, in.readID) && putStr(fp, in.contig) && put(fp, in.cal_offset) && put(fp, in.cal_scale) && put(fp, sl) && put(fp, st) &&
+              put(fp, sc) && put(fp, split) && put(fp, rev) && put(fp, rs) && putStr(fp, in.querySeq) && putStr(fp, in.refSlice) && put(fp, nc);
+    ok = ok && (nc == 0 || (fwrite(in.cigarOp.data(), 4, nc, fp) == nc && fwrite(in.cigarLen.data(), 4, nc, fp) == nc));
+    ok = ok && put(fp, na) && (na == 0 || fwrite(in.adc, 2, na, fp) == na);
+    if (ok) n++;
+    return ok;
+}
+bool ReadContainerWriter::close() {
+    FILE *fp = (FILE *)f; if (!fp) return false;
+    f = nullptr;
+    const bool ok = fseek(fp, 8, SEEK_SET) == 0 && put(fp, n);
+    return (fclose(fp) == 0) && ok;
+}
+
+bool ReadContainerReader::open(const std::string &path) {
+    close();
+    FILE *fp = fopen(path.c_str(), "rb"); if (!fp) return false;
+    char magic[4]; uint32_t ver = 0;
+    if (fread(magic, 1, 4, fp) != 4 || memcmp(magic, "DNRC", 4) != 0 || !get(fp, ver) || ver != 1 || !get(fp, n)) { fclose(fp); return false; }
+    f = fp; seen = 0; bad = false;
+    return true;
+}
+bool ReadContainerReader::next(OwnedRead &o) {
+    FILE *fp = (FILE *)f; if (!fp || seen >= n) return false;
+    ReadInput &in = o.in;
+    uint8_t split = 0, rev = 0; int32_t sl = 0, st = 0, sc = 0, rs = 0; uint32_t nc = 0; uint64_t na = 0;
+    bool ok = getStr(fp, in.readID, 1u << 16) && getStr(fp, in.contig, 1u << 16) && get(fp, in.cal_offset) && get(fp, in.cal_scale) && get(fp, sl) &&
+              get(fp, st) && get(fp, sc) && get(fp, split) && get(fp, rev) && get(fp, rs) && getStr(fp, in.querySeq, 1u << 30) &&
+              getStr(fp, in.refSlice, 1u << 30) && get(fp, nc) && nc <= (1u << 28);
+    if (ok) { in.cigarOp.resize(nc); in.cigarLen.resize(nc); ok = nc == 0 || (fread(in.cigarOp.data(), 4, nc, fp) == nc && fread(in.cigarLen.data(), 4, nc, fp) == nc); }
+    ok = ok && get(fp, na) && na <= (1ull << 33);
+    if (ok) { o.adc.resize((size_t)na); ok = na == 0 || fread(o.adc.data(), 2, (size_t)na, fp) == na; }
+    if (!ok) { bad = true; return false; }
+    in.signalLength = sl; in.signalTrim = st; in.signalStartCoord = sc; in.isSplit = split != 0; in.isReverse = rev != 0; in.refStart = rs;
+    in.adc = o.adc.data(); in.n_adc = o.adc.size();
+    seen++;
+    return true;
+}
+void ReadContainerReader::close() { if (f) fclose((FILE *)f); f = nullptr; }
+
 // ---- output ----------------------------------------------------------------------------------------------------
 std::string formatDetectRecord(const std::string &readID, const std::string &contig, int refStart, int refEnd, bool isReverse,
                                size_t n, const uint32_t *coord, const char *kmer9, const float *probs, uint32_t *nCalls) {
@@ -355,6 +416,49 @@ int dnh_batch_add(void *b, const char *read_id, const char *contig, const int16_
     in.cigarOp.assign(cigar_op, cigar_op + n_cigar); in.cigarLen.assign(cigar_len, cigar_len + n_cigar);
     in.refStart = ref_start; in.isReverse = is_reverse != 0;
     return ((ReadBatch *)b)->add(in);
+}
+
+// ---- binary read container: writer handle, and "load reads [first, first + count) of a container into a batch" ----
+void *dnh_container_create(const char *path) {
+    DNAscent::ReadContainerWriter *w = new DNAscent::ReadContainerWriter();
+    if (!w->open(path)) { delete w; return nullptr; }
+    return w;
+}
+int dnh_container_add(void *w, const char *read_id, const char *contig, const int16_t *adc, uint64_t n_adc, float cal_offset, float cal_scale,
+                      int signal_length, int signal_trim, int signal_start, int is_split, const char *query_seq, uint32_t n_query,
+                      const char *ref_slice, uint32_t n_ref, const uint32_t *cigar_op, const uint32_t *cigar_len, uint32_t n_cigar, int ref_start,
+                      int is_reverse) {
+    ReadInput in;
+    in.readID = read_id; in.contig = contig;
+    in.adc = adc; in.n_adc = (size_t)n_adc; in.cal_offset = cal_offset; in.cal_scale = cal_scale;
+    in.signalLength = signal_length; in.signalTrim = signal_trim; in.signalStartCoord = signal_start; in.isSplit = is_split != 0;
+    in.querySeq.assign(query_seq, n_query); in.refSlice.assign(ref_slice, n_ref);
+    in.cigarOp.assign(cigar_op, cigar_op + n_cigar); in.cigarLen.assign(cigar_len, cigar_len + n_cigar);
+    in.refStart = ref_start; in.isReverse = is_reverse != 0;
+    return ((DNAscent::ReadContainerWriter *)w)->add(in) ? 0 : -1;
+}
+int dnh_container_close(void *w) {
+    DNAscent::ReadContainerWriter *W = (DNAscent::ReadContainerWriter *)w;
+    const bool ok = W->close();
+    delete W;
+    return ok ? 0 : -1;
+}
+// returns the number of reads in the file (-1: cannot be opened / not a container)
+int64_t dnh_container_count(const char *path) {
+    DNAscent::ReadContainerReader r;
+    return r.open(path) ? (int64_t)r.count() : -1;
+}
+// adds reads [first, first + count) to the batch; returns how many the batch accepted, or -1 on a malformed file
+int64_t dnh_container_load(void *b, const char *path, uint64_t first, uint64_t count) {
+    DNAscent::ReadContainerReader r;
+    if (!r.open(path)) return -1;
+    DNAscent::OwnedRead o;
+    int64_t accepted = 0;
+    for (uint64_t i = 0; i < first + count; i++) {
+        if (!r.next(o)) { if (r.failed()) return -1; break; }
+        if (i >= first && ((ReadBatch *)b)->add(o.in) >= 0) accepted++;
+    }
+    return accepted;
 }
 
 void dnh_batch_desc(void *b, dn_batch_desc *out) { *out = ((ReadBatch *)b)->desc(); }

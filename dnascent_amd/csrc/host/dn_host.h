@@ -62,6 +62,36 @@ public:
     std::vector<dn_read_summary> summary;               // filled by normaliseEvents / eventalign
 };
 
+// ---- binary read container ----------------------------------------------------------------------------
+// The reference ingests reads through htslib (BAM record, CIGAR, tags) and libpod5 / fast5 (signal, calibration); neither
+// library is available to this build.  Hosts without them -- and the tests -- hand reads over in a flat little-endian file
+// holding exactly the fields of ReadInput (what reads.h:210-287 + pod5.cpp:24-93 extract):
+//   file    "DNRC" u32 version (1) u64 n_reads, then n_reads records
+//   record  str readID, str contig (u32 length + bytes); f32 cal_offset, cal_scale; i32 signalLength, signalTrim,
+//           signalStartCoord; u8 isSplit, isReverse; i32 refStart; str querySeq; str refSlice;
+//           u32 n_cigar, u32 op[n], u32 len[n]; u64 n_adc, i16 adc[n]
+struct OwnedRead { ReadInput in; std::vector<int16_t> adc; };             // in.adc points into adc
+class ReadContainerWriter {
+public:
+    bool open(const std::string &path);
+    bool add(const ReadInput &in);
+    bool close();                                                          // patches the read count into the header
+    ~ReadContainerWriter() { if (f) close(); }
+private:
+    void *f = nullptr; uint64_t n = 0;
+};
+class ReadContainerReader {
+public:
+    bool open(const std::string &path);                                    // false: missing file / bad magic / version
+    uint64_t count() const { return n; }
+    bool next(OwnedRead &out);                                             // false at the end or on a truncated record
+    bool failed() const { return bad; }
+    void close();
+    ~ReadContainerReader() { close(); }
+private:
+    void *f = nullptr; uint64_t n = 0, seen = 0; bool bad = false;
+};
+
 // normaliseEvents for every read of the batch (event_handling.h:13).  Throws nothing: returns a DN_* code.
 int normaliseEvents(dn_ctx *ctx, ReadBatch &batch);
 int eventalign(dn_ctx *ctx, ReadBatch &batch);

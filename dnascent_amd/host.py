@@ -43,6 +43,15 @@ def lib():
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.dnh_align_write.restype = C.c_int
         L.dnh_align_write.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
+        L.dnh_container_create.restype = C.c_void_p
+        L.dnh_container_create.argtypes = [C.c_char_p]
+        L.dnh_container_add.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int]
+        L.dnh_container_close.argtypes = [C.c_void_p]
+        L.dnh_container_count.restype = C.c_int64
+        L.dnh_container_count.argtypes = [C.c_char_p]
+        L.dnh_container_load.restype = C.c_int64
+        L.dnh_container_load.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64]
         L.dnh_hmm_write.restype = C.c_int
         L.dnh_hmm_write.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p]
         L.dnh_detect_header.restype = C.c_uint64
@@ -107,6 +116,28 @@ def modbam(query_idx, ref_idx, kmer_s9, probs, ref2del):
     return k, mm.value.decode(), ml[:2 * k].copy()
 
 
+def write_container(path, synth_reads, signal_length=-1, signal_trim=0, signal_start=0, is_split=False):
+    """DNAscent::ReadContainerWriter: the binary read container hosts without htslib / libpod5 (and the tests) ingest from."""
+    w = lib().dnh_container_create(path.encode())
+    if not w:
+        raise IOError(path)
+    for sr in synth_reads:
+        q = np.ascontiguousarray(revcomp(sr.basecall) if sr.is_reverse else sr.basecall)
+        f = np.ascontiguousarray(revcomp(sr.refseq) if sr.is_reverse else sr.refseq)
+        adc = np.ascontiguousarray(sr.adc)
+        rc = lib().dnh_container_add(w, sr.read_id.encode(), sr.contig.encode(), adc.ctypes.data, adc.shape[0], sr.cal_offset, sr.cal_scale,
+                                     signal_length, signal_trim, signal_start, int(is_split), q.ctypes.data, q.shape[0], f.ctypes.data,
+                                     f.shape[0], sr.cigar_op.ctypes.data, sr.cigar_len.ctypes.data, sr.cigar_op.shape[0], sr.ref_start,
+                                     int(sr.is_reverse))
+        assert rc == 0
+    if lib().dnh_container_close(w) != 0:
+        raise IOError(path)
+
+
+def container_count(path):
+    return int(lib().dnh_container_count(path.encode()))
+
+
 class ReadBatch:
     """DNAscent::ReadBatch: reads packed as SoA, ready for dn_batch_upload."""
 
@@ -135,6 +166,10 @@ class ReadBatch:
         if rc >= 0:
             self.reads.append(sr)
         return rc
+
+    def add_container(self, path, first=0, count=1 << 62):
+        """reads [first, first + count) of a binary read container; returns how many were accepted (-1: malformed file)"""
+        return int(lib().dnh_container_load(self.h, path.encode(), first, count))
 
     def size(self):
         return int(lib().dnh_batch_size(self.h))
