@@ -257,6 +257,22 @@ def main():
             out["roofline_solo"] = {"bound": "hbm", "kernel": "k2_fill", "achieved": alg_bytes / (solo_fill_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": alg_bytes / (solo_fill_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "mean_launch_ms": solo_fill_ms,
                                     "note": "one batch in flight, outside the timed region"}
+        if args.scope == "banded" and (args.reads, args.bases) == (1000, 20000):
+            # what actually binds this scope: instruction issue.  Wave-instructions per step from the committed PMC
+            # pass of the same workload (profiles/r01_e_pmc_instruction_mix.csv, counters cannot be read inside a timed run),
+            # rate = that count / the measured step time; peak = 1024 SIMDs x one VALU wave-instruction per 4 cycles at 2.4 GHz
+            try:
+                valu = salu = 0.0
+                for line in open(os.path.join(ROOT, "profiles", "r01_e_pmc_instruction_mix.csv")):
+                    f = line.strip().split(",")
+                    if len(f) >= 3 and not line.startswith("#") and f[0] != "kernel":
+                        valu += float(f[1]); salu += float(f[2])
+                step_s = out["ms_per_step"] / 1e3
+                out["roofline_issue"] = {"bound": "valu_issue", "achieved": valu / step_s / 1e9, "peak": 1024 * 2.4 / 4.0, "unit": "G wave-instr/s",
+                                         "frac": valu / step_s / 1e9 / (1024 * 2.4 / 4.0), "valu_per_step": valu, "salu_per_step": salu,
+                                         "note": "instruction counts from the committed PMC pass; informational, `roofline` above follows the contract"}
+            except Exception:
+                pass
         if args.scope == "full":
             # dominant stage = the CNN: algorithmic flops = 2 x MACs of the description x positions (3.7 MFLOP x L);
             # peak = the dense 16-bit MFMA rate (2.5 PFLOP/s) / the products per fp32 product of the split in use: 3 for the two-piece
