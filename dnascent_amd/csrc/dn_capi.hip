@@ -900,7 +900,7 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *npos, const uint64
     for (uint32_t r = 0; r < n; r++) {
         const unsigned np = npos[r];
         if (rows + np + 8 > cap && r > r0) {
-            const uint64_t rr = (rows + 127) / 128 * 128;
+            const uint64_t rr = (rows + 255) / 256 * 256;
             passes.push_back({ r0, r, (unsigned)rr, max_pos, pass_pos }); max_rows = std::max(max_rows, rr);
             r0 = r; rows = 8; max_pos = 1; pass_pos = 0;
         }
@@ -909,7 +909,7 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *npos, const uint64
         if (rows >= (1ull << 31)) return fail(c, DN_ERR_OVERFLOW, "sequence %u has too many positions for one CNN pass", r);
         max_pos = std::max(max_pos, np);
     }
-    { const uint64_t rr = (rows + 127) / 128 * 128; passes.push_back({ r0, n, (unsigned)rr, max_pos, pass_pos }); max_rows = std::max(max_rows, rr); }
+    { const uint64_t rr = (rows + 255) / 256 * 256; passes.push_back({ r0, n, (unsigned)rr, max_pos, pass_pos }); max_rows = std::max(max_rows, rr); }
     int rc;
     for (int b = 0; b < c->cnn_nbuf; b++)
         if ((rc = dgrow(c, c->cnn_buf[b], (size_t)max_rows * 256 * sizeof(float)))) return rc;

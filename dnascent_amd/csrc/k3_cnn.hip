@@ -215,13 +215,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][BN / 64], float *
 // Workgroup numbering of the conv kernels (1-D grid): consecutive workgroup ids go round-robin to the 8 XCDs, each with its own
 // L2.  Id L runs on XCD L % 8; on one XCD consecutive ids walk the COLUMN tiles of one row tile before moving to the next row
 // tile, so the second (third, fourth) read of the same activation rows hits that XCD's L2 instead of HBM.
-__device__ __forceinline__ bool conv_tile(int cout, int BN, int rows, int &m0, int &n0) {
+__device__ __forceinline__ bool conv_tile(int cout, int BN, int rows, int &m0, int &n0, int BM = CNN_BM) {
     const int nct = cout / BN;
     const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
-    m0 = ((slot / nct) * 8 + xcd) * CNN_BM; n0 = (slot % nct) * BN;
+    m0 = ((slot / nct) * 8 + xcd) * BM; n0 = (slot % nct) * BN;
     return m0 < rows;
 }
-static inline unsigned conv_grid(unsigned rows, int cout, int BN) { return ((rows / CNN_BM + 7) / 8) * 8 * (unsigned)(cout / BN); }
+static inline unsigned conv_grid(unsigned rows, int cout, int BN, int BM = CNN_BM) { return ((rows / BM + 7) / 8) * 8 * (unsigned)(cout / BN); }
 
 template <int BN, int NBUF, bool ADD>
 __global__ __launch_bounds__(256) void k3_conv(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wt,
@@ -354,20 +354,25 @@ template <int NP> __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32
 // Loop order: input-channel block outermost, taps inside.  The A tile of a channel block (128 + k - 1 rows) is split and
 // staged ONCE and every tap reads it at a row offset, so a k-tap layer converts each activation once instead of k times;
 // only the B tile changes per step.  Weights are laid out [channel block][tap][piece][cout][32] to match.
+// BM = 256 (8 wavefronts) halves the weight traffic per flop: every step streams a fresh B tile from L2, and with 128-row
+// workgroups that stream alone takes ~2/3 of the L2 bandwidth on the long-K layers.  Measured: 17 taps x 128 channels -8 %,
+// 9 x 128 -6 %, but the 3-tap layers +8 % (two 512-thread workgroups per CU need <= 128 VGPRs: 44 bytes of scratch), so only
+// layers with >= 9 taps and >= 128 input channels take it.
 #define CNN_AROWS (CNN_BM + 16)
-template <int BN, bool ADD, int NP>
-__global__ __launch_bounds__(256) void k3_conv_split(const float *__restrict__ X, float *__restrict__ Y, const uint16_t *__restrict__ Wb,
+template <int BN, bool ADD, int NP, int BM = CNN_BM>
+__global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const float *__restrict__ X, float *__restrict__ Y, const uint16_t *__restrict__ Wb,
                                                      const float *__restrict__ scale, const float *__restrict__ shift,
                                                      const float *__restrict__ Add, const uint8_t *__restrict__ valid, int rows, int k,
                                                      int cin, int cout, int relu, float post, unsigned *range_flag) {
-    __shared__ __attribute__((aligned(16))) uint16_t As[NP][CNN_AROWS * CNN_BP];
+    __shared__ __attribute__((aligned(16))) uint16_t As[NP][(BM + 16) * CNN_BP];
     __shared__ __attribute__((aligned(16))) uint16_t Bs[NP][BN * CNN_BP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int m0, n0;
-    if (!conv_tile(cout, BN, rows, m0, n0)) return;
+    if (!conv_tile(cout, BN, rows, m0, n0, BM)) return;
     constexpr int NJ = BN / 64;
-    constexpr int NBQ = BN / 64;                          // 16-byte B chunks per thread per piece
+    constexpr int LR = BM / 2;                            // rows one loader pass covers (4 threads per row)
+    constexpr int NBQ = BN / LR;                          // 16-byte B chunks per thread per piece
     f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(256) void k3_conv_split(const float *__restrict__ X
     const int half = (k - 1) / 2;
     const int cblocks = cin >> 5;
     const int steps = k * cblocks;
-    const int arows = CNN_BM + k - 1;
+    const int arows = BM + k - 1;
     const int l_r = tid >> 2, l_k = (tid & 3) * 8;        // loader: 64 rows x 4 chunks of 8 elements per pass
     f32x4 ra[3][2]; bool pin[3];
     u32x4 rb[NP][NBQ];
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(256) void k3_conv_split(const float *__restrict__ X
     auto gloadA = [&](int cb) {
 #pragma unroll
         for (int p = 0; p < 3; p++) {
-            const int ar = p * 64 + l_r;                   // row of the staged tile; global row = m0 - half + ar
+            const int ar = p * LR + l_r;                   // row of the staged tile; global row = m0 - half + ar
             const int src = m0 - half + ar;
             const bool in = ar < arows && src >= 0 && src < rows;
             const float *xp = X + (size_t)(in ? src : m0) * cin + (cb << 5) + l_k;
@@ -399,15 +404,15 @@ __global__ __launch_bounds__(256) void k3_conv_split(const float *__restrict__ X
         for (int pc = 0; pc < NP; pc++) {
             const uint16_t *wb = Wb + ((size_t)(s * NP + pc) * cout + n0) * 32;
 #pragma unroll
-            for (int q = 0; q < NBQ; q++) rb[pc][q] = *reinterpret_cast<const u32x4 *>(wb + (size_t)(q * 64 + l_r) * 32 + l_k);
+            for (int q = 0; q < NBQ; q++) rb[pc][q] = *reinterpret_cast<const u32x4 *>(wb + (size_t)(q * LR + l_r) * 32 + l_k);
         }
     };
     auto lstoreA = [&]() {
 #pragma unroll
         for (int p = 0; p < 3; p++) {
-            if (p * 64 + l_r < CNN_AROWS) {
+            if (p * LR + l_r < BM + 16) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                const int o = (p * 64 + l_r) * CNN_BP + l_k;
+                const int o = (p * LR + l_r) * CNN_BP + l_k;
                 if (NP == 3) {
                     bf16x8 h, m, l;
                     split3(pin[p] ? ra[p][0] : z, pin[p] ? ra[p][1] : z, h, m, l);
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(256) void k3_conv_split(const float *__restrict__ X
 #pragma unroll
         for (int pc = 0; pc < NP; pc++)
 #pragma unroll
-            for (int q = 0; q < NBQ; q++) *reinterpret_cast<u32x4 *>(&Bs[pc][(q * 64 + l_r) * CNN_BP + l_k]) = rb[pc][q];
+            for (int q = 0; q < NBQ; q++) *reinterpret_cast<u32x4 *>(&Bs[pc][(q * LR + l_r) * CNN_BP + l_k]) = rb[pc][q];
     };
     gloadA(0); gloadB(0);
     lstoreA(); lstoreB();
@@ -932,6 +937,7 @@ struct CnnRun {
 };
 
 static bool k3_sep_ws_enabled() { static const bool on = !(getenv("DN_CNN_SEP_WS") && atoi(getenv("DN_CNN_SEP_WS")) == 0); return on; }
+static bool k3_bm256_enabled() { static const bool on = !(getenv("DN_CNN_BM256") && atoi(getenv("DN_CNN_BM256")) == 0); return on; }
 static bool k3_fuse_enabled() { static const bool on = !(getenv("DN_CNN_FUSE") && atoi(getenv("DN_CNN_FUSE")) == 0); return on; }
 
 // a depthwise op can be folded into the pointwise convolution that follows it when nothing else reads its output
@@ -1020,7 +1026,11 @@ int k3_run(const CnnRun &c, hipStream_t st) {
 #define CONV_GO_SP(BN_, ADD_, NP_) hipLaunchKernelGGL((k3_conv_split<BN_, ADD_, NP_>), dim3(conv_grid(rows, o.cout, BN_)), dim3(256), 0, st, \
         pb[o.src], pb[o.dst], c.wts_split + c.wb_off[i], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu, \
         c.post[i], c.range_flag)
-#define CONV_GO_BF(BN_, ADD_) do { if (c.pieces == 3) CONV_GO_SP(BN_, ADD_, 3); else CONV_GO_SP(BN_, ADD_, 2); } while (0)
+#define CONV_GO_BM(BN_, ADD_) hipLaunchKernelGGL((k3_conv_split<BN_, ADD_, 2, 256>), dim3(conv_grid(rows, o.cout, BN_, 256)), dim3(512), 0, st, \
+        pb[o.src], pb[o.dst], c.wts_split + c.wb_off[i], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu, \
+        c.post[i], c.range_flag)
+#define CONV_GO_BF(BN_, ADD_) do { if (c.pieces == 3) CONV_GO_SP(BN_, ADD_, 3); else if (BN_ == 128 && o.k >= 9 && o.cin >= 128 && rows % 256 == 0 && k3_bm256_enabled()) CONV_GO_BM(128, ADD_); \
+        else CONV_GO_SP(BN_, ADD_, 2); } while (0)
                 if (c.wts_split) {
                     if (o.cout % 128 == 0) { if (add) CONV_GO_BF(128, true); else CONV_GO_BF(128, false); }
                     else { if (add) CONV_GO_BF(64, true); else CONV_GO_BF(64, false); }
@@ -1028,6 +1038,7 @@ int k3_run(const CnnRun &c, hipStream_t st) {
                 else { if (add) CONV_GO(64, 1, true); else CONV_GO(64, 1, false); }
 #undef CONV_GO
 #undef CONV_GO_BF
+#undef CONV_GO_BM
 #undef CONV_GO_SP
                 break;
             }
