@@ -118,6 +118,95 @@ __global__ __launch_bounds__(64) void k1_scan(BatchDev B) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k1_scan4: the same scan with FOUR reads per wavefront.  The order-exact chain is two dependent fp64 adds per sample, issued as
+// whole-wavefront instructions whatever the number of active lanes; k1_scan keeps 16 lanes busy with them (one read), so with
+// eight batches in flight -- when the vector issue slots, not the latency of one chain, are what is scarce -- three quarters of
+// every such instruction are wasted.  Here each 16-lane row of the wavefront runs the chain of its own read (EXEC narrowed with
+// the 16-bit pattern replicated four times: two 32-bit scalar moves, s_mov_b64 takes no 64-bit literal), so a batch costs a quarter of the vector instructions for the same chain latency.
+// Reads of different lengths: a finished (or absent) read keeps adding +0.0, which is exact (the running sums are never -0.0:
+// they start at +0.0 and round-to-nearest never produces -0.0 from a sum with a +0.0 or non-zero operand), and writes nothing.
+// The carry of a row (its lane 15) returns through LDS: the row stores its 16 results and reads the last one back.
+// ------------------------------------------------------------------------------------------------
+#define SCAN4_ADD8(v, o, m0, m1, m2, m3, m4, m5, m6, m7)                                                                         \
+    {                                                                                                                             \
+        unsigned long long sv_;                                                                                                   \
+        asm volatile("s_mov_b64 %2, exec\n\t"                                                                                     \
+                     "s_mov_b32 exec_lo, " m0 "\n\ts_mov_b32 exec_hi, " m0 "\n\tv_add_f64 %0, %0, %3\n\tv_add_f64 %1, %1, %4\n\t"                                \
+                     "s_mov_b32 exec_lo, " m1 "\n\ts_mov_b32 exec_hi, " m1 "\n\tv_add_f64 %0, %0, %5\n\tv_add_f64 %1, %1, %6\n\t"                                \
+                     "s_mov_b32 exec_lo, " m2 "\n\ts_mov_b32 exec_hi, " m2 "\n\tv_add_f64 %0, %0, %7\n\tv_add_f64 %1, %1, %8\n\t"                                \
+                     "s_mov_b32 exec_lo, " m3 "\n\ts_mov_b32 exec_hi, " m3 "\n\tv_add_f64 %0, %0, %9\n\tv_add_f64 %1, %1, %10\n\t"                               \
+                     "s_mov_b32 exec_lo, " m4 "\n\ts_mov_b32 exec_hi, " m4 "\n\tv_add_f64 %0, %0, %11\n\tv_add_f64 %1, %1, %12\n\t"                              \
+                     "s_mov_b32 exec_lo, " m5 "\n\ts_mov_b32 exec_hi, " m5 "\n\tv_add_f64 %0, %0, %13\n\tv_add_f64 %1, %1, %14\n\t"                              \
+                     "s_mov_b32 exec_lo, " m6 "\n\ts_mov_b32 exec_hi, " m6 "\n\tv_add_f64 %0, %0, %15\n\tv_add_f64 %1, %1, %16\n\t"                              \
+                     "s_mov_b32 exec_lo, " m7 "\n\ts_mov_b32 exec_hi, " m7 "\n\tv_add_f64 %0, %0, %17\n\tv_add_f64 %1, %1, %18\n\t"                              \
+                     "s_mov_b64 exec, %2"                                                                                         \
+                     : "+v"(s), "+v"(q), "=&s"(sv_)                                                                               \
+                     : "v"(v[o + 0].x), "v"(v[o + 0].y), "v"(v[o + 1].x), "v"(v[o + 1].y), "v"(v[o + 2].x), "v"(v[o + 2].y),        \
+                       "v"(v[o + 3].x), "v"(v[o + 3].y), "v"(v[o + 4].x), "v"(v[o + 4].y), "v"(v[o + 5].x), "v"(v[o + 5].y),        \
+                       "v"(v[o + 6].x), "v"(v[o + 6].y), "v"(v[o + 7].x), "v"(v[o + 7].y));                                        \
+    }
+
+__global__ __launch_bounds__(64) void k1_scan4(BatchDev B) {
+    __shared__ double2 buf[4][SCAN_CHUNK];
+    const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
+    const int r = blockIdx.x * 4 + g;
+    const bool have = r < B.n_reads;
+    const uint64_t s0 = have ? B.samp_off[r] : 0ull;
+    const unsigned n = have ? (unsigned)(B.samp_off[r + 1] - s0) : 0u;
+    const int16_t *a = B.adc + s0;
+    double2 *out = B.psum + s0;
+    const float off = have ? B.cal_off[r] : 0.0f, sc = have ? B.cal_scale[r] : 0.0f;
+    unsigned nmax = n;
+    nmax = max(nmax, (unsigned)__shfl_xor((int)nmax, 16)); nmax = max(nmax, (unsigned)__shfl_xor((int)nmax, 32));
+    nmax = (unsigned)__builtin_amdgcn_readfirstlane((int)nmax);          // longest of the four reads (wave-uniform)
+    double s = 0.0, q = 0.0;
+    double2 *mybuf = buf[g];
+    int16_t nxt[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const unsigned i = (unsigned)(j * 16 + l); nxt[j] = i < n ? a[i] : (int16_t)0; }
+    for (unsigned base = 0; base < nmax; base += SCAN_CHUNK) {
+        const unsigned cnt = base < n ? min((unsigned)SCAN_CHUNK, n - base) : 0u;    // samples of THIS row's read in the chunk
+        // ---- parallel: convert + square, 16 samples per lane (lanes of a row take consecutive samples) ----
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const unsigned i = (unsigned)(j * 16 + l);
+            const float v = ((float)nxt[j] + off) * sc;            // pod5.cpp:60
+            const double x = (double)v;
+            mybuf[i] = i < cnt ? make_double2(x, x * x) : make_double2(0.0, 0.0);
+        }
+        {
+            const unsigned nb = base + SCAN_CHUNK;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { const unsigned i = nb + (unsigned)(j * 16 + l); nxt[j] = i < n ? a[i] : (int16_t)0; }
+        }
+        LDS_FENCE();
+        unsigned cmax = cnt;
+        cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, 16)); cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, 32));
+        const unsigned ngroups = ((unsigned)__builtin_amdgcn_readfirstlane((int)cmax) + 15u) >> 4;
+        // ---- serial, order-exact (event_detection.c:45-46), four reads at once ----
+        for (unsigned gq = 0; gq < ngroups; gq++) {
+            double2 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = mybuf[gq * 16 + j];
+            SCAN4_ADD8(v, 0, "0xffffffff", "0xfffefffe", "0xfffcfffc", "0xfff8fff8", "0xfff0fff0", "0xffe0ffe0", "0xffc0ffc0", "0xff80ff80")
+            SCAN4_ADD8(v, 8, "0xff00ff00", "0xfe00fe00", "0xfc00fc00", "0xf800f800", "0xf000f000", "0xe000e000", "0xc000c000", "0x80008000")
+            mybuf[gq * 16 + l] = make_double2(s, q);
+            LDS_FENCE();
+            const double2 c = mybuf[gq * 16 + 15];                 // the row's lane 15: running sums after the 16th sample
+            s = c.x; q = c.y;
+        }
+        LDS_FENCE();
+        // ---- parallel: write-out, 256 contiguous bytes per row and store ----
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const unsigned i = (unsigned)(j * 16 + l);
+            if (i < cnt) out[base + i] = mybuf[i];
+        }
+        LDS_FENCE();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k1_tstat: one thread per sample
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double2 prefix_at(const double2 *P, unsigned j) {   // {sum[j], sumsq[j]}
@@ -461,7 +550,9 @@ __global__ __launch_bounds__(64) void k1_events(BatchDev B, unsigned *scratch_u3
 // launch helpers (called from dn_capi.hip)
 // ------------------------------------------------------------------------------------------------
 void k1_launch_scan(const BatchDev &B, hipStream_t st) {
-    hipLaunchKernelGGL(k1_scan, dim3(B.n_reads), dim3(64), 0, st, B);
+    static const bool scan4 = !(getenv("DN_SCAN4") && atoi(getenv("DN_SCAN4")) == 0);
+    if (scan4) hipLaunchKernelGGL(k1_scan4, dim3((B.n_reads + 3) / 4), dim3(64), 0, st, B);
+    else hipLaunchKernelGGL(k1_scan, dim3(B.n_reads), dim3(64), 0, st, B);
 }
 void k1_launch_tstat(const BatchDev &B, unsigned max_samples, hipStream_t st) {
     hipLaunchKernelGGL(k1_tstat, dim3((max_samples + 255) / 256, B.n_reads), dim3(256), 0, st, B);
