@@ -216,57 +216,68 @@ __device__ __forceinline__ double2 prefix_at(const double2 *P, unsigned j) {   /
 // Division by the window length (3 or 6) as multiply + FMA correction: q = a r; q' = fma(fma(-q, d, a), r, q) with r = RN(1 / d)
 // is the correctly rounded a / d (Markstein).  Checked against IEEE division for d = 3 and 6: fp32 EXHAUSTIVELY (every finite
 // input; the only mismatches have |a / d| < 4 FLT_MIN, hence the guard), fp64 on 6.4e9 random + mantissa-edge cases with
-// exponents within 2^+-200 (guarded likewise).  The guards fall back to the hardware division sequence.
-__device__ __forceinline__ float div_w(float a, float d, float r) {
-    if (!(fabsf(a) >= 1e-30f)) return a / d;              // tiny, zero, NaN: literal division
-    const float q = a * r;
-    return __builtin_fmaf(__builtin_fmaf(-q, d, a), r, q);
-}
-__device__ __forceinline__ double div_w(double a, double d, double r) {
-    if (!(fabs(a) >= 1e-60 && fabs(a) <= 1e60)) return a / d;
-    const double q = a * r;
-    return fma(fma(-q, d, a), r, q);
-}
-
+// exponents within 2^+-200 (guarded likewise).  Outside the guards divq<false> raises `bad` and the wavefront repeats the
+// statistic with the hardware division sequence (divq<true>).
 // (float)(fabs((double)dm) / sqrt((double)vw)) of event_detection.c:111 -- an IEEE fp64 sqrt and an IEEE fp64 division (~55
 // instructions) whose result is immediately rounded to fp32.  Fast path: y = |dm| * rsqrt(vw) from v_rsq_f64 + two Newton steps
 // is within ~2^-50 relative (< 10 ulp64) of the reference's double q; (float)y == (float)q unless a rounding boundary of fp32
 // (a midpoint between two floats: low 29 mantissa bits == 0x10000000) lies between them.  y within 1024 ulp64 of such a
 // midpoint (64 would do for a 2^-26 v_rsq_f64; 1024 = 2^-43 relative is kept as slack) -- 4e-6 of all inputs -- or outside the
 // normal fp32 range takes the exact path; everything else is bit-identical by construction.
-__device__ __forceinline__ float tstat_ratio(float dm, float vw) {
+// One t-statistic.  EXACT = false: every division runs its fast form unconditionally and `bad` collects the cases the fast forms
+// are not proven for (operands outside the verified ranges of div_w, ratio near an fp32 rounding boundary); EXACT = true: the
+// literal IEEE operations.  The kernel evaluates both windows fast and repeats a wavefront exactly only if any lane raised
+// `bad` (4e-6 of the samples): ONE wave-level branch per thread instead of eleven data-dependent ones -- on this kernel the
+// scalar unit (branch bookkeeping), not the vector unit, was the larger instruction stream.
+template <bool EXACT> __device__ __forceinline__ float divq(float a, float d, float r, bool &bad) {
+    if (EXACT) return a / d;
+    bad = bad || !(fabsf(a) >= 1e-30f || a == 0.0f);            // tiny / NaN: outside the exhaustively verified range (+0 is fine)
+    const float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, d, a), r, q);
+}
+template <bool EXACT> __device__ __forceinline__ double divq(double a, double d, double r, bool &bad) {
+    if (EXACT) return a / d;
+    bad = bad || !((fabs(a) >= 1e-60 && fabs(a) <= 1e60) || a == 0.0);
+    const double q = a * r;
+    return fma(fma(-q, d, a), r, q);
+}
+template <bool EXACT> __device__ __forceinline__ float tstat_ratio(float dm, float vw, bool &bad) {
     const double a = fabs((double)dm), v = (double)vw;
+    if (EXACT) return (float)(a / sqrt(v));
     double s = __builtin_amdgcn_rsq(v);
     s = s * fma(-0.5 * v * s, s, 1.5);
     s = s * fma(-0.5 * v * s, s, 1.5);
     const double y = a * s;
     const unsigned lo = (unsigned)__double_as_longlong(y) & 0x1FFFFFFFu;
-    const bool risky = (lo - 0x0FFFFC00u) <= 0x800u || !((y > 0x1p-100 && y < 0x1p100) || y == 0.0);
-    if (__builtin_expect(__any(risky), 0)) return (float)(a / sqrt(v));
+    bad = bad || (lo - 0x0FFFFC00u) <= 0x800u || !((y > 0x1p-100 && y < 0x1p100) || y == 0.0);
     return (float)y;
 }
 
-template <unsigned W>
-__device__ __forceinline__ float tstat_at(const double2 *P, unsigned n, unsigned i) {
+template <unsigned W, bool EXACT>
+__device__ __forceinline__ float tstat_at(const double2 *P, unsigned n, unsigned i, bool &bad) {
     constexpr unsigned w = W;
-    if (n < 2 * w) return 0.0f;                                  // :76-81
-    if (i < w || i > n - w) return 0.0f;                         // :83-86, loop bound :89 is inclusive
+    const bool valid = n >= 2 * w && i >= w && i <= n - w;       // :76-86, loop bound :89 is inclusive; elsewhere the statistic is 0
+    const unsigned ii = valid ? i : w;                           // a position whose loads are in range whenever n >= 2 w
     constexpr float wf = (float)W;
     constexpr float rwf = 1.0f / wf;                             // RN(1 / w), folded by the compiler exactly as IEEE division
     constexpr double wd = (double)wf, rwd = 1.0 / wd;
-    const double2 a = prefix_at(P, i - w), b = prefix_at(P, i), c = prefix_at(P, i + w);
+    const double2 z = make_double2(0.0, 0.0);
+    const double2 a = n >= 2 * w ? prefix_at(P, ii - w) : z, b = n >= 2 * w ? prefix_at(P, ii) : z, c = n >= 2 * w ? prefix_at(P, ii + w) : z;
+    bool mybad = false;
     const double sum1 = b.x - a.x, sumsq1 = b.y - a.y;           // :90-95 (sum[0] == 0, so i == w is the same expression)
     const float sum2 = (float)(c.x - b.x);                       // :96
     const float sumsq2 = (float)(c.y - b.y);                     // :97
-    const float mean1 = (float)div_w(sum1, wd, rwd);             // :98
-    const float mean2 = div_w(sum2, wf, rwf);                    // :99
+    const float mean1 = (float)divq<EXACT>(sum1, wd, rwd, mybad);            // :98
+    const float mean2 = divq<EXACT>(sum2, wf, rwf, mybad);                   // :99
     const float m1sq = mean1 * mean1, m2sq = mean2 * mean2;
-    const float s2w = div_w(sumsq2, wf, rwf);
-    float var = (float)(((div_w(sumsq1, wd, rwd) - (double)m1sq) + (double)s2w) - (double)m2sq);   // :100-101
+    const float s2w = divq<EXACT>(sumsq2, wf, rwf, mybad);
+    float var = (float)(((divq<EXACT>(sumsq1, wd, rwd, mybad) - (double)m1sq) + (double)s2w) - (double)m2sq);   // :100-101
     var = fmaxf(var, FLT_MIN);                                   // :104
     const float dm = mean2 - mean1;                              // :110
-    const float vw = div_w(var, wf, rwf);
-    return tstat_ratio(dm, vw);                                  // :111
+    const float vw = divq<EXACT>(var, wf, rwf, mybad);
+    const float t = tstat_ratio<EXACT>(dm, vw, mybad);           // :111
+    bad = bad || (valid && mybad);
+    return valid ? t : 0.0f;
 }
 
 __global__ __launch_bounds__(256) void k1_tstat(BatchDev B) {
@@ -276,8 +287,12 @@ __global__ __launch_bounds__(256) void k1_tstat(BatchDev B) {
     const unsigned i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const double2 *P = B.psum + s0;
-    B.t1[s0 + i] = tstat_at<3>(P, n, i);                          // event_detection.h:19-25
-    B.t2[s0 + i] = tstat_at<6>(P, n, i);
+    bool bad = false;
+    float t1 = tstat_at<3, false>(P, n, i, bad);                  // event_detection.h:19-25
+    float t2 = tstat_at<6, false>(P, n, i, bad);
+    if (__builtin_expect(__any(bad), 0)) { bool x = false; t1 = tstat_at<3, true>(P, n, i, x); t2 = tstat_at<6, true>(P, n, i, x); }
+    B.t1[s0 + i] = t1;
+    B.t2[s0 + i] = t2;
 }
 
 // ------------------------------------------------------------------------------------------------
