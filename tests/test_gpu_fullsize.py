@@ -7,7 +7,7 @@ running the oracle over everything would take minutes.  Size-independent propert
   * monotonicity     the rough alignment of every passing read is a monotone path (event and k-mer indices never decrease,
                      consecutive pairs differ by one of the three moves), event spans ascend without overlap;
   * spot parity      a sample of the reads -- both strands, first / middle / last of the batch -- against the oracle, bit-exact;
-  * eventalign, --HMM and the CNN at full size (20 M positions, several CNN passes): every probability row sums to 1, and a
+  * eventalign (incl. the `align` table), --HMM and the CNN at full size (20 M positions, several CNN passes): every probability row sums to 1, and a
                      read's tensors, HMM calls and probabilities are bit-identical whatever its place in the batch (other
                      pass, other neighbours, other rows).
 """
@@ -54,6 +54,10 @@ def _aux_digest(ctx, s, i):
     calls = ctx.hmm_calls(i, int(s["n_hmm_calls"][i]))
     for k in ("pos_on_ref", "n_events", "llr"):
         h.update(np.ascontiguousarray(calls[k]).tobytes())
+    t = ctx.align_table(i, int(ctx.align_rows(len(s))[i]))
+    assert t["coord"].shape[0] > 100000 and set(np.unique(t["kind"]).tolist()) <= {0, 1}
+    for k in ("coord", "ref_pos", "value", "kind"):
+        h.update(np.ascontiguousarray(t[k]).tobytes())
     return h.hexdigest()
 
 
@@ -96,7 +100,10 @@ def test_full_size_batch_properties(model):
     d_fwd = [_per_read_digest(s1, i) for i in range(N_READS)]
     desc, blob, _ = cnn_model.default_model()
     ctx.load_cnn(desc, blob); ctx.load_fit_models(*synth.fit_models())
+    ctx.set_align_table(True)                                # `DNAscent align` table too: 230 M rows at this size
     ctx.run("hmm"); ctx.run("eventalign"); ctx.run("cnn"); ctx.sync()
+    rows_fwd = ctx.align_rows(N_READS)
+    assert int(rows_fwd.sum()) > 200e6
     sp = ctx.summaries().copy()
     probe = [i for i in range(0, N_READS, 10) if sp["status"][i] == 0]
     p_fwd = {}
