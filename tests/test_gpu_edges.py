@@ -78,3 +78,13 @@ def test_stage_order_is_enforced(model):
     with pytest.raises(hip.DnError):
         ctx.run("hmm")                                   # fit models not loaded
     ctx.close()
+
+
+def test_kernel_variants_behind_switches_are_bit_identical():
+    """The alternative kernel forms kept for A/B measurements (offset-keyed band fill, one-read-per-wavefront scan, 128-row long-K
+    convolutions, single-role / unfused separable layers) give the same summaries, alignment pairs, prefix sums and probabilities
+    as the defaults, bit for bit (tools/variant_check.py: one process per switch)."""
+    import os, subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "variant_check.py")
+    out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and "variants agree: True" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
