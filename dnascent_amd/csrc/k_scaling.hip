@@ -191,7 +191,7 @@ __device__ __forceinline__ void for_each_slope(const double *x, const double *y,
     }
 }
 
-__global__ __launch_bounds__(256) void k_theilsen(BatchDev B, const double *host_consts /* unused */) {
+__global__ __launch_bounds__(256) void k_theilsen(BatchDev B, int force_full_histogram /* diagnostics: take the general path */) {
     __shared__ double x[TS_MAXP], y[TS_MAXP];
     __shared__ unsigned hist[2048];
     __shared__ unsigned long long cand[TS_CAND];
@@ -236,22 +236,44 @@ __global__ __launch_bounds__(256) void k_theilsen(BatchDev B, const double *host
     unsigned *hist2 = reinterpret_cast<unsigned *>(cand);         // 2 x 2048 counters, dead before the candidates are collected
     for (int j = tid; j < 2048; j += 256) { hist[j] = 0; hist2[j] = 0; hist2[2048 + j] = 0; }
     __syncthreads();
+    // The first level only has to say WHICH exponent bucket holds the median, and it is almost always one of the two around 1:
+    // instead of a 2048-bin histogram (a data-dependent loop of wave-aggregated LDS atomics per 64 slopes) the common pass just
+    // counts the slopes below / inside the two buckets with ballots.  Only if the median lies outside them is the full
+    // first-level histogram built in an extra pass.
+    unsigned nBelow = 0, nA = 0, nB = 0;                          // wave-uniform counters
     for_each_slope(x, y, np, [&](unsigned long long k, bool act) {
         const unsigned top = (unsigned)(k >> 53);
-        hist_add_agg(hist, top, act);
-        if (act && (top == GA || top == GB)) atomicAdd(&hist2[(top == GB ? 2048u : 0u) + ((unsigned)(k >> 42) & 2047u)], 1u);
+        const bool inB = act && top == GB, inA = act && top == GA && !inB;   // (0.75 and 1.5 share their 10 leading exponent bits: GA == GB)
+        nBelow += (unsigned)__popcll(__ballot(act && top < GA));
+        nA += (unsigned)__popcll(__ballot(inA)); nB += (unsigned)__popcll(__ballot(inB));
+        if (inA || inB) atomicAdd(&hist2[(inB ? 2048u : 0u) + ((unsigned)(k >> 42) & 2047u)], 1u);
     });
+    if ((tid & 63) == 0) { atomicAdd(&hist[0], nBelow); atomicAdd(&hist[1], nA); atomicAdd(&hist[2], nB); }   // hist[] is free here
     __syncthreads();
+    const unsigned tBelow = hist[0], tA = hist[1], tB = hist[2];
+    const bool around_one = !force_full_histogram && want >= tBelow && want < tBelow + tA + tB;     // block-uniform
+    __syncthreads();
+    if (!around_one) {
+        for (int j = tid; j < 2048; j += 256) hist[j] = 0;
+        __syncthreads();
+        for_each_slope(x, y, np, [&](unsigned long long k, bool act) { hist_add_agg(hist, (unsigned)(k >> 53), act); });
+        __syncthreads();
+    }
     if (tid == 0) {
-        unsigned cum = 0, d = 2047;
-        for (unsigned b = 0; b < 2048; b++) { if (want < cum + hist[b]) { d = b; break; } cum += hist[b]; }
-        unsigned rank = want - cum, d2 = 0xffffffffu;
-        if (d == GA || d == GB) {
-            const unsigned *h2 = hist2 + (d == GB ? 2048u : 0u);
+        unsigned d, rank, d2 = 0xffffffffu;
+        if (around_one) {
+            const bool inGA = want < tBelow + tA;                   // tA counts top == GA && top != GB only
+            d = inGA ? GA : GB;
+            rank = want - tBelow - (inGA ? 0u : tA);
+            const unsigned *h2 = hist2 + (inGA ? 0u : 2048u);
             unsigned c2 = 0; d2 = 2047;
             for (unsigned b = 0; b < 2048; b++) { if (rank < c2 + h2[b]) { d2 = b; break; } c2 += h2[b]; }
             cnt0 = h2[d2];                                        // slopes sharing the 22 leading bits
             rank -= c2;
+        } else {
+            unsigned cum = 0; d = 2047;
+            for (unsigned b = 0; b < 2048; b++) { if (want < cum + hist[b]) { d = b; break; } cum += hist[b]; }
+            rank = want - cum;                                    // d is neither GA nor GB here: no second level
         }
         sel_digit = d; sel_digit2 = d2; sel_rank = rank;
     }
@@ -398,5 +420,7 @@ void ks_launch_prep(const BatchDev &B, unsigned max_events, hipStream_t st) {
     hipLaunchKernelGGL(k_prep, dim3((max_events + 255) / 256, B.n_reads), dim3(256), 0, st, B);
 }
 void ks_launch_theilsen(const BatchDev &B, hipStream_t st) {
-    hipLaunchKernelGGL(k_theilsen, dim3(B.n_reads), dim3(256), 0, st, B, (const double *)nullptr);
+    // DN_TS_FULL=1: always build the full first-level histogram (the path a median slope outside [0.5, 2) takes; same results)
+    static const int full = (getenv("DN_TS_FULL") && atoi(getenv("DN_TS_FULL")) != 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_theilsen, dim3(B.n_reads), dim3(256), 0, st, B, full);
 }
