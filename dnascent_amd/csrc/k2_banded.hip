@@ -758,6 +758,7 @@ __device__ __forceinline__ float lp_match_dev(double x, double mu, const FillCon
 
 __global__ __launch_bounds__(256) void k2_post(BatchDev B, const uint8_t *path_from, float *path_lp, FillConsts fc) {
     __shared__ int redi[4];
+    __shared__ double emd[64];                            // the 64 emissions of a chunk, widened, for the ordered sum
     const int r = blockIdx.x;
     const int tid = threadIdx.x;
     ReadRes &R = B.res[r];
@@ -832,12 +833,17 @@ __global__ __launch_bounds__(256) void k2_post(BatchDev B, const uint8_t *path_f
             if (w < n) { v = lp[n - 1 - w]; f = pf[n - 1 - w]; }
             const unsigned lim = min(64u, n - wb);
             unsigned long long m2 = __ballot(f == 2u);                        // bit i: walk step wb + i came from the left
+            // the operands come back as broadcast LDS reads (their own issue port): ONE vector instruction per step, the add
+            // (a v_readlane + v_cvt_f64_f32 + v_add_f64 chain was three)
+            emd[tid] = (double)v;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // one wavefront: LDS operations are in order
             if (lim == 64u) {
 #pragma unroll 16
-                for (unsigned i = 0; i < 64u; i++) sum_em += (double)bcast_f(v, (int)i);
+                for (unsigned i = 0; i < 64u; i++) sum_em += emd[i];
             } else {
-                for (unsigned i = 0; i < lim; i++) sum_em += (double)bcast_f(v, (int)i);
+                for (unsigned i = 0; i < lim; i++) sum_em += emd[i];
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (m2 == 0ull) { gap = 0; continue; }
             const unsigned long long valid = lim == 64u ? ~0ull : ((1ull << lim) - 1ull);
             const unsigned long long inv = (~m2) & valid;                     // the steps of the chunk that are NOT from the left
