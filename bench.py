@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- raw-signal Msamples/s of the `detect` hot path on MI355X (BASELINE.json metric).
 
-Workload at N=1 (BASELINE.json configs[1]): 1 000 synthetic 20 kb R10.4.1 reads on one MI355X, banded-HMM scope
-(CNN stubbed): one STEP = one pass of normaliseEvents (segmentation -> rough scaling -> adaptive banded alignment +
-backtrack + QC -> Theil-Sen) over the batch, inputs already resident in HBM.  For N>1 every rank owns its own 1 000
-reads (reads shard with no data-path collective: weak scaling); value = samples of all ranks / max-over-ranks time.
+Default workload (BASELINE.json configs[2]): a stream of synthetic 50 kb R10.4.1 reads through the FULL pipeline on one
+MI355X.  One STEP = one batch of --reads-per-step reads (default 500): host -> HBM upload, normaliseEvents (segmentation,
+rough scaling, adaptive banded alignment + backtrack + QC, Theil-Sen), eventalign (windowed Viterbi + feature fill), the
+BrdU/EdU CNN, the bulk result back on the host (dn_collect) and -- unless --emit 0 -- the .detect records formatted and
+written.  `--steps 20` (the default) is exactly the 10 000 reads of configs[2].  The timed region starts before the first
+upload of the first timed batch and ends when the last batch's records are on the host ("first H2D to last
+result on host"); every batch is distinct (own seeds), nothing is resident beforehand and nothing is skipped.  ONE host
+thread drives --inflight contexts (DNAscent::streamDetect).  For N > 1 every rank owns its own stream of reads (reads shard
+with no data-path collective: weak scaling) and the per-call results {coordinate, P(EdU), P(BrdU)} of all ranks are
+gathered to rank 0 inside the timed region; value = samples of all ranks / max-over-ranks time.
 
-Prints ONE JSON line on rank 0.  The `roofline` object is for the dominant kernel (k2_fill, the banded DP): achieved =
-ALGORITHMIC bytes per launch (n_bands*100 trace bytes + 4*(E+K) input bytes + 9*n_aligned backtrack
-bytes, summed over the reads of the launch) / that kernel's mean launch duration measured with HIP events on the
-library's stream inside the timed region.  `cpu_baseline` times the oracle (our CPU restatement, kind "port") on a
-bounded sample of the same reads on the host cores.
+`--scope banded` is BASELINE.json configs[1] (1 000 x 20 kb, normaliseEvents only, batch resident in HBM, CNN stubbed): the
+scope the adaptive-banded kernel's HBM roofline is quoted on.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel of the run: the CNN (all layers of one batch = one
+"launch" of dn_run_cnn) against the dense fp16 MFMA peak in the full scope, k2_fill against the HBM peak in the banded
+scope; achieved = ALGORITHMIC flops / bytes per launch / mean launch duration from HIP events on the
+library's streams inside the timed region.  `cpu_baseline` times the oracle (CPU restatement, kind "port") with OpenMP
+schedule(dynamic) on all host cores over a bounded sample of the same reads.
 """
 import argparse
 import json
@@ -27,76 +36,75 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK = 2500.0         # dense fp16 / bf16 MFMA TFLOP/s (MI355X_MICROARCH.md; the 2:1-sparsity figure is not used)
+MFMA_F32_PEAK = 157.0
 
 
-def make_batch(n_reads, n_bases, seed0, model):
-    from dnascent_amd import host, synth
-    batch = host.ReadBatch()
-    reads = []
-    for i in range(n_reads):
-        r = synth.make_read(seed0 + i, n_bases, model=model, is_reverse=bool(i & 1), sub_rate=0.002, ins_rate=0.001,
-                            del_rate=0.001)
-        assert batch.add_synth(r) >= 0
-        reads.append(r)
-    return batch, reads
+def cnn_macs(desc):
+    return sum(o["k"] * o["cin"] * o["cout"] for o in desc["ops"] if o["op"] == "conv") + \
+           sum(o["k"] * o["c"] for o in desc["ops"] if o["op"] == "dwconv") + 47040 + 64 * 3
 
 
-def cpu_baseline(reads, model, budget_s=20.0, full=False):
-    """Oracle (CPU restatement of the reference path) on a bounded sample, one read per thread like detect.cpp:852.
-    full: + eventalign, and the CNN through the stock-PyTorch CPU rendering of the same model description (fp32)."""
+def cpu_baseline(model, n_bases, seed0, full, budget_reads):
+    """The oracle (CPU restatement of the reference path) with OpenMP, one read per thread, schedule(dynamic) -- the shape of the
+    reference's own loop (detect.cpp:852) -- over a bounded sample of the workload's reads.  full: + eventalign, and the CNN's
+    cost from the stock-PyTorch CPU rendering of the same model description (fp32, all cores) on a sample of the positions."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
-    from concurrent.futures import ThreadPoolExecutor
+    from dnascent_amd import synth
     cores = os.cpu_count() or 1
-    cnn = None
-    if full:
+    n = max(1, min(budget_reads, cores))
+    reads = [synth.make_read(seed0 + i, n_bases, model=model, is_reverse=bool(i & 1), sub_rate=0.002, ins_rate=0.001, del_rate=0.001)
+             for i in range(n)]
+    secs, samples, positions, ok = po.bench_reads(reads, model, full, cores)
+    what = "oracle normaliseEvents%s, OpenMP schedule(dynamic), %d threads: %.1f s" % (" + eventalign" if full else "", cores, secs)
+    cnn_s = 0.0
+    if full and positions:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import cnn_torch_ref
         import torch
         from dnascent_amd import cnn_model
-        torch.set_num_threads(1)                        # one read per thread, like the reference's OpenMP loop
-        cnn = (cnn_torch_ref, cnn_model.default_model()[2])
-
-    def one(r):
-        o = po.OracleRead(r, model)      # includes int16 -> pA and CIGAR flattening, as the GPU path does
-        st = o.normalise()
-        if full and st == 0 and o.eventalign() == 0:
-            pos = o.positions()
-            cnn[0].run(cnn[1], pos["core"], pos["residual"], pos["signal"])
-        n = r.n_samples()
+        torch.set_num_threads(cores)
+        o = po.OracleRead(reads[0], model)
+        assert o.normalise() == 0 and o.eventalign() == 0
+        pos = o.positions()
         o.free()
-        return n
-
-    t0 = time.time()
-    one(reads[0])
-    per = max(time.time() - t0, 1e-3)
-    n = int(max(cores, min(len(reads), budget_s / per * cores)))
-    n = min(n, len(reads))
-    sample = reads[:n]
-    t0 = time.time()
-    with ThreadPoolExecutor(cores) as ex:      # ctypes releases the GIL inside the oracle
-        samples = sum(ex.map(one, sample))
-    dt = time.time() - t0
-    what = "oracle normaliseEvents + eventalign + PyTorch CPU fp32 CNN" if full else "oracle normaliseEvents (CNN excluded)"
-    return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%d of the %d-base reads of the workload, %s, %.1f s" % (n, reads[0].refseq.shape[0], what, dt)}
+        k = min(len(pos["core"]), 20000)
+        ref = cnn_model.default_model()[2]
+        t0 = time.time()
+        reps = 0
+        while time.time() - t0 < 4.0 or reps < 2:
+            cnn_torch_ref.run(ref, pos["core"][:k], pos["residual"][:k], pos["signal"][:k])
+            reps += 1
+        pos_per_s = reps * k / (time.time() - t0)
+        cnn_s = positions / pos_per_s
+        what += "; CNN: PyTorch CPU fp32 rendering at %.0f positions/s (all cores), %d positions of the sample -> %.1f s" % (pos_per_s, positions, cnn_s)
+    return {"value": samples / (secs + cnn_s) / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d of the %d-base reads of the workload (%d pass QC); %s" % (n, n_bases, ok, what)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--reads", type=int, default=1000)
-    ap.add_argument("--bases", type=int, default=20000)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scope", choices=["full", "banded"], default="full",
+                    help="full = BASELINE configs[2] (default): streamed 50 kb reads, whole pipeline, H2D to results on host; "
+                         "banded = configs[1]: 1 000 x 20 kb resident batch, normaliseEvents only (CNN stubbed)")
+    ap.add_argument("--reads-per-step", type=int, default=None, help="reads per batch (default 500 full / 1000 banded)")
+    ap.add_argument("--bases", type=int, default=None, help="bases per read (default 50000 full / 20000 banded)")
+    ap.add_argument("--inflight", type=int, default=None,
+                    help="batches in flight per GPU, each on its own context / stream / workspace (default 4 full / 8 banded)")
+    ap.add_argument("--emit", type=int, default=1, help="full scope: format + write the .detect records inside the timed region")
+    ap.add_argument("--out", default=None, help="full scope: .detect output path (default: formatted and counted, not written)")
+    ap.add_argument("--cnn-math", choices=["f16x3", "bf16x6", "fp32"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scope", choices=["banded", "full"], default="banded",
-                    help="banded = BASELINE configs[1] (the default, CNN stubbed); full = configs[2]'s pipeline at this batch size: "
-                         "normalise + eventalign + CNN, probabilities left in HBM")
-    ap.add_argument("--inflight", type=int, default=8,
-                    help="batches in flight per GPU (each on its own context/stream/workspace); every stage is latency-bound "
-                         "at <= 1 wavefront per SIMD for a 1000-read batch, so consecutive steps are overlapped")
     args = ap.parse_args()
+    full = args.scope == "full"
+    rps = args.reads_per_step or (500 if full else 1000)
+    bases = args.bases or (50000 if full else 20000)
+    inflight = args.inflight or (4 if full else 8)
+    os.environ.setdefault("DN_CNN_ROWS", str(2 << 20))      # activation rows resident per CNN pass and context: 2 Mi rows = 8 GiB
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -114,124 +122,150 @@ def main():
             torch.cuda.set_device(local_rank % ndev)
         dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from dnascent_amd import hip, synth
+    from dnascent_amd import cnn_model, hip, host, shard, synth
     model = synth.pore_model()
     dev = (local_rank % max(1, hip.lib().dn_device_count())) if world > 1 else 0
     red_dev = "cuda" if (dist is not None and os.environ.get("DN_BENCH_BACKEND", "nccl") == "nccl") else "cpu"
-    nctx = max(1, min(args.inflight, args.steps))
+    cnn_desc, cnn_blob, _ = cnn_model.default_model()
+    n_batches = (args.warmup + args.steps) if full else 1
+    nctx = max(1, min(inflight, args.steps if not full else n_batches))
     ctxs = [hip.Context(dev) for _ in range(nctx)]
-    batch, reads = make_batch(args.reads, args.bases, 1000003 * (rank + 1), model)
-    stages = ["normalise"] if args.scope == "banded" else ["normalise", "eventalign", "cnn"]
-    cnn_desc = None
-    if args.scope == "full":
-        from dnascent_amd import cnn_model
-        cnn_desc, cnn_blob, _ = cnn_model.default_model()
     for c in ctxs:
         c.load_pore_model(model, 0.14)
-        if cnn_desc is not None:
+        if full:
             c.load_cnn(cnn_desc, cnn_blob)
-        batch.upload(c)                    # inputs resident in HBM before the timed region (one copy per in-flight slot)
-    ctx = ctxs[0]
-    samples_per_step = batch.samples()
+            if args.cnn_math:
+                c.cnn_set_math(args.cnn_math)
+    cnn_math = args.cnn_math or os.environ.get("DN_CNN_MATH", "f16x3")
 
-    def sync_all():
-        for c in ctxs:
-            c.sync()
+    # ---- the reads: every batch of the stream is distinct (seeds by rank / batch / read) ----
+    t_gen = time.perf_counter()
+    seed_base = 1000003 * (rank + 1)
+    batches = []
+    for b in range(n_batches):
+        B = host.ReadBatch()
+        got = B.fill_synth(model, seed_base + b * rps, rps, bases)
+        assert got == rps, (got, rps)
+        batches.append(B)
+    t_gen = time.perf_counter() - t_gen
 
     def barrier():
-        sync_all()
+        for c in ctxs:
+            c.sync()
         if dist is not None:
             torch.cuda.synchronize()
             dist.barrier()
 
-    def run_steps(k):
-        """k steps in total; slot j runs steps j, j+nctx, ... on its own host thread (dn_run_banded syncs its stream)."""
-        if nctx == 1:
-            for _ in range(k):
-                for st in stages:
-                    ctx.run(st)
-            ctx.sync()
-            return
-        import threading
+    gather_s = 0.0
+    if full:
+        warm, timed = batches[:args.warmup], batches[args.warmup:]
+        if warm:
+            host.stream_detect(ctxs, warm, emit=bool(args.emit), out_path=None)
+        barrier()
+        for c in ctxs:
+            c.profile(True)
+            c.profile_reset()
+        t0 = time.perf_counter()
+        if dist is not None:
+            # the path's only exchange: the binary per-call results of every rank to the writer rank, one grouped
+            # send / recv over RCCL, inside the timed region
+            st, kept = host.stream_detect(ctxs, timed, emit=bool(args.emit), out_path=args.out, keep=True)
+            tg = time.perf_counter()
+            got = shard.gather_calls(dist, kept["read_calls"], kept["coord"], kept["p_edu"], kept["p_brdu"], dst=0, device=red_dev)
+            if rank == 0:
+                assert len(got) == world and all(int(g[0].sum()) == g[1].shape[0] for g in got)
+            gather_s = time.perf_counter() - tg
+            torch.cuda.synchronize()
+        else:
+            st = host.stream_detect(ctxs, timed, emit=bool(args.emit), out_path=args.out)
+        dt = time.perf_counter() - t0
+        barrier()
+        samples_total = float(st.samples)
+        last = ctxs[(len(timed) - 1) % nctx]
+        last.n_reads = timed[-1].size()
+        summ = last.summaries()
+    else:
+        B = batches[0]
+        for c in ctxs:
+            B.upload(c)                    # configs[1]: inputs resident in HBM before the timed region (one copy per in-flight slot)
+        samples_step = B.samples()
 
-        errors = []
+        def run_steps(k):
+            for i in range(k):
+                c = ctxs[i % nctx]
+                if i >= nctx:
+                    c.sync()               # the slot's previous step; every dn_run_* only enqueues
+                c.run("normalise")
+            for c in ctxs:
+                c.sync()
+        run_steps(max(args.warmup, nctx if args.warmup else 0))
+        barrier()
+        for c in ctxs:
+            c.profile(True)
+            c.profile_reset()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        if dist is not None:
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        barrier()
+        samples_total = float(samples_step) * args.steps
+        st = None
+        summ = ctxs[0].summaries()
+        for j, c in enumerate(ctxs[1:], 1):       # every slot ran the same batch concurrently: results must agree bit for bit
+            if c.summaries().tobytes() != summ.tobytes():
+                raise SystemExit("bench: in-flight slot %d disagrees with slot 0 on the per-read results" % j)
 
-        def worker(j):
-            try:
-                for _ in range(j, k, nctx):
-                    for st in stages:
-                        ctxs[j].run(st)
-                ctxs[j].sync()
-            except BaseException as e:          # a failed step must fail the run, not shorten it
-                errors.append(e)
-        th = [threading.Thread(target=worker, args=(j,)) for j in range(nctx)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        if errors:
-            raise errors[0]
-
-    run_steps(max(args.warmup, nctx if args.warmup else 0))
-    barrier()
-    for c in ctxs:
-        c.profile(True)
-        c.profile_reset()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    if dist is not None:
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    barrier()
     prof = {}
     for c in ctxs:
         for k, v in c.profile_get().items():
             a = prof.get(k, (0.0, 0))
             prof[k] = (a[0] + v[0], a[1] + v[1])
         c.profile(False)
-    summ = ctx.summaries()
-    # every in-flight slot ran the same batch concurrently with the others: their per-read results must be identical bit for bit
-    # (outside the timed region; a disagreement fails the run instead of reporting a number)
-    for j, c in enumerate(ctxs[1:], 1):
-        if c.summaries().tobytes() != summ.tobytes():
-            raise SystemExit("bench: in-flight slot %d disagrees with slot 0 on the per-read results" % j)
-    # the same kernel with the GPU to itself (not part of the timed region): one batch, nothing else in flight
-    solo_fill_ms = None
-    if nctx > 1 and rank == 0:
-        ctx.profile(True); ctx.profile_reset()
-        for _ in range(2):
-            ctx.run("normalise")
-        ctx.sync()
-        pf = ctx.profile_get().get("k2_fill")
-        if pf and pf[1]:
-            solo_fill_ms = pf[0] / pf[1]
-        ctx.profile(False)
+
+    # the same kernels with the GPU to itself (outside the timed region): one batch, nothing else in flight
+    solo = {}
+    if rank == 0:
+        c = ctxs[0]
+        c.profile(True); c.profile_reset()
+        sb = batches[-1]
+        sb.upload(c)
+        c.run("detect" if full else "normalise")
+        c.sync()
+        if full:
+            c.collect()
+        for k, v in c.profile_get().items():
+            if v[1]:
+                solo[k] = v[0] / v[1]
+        c.profile(False)
+        summ = c.summaries()
 
     # the only collectives of the path: MAX of the elapsed time, SUM of the counters (dnascent_amd/shard.py)
-    from dnascent_amd import shard
-    total_samples = float(samples_per_step)
     if dist is not None:
         dt = shard.reduce_max(dist, dt, device=red_dev)
-        total_samples = shard.reduce_counters(dist, [total_samples], device=red_dev)[0]
+        samples_total = shard.reduce_counters(dist, [samples_total], device=red_dev)[0]
 
     if rank == 0:
-        fill_ms, fill_n = prof["k2_fill"]
         ok = summ["status"] != 5
         alg_bytes = float(np.sum(summ["n_bands"][ok].astype(np.float64) * 100.0 +
                                  4.0 * (summ["n_events"][ok].astype(np.float64) + summ["n_kmers_query"][ok]) +
-                                 9.0 * summ["n_aligned"][ok]))
+                                 9.0 * summ["n_aligned"][ok]))           # trace + inputs + backtrack, per launch (= one batch)
+        fill_ms, fill_n = prof.get("k2_fill", (0.0, 0))
         fill_s = (fill_ms / max(fill_n, 1)) / 1e3
-        achieved = alg_bytes / fill_s / 1e9 if fill_s > 0 else 0.0
-        traffic = None
-        try:   # HBM bytes per launch from the committed PMC passes (cannot be collected inside a timed run)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_k2_fill.json")))
-            if pm["workload"] == {"reads": args.reads, "bases": args.bases}:
-                traffic = pm["write_bytes"] + pm["fetch_bytes_corrected"]
-        except Exception:
-            traffic = None
+        roof_banded = {"bound": "hbm", "kernel": "k2_fill", "achieved": alg_bytes / fill_s / 1e9 if fill_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": (alg_bytes / fill_s / 1e9 / HBM_PEAK_GBS) if fill_s > 0 else 0.0, "traffic": None,
+                       "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": fill_ms / max(fill_n, 1)}
+        if "k2_fill" in solo:
+            roof_banded["solo_launch_ms"] = solo["k2_fill"]
+            roof_banded["solo_frac"] = alg_bytes / (solo["k2_fill"] / 1e3) / 1e9 / HBM_PEAK_GBS
+        pm_path = os.path.join(ROOT, "profiles", "r02_pmc_k2_fill.json")
+        if os.path.exists(pm_path):          # HBM bytes per launch from the committed PMC passes (cannot be collected inside a timed run)
+            pm = json.load(open(pm_path))
+            if pm.get("workload") == {"reads": rps, "bases": bases}:
+                roof_banded["traffic"] = pm["write_bytes"] + pm["fetch_bytes_corrected"]
         out = {
-            "metric": "raw-signal Msamples/sec (whole node) on `detect`",
-            "value": total_samples * args.steps / dt / 1e6,
+            "metric": "raw-signal Msamples/sec (whole node) on `detect`" + ("" if full else " -- banded-HMM scope only (configs[1])"),
+            "value": samples_total / dt / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -240,59 +274,48 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32/f64",
+            "dtype": ("f32/f64 (CNN: fp32 products as %s on the 16-bit matrix cores)" % cnn_math) if full else "f32/f64",
             "data": "synthetic",
-            "config": {"workload": "%d synthetic %d kb R10.4.1 reads per GPU, banded-HMM scope (segmentation + rough scaling + "
-                                   "adaptive banded alignment + backtrack/QC + Theil-Sen), CNN stubbed" % (args.reads, args.bases // 1000),
-                       "reads_per_gpu": args.reads, "bases_per_read": args.bases, "samples_per_gpu_step": int(samples_per_step),
-                       "reads_passing_qc": int(np.sum(summ["status"] == 0)), "parallelism": "reads sharded, %d rank(s), %d batches in flight per GPU" % (world, nctx)},
-            "roofline": {"bound": "hbm", "kernel": "k2_fill", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": fill_ms / max(fill_n, 1)},
             "kernel_ms_per_launch": {k: v[0] / v[1] for k, v in prof.items() if v[1]},
+            "kernel_ms_solo": solo,
         }
-        if solo_fill_ms:
-            # launch durations in the timed region are stretched by the other batches in flight (the kernels time-share the
-            # SIMDs); the kernel's own rate is what it reaches with one batch on the GPU
-            out["roofline_solo"] = {"bound": "hbm", "kernel": "k2_fill", "achieved": alg_bytes / (solo_fill_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": alg_bytes / (solo_fill_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "mean_launch_ms": solo_fill_ms,
-                                    "note": "one batch in flight, outside the timed region"}
-        if args.scope == "banded" and (args.reads, args.bases) == (1000, 20000):
-            # what actually binds this scope: instruction issue.  Wave-instructions per step from the committed PMC
-            # pass of the same workload (profiles/r01_e_pmc_instruction_mix.csv, counters cannot be read inside a timed run),
-            # rate = that count / the measured step time; peak = 1024 SIMDs x one VALU wave-instruction per 4 cycles at 2.4 GHz
-            try:
-                valu = salu = 0.0
-                for line in open(os.path.join(ROOT, "profiles", "r01_e_pmc_instruction_mix.csv")):
-                    f = line.strip().split(",")
-                    if len(f) >= 3 and not line.startswith("#") and f[0] != "kernel":
-                        valu += float(f[1]); salu += float(f[2])
-                step_s = out["ms_per_step"] / 1e3
-                out["roofline_issue"] = {"bound": "valu_issue", "achieved": valu / step_s / 1e9, "peak": 1024 * 2.4 / 4.0, "unit": "G wave-instr/s",
-                                         "frac": valu / step_s / 1e9 / (1024 * 2.4 / 4.0), "valu_per_step": valu, "salu_per_step": salu,
-                                         "note": "instruction counts from the committed PMC pass; informational, `roofline` above follows the contract"}
-            except Exception:
-                pass
-        if args.scope == "full":
-            # dominant stage = the CNN: algorithmic flops = 2 x MACs of the description x positions (3.7 MFLOP x L);
-            # peak = the dense 16-bit MFMA rate (2.5 PFLOP/s) / the products per fp32 product of the split in use: 3 for the two-piece
-            # fp16 split (default), 6 for the three-piece bf16 split; 157 for exact fp32 MFMA.  See DESIGN.md s4b
-            cnn_math = os.environ.get("DN_CNN_MATH", "f16x3")
-            cnn_peak = {"f16x3": 2500.0 / 3, "bf16x6": 2500.0 / 6, "fp32": 157.0}[cnn_math]
-            mac = sum(o["k"] * o["cin"] * o["cout"] for o in cnn_desc["ops"] if o["op"] == "conv") + 47040
+        if full:
             pos = float(np.sum(summ["n_positions"][summ["status"] == 0]))
-            cnn_ms, cnn_n = prof["k3_cnn"]
-            ach = 2.0 * mac * pos / ((cnn_ms / max(cnn_n, 1)) / 1e3) / 1e12
-            out["config"]["workload"] = out["config"]["workload"].replace("banded-HMM scope (segmentation + rough scaling + adaptive banded "
-                                                                          "alignment + backtrack/QC + Theil-Sen), CNN stubbed",
-                                                                          "full pipeline (normalise + eventalign + CNN, %s math)" % cnn_math)
-            out["config"]["cnn_positions_per_gpu_step"] = int(pos)
-            out["roofline_banded"] = out["roofline"]
-            out["roofline"] = {"bound": "mfma", "kernel": "k3_cnn (all layers of one pass)", "achieved": ach, "peak": cnn_peak, "unit": "TFLOP/s",
-                               "frac": ach / cnn_peak, "traffic": None, "mean_launch_ms": cnn_ms / max(cnn_n, 1),
-                               "algorithmic_flops_per_launch": 2.0 * mac * pos}
+            mac = cnn_macs(cnn_desc)
+            cnn_ms, cnn_n = prof.get("k3_cnn", (0.0, 0))
+            flops = 2.0 * mac * pos
+            peak = MFMA_F32_PEAK if cnn_math == "fp32" else MFMA_F16_PEAK
+            ach = flops / ((cnn_ms / max(cnn_n, 1)) / 1e3) / 1e12 if cnn_ms > 0 else 0.0
+            issued = {"f16x3": 3.0, "bf16x6": 6.0, "fp32": 1.0}[cnn_math]
+            out["config"] = {
+                "workload": "%d synthetic %d kb R10.4.1 reads per GPU (BASELINE configs[2] = 10 000 at --steps 20), full pipeline: upload, "
+                            "normaliseEvents, eventalign, CNN (%s), results on host%s" % (args.steps * rps, bases // 1000, cnn_math,
+                                                                                          ", .detect records formatted" + (" and written" if args.out else "") if args.emit else ""),
+                "reads_per_step": rps, "bases_per_read": bases, "reads_per_gpu": args.steps * rps, "samples_per_gpu": int(st.samples),
+                "reads_passing_qc_per_gpu": int(st.reads_ok), "calls_per_gpu": int(st.calls),
+                "parallelism": "reads sharded, %d rank(s), %d batches in flight per GPU, one host thread per rank" % (world, nctx)}
+            out["roofline"] = {"bound": "mfma", "kernel": "k3_cnn (all layers of one batch)", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": None, "algorithmic_flops_per_launch": flops, "mean_launch_ms": cnn_ms / max(cnn_n, 1),
+                               "issued_frac": ach * issued / peak,
+                               "note": "achieved = algorithmic fp32 flops (2 x MACs x positions) / launch time; every fp32 product is issued as %g "
+                                       "16-bit MFMA products (issued_frac counts those)" % issued}
+            if "k3_cnn" in solo:
+                out["roofline"]["solo_launch_ms"] = solo["k3_cnn"]
+                out["roofline"]["solo_frac"] = flops / (solo["k3_cnn"] / 1e3) / 1e12 / peak
+            out["roofline_banded"] = roof_banded
+            out["host"] = {"datagen_s": t_gen, "upload_s": st.seconds_upload, "collect_wait_s": st.seconds_collect, "emit_s": st.seconds_emit,
+                           "gather_s": gather_s, "emission": {"records_per_s": st.calls / st.seconds_emit if st.seconds_emit > 0 else None,
+                                                              "MB_per_s": st.bytes_out / st.seconds_emit / 1e6 if st.seconds_emit > 0 else None,
+                                                              "bytes": int(st.bytes_out)}}
+        else:
+            out["config"] = {"workload": "%d synthetic %d kb R10.4.1 reads per GPU, banded-HMM scope (segmentation + rough scaling + adaptive "
+                                         "banded alignment + backtrack/QC + Theil-Sen), batch resident in HBM, CNN stubbed" % (rps, bases // 1000),
+                             "reads_per_gpu": rps, "bases_per_read": bases, "samples_per_gpu_step": int(samples_step),
+                             "reads_passing_qc": int(np.sum(summ["status"] == 0)),
+                             "parallelism": "reads sharded, %d rank(s), %d batches in flight per GPU, one host thread per rank" % (world, nctx)}
+            out["roofline"] = roof_banded
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(reads, model, full=(args.scope == "full"))
+            out["cpu_baseline"] = cpu_baseline(model, bases, seed_base, full, budget_reads=256)
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()

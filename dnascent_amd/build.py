@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "lib")
 HIP_SO = os.path.join(LIB, "libdnascent_hip.so")
 HOST_SO = os.path.join(LIB, "libdnascent_host.so")
 
-HIP_SOURCES = ["dn_capi.hip", "k1_segment.hip", "k2_banded.hip", "k_scaling.hip", "k2b_viterbi.hip", "k3_cnn.hip", "k_hmm.hip"]
+HIP_SOURCES = ["dn_capi.hip", "k1_segment.hip", "k2_banded.hip", "k_scaling.hip", "k2b_viterbi.hip", "k3_cnn.hip", "k_hmm.hip", "k_collect.hip"]
 HOST_SOURCES = ["host/dn_synth.c", "host/dn_host.cpp"]
 
 

@@ -24,11 +24,10 @@ void ks_launch_quantile(const BatchDev &, hipStream_t);
 void ks_launch_prep(const BatchDev &, unsigned, hipStream_t);
 void ks_launch_theilsen(const BatchDev &, hipStream_t);
 int k2_selftest_run(hipStream_t);
-void k2_launch_fill(const BatchDev &, const void *, const void *, bool, hipStream_t);
+void k2_launch_fill(const BatchDev &, const void *, const void *, hipStream_t);
 void k2_launch_chase(const BatchDev &, uint8_t *, hipStream_t);
 void k2_launch_post(const BatchDev &, const uint8_t *, float *, const void *, hipStream_t);
 void k2b_launch(const BatchDev &, const void *, const void *, const void *, unsigned, hipStream_t);
-int k2_fill_variant();
 struct CnnRows { const unsigned *row_off; const uint8_t *valid; unsigned rows, r0, r1; const unsigned *n_pos; const uint64_t *io_off; };
 struct CnnRun { const dn_cnn_op *ops; int n_ops; const float *wts; float *buf[8]; int n_buf; CnnRows rows; uint8_t *valid;
                  const float *core, *resid, *sig; float *probs; unsigned max_pos; const uint16_t *wts_split; const int64_t *wb_off;
@@ -43,11 +42,18 @@ void k_hmm_launch(const BatchDev &, const void *, const void *, const void *, un
 struct BandConstsH { double lp_stay, lp_step; };
 struct FillConstsH { double lp_skip, lp_trim, C, sigma, rsigma; };
 struct VitConstsH { double D2D, D2M, I2M, M2D, M2I, I2I; double c, d2, rd2, logc; double initD[66]; };
-struct VitReadH { double iM2M, eM2M, eM2MorD, eOrI; };
+struct VitReadH { double iM2M, eM2M, eM2MorD, eOrI; int fail, pad; };   // fail: eln() of a negative number (the reference throws NegativeLog)
 struct EaDevH { unsigned *coord, *qidx, *ridx; int *indel; unsigned *nsig; float *sig, *core, *resid;
                 unsigned *win_ref, *win_len, *win_T; double *win_score;
                 unsigned *al_coord, *al_rpos; double *al_val; unsigned char *al_kind; const unsigned long long *al_off; unsigned *al_n; };
 void k2b_rowcap_launch(const BatchDev &, unsigned long long *, hipStream_t);
+// k_collect.hip: per-read call counts (centre base T), their exclusive scan, ordered compaction of the per-call outputs
+struct CollectDev { const unsigned *coord, *qidx, *ridx; const float *probs; unsigned *cnt; unsigned long long *off;
+                    unsigned *o_coord, *o_qidx, *o_ridx; float *o_edu, *o_brdu; char *o_kmer; };
+void kc_launch_count(const BatchDev &, const void *, unsigned, hipStream_t);
+void kc_launch_scan(const BatchDev &, const void *, hipStream_t);
+void kc_launch_pack(const BatchDev &, const void *, unsigned, hipStream_t);
+void kc_launch_npos(const BatchDev &, unsigned *, hipStream_t);
 
 namespace {
 
@@ -79,9 +85,21 @@ struct dn_ctx {
     std::vector<uint64_t> h_samp_off, h_base_off, h_ref_off, h_chunk_off, h_ev_off, h_aln_off, h_trace_off;
     unsigned max_samples = 0, max_chunks = 0, max_len = 0, max_evcap = 0;
     std::vector<ReadRes> h_res;
-    DevBuf trace, bandc;
     uint8_t *d_path_from = nullptr; float *d_path_lp = nullptr;
     uint64_t *d_trace_off = nullptr;
+    void *d_bandc = nullptr;
+    // stream-ordered host work (hipLaunchHostFunc): page-locked mirrors of the per-read scalars and of the per-read constants
+    // the reference obtains from libm; grow-only, sized for the largest batch seen
+    ReadRes *p_res = nullptr; BandConstsH *p_bandc = nullptr; VitReadH *p_vit = nullptr; size_t p_cap = 0;
+    int async_err = 0; uint32_t async_err_read = 0;     // written by host functions on the runtime's callback thread, read after a sync
+    uint32_t n_batch = 0;                               // reads of the resident batch (what the host functions loop over)
+    // dn_collect: device-side compaction + page-locked result block
+    unsigned *d_call_cnt = nullptr; unsigned long long *d_call_off = nullptr;
+    DevBuf col_dev; void *col_host = nullptr; size_t col_host_cap = 0;
+    unsigned long long *p_call_off = nullptr; dn_read_summary *p_summary = nullptr;
+    bool upload_pinned = false;
+    size_t n_ref_T = 0; char *d_col = nullptr;
+    unsigned *p_cnn_rowoff = nullptr; uint64_t *p_cnn_iooff = nullptr; size_t cnn_meta_cap = 0; unsigned *p_cnn_flag = nullptr; bool cnn_pending = false;
     FillConstsH fc{};
     std::vector<int64_t> cnn_wb_off, cnn_wh_off; uint16_t *d_cnn_wb = nullptr, *d_cnn_wh = nullptr; size_t cnn_nwb = 0, cnn_nwh = 0; int cnn_math = DN_CNN_MATH_F16X3;
     std::vector<float> cnn_post, cnn_one; unsigned *d_cnn_flag = nullptr; uint64_t cnn_escalations = 0; bool cnn_f16_off = false;
@@ -117,6 +135,11 @@ static int fail(dn_ctx *c, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail((c), DN_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// smallest new slab; DN_SLAB_MIN_MB exists for the test that forces the exact-size retry of dalloc
+static size_t slab_min_bytes() {
+    const char *e = getenv("DN_SLAB_MIN_MB");
+    return (size_t)(e ? strtoull(e, nullptr, 10) : 256ull) << 20;
+}
 template <class T>
 static int dalloc(dn_ctx *c, T **p, size_t n) {
     const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
@@ -127,12 +150,16 @@ static int dalloc(dn_ctx *c, T **p, size_t n) {
     // a new slab: at least 256 MiB or half of what is already held, so a handful of slabs cover any steady-state batch size
     size_t held = 0;
     for (const dn_ctx::Slab &s : c->slabs) held += s.cap;
-    const size_t cap = std::max(bytes, std::max<size_t>((size_t)256 << 20, held / 2));
+    const size_t cap = std::max(bytes, std::max<size_t>(slab_min_bytes(), held / 2));
     void *q = nullptr;
+    size_t got = cap;
     hipError_t e = hipMalloc(&q, cap);
-    if (e != hipSuccess && cap > bytes) e = hipMalloc(&q, bytes);          // memory is tight: exactly what is needed
-    if (e != hipSuccess) return fail(c, DN_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
-    const size_t got = (e == hipSuccess && q) ? std::max(bytes, cap) : bytes;
+    if (e != hipSuccess && cap > bytes) {                                  // memory is tight: exactly what is needed
+        (void)hipGetLastError();                                           // the failed attempt must not surface after the next launch
+        got = bytes; q = nullptr;
+        e = hipMalloc(&q, bytes);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(c, DN_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
     c->slabs.push_back({ (char *)q, got, bytes }); c->dev_bytes += got;
     c->slab_cur = c->slabs.size() - 1;
     *p = (T *)q;
@@ -255,8 +282,15 @@ void dn_ctx_destroy(dn_ctx *c) {
     hipStreamSynchronize(c->stream);
     prof_collect(c);
     dfree_slabs(c);
-    if (c->trace.p) hipFree(c->trace.p);
-    if (c->bandc.p) hipFree(c->bandc.p);
+    if (c->p_res) hipHostFree(c->p_res);
+    if (c->p_bandc) hipHostFree(c->p_bandc);
+    if (c->p_vit) hipHostFree(c->p_vit);
+    if (c->p_call_off) hipHostFree(c->p_call_off);
+    if (c->p_summary) hipHostFree(c->p_summary);
+    if (c->col_host) hipHostFree(c->col_host);
+    if (c->p_cnn_rowoff) { hipHostFree(c->p_cnn_rowoff); hipHostFree(c->p_cnn_iooff); }
+    if (c->p_cnn_flag) hipHostFree(c->p_cnn_flag);
+    if (c->col_dev.p) hipFree(c->col_dev.p);
     if (c->d_model) hipFree(c->d_model);
     if (c->d_model_pos) hipFree(c->d_model_pos);
     if (c->d_model_sorted) hipFree(c->d_model_sorted);
@@ -277,10 +311,11 @@ void dn_ctx_destroy(dn_ctx *c) {
 
 const char *dn_last_error(const dn_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
+static int async_status(dn_ctx *c);
 int dn_sync(dn_ctx *c) {
     if (!c) return DN_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return DN_OK;
+    return async_status(c);
 }
 
 size_t dn_device_bytes(const dn_ctx *c) { return c ? c->dev_bytes : 0; }
@@ -364,7 +399,7 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     c->h_is_rev.assign(d->is_reverse, d->is_reverse + n);
     c->hmm_done = false;
     const uint64_t S = c->h_samp_off[n], NB = c->h_base_off[n], NR = c->h_ref_off[n];
-    c->h_chunk_off.assign(n + 1, 0); c->h_ev_off.assign(n + 1, 0); c->h_aln_off.assign(n + 1, 0);
+    c->h_chunk_off.assign(n + 1, 0); c->h_ev_off.assign(n + 1, 0); c->h_aln_off.assign(n + 1, 0); c->h_trace_off.assign(n + 1, 0);
     c->max_samples = c->max_chunks = c->max_len = c->max_evcap = 0;
     for (uint32_t r = 0; r < n; r++) {
         const uint64_t ns = c->h_samp_off[r + 1] - c->h_samp_off[r];
@@ -378,6 +413,9 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
         c->h_chunk_off[r + 1] = c->h_chunk_off[r] + nch;
         c->h_ev_off[r + 1] = c->h_ev_off[r] + evcap;
         c->h_aln_off[r + 1] = c->h_aln_off[r] + evcap + nb + 8;
+        // trace rows (32 B each): n_bands = events + k-mers + 2 is only known on the device, so the allocation takes the bound
+        // events <= evcap -- nothing on the host has to wait for the segmentation.  Padded for whole-tile loads / 8-row stores.
+        c->h_trace_off[r + 1] = c->h_trace_off[r] + ((evcap + nb + 2 + DN_TPAD + 7) & ~7ull);
         c->max_samples = std::max<unsigned>(c->max_samples, (unsigned)ns);
         c->max_chunks = std::max<unsigned>(c->max_chunks, (unsigned)nch);
         c->max_len = std::max<unsigned>(c->max_len, (unsigned)std::max(nb, nr));
@@ -397,6 +435,7 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     UP(chunk_off, c->h_chunk_off.data(), n + 1);
     UP(ev_off, c->h_ev_off.data(), n + 1);
     UP(aln_off, c->h_aln_off.data(), n + 1);
+    UP(trace_off, c->h_trace_off.data(), n + 1);
 #undef UP
 #define AL(field, cnt) if ((rc = dalloc(c, &B.field, (size_t)(cnt)))) return rc
     AL(psum, S); AL(t1, S); AL(t2, S);
@@ -408,7 +447,26 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
 #undef AL
     if ((rc = dalloc(c, &c->d_path_from, (size_t)NAL))) return rc;
     if ((rc = dalloc(c, &c->d_path_lp, (size_t)NAL))) return rc;
-    if ((rc = dalloc(c, &c->d_trace_off, (size_t)n + 1))) return rc;
+    if ((rc = dalloc(c, &B.trace, (size_t)c->h_trace_off[n] * DN_TROW))) return rc;
+    { BandConstsH *bcp = nullptr; if ((rc = dalloc(c, &bcp, (size_t)n))) return rc; c->d_bandc = bcp; }
+    if ((rc = dalloc(c, &c->d_call_cnt, (size_t)n)) || (rc = dalloc(c, &c->d_call_off, (size_t)n + 1))) return rc;
+    {   // dn_collect's packed arrays: a call is a thymidine of referenceSeqMappedTo (detect.cpp:690), so their count is the bound
+        size_t nt = 0;
+        for (uint64_t i = 0; i < NR; i++) nt += d->refseq[i] == 'T';
+        c->n_ref_T = (nt + 3) & ~(size_t)3;
+        if ((rc = dalloc(c, &c->d_col, std::max<size_t>(c->n_ref_T, 4) * (5 * 4 + DN_KMER)))) return rc;
+    }
+    if (n > c->p_cap) {                                   // page-locked mirrors for the stream-ordered host functions
+        if (c->p_res) { hipHostFree(c->p_res); hipHostFree(c->p_bandc); hipHostFree(c->p_vit); hipHostFree(c->p_call_off); hipHostFree(c->p_summary); }
+        c->p_res = nullptr; c->p_bandc = nullptr; c->p_vit = nullptr; c->p_call_off = nullptr; c->p_summary = nullptr; c->p_cap = 0;
+        const size_t cap = (size_t)n + n / 4 + 16;
+        HIPCHK(c, hipHostMalloc((void **)&c->p_res, cap * sizeof(ReadRes), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->p_bandc, cap * sizeof(BandConstsH), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->p_vit, cap * sizeof(VitReadH), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->p_call_off, (cap + 1) * sizeof(unsigned long long), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->p_summary, cap * sizeof(dn_read_summary), hipHostMallocDefault));
+        c->p_cap = cap;
+    }
     if ((rc = dalloc(c, &c->ea.coord, (size_t)NR)) || (rc = dalloc(c, &c->ea.qidx, (size_t)NR)) || (rc = dalloc(c, &c->ea.ridx, (size_t)NR)) ||
         (rc = dalloc(c, &c->ea.indel, (size_t)NR)) || (rc = dalloc(c, &c->ea.nsig, (size_t)NR)) || (rc = dalloc(c, &c->ea.sig, (size_t)NR * DN_RAWDEPTH)) ||
         (rc = dalloc(c, &c->ea.core, (size_t)NR)) || (rc = dalloc(c, &c->ea.resid, (size_t)NR)) || (rc = dalloc(c, &c->ea.win_ref, (size_t)NR)) ||
@@ -417,8 +475,16 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     c->max_ref = 0;
     for (uint32_t r = 0; r < n; r++) c->max_ref = std::max<unsigned>(c->max_ref, (unsigned)(c->h_ref_off[r + 1] - c->h_ref_off[r]));
     HIPCHK(c, hipMemsetAsync(B.res, 0, n * sizeof(ReadRes), c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // Page-locked input arrays (dn_host_alloc / dn_host_register) make the whole upload asynchronous; with pageable memory the
+    // runtime may still be reading the caller's arrays when hipMemcpyAsync returns, so the call waits for the copies.
+    {
+        hipPointerAttribute_t at;
+        c->upload_pinned = hipPointerGetAttributes(&at, d->adc) == hipSuccess && at.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+        if (!c->upload_pinned) HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     c->h_res.assign(n, ReadRes{});
+    c->n_batch = n; c->async_err = 0;
     c->have_batch = true; c->stage = 1;
     return DN_OK;
 }
@@ -453,40 +519,37 @@ int dn_run_rough_scaling(dn_ctx *c) {
     return DN_OK;
 }
 
-int dn_run_banded(dn_ctx *c) {
-    int rc = need(c, 3, "dn_run_banded"); if (rc) return rc;
-    if (c->B.n_reads == 0) { c->stage = std::max(c->stage, 4); return DN_OK; }
-    const uint32_t n = (uint32_t)c->B.n_reads;
-    // the trace size depends on the number of events found on the device: one small D2H + host-side offsets.
-    HIPCHK(c, hipMemcpyAsync(c->h_res.data(), c->B.res, n * sizeof(ReadRes), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->h_trace_off.assign(n + 1, 0);
-    std::vector<BandConstsH> bc(n);
-    unsigned max_events = 1;
-    for (uint32_t r = 0; r < n; r++) {
-        const ReadRes &R = c->h_res[r];
-        if (R.seg_overflow) return fail(c, DN_ERR_OVERFLOW, "segmentation workspace overflow in read %u", r);
+// Host functions (hipLaunchHostFunc): they run on the runtime's callback thread between two stream operations, touch only the
+// context's page-locked mirrors and call no HIP API.  They exist because three per-read constants of the reference come out of
+// libm (log / exp of values that depend on the event count found on the device): computing them with the HOST's libm keeps them
+// bit-identical to the reference's, and doing it stream-ordered keeps the host thread out of the pipeline.
+static void hf_band_consts(void *p) {
+    dn_ctx *c = (dn_ctx *)p;
+    for (uint32_t r = 0; r < c->n_batch; r++) {
+        const ReadRes &R = c->p_res[r];
+        if (R.seg_overflow && !c->async_err) { c->async_err = DN_ERR_OVERFLOW; c->async_err_read = r; }
         const uint64_t E = R.n_events, K = R.n_kq;
-        c->h_trace_off[r + 1] = c->h_trace_off[r] + (E + K + 2 + 64);
-        max_events = std::max<unsigned>(max_events, (unsigned)E);
         // event_handling.cpp:174-182, with the host libm (the reference's own calls)
         const double epk = (double)E / (double)K;
         const double p_stay = 1 - (1 / (epk + 1));
         const double lp_skip = log(1e-30);
         const double lp_stay = log(p_stay);
-        bc[r].lp_stay = lp_stay;
-        bc[r].lp_step = log(1.0 - exp(lp_skip) - exp(lp_stay));
+        c->p_bandc[r].lp_stay = lp_stay;
+        c->p_bandc[r].lp_step = log(1.0 - exp(lp_skip) - exp(lp_stay));
     }
-    const size_t tbytes = (size_t)c->h_trace_off[n] * DN_TROW;
-    if ((rc = dgrow(c, c->trace, tbytes))) return rc;
-    if ((rc = dgrow(c, c->bandc, n * sizeof(BandConstsH)))) return rc;
-    c->B.trace = (uint8_t *)c->trace.p;
-    c->B.trace_off = c->d_trace_off;
-    HIPCHK(c, hipMemcpyAsync(c->d_trace_off, c->h_trace_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->bandc.p, bc.data(), n * sizeof(BandConstsH), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // bc is a local
-    { Timed t(c, DN_K_PREP);       ks_launch_prep(c->B, max_events, c->stream); }
-    { Timed t(c, DN_K_BAND_FILL);  k2_launch_fill(c->B, c->bandc.p, &c->fc, c->use_dpp, c->stream); }
+}
+
+int dn_run_banded(dn_ctx *c) {
+    int rc = need(c, 3, "dn_run_banded"); if (rc) return rc;
+    if (c->B.n_reads == 0) { c->stage = std::max(c->stage, 4); return DN_OK; }
+    const uint32_t n = (uint32_t)c->B.n_reads;
+    // per-read band penalties depend on the number of events found on the device: D2H of the per-read scalars into page-locked
+    // memory, host libm in a stream-ordered host function, H2D of the constants -- the calling thread never waits
+    HIPCHK(c, hipMemcpyAsync(c->p_res, c->B.res, n * sizeof(ReadRes), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipLaunchHostFunc(c->stream, hf_band_consts, c));
+    HIPCHK(c, hipMemcpyAsync(c->d_bandc, c->p_bandc, n * sizeof(BandConstsH), hipMemcpyHostToDevice, c->stream));
+    { Timed t(c, DN_K_PREP);       ks_launch_prep(c->B, c->max_evcap, c->stream); }
+    { Timed t(c, DN_K_BAND_FILL);  k2_launch_fill(c->B, c->d_bandc, &c->fc, c->stream); }
     { Timed t(c, DN_K_BAND_TRACE); k2_launch_chase(c->B, c->d_path_from, c->stream);
                                    k2_launch_post(c->B, c->d_path_from, c->d_path_lp, &c->fc, c->stream); }
     HIPCHK(c, hipGetLastError());
@@ -524,30 +587,31 @@ static double h_lnSum(double a, double b) {           // probability.cpp:50-76
     return b + h_eln(1.0 + (std::isnan(a - b) ? 0.0 : exp(a - b)), &neg);
 }
 
+static void hf_viterbi_consts(void *p) {
+    dn_ctx *c = (dn_ctx *)p;
+    for (uint32_t r = 0; r < c->n_batch; r++) {
+        const ReadRes &R = c->p_res[r];
+        VitReadH &v = c->p_vit[r];
+        int neg = 0;
+        const double iM2M = h_eln(1. - (1. / R.events_per_base), &neg);                 // alignment.cpp:207
+        const double eM2M = h_eln(1.0 - c->vc.M2D - c->vc.M2I - iM2M, &neg);            // :208 (sic: log values)
+        v.iM2M = iM2M; v.eM2M = eM2M;
+        v.eM2MorD = h_lnSum(eM2M, c->vc.M2D);                                            // :209
+        v.eOrI = h_lnSum(eM2M, iM2M);                                                    // :210
+        v.fail = (R.status == 0 && neg) ? 1 : 0;                                         // the reference throws NegativeLog
+        v.pad = 0;
+    }
+}
+
 int dn_run_eventalign(dn_ctx *c) {
     int rc = need(c, 5, "dn_run_eventalign"); if (rc) return rc;
     if (c->B.n_reads == 0) { c->stage = std::max(c->stage, 6); return DN_OK; }
     const uint32_t n = (uint32_t)c->B.n_reads;
-    // per-read transitions depend on eventsPerBase (alignment.cpp:207-210): one small D2H, host libm, one small H2D
-    HIPCHK(c, hipMemcpyAsync(c->h_res.data(), c->B.res, n * sizeof(ReadRes), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<VitReadH> vr(n);
-    std::vector<int> newstat(n, -1);
-    for (uint32_t r = 0; r < n; r++) {
-        const ReadRes &R = c->h_res[r];
-        int neg = 0;
-        const double iM2M = h_eln(1. - (1. / R.events_per_base), &neg);                 // :207
-        const double eM2M = h_eln(1.0 - c->vc.M2D - c->vc.M2I - iM2M, &neg);            // :208 (sic: log values)
-        vr[r].iM2M = iM2M; vr[r].eM2M = eM2M;
-        vr[r].eM2MorD = h_lnSum(eM2M, c->vc.M2D);                                        // :209
-        vr[r].eOrI = h_lnSum(eM2M, iM2M);                                                // :210
-        if (R.status == 0 && neg) newstat[r] = DN_READ_FAIL_NEGATIVE_LOG;                // the reference throws NegativeLog
-    }
-    for (uint32_t r = 0; r < n; r++)
-        if (newstat[r] >= 0) HIPCHK(c, hipMemcpyAsync(&c->B.res[r].status, &newstat[r], sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_vitread, vr.data(), n * sizeof(VitReadH), hipMemcpyHostToDevice, c->stream));
+    // per-read transitions depend on eventsPerBase (alignment.cpp:207-210): small D2H, host libm in a host function, small H2D
+    HIPCHK(c, hipMemcpyAsync(c->p_res, c->B.res, n * sizeof(ReadRes), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipLaunchHostFunc(c->stream, hf_viterbi_consts, c));
+    HIPCHK(c, hipMemcpyAsync(c->d_vitread, c->p_vit, n * sizeof(VitReadH), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->ea.sig, 0, (size_t)c->h_ref_off[n] * DN_RAWDEPTH * sizeof(float), c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // vr / newstat are locals
     c->ea.al_coord = nullptr; c->ea.al_rpos = nullptr; c->ea.al_val = nullptr; c->ea.al_kind = nullptr; c->ea.al_off = nullptr; c->ea.al_n = nullptr;
     c->have_align = false;
     if (c->want_align) {
@@ -615,30 +679,105 @@ static int fetch_res(dn_ctx *c) {
     return DN_OK;
 }
 
+static int cnn_settle(dn_ctx *c);
+static void fill_summary(const dn_ctx *c, int r, const ReadRes &R, dn_read_summary &s) {
+    memset(&s, 0, sizeof(s));
+    s.status = R.status;
+    s.n_samples = (uint32_t)(c->h_samp_off[r + 1] - c->h_samp_off[r]);
+    s.n_scrappie = R.n_scrappie; s.n_events = R.n_events;
+    s.n_kmers_query = R.n_kq; s.n_kmers_ref = R.n_kr;
+    s.n_bands = R.n_bands; s.band_cells = (uint64_t)R.n_bands * DN_BANDWIDTH;
+    s.rough_shift = R.q_shift; s.rough_scale = R.q_scale;
+    s.end_event = R.end_event; s.n_aligned = R.n_aligned;
+    s.avg_log_emission = R.avg_log_emission; s.spanned = R.spanned; s.max_gap = R.max_gap; s.n_cleaned = R.n_cleaned;
+    s.ts_slope = R.ts_slope; s.ts_intercept = R.ts_intercept;
+    s.shift = R.shift; s.scale = R.scale; s.events_per_base = R.events_per_base;
+    s.n_positions = R.n_positions; s.n_windows = R.n_windows; s.detector_rechecks = R.rechecks;
+    s.n_hmm_calls = c->hmm_done && r < (int)c->h_nhmm.size() ? c->h_nhmm[r] : 0;
+}
+
+// errors raised by stream-ordered host functions surface at the next call that synchronises
+static int async_status(dn_ctx *c) {
+    if (c->async_err == DN_ERR_OVERFLOW) return fail(c, DN_ERR_OVERFLOW, "segmentation workspace overflow in read %u", c->async_err_read);
+    return c->async_err ? fail(c, c->async_err, "asynchronous stage failed") : DN_OK;
+}
+
 int dn_get_summaries(dn_ctx *c, dn_read_summary *out) {
     int rc = need(c, 1, "dn_get_summaries"); if (rc) return rc;
     if (c->B.n_reads == 0) return DN_OK;
     if (!out) return DN_ERR_ARG;
     if ((rc = fetch_res(c))) return rc;
-    for (int r = 0; r < c->B.n_reads; r++) {
-        const ReadRes &R = c->h_res[r];
-        dn_read_summary &s = out[r];
-        memset(&s, 0, sizeof(s));
-        s.status = R.status;
-        s.n_samples = (uint32_t)(c->h_samp_off[r + 1] - c->h_samp_off[r]);
-        s.n_scrappie = R.n_scrappie; s.n_events = R.n_events;
-        s.n_kmers_query = R.n_kq; s.n_kmers_ref = R.n_kr;
-        s.n_bands = R.n_bands; s.band_cells = (uint64_t)R.n_bands * DN_BANDWIDTH;
-        s.rough_shift = R.q_shift; s.rough_scale = R.q_scale;
-        s.end_event = R.end_event; s.n_aligned = R.n_aligned;
-        s.avg_log_emission = R.avg_log_emission; s.spanned = R.spanned; s.max_gap = R.max_gap; s.n_cleaned = R.n_cleaned;
-        s.ts_slope = R.ts_slope; s.ts_intercept = R.ts_intercept;
-        s.shift = R.shift; s.scale = R.scale; s.events_per_base = R.events_per_base;
-        s.n_positions = R.n_positions; s.n_windows = R.n_windows; s.detector_rechecks = R.rechecks;
-        s.n_hmm_calls = c->hmm_done && r < (int)c->h_nhmm.size() ? c->h_nhmm[r] : 0;
-    }
+    if ((rc = async_status(c))) return rc;
+    for (int r = 0; r < c->B.n_reads; r++) fill_summary(c, r, c->h_res[r], out[r]);
     return DN_OK;
 }
+
+int dn_collect(dn_ctx *c, dn_result_batch *out) {
+    int rc = need(c, 7, "dn_collect"); if (rc) return rc;
+    if (!out) return DN_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    const uint32_t n = (uint32_t)c->B.n_reads;
+    if (n == 0) return DN_OK;
+    if ((rc = cnn_settle(c))) return rc;                  // the stream is idle from here on
+    if ((rc = async_status(c))) return rc;
+    CollectDev cd{};
+    cd.coord = c->ea.coord; cd.qidx = c->ea.qidx; cd.ridx = c->ea.ridx; cd.probs = c->d_probs;
+    cd.cnt = c->d_call_cnt; cd.off = c->d_call_off;
+    // packed device arrays: every call is a 'T' of referenceSeqMappedTo, so the batch's T count bounds them (slab space set aside
+    // at upload); they are compacted on the device before the exact number is known on the host
+    const size_t cap = c->n_ref_T;
+    char *blk = (char *)c->d_col;
+    cd.o_coord = (unsigned *)blk; cd.o_qidx = cd.o_coord + cap; cd.o_ridx = cd.o_qidx + cap;
+    cd.o_edu = (float *)(cd.o_ridx + cap); cd.o_brdu = cd.o_edu + cap; cd.o_kmer = (char *)(cd.o_brdu + cap);
+    kc_launch_count(c->B, &cd, c->max_ref, c->stream);
+    kc_launch_scan(c->B, &cd, c->stream);
+    kc_launch_pack(c->B, &cd, c->max_ref, c->stream);
+    HIPCHK(c, hipMemcpyAsync(c->p_res, c->B.res, n * sizeof(ReadRes), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->p_call_off, c->d_call_off, (n + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    const size_t total = (size_t)c->p_call_off[n];
+    if (total > cap) return fail(c, DN_ERR_OVERFLOW, "dn_collect: %zu calls exceed the reference's %zu thymidines", total, cap);
+    // page-locked result block, grow-only: [coord][query_idx][ref_idx][p_edu][p_brdu][kmer9], each `total` long
+    const size_t tot4 = (total + 3) & ~(size_t)3;
+    const size_t bytes = tot4 * (5 * 4 + DN_KMER) + 64;
+    if (bytes > c->col_host_cap) {
+        if (c->col_host) hipHostFree(c->col_host);
+        c->col_host = nullptr; c->col_host_cap = 0;
+        const size_t want = bytes + bytes / 4;
+        HIPCHK(c, hipHostMalloc(&c->col_host, want, hipHostMallocDefault));
+        c->col_host_cap = want;
+    }
+    uint32_t *h_coord = (uint32_t *)c->col_host, *h_qidx = h_coord + tot4, *h_ridx = h_qidx + tot4;
+    float *h_edu = (float *)(h_ridx + tot4), *h_brdu = h_edu + tot4; char *h_kmer = (char *)(h_brdu + tot4);
+    if (total) {
+        HIPCHK(c, hipMemcpyAsync(h_coord, cd.o_coord, total * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_qidx, cd.o_qidx, total * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_ridx, cd.o_ridx, total * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_edu, cd.o_edu, total * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_brdu, cd.o_brdu, total * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_kmer, cd.o_kmer, total * DN_KMER, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    memcpy(c->h_res.data(), c->p_res, n * sizeof(ReadRes));
+    for (uint32_t r = 0; r < n; r++) fill_summary(c, (int)r, c->p_res[r], c->p_summary[r]);
+    out->n_reads = n; out->summary = c->p_summary;
+    out->call_off = (const uint64_t *)c->p_call_off; out->n_calls = total;
+    out->ref_coord = h_coord; out->query_idx = h_qidx; out->ref_idx = h_ridx; out->p_edu = h_edu; out->p_brdu = h_brdu; out->kmer9 = h_kmer;
+    return DN_OK;
+}
+
+int dn_host_alloc(size_t bytes, void **p) {
+    if (!p) return DN_ERR_ARG;
+    *p = nullptr;
+    return hipHostMalloc(p, std::max<size_t>(bytes, 1), hipHostMallocDefault) == hipSuccess ? DN_OK : DN_ERR_HIP;
+}
+void dn_host_free(void *p) { if (p) (void)hipHostFree(p); }
+int dn_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return DN_ERR_ARG;
+    return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? DN_OK : DN_ERR_HIP;
+}
+int dn_host_unregister(void *p) { return (p && hipHostUnregister(p) == hipSuccess) ? DN_OK : DN_ERR_HIP; }
 
 #define CHECK_READ(stage_, name_)                                     \
     int rc = need(c, stage_, name_); if (rc) return rc;              \
@@ -717,23 +856,21 @@ int dn_get_trace(dn_ctx *c, uint32_t read, uint8_t *trace, int32_t *band_event, 
     CHECK_READ(4, "dn_get_trace");
     if ((rc = fetch_res(c))) return rc;
     const size_t nb = c->h_res[read].n_bands;
-    std::vector<uint8_t> rows(nb * DN_TROW);
-    if ((rc = d2h(c, rows.data(), c->B.trace + c->h_trace_off[read] * DN_TROW, nb * DN_TROW))) return rc;
-    const bool slot_rows = k2_fill_variant() == 6;
+    std::vector<uint64_t> rows(nb * (DN_TROW / 8));
+    if ((rc = d2h(c, (uint8_t *)rows.data(), c->B.trace + c->h_trace_off[read] * DN_TROW, nb * DN_TROW))) return rc;
+    // rows are planar 2-bit codes by slot (k2_banded.hip put_row): {A0, A1, B0, B1}; slot s = event & 127, register s & 1, lane s >> 1
+    auto code = [&](size_t b, int ev) -> unsigned {
+        const unsigned sl = (unsigned)ev & 127u, l = sl >> 1;
+        const uint64_t *w = rows.data() + b * 4 + (sl & 1u) * 2;
+        return (unsigned)((w[0] >> l) & 1ull) | ((unsigned)((w[1] >> l) & 1ull) << 1);
+    };
     int32_t ev_prev = 48;
     for (size_t b = 0; b < nb; b++) {
-        const uint8_t *p = rows.data() + b * DN_TROW;
-        int32_t ev;
-        if (slot_rows) {
-            // k2_fill6 rows are indexed by event & 127 with 0xFF outside the band; the corner moves by exactly one per band:
-            // the band moved down iff the slot of event ev_prev + 1 is in the band
-            ev = (b == 0) ? 49 : ((p[(ev_prev + 1) & 127] != 0xFF) ? ev_prev + 1 : ev_prev);
-            if (trace) for (int o = 0; o < DN_BANDWIDTH; o++) trace[b * DN_BANDWIDTH + o] = p[(ev - o) & 127];
-            ev_prev = ev;
-        } else {
-            if (trace) memcpy(trace + b * DN_BANDWIDTH, p, DN_BANDWIDTH);
-            memcpy(&ev, p + 104, 4);                  // ll.event_idx; ll.event_idx + ll.kmer_idx == band - 2 for every band
-        }
+        // code 3 marks the 28 slots outside the band; the corner moves by exactly one per band: the band moved down iff the slot of
+        // event ev_prev + 1 is in the band
+        const int32_t ev = (b == 0) ? 49 : ((code(b, ev_prev + 1) != 3u) ? ev_prev + 1 : ev_prev);
+        if (trace) for (int o = 0; o < DN_BANDWIDTH; o++) trace[b * DN_BANDWIDTH + o] = (uint8_t)code(b, ev - o);
+        ev_prev = ev;
         if (band_event) band_event[b] = ev;
         if (band_kmer) band_kmer[b] = (int32_t)b - 2 - ev;
     }
@@ -779,12 +916,27 @@ int dn_load_cnn(dn_ctx *c, const dn_cnn_op *ops, uint32_t n_ops, const float *we
         if (o.cin > 256 || o.cout > 256) return fail(c, DN_ERR_ARG, "cnn op %u: more than 256 channels", i);
         const uint32_t nb = n_buffers;
         if ((uint32_t)o.src >= nb || (uint32_t)o.dst >= nb || (uint32_t)o.a >= nb || (uint32_t)o.b >= nb) return fail(c, DN_ERR_ARG, "cnn op %u: buffer index out of range", i);
-        if ((o.op == DN_CNN_CONV || o.op == DN_CNN_CONV_ADD) && (o.cin % 32 || o.cout % 64 || !(o.k & 1) || o.k > 17)) return fail(c, DN_ERR_ARG, "cnn op %u: conv shape not supported", i);
+        // this is the trust boundary for model files: every offset + extent must lie inside the blob
+        auto inside = [&](int64_t off, uint64_t len) { return off >= 0 && (uint64_t)off <= n_weights && len <= n_weights - (uint64_t)off; };
+        const bool conv = o.op == DN_CNN_CONV || o.op == DN_CNN_CONV_ADD;
+        if ((conv || o.op == DN_CNN_DWCONV || o.op == DN_CNN_DENSE_SOFTMAX || o.op == DN_CNN_ADD_RELU) && (o.cin <= 0 || o.cout <= 0))
+            return fail(c, DN_ERR_ARG, "cnn op %u: channel counts must be positive", i);
+        if ((conv || o.op == DN_CNN_DWCONV) && o.k <= 0) return fail(c, DN_ERR_ARG, "cnn op %u: kernel width must be positive", i);
+        if (conv && (o.cin % 32 || o.cout % 64 || !(o.k & 1) || o.k > 17)) return fail(c, DN_ERR_ARG, "cnn op %u: conv shape not supported", i);
         if (o.op == DN_CNN_DWCONV && (o.cin % 4 || (o.k != 3 && o.k != 5 && o.k != 7 && o.k != 9 && o.k != 17)))
             return fail(c, DN_ERR_ARG, "cnn op %u: depthwise shape not supported", i);
         // a convolution reads rows (halo) and channels that other workgroups of the same launch write: never in place
-        if ((o.op == DN_CNN_CONV || o.op == DN_CNN_CONV_ADD || o.op == DN_CNN_DWCONV) && o.src == o.dst) return fail(c, DN_ERR_ARG, "cnn op %u: convolution in place (src == dst)", i);
-        if ((o.op == DN_CNN_CONV || o.op == DN_CNN_CONV_ADD) && (o.w < 0 || (uint64_t)o.w + (uint64_t)o.k * o.cin * o.cout > n_weights)) return fail(c, DN_ERR_ARG, "cnn op %u: weights out of range", i);
+        if ((conv || o.op == DN_CNN_DWCONV) && o.src == o.dst) return fail(c, DN_ERR_ARG, "cnn op %u: convolution in place (src == dst)", i);
+        if (conv && (!inside(o.w, (uint64_t)o.k * o.cin * o.cout) || !inside(o.scale, (uint64_t)o.cout) || !inside(o.shift, (uint64_t)o.cout)))
+            return fail(c, DN_ERR_ARG, "cnn op %u: weights out of range", i);
+        if (o.op == DN_CNN_DWCONV && !inside(o.w, (uint64_t)o.k * o.cin)) return fail(c, DN_ERR_ARG, "cnn op %u: depthwise weights out of range", i);
+        if (o.op == DN_CNN_DENSE_SOFTMAX && (!inside(o.w, (uint64_t)o.cin * o.cout) || !inside(o.shift, (uint64_t)o.cout)))
+            return fail(c, DN_ERR_ARG, "cnn op %u: dense weights out of range", i);
+        if (o.op == DN_CNN_ENCODE_GRU) {
+            if (o.cout != 64) return fail(c, DN_ERR_ARG, "cnn op %u: the encoder writes 64 channels", i);
+            const uint64_t ext[6] = { 48, 16 * 48, 96, 16 * 48, 16 * 48, 96 };     // kernel / recurrent / bias of the two GRUs
+            for (int j = 0; j < 6; j++) if (!inside(o.aux[j], ext[j])) return fail(c, DN_ERR_ARG, "cnn op %u: GRU weights out of range", i);
+        }
     }
     // conv kernels [k][cin][cout] (Keras order) -> [k][cin / 32][cout][32]: the B tile of k3_conv is then a straight copy
     std::vector<float> wl(weights, weights + n_weights);
@@ -887,18 +1039,34 @@ int dn_cnn_set_math(dn_ctx *c, int mode) {
     return DN_OK;
 }
 
-// the CNN over n sequences whose input tensors (core, residual, signal) are already on the device
-static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *npos, const uint64_t *io_off, const float *d_core, const float *d_resid,
-                       const float *d_sig, float *d_probs) {
+// the CNN over n sequences whose input tensors (core, residual, signal) are already on the device.
+// ub[r] (host) bounds the positions of sequence r; the actual counts are on the device (d_npos: 0 = nothing to do).  Activation
+// rows are laid out from the BOUNDS -- sequence r owns ub[r] rows + CNN_PAD zero rows, of which the first d_npos[r] are live and
+// the rest stay zero / invalid -- so the pass partition, every row offset and every grid size are known without reading anything
+// back: the whole network is enqueued without a host synchronisation.  (After eventalign ub = reference length - 8 and a passing
+// read fills ~95 % of it.)  check_now: examine the fp16 range flag after every pass (dn_cnn_infer); otherwise the flag is copied
+// to page-locked memory at the end and examined by whoever synchronises next (cnn_settle).
+static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned *d_npos, const uint64_t *io_off, const float *d_core,
+                       const float *d_resid, const float *d_sig, float *d_probs, bool check_now) {
     if (c->cnn_ops.empty()) return fail(c, DN_ERR_STATE, "dn_load_cnn must be called first");
-    // sequences are packed end to end, CNN_PAD (8) zero rows around each; passes of at most cnn_row_cap() rows
     const uint64_t cap = cnn_row_cap();
-    std::vector<unsigned> row_off(n, 0u);
+    int rc;
+    // page-locked staging of the per-sequence tables (the H2D copies below must not read pageable memory after this call returns)
+    if (n > c->cnn_meta_cap) {
+        if (c->p_cnn_rowoff) { hipHostFree(c->p_cnn_rowoff); hipHostFree(c->p_cnn_iooff); }
+        c->p_cnn_rowoff = nullptr; c->p_cnn_iooff = nullptr; c->cnn_meta_cap = 0;
+        const size_t m = (size_t)n + n / 4 + 16;
+        HIPCHK(c, hipHostMalloc((void **)&c->p_cnn_rowoff, m * sizeof(unsigned), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->p_cnn_iooff, m * sizeof(uint64_t), hipHostMallocDefault));
+        c->cnn_meta_cap = m;
+    }
+    unsigned *row_off = c->p_cnn_rowoff;
+    memcpy(c->p_cnn_iooff, io_off, n * sizeof(uint64_t));
     struct Pass { uint32_t r0, r1; unsigned rows, max_pos, n_pos; };
     std::vector<Pass> passes;
     uint64_t rows = 8; unsigned max_pos = 1, pass_pos = 0; uint32_t r0 = 0; uint64_t max_rows = 0;
     for (uint32_t r = 0; r < n; r++) {
-        const unsigned np = npos[r];
+        const unsigned np = ub[r];
         if (rows + np + 8 > cap && r > r0) {
             const uint64_t rr = (rows + 255) / 256 * 256;
             passes.push_back({ r0, r, (unsigned)rr, max_pos, pass_pos }); max_rows = std::max(max_rows, rr);
@@ -910,17 +1078,15 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *npos, const uint64
         max_pos = std::max(max_pos, np);
     }
     { const uint64_t rr = (rows + 255) / 256 * 256; passes.push_back({ r0, n, (unsigned)rr, max_pos, pass_pos }); max_rows = std::max(max_rows, rr); }
-    int rc;
     for (int b = 0; b < c->cnn_nbuf; b++)
         if ((rc = dgrow(c, c->cnn_buf[b], (size_t)max_rows * 256 * sizeof(float)))) return rc;
     if ((rc = dgrow(c, c->cnn_enclen, (size_t)max_rows)) || (rc = dgrow(c, c->cnn_enchist, 64 * sizeof(unsigned))) ||
         (rc = dgrow(c, c->cnn_permsrc, (size_t)max_rows * sizeof(uint64_t))) || (rc = dgrow(c, c->cnn_permrow, (size_t)max_rows * sizeof(unsigned)))) return rc;
     if ((rc = dgrow(c, c->cnn_valid, (size_t)max_rows)) || (rc = dgrow(c, c->cnn_rowoff, n * sizeof(unsigned))) ||
-        (rc = dgrow(c, c->cnn_npos, n * sizeof(unsigned))) || (rc = dgrow(c, c->cnn_iooff, n * sizeof(uint64_t)))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->cnn_rowoff.p, row_off.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->cnn_npos.p, npos, n * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->cnn_iooff.p, io_off, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));           // the sources are locals of the callers
+        (rc = dgrow(c, c->cnn_iooff, n * sizeof(uint64_t)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->cnn_rowoff.p, row_off, n * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->cnn_iooff.p, c->p_cnn_iooff, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    if (!c->p_cnn_flag) HIPCHK(c, hipHostMalloc((void **)&c->p_cnn_flag, sizeof(unsigned), hipHostMallocDefault));
     Timed t(c, DN_K_CNN);
     for (const Pass &ps : passes) {
         HIPCHK(c, hipMemsetAsync(c->cnn_valid.p, 0, (size_t)ps.rows, c->stream));
@@ -930,7 +1096,7 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *npos, const uint64
         run.n_buf = c->cnn_nbuf;
         run.rows.row_off = (const unsigned *)c->cnn_rowoff.p; run.rows.valid = (const uint8_t *)c->cnn_valid.p; run.rows.rows = ps.rows;
         run.rows.r0 = ps.r0; run.rows.r1 = ps.r1;
-        run.rows.n_pos = (const unsigned *)c->cnn_npos.p; run.rows.io_off = (const uint64_t *)c->cnn_iooff.p;
+        run.rows.n_pos = d_npos; run.rows.io_off = (const uint64_t *)c->cnn_iooff.p;
         run.valid = (uint8_t *)c->cnn_valid.p;
         run.n_pass_pos = ps.n_pos; run.enc_len = (uint8_t *)c->cnn_enclen.p; run.enc_hist = (unsigned *)c->cnn_enchist.p;
         run.perm_src = (uint64_t *)c->cnn_permsrc.p; run.perm_row = (unsigned *)c->cnn_permrow.p;
@@ -944,33 +1110,65 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *npos, const uint64
             run.post = math == DN_CNN_MATH_F16X3 ? c->cnn_post.data() : c->cnn_one.data();
             run.range_flag = c->d_cnn_flag;
             if (k3_run(run, c->stream)) return fail(c, DN_ERR_ARG, "unsupported op in the CNN description");
-            if (math != DN_CNN_MATH_F16X3) break;
-            unsigned flag = 0;
-            HIPCHK(c, hipMemcpyAsync(&flag, c->d_cnn_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            if (math != DN_CNN_MATH_F16X3 || !check_now) break;
+            HIPCHK(c, hipMemcpyAsync(c->p_cnn_flag, c->d_cnn_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (!flag) break;
+            if (!*c->p_cnn_flag) break;
             HIPCHK(c, hipMemsetAsync(c->d_cnn_flag, 0, sizeof(unsigned), c->stream));
             c->cnn_escalations++;
             c->cnn_f16_off = true;                          // this model's activations do not fit: stay on bf16 pieces from now on
             math = DN_CNN_MATH_BF16X6;
         }
     }
+    if (!check_now) HIPCHK(c, hipMemcpyAsync(c->p_cnn_flag, c->d_cnn_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipGetLastError());
     return DN_OK;
 }
 
 uint64_t dn_cnn_range_escalations(dn_ctx *c) { return c ? c->cnn_escalations : 0; }
 
+static int cnn_enqueue_batch(dn_ctx *c) {
+    const uint32_t n = (uint32_t)c->B.n_reads;
+    // bound of a read's positions: one per 9-mer of referenceSeqMappedTo (alignment.cpp:547: reference index < length - 8)
+    std::vector<unsigned> ub(n);
+    for (uint32_t r = 0; r < n; r++) ub[r] = (unsigned)(c->h_ref_off[r + 1] - c->h_ref_off[r]) - (DN_KMER - 1);
+    int rc;
+    if ((rc = dgrow(c, c->cnn_npos, n * sizeof(unsigned)))) return rc;
+    kc_launch_npos(c->B, (unsigned *)c->cnn_npos.p, c->stream);      // positions eventalign found; 0 for reads that failed
+    return cnn_execute(c, n, ub.data(), (const unsigned *)c->cnn_npos.p, c->h_ref_off.data(), c->ea.core, c->ea.resid, c->ea.sig, c->d_probs, false);
+}
+
+// after dn_run_cnn: wait for the stream, and if some activation left fp16's range repeat the batch with bf16 pieces
+static int cnn_settle(dn_ctx *c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->cnn_pending) return DN_OK;
+    c->cnn_pending = false;
+    if (c->p_cnn_flag && *c->p_cnn_flag) {
+        HIPCHK(c, hipMemsetAsync(c->d_cnn_flag, 0, sizeof(unsigned), c->stream));
+        *c->p_cnn_flag = 0;
+        c->cnn_escalations++;
+        c->cnn_f16_off = true;
+        int rc = cnn_enqueue_batch(c);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return DN_OK;
+}
+
 int dn_run_cnn(dn_ctx *c) {
     int rc = need(c, 6, "dn_run_cnn"); if (rc) return rc;
     if (c->B.n_reads == 0) { c->stage = std::max(c->stage, 7); return DN_OK; }
-    const uint32_t n = (uint32_t)c->B.n_reads;
-    if ((rc = fetch_res(c))) return rc;                      // rows per read = positions found by eventalign (small D2H)
-    std::vector<unsigned> npos(n);
-    for (uint32_t r = 0; r < n; r++) npos[r] = c->h_res[r].status == 0 ? c->h_res[r].n_positions : 0;
-    if ((rc = cnn_execute(c, n, npos.data(), c->h_ref_off.data(), c->ea.core, c->ea.resid, c->ea.sig, c->d_probs))) return rc;
+    if ((rc = cnn_enqueue_batch(c))) return rc;
+    c->cnn_pending = true;
     c->stage = 7;
     return DN_OK;
+}
+
+int dn_run_detect(dn_ctx *c) {
+    int rc;
+    if ((rc = dn_run_normalise(c))) return rc;
+    if ((rc = dn_run_eventalign(c))) return rc;
+    return dn_run_cnn(c);
 }
 
 int dn_cnn_infer(dn_ctx *c, uint32_t n_seq, const uint32_t *len, const float *core, const float *residual, const float *signal, float *probs) {
@@ -982,17 +1180,21 @@ int dn_cnn_infer(dn_ctx *c, uint32_t n_seq, const uint32_t *len, const float *co
     if (L == 0) return DN_OK;
     int rc;
     if ((rc = dgrow(c, c->cnn_in[0], L * sizeof(float))) || (rc = dgrow(c, c->cnn_in[1], L * sizeof(float))) ||
-        (rc = dgrow(c, c->cnn_in[2], L * DN_RAWDEPTH * sizeof(float))) || (rc = dgrow(c, c->cnn_out, L * 3 * sizeof(float)))) return rc;
+        (rc = dgrow(c, c->cnn_in[2], L * DN_RAWDEPTH * sizeof(float))) || (rc = dgrow(c, c->cnn_out, L * 3 * sizeof(float))) ||
+        (rc = dgrow(c, c->cnn_npos, n_seq * sizeof(unsigned)))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->cnn_in[0].p, core, L * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->cnn_in[1].p, residual, L * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->cnn_in[2].p, signal, L * DN_RAWDEPTH * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    if ((rc = cnn_execute(c, n_seq, len, off.data(), (const float *)c->cnn_in[0].p, (const float *)c->cnn_in[1].p, (const float *)c->cnn_in[2].p,
-                          (float *)c->cnn_out.p))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->cnn_npos.p, len, n_seq * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));           // the sources are the caller's pageable arrays
+    if ((rc = cnn_execute(c, n_seq, len, (const unsigned *)c->cnn_npos.p, off.data(), (const float *)c->cnn_in[0].p, (const float *)c->cnn_in[1].p,
+                          (const float *)c->cnn_in[2].p, (float *)c->cnn_out.p, true))) return rc;
     return d2h(c, probs, (const float *)c->cnn_out.p, L * 3);
 }
 
 int dn_get_probabilities(dn_ctx *c, uint32_t read, float *probs) {
     CHECK_READ(7, "dn_get_probabilities");
+    if ((rc = cnn_settle(c))) return rc;
     if ((rc = fetch_res(c))) return rc;
     return d2h(c, probs, c->d_probs + c->h_ref_off[read] * 3, (size_t)c->h_res[read].n_positions * 3);
 }

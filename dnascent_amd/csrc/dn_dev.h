@@ -5,7 +5,8 @@
 #include <stdint.h>
 
 #define DN_W 100            // band width (config.h:41)
-#define DN_TROW 128         // bytes per stored trace row: 100 trace bytes + band metadata, one full 128-B line
+#define DN_TROW 32          // bytes per stored trace row: 128 slots x 2-bit from-code, planar (k2_banded.hip put_row)
+#define DN_TPAD 264         // rows of padding per read: k2_chase loads whole 256-row tiles, k2_fill6 stores whole 8-row groups
 #define DN_K 9
 #define DN_RAWDEPTH_DEV 20 // reads.h:12 RAWDEPTH
 #define DN_SEG_CHUNK 1024   // samples per speculative detector chunk

@@ -1,7 +1,11 @@
 // dn_host.cpp -- host side above the C-ABI: read model, CIGAR flattening, batch packing, stage drivers.
 #include "dn_host.h"
+#include "dn_synth.h"
 
+#include <math.h>
+#include <stdio.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 
@@ -189,37 +193,75 @@ bool ReadContainerReader::next(OwnedRead &o) {
 void ReadContainerReader::close() { if (f) fclose((FILE *)f); f = nullptr; }
 
 // ---- output ----------------------------------------------------------------------------------------------------
-std::string formatDetectRecord(const std::string &readID, const std::string &contig, int refStart, int refEnd, bool isReverse,
-                               size_t n, const uint32_t *coord, const char *kmer9, const float *probs, uint32_t *nCalls) {
+// std::to_string(float) == printf("%f") of the value widened to double: 6 decimals, correctly rounded (glibc prints the exact
+// binary value, ties to even).  For a probability the exact answer is cheap: p is a float (24 significant bits) and
+// 10^6 = 2^6 * 15625 with 15625 < 2^14, so p * 1e6 is EXACT in double (<= 38 bits) and rint() -- nearest, ties to even on an
+// exact value -- is the integer glibc prints.  Anything outside [0, 1] (or NaN) takes snprintf.  tests/test_output.py compares
+// both on every float around the rounding boundaries.
+static inline char *put_prob(char *o, float pf) {
+    const double p = (double)pf;
+    if (!(p >= 0.0 && p <= 1.0) || signbit(p)) return o + snprintf(o, 48, "%f", p);
+    unsigned n = (unsigned)rint(p * 1e6);
+    if (n >= 1000000u) { memcpy(o, "1.000000", 8); return o + 8; }
+    o[0] = '0'; o[1] = '.';
+    for (int i = 7; i >= 2; i--) { o[i] = (char)('0' + n % 10u); n /= 10u; }
+    return o + 8;
+}
+static inline char *put_u32(char *o, uint32_t v) {
+    char t[10]; int k = 0;
+    do { t[k++] = (char)('0' + v % 10u); v /= 10u; } while (v);
+    while (k) *o++ = t[--k];
+    return o;
+}
+
+char *formatProbForTest(char *o, float p) { return put_prob(o, p); }
+
+// the record of one read from its CALLS (positions whose strand 9-mer has 'T' in the middle, detect.cpp:690), creation order
+static std::string formatDetectCalls(const std::string &readID, const std::string &contig, int refStart, int refEnd, bool isReverse,
+                                     size_t n, const uint32_t *coord, const char *kmer9, const float *pEdU, const float *pBrdU) {
     std::string out = ">" + readID + " " + contig + " " + std::to_string(refStart) + " " + std::to_string(refEnd) + " " +
                       (isReverse ? "rev" : "fwd") + "\n";
-    out.reserve(out.size() + n * 12);
-    char line[96];
-    uint32_t calls = 0;
+    const size_t head = out.size();
+    out.resize(head + n * 128);                              // a line is at most 10 + 1 + 47 + 1 + 47 + 1 + 9 + 1 bytes
+    char *o = &out[head];
     for (size_t q = 0; q < n; q++) {
         const size_t i = isReverse ? n - 1 - q : q;          // std::reverse of the line vector (:722)
+        o = put_u32(o, coord[i]); *o++ = '\t';
+        o = put_prob(o, pEdU[i]); *o++ = '\t';
+        o = put_prob(o, pBrdU[i]); *o++ = '\t';
         const char *km = kmer9 + i * 9;
-        if (km[4] != 'T') continue;
-        std::string ks(km, 9);
-        if (isReverse) ks = reverseComplement(ks);
-        // std::to_string(float) formats with "%f" (6 decimals) after promotion to double
-        const int len = snprintf(line, sizeof line, "%u\t%f\t%f\t", coord[i], (double)probs[i * 3 + 2], (double)probs[i * 3 + 1]);
-        out.append(line, (size_t)len);
-        out += ks; out += '\n';
-        calls++;
+        if (isReverse) {                                     // reverseComplement of the 9-mer (:699): A/C/G/T only reach here (T-centred, ACGT windows)
+            for (int z = 0; z < 9; z++) {
+                const char c = km[8 - z];
+                o[z] = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'G' ? 'C' : c == 'C' ? 'G' : c;
+            }
+        } else memcpy(o, km, 9);
+        o[9] = '\n';
+        o += 10;
     }
-    if (nCalls) *nCalls = calls;
+    out.resize((size_t)(o - out.data()));
     return out;
 }
 
-void modBamFields(size_t n, const uint32_t *queryIdx, const uint32_t *refIdx, const char *kmer9, const float *probs,
-                  const uint8_t *ref2del, std::string &MM, std::vector<uint8_t> &ML) {
+std::string formatDetectRecord(const std::string &readID, const std::string &contig, int refStart, int refEnd, bool isReverse,
+                               size_t n, const uint32_t *coord, const char *kmer9, const float *probs, uint32_t *nCalls) {
+    std::vector<uint32_t> c; std::vector<char> km; std::vector<float> e, b;
+    for (size_t i = 0; i < n; i++) {
+        if (kmer9[i * 9 + 4] != 'T') continue;               // detect.cpp:690
+        c.push_back(coord[i]); km.insert(km.end(), kmer9 + i * 9, kmer9 + i * 9 + 9);
+        e.push_back(probs[i * 3 + 2]); b.push_back(probs[i * 3 + 1]);       // class 2 -> EdU, class 1 -> BrdU (:695)
+    }
+    if (nCalls) *nCalls = (uint32_t)c.size();
+    return formatDetectCalls(readID, contig, refStart, refEnd, isReverse, c.size(), c.data(), km.data(), e.data(), b.data());
+}
+
+static void modBamCalls(size_t n, const uint32_t *queryIdx, const uint32_t *refIdx, const float *pEdU, const float *pBrdU,
+                        const uint8_t *ref2del, std::string &MM, std::vector<uint8_t> &ML) {
     // queryIndexToCalls is a std::map<unsigned, pair<float, float>>: flat (key, position) pairs, stable sort by key, the LAST
     // entry of every key wins (operator[] assignment)
     std::vector<std::pair<uint32_t, uint32_t>> kv;
     for (size_t i = 0; i < n; i++) {
-        if (kmer9[i * 9 + 4] != 'T') continue;
-        if (ref2del[refIdx[i]]) continue;
+        if (ref2del[refIdx[i]]) continue;                    // detect.cpp:704
         kv.push_back({queryIdx[i], (uint32_t)i});
     }
     std::stable_sort(kv.begin(), kv.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) { return a.first < b.first; });
@@ -232,34 +274,107 @@ void modBamFields(size_t n, const uint32_t *queryIdx, const uint32_t *refIdx, co
         const std::string d = "," + std::to_string(q - prev);
         fb += d; fe += d;
         prev = q + 1;
-        edu.push_back(static_cast<uint8_t>(probs[i * 3 + 2] * 255.0));
-        brdu.push_back(static_cast<uint8_t>(probs[i * 3 + 1] * 255.0));
+        edu.push_back(static_cast<uint8_t>(pEdU[i] * 255.0));
+        brdu.push_back(static_cast<uint8_t>(pBrdU[i] * 255.0));
     }
     MM = fb + ";" + fe + ";";
     ML = brdu;
     ML.insert(ML.end(), edu.begin(), edu.end());
 }
 
+void modBamFields(size_t n, const uint32_t *queryIdx, const uint32_t *refIdx, const char *kmer9, const float *probs,
+                  const uint8_t *ref2del, std::string &MM, std::vector<uint8_t> &ML) {
+    std::vector<uint32_t> q, r; std::vector<float> e, b;
+    for (size_t i = 0; i < n; i++) {
+        if (kmer9[i * 9 + 4] != 'T') continue;
+        q.push_back(queryIdx[i]); r.push_back(refIdx[i]); e.push_back(probs[i * 3 + 2]); b.push_back(probs[i * 3 + 1]);
+    }
+    modBamCalls(q.size(), q.data(), r.data(), e.data(), b.data(), ref2del, MM, ML);
+}
+
+// the output half of runCNN for a collected batch: one record (or one MM / ML pair) per passing read, formatted in parallel
+// (the reference formats inside its per-read OpenMP loop, detect.cpp:896; here the reads of a batch are spread over the host cores)
+void formatCalls(const ReadBatch &batch, const dn_result_batch &res, bool humanReadable, std::vector<ReadCalls> &calls) {
+    const long n = (long)batch.size();
+    calls.assign((size_t)n, ReadCalls());
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long r = 0; r < n; r++) {
+        if (res.summary[r].status != DN_READ_OK) continue;                 // detect.cpp:879-894: failed reads are counted, not written
+        const uint64_t o = res.call_off[r], k = res.call_off[r + 1] - o;
+        calls[r].nCalls = (uint32_t)k;
+        if (humanReadable)
+            calls[r].humanReadable_detectOut = formatDetectCalls(batch.readID[r], batch.contig[r], batch.ref_start[r], batch.ref_end[r],
+                                                                 batch.is_reverse[r] != 0, k, res.ref_coord + o, res.kmer9 + 9 * o, res.p_edu + o, res.p_brdu + o);
+        else
+            modBamCalls(k, res.query_idx + o, res.ref_idx + o, res.p_edu + o, res.p_brdu + o, batch.ref2del.data() + batch.refseq_off[r],
+                        calls[r].MM, calls[r].ML);
+    }
+}
+
 int runCNN(dn_ctx *ctx, ReadBatch &batch, bool humanReadable, std::vector<ReadCalls> &calls) {
     int rc = dn_run_cnn(ctx);
     if (rc) return rc;
-    const size_t n = batch.size();
-    calls.assign(n, ReadCalls());
-    std::vector<uint32_t> coord, qidx, ridx; std::vector<char> kmer; std::vector<float> probs;
-    for (size_t r = 0; r < n; r++) {
-        const dn_read_summary &s = batch.summary[r];
-        if (s.status != DN_READ_OK) continue;               // detect.cpp:879-894: failed reads are counted, not written
-        const size_t np = s.n_positions;
-        coord.resize(np); qidx.resize(np); ridx.resize(np); kmer.resize(np * 9); probs.resize(np * 3);
-        if ((rc = dn_get_positions(ctx, (uint32_t)r, coord.data(), qidx.data(), ridx.data(), nullptr, kmer.data(), nullptr, nullptr, nullptr, nullptr))) return rc;
-        if ((rc = dn_get_probabilities(ctx, (uint32_t)r, probs.data()))) return rc;
-        if (humanReadable)
-            calls[r].humanReadable_detectOut = formatDetectRecord(batch.readID[r], batch.contig[r], batch.ref_start[r], batch.ref_end[r],
-                                                                  batch.is_reverse[r] != 0, np, coord.data(), kmer.data(), probs.data(), &calls[r].nCalls);
-        else
-            modBamFields(np, qidx.data(), ridx.data(), kmer.data(), probs.data(), batch.ref2del.data() + batch.refseq_off[r], calls[r].MM, calls[r].ML);
-    }
+    dn_result_batch res;
+    if ((rc = dn_collect(ctx, &res))) return rc;            // ONE device-to-host transfer per output array for the whole batch
+    if (res.n_reads != batch.size()) return DN_ERR_STATE;
+    batch.summary.assign(res.summary, res.summary + res.n_reads);
+    formatCalls(batch, res, humanReadable, calls);
     return DN_OK;
+}
+
+// ---- the buffer-of-reads loop of detect.cpp:821-907 with several batches in flight on one GPU, driven by ONE host thread ----
+// Batch i runs on context i % n_ctx.  Nothing in the loop waits except dn_collect of the OLDEST batch in flight, and while the
+// host formats and writes its records the GPU works on the n_ctx - 1 younger batches.  Records are written in input order.
+int streamDetect(dn_ctx **ctxs, int n_ctx, ReadBatch **batches, int n_batches, bool emit, const char *outPath, const char *header,
+                 StreamStats *st, StreamKeep *keep) {
+    StreamStats S{};
+    FILE *f = nullptr;
+    if (emit && outPath) { f = fopen(outPath, "wb"); if (!f) return DN_ERR_ARG; if (header) fwrite(header, 1, strlen(header), f); }
+    std::vector<ReadCalls> calls;
+    const auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; };
+    const double t0 = now();
+    int rc = DN_OK;
+    for (int i = 0; i < n_batches + n_ctx && rc == DN_OK; i++) {
+        dn_ctx *ctx = ctxs[i % n_ctx];
+        const int j = i - n_ctx;                             // the batch this context has been working on
+        if (j >= 0 && j < n_batches) {
+            ReadBatch &B = *batches[j];
+            dn_result_batch res;
+            const double a = now();
+            if ((rc = dn_collect(ctx, &res))) break;
+            const double b = now();
+            S.seconds_collect += b - a;
+            S.reads += res.n_reads; S.calls += res.n_calls; S.samples += B.totalSamples();
+            B.summary.assign(res.summary, res.summary + res.n_reads);
+            for (uint32_t r = 0; r < res.n_reads; r++) S.reads_ok += res.summary[r].status == DN_READ_OK;
+            if (keep) {
+                for (uint32_t r = 0; r < res.n_reads; r++) keep->read_calls.push_back(res.call_off[r + 1] - res.call_off[r]);
+                keep->coord.insert(keep->coord.end(), res.ref_coord, res.ref_coord + res.n_calls);
+                keep->p_edu.insert(keep->p_edu.end(), res.p_edu, res.p_edu + res.n_calls);
+                keep->p_brdu.insert(keep->p_brdu.end(), res.p_brdu, res.p_brdu + res.n_calls);
+            }
+            if (emit) {
+                formatCalls(B, res, true, calls);
+                for (size_t r = 0; r < calls.size(); r++) {
+                    if (res.summary[r].status != DN_READ_OK) continue;
+                    S.bytes_out += calls[r].humanReadable_detectOut.size();
+                    if (f) fwrite(calls[r].humanReadable_detectOut.data(), 1, calls[r].humanReadable_detectOut.size(), f);
+                }
+                S.seconds_emit += now() - b;
+            }
+        }
+        if (i < n_batches) {
+            const double a = now();
+            const dn_batch_desc d = batches[i]->desc();
+            if ((rc = dn_batch_upload(ctx, &d))) break;
+            S.seconds_upload += now() - a;
+            if ((rc = dn_run_detect(ctx))) break;
+        }
+    }
+    if (f) fclose(f);
+    S.seconds_total = now() - t0;
+    if (st) *st = S;
+    return rc;
 }
 
 static inline uint32_t kmer2index9(const char *k) {                     // data_IO.cpp:129-141: A0 T1 G2 C3, unknown -> 0
@@ -524,6 +639,68 @@ int dnh_detect_write(void *ctx, void *b, const char *path, const char *header) {
     return written;
 }
 
+// n_reads synthetic reads (dn_synth.c: seeds seed0 .. seed0 + n - 1, every odd one on the reverse strand) generated on all host
+// cores and added to the batch in seed order -- the bench's 10 000 x 50 kb stream would take minutes read by read from Python.
+// Returns the number of reads the batch accepted.
+int dnh_batch_fill_synth(void *b, const double *model_mean, uint64_t seed0, uint32_t n_reads, uint32_t n_bases, double noise_pa,
+                         double sub_rate, double ins_rate, double del_rate) {
+    ReadBatch *B = (ReadBatch *)b;
+    struct Gen { std::vector<char> ref, bc; std::vector<uint32_t> op, len; std::vector<int16_t> adc; dns_read_out o; int rc; };
+    int accepted = 0;
+    const uint32_t chunk = 64;                              // reads generated at a time (bounds the temporary memory)
+    for (uint32_t c0 = 0; c0 < n_reads; c0 += chunk) {
+        const uint32_t m = std::min(chunk, n_reads - c0);
+        std::vector<Gen> g(m);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (long i = 0; i < (long)m; i++) {
+            Gen &G = g[(size_t)i];
+            dns_read_spec sp; memset(&sp, 0, sizeof sp);
+            sp.seed = seed0 + c0 + (uint64_t)i; sp.n_bases = n_bases; sp.ref_start = 1000; sp.is_reverse = (int)((c0 + i) & 1u);
+            sp.noise_pa = noise_pa; sp.mean_dwell = 11.5; sp.sub_rate = sub_rate; sp.ins_rate = ins_rate; sp.del_rate = del_rate;
+            const size_t capq = 2 * (size_t)n_bases + 8;
+            G.ref.resize(n_bases); G.bc.resize(capq); G.op.resize(capq); G.len.resize(capq); G.adc.resize(dns_max_samples(n_bases));
+            memset(&G.o, 0, sizeof G.o);
+            G.o.refseq = G.ref.data(); G.o.basecall = G.bc.data(); G.o.cigar_op = G.op.data(); G.o.cigar_len = G.len.data(); G.o.adc = G.adc.data();
+            G.rc = dns_make_read(model_mean, &sp, &G.o);
+        }
+        for (uint32_t i = 0; i < m; i++) {
+            Gen &G = g[i];
+            if (G.rc) continue;
+            char id[64]; snprintf(id, sizeof id, "synth-%016llx", (unsigned long long)(seed0 + c0 + i));
+            ReadInput in;
+            in.readID = id; in.contig = "chrSynth";
+            in.adc = G.adc.data(); in.n_adc = G.o.n_samples; in.cal_offset = G.o.cal_offset; in.cal_scale = G.o.cal_scale;
+            // the generator emits strand-direction sequences; ReadInput takes what a BAM / FASTA hold (reference-forward)
+            const std::string bc(G.bc.data(), G.o.n_base), rf(G.ref.data(), G.o.n_ref);
+            in.querySeq = G.o.is_reverse ? DNAscent::reverseComplement(bc) : bc;
+            in.refSlice = G.o.is_reverse ? DNAscent::reverseComplement(rf) : rf;
+            in.cigarOp.assign(G.op.data(), G.op.data() + G.o.n_cigar); in.cigarLen.assign(G.len.data(), G.len.data() + G.o.n_cigar);
+            in.refStart = G.o.ref_start; in.isReverse = G.o.is_reverse != 0;
+            if (B->add(in) >= 0) accepted++;
+        }
+    }
+    return accepted;
+}
+
+int dnh_stream_detect(void **ctxs, int n_ctx, void **batches, int n_batches, int emit, const char *out_path, const char *header,
+                      DNAscent::StreamStats *st, void *keep) {
+    return DNAscent::streamDetect((dn_ctx **)ctxs, n_ctx, (ReadBatch **)batches, n_batches, emit != 0, out_path, header, st,
+                                  (DNAscent::StreamKeep *)keep);
+}
+void *dnh_keep_new(void) { return new DNAscent::StreamKeep(); }
+void dnh_keep_free(void *k) { delete (DNAscent::StreamKeep *)k; }
+// which: 0 read_calls (u64), 1 coord (u32), 2 p_edu (f32), 3 p_brdu (f32); returns the element count, *p the data
+uint64_t dnh_keep_get(void *k, int which, const void **p) {
+    DNAscent::StreamKeep *K = (DNAscent::StreamKeep *)k;
+    switch (which) {
+        case 0: *p = K->read_calls.data(); return K->read_calls.size();
+        case 1: *p = K->coord.data(); return K->coord.size();
+        case 2: *p = K->p_edu.data(); return K->p_edu.size();
+        case 3: *p = K->p_brdu.data(); return K->p_brdu.size();
+    }
+    *p = nullptr; return 0;
+}
+
 // --HMM output step for an uploaded + normalised batch (detect.cpp:885 + writer); returns reads written or a negative code
 int dnh_hmm_write(void *ctx, void *b, const char *path, const char *header) {
     ReadBatch *B = (ReadBatch *)b;
@@ -548,6 +725,18 @@ uint64_t dnh_detect_header(const char *alignment, const char *genome, const char
                                                       version, commit);
     if (s.size() <= cap) memcpy(buf, s.data(), s.size());
     return s.size();
+}
+
+// test hook: n probabilities through the fast formatter and through snprintf("%f"); returns the number of differing strings
+uint64_t dnh_check_prob_format(const float *p, uint64_t n) {
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        char a[64], b[64];
+        char *e = DNAscent::formatProbForTest(a, p[i]); *e = 0;
+        snprintf(b, sizeof b, "%f", (double)p[i]);
+        bad += strcmp(a, b) != 0;
+    }
+    return bad;
 }
 
 int dnh_revcomp(const char *in, uint32_t n, char *out) {

@@ -113,8 +113,28 @@ std::string formatDetectRecord(const std::string &readID, const std::string &con
 // deletions skipped, later positions overwrite earlier ones with the same query index
 void modBamFields(size_t n, const uint32_t *queryIdx, const uint32_t *refIdx, const char *kmer9, const float *probs,
                   const uint8_t *ref2del, std::string &MM, std::vector<uint8_t> &ML);
-// CNN for every read of the batch that passed eventalign, then the per-read output above; failed reads get empty calls
+// CNN for every read of the batch that passed eventalign (dn_run_cnn), the bulk result (dn_collect: one transfer per output
+// array for the whole batch), then the per-read output above, formatted in parallel; failed reads get empty calls.
+// batch.summary is refreshed from the collected result.
 int runCNN(dn_ctx *ctx, ReadBatch &batch, bool humanReadable, std::vector<ReadCalls> &calls);
+char *formatProbForTest(char *o, float p);               // the "%f" fast path of the record formatter (tests compare it with snprintf)
+// the output half alone, for a batch whose result has been collected
+void formatCalls(const ReadBatch &batch, const dn_result_batch &res, bool humanReadable, std::vector<ReadCalls> &calls);
+
+// The buffer-of-reads loop of detect.cpp:821-907 as a stream: batch i is uploaded to context i % n_ctx and its whole per-read
+// body (normaliseEvents -> eventalign -> runCNN) enqueued; ONE host thread keeps n_ctx batches in flight and only ever waits for
+// the oldest one (dn_collect).  emit: format the .detect records of every collected batch (in parallel) and write them, in input
+// order, to outPath (nullptr: formatted and counted, not written).  Every context needs its pore model and CNN loaded.
+struct StreamKeep {                     // optional: the binary per-call results of the whole stream, kept for the gather to the writer rank
+    std::vector<uint64_t> read_calls;  // calls of every read, in stream order (0 for failed reads)
+    std::vector<uint32_t> coord; std::vector<float> p_edu, p_brdu;
+};
+struct StreamStats {
+    double seconds_total, seconds_upload, seconds_collect, seconds_emit;   // wall time of the call / spent inside uploads, collects, emission
+    uint64_t reads, reads_ok, samples, calls, bytes_out;
+};
+int streamDetect(dn_ctx **ctxs, int n_ctx, ReadBatch **batches, int n_batches, bool emit, const char *outPath, const char *header,
+                 StreamStats *st, StreamKeep *keep = nullptr);
 
 // `detect --HMM` (detect.cpp:885): llAcrossRead for every read that passed normaliseEvents; fills
 // calls[i].humanReadable_detectOut with ">readID contig start end strand" + "pos\tlogLR\tkmerRef\tkmerQuery" lines (:414, :571)

@@ -1,19 +1,19 @@
 // k2_banded.hip -- K2: adaptive banded event-to-9mer alignment (event_handling.cpp:148-448) on gfx950.
 //
-//   k2_fill6  (default) one wavefront per read, EVENT-KEYED slots: the cell of event e lives in slot e & 127 for as long as
-//             e is in the band, so x is stationary, the neighbours sit at fixed offsets, the k-mer level rotates by one
-//             slot every band regardless of the Suzuki move, and the move only changes which slots are active (see the
-//             comment above the kernel).  The whole recurrence lives in registers; the value that enters a band is
-//             wave-uniform and fetched one band ahead through the scalar unit (s_load), so the loop holds no vector load
-//             and never waits on vmcnt.  Per band one 128-byte row is stored: the from-codes by slot, 0xFF outside the band.
-//   k2_fill5  (DN_FILL_VARIANT=5) the offset-keyed predecessor, kept for A/B measurements: cells keyed by band offset,
-//             both moves' operands formed with DPP and picked with v_cndmask; rows hold 100 from-codes + the band corner.
-//             Arithmetic of both is the reference's, cast by cast (float scores, candidates evaluated in fp64 and
-//             rounded back; event_handling.cpp:116-137, :296-306); the fp64 division by sigma is done exactly
-//             with an FMA-corrected reciprocal (3 ops, brute-force verified against IEEE division).
-//   k2_chase  backtrack (event_handling.cpp:356-412), one wavefront per read: trace rows are staged through a
-//             double-buffered LDS tile (coalesced 16-B loads); with slot rows one LDS read fetches the from-codes of the
-//             40 cells reachable in the next three moves and four dependent v_readlane walk that tree.
+//   k2_fill6  one wavefront per read, EVENT-KEYED slots: the cell of event e lives in slot e & 127 for as long as e is in the
+//             band, so x is stationary, the neighbours sit at fixed offsets, the k-mer level rotates by one slot every band
+//             regardless of the Suzuki move, and the move only changes which slots are active (see the comment above the
+//             kernel).  The whole recurrence lives in registers; the value that enters a band is wave-uniform and fetched
+//             one band ahead through the scalar unit (s_load), so the loop holds no vector load and never waits on vmcnt.
+//             Per band one 32-byte row is produced: 2-bit from-codes by slot as four 64-bit lane masks (put_row); eight rows
+//             leave in one 256-byte store.  Arithmetic is the reference's, cast by cast (float scores, candidates evaluated in
+//             fp64 and rounded back; event_handling.cpp:116-137, :296-306); the fp64 division by sigma is done exactly with an
+//             FMA-corrected reciprocal (3 ops, brute-force verified against IEEE division).  (The offset-keyed predecessor
+//             k2_fill5 and its ablation switches live in tools/k2_fill5_ablation.hip, outside the product.)
+//   k2_chase  backtrack (event_handling.cpp:356-412), one wavefront per read: trace rows are staged through a double-buffered
+//             LDS tile (coalesced 16-B loads); one LDS read per lane fetches the from-code of one of the 40 cells reachable in
+//             the next three moves and four dependent v_readlane walk that tree.  Output: the 2-bit code stream.
+//   k2_expand code stream -> (event, kmer, from) arrays in forward order, coalesced.
 //   k2_post   per-read block: emission log-probabilities of the path, the QC triple (:420-441), and the
 //             cleaned (signal, rank) pairs for Theil-Sen, with every order-dependent fp64 sum accumulated in the
 //             reference's order.
@@ -103,9 +103,13 @@ struct FillConsts {
     double sigma, rsigma;    // rsigma = RN(1/sigma)
 };
 
-// one cell of the recurrence (event_handling.cpp:280-311 + :116-137)
-__device__ __forceinline__ void cell(float diag, float up, float left, double x, double mu, const FillConsts &fc,
-                                     double lp_step, double lp_stay, float &score, unsigned &from) {
+
+// one cell of the recurrence (event_handling.cpp:280-311 + :116-137).  The diagonal operand arrives already widened: "diag" of
+// band b is "up" of band b - 1, whose (double) conversion band b - 1 computed anyway.  The from-code is returned as the two
+// compare results it is made of (eu: max == up, el: max == left): the caller turns them into wave-wide masks, which is the
+// form the 2-bit trace rows are stored in.
+__device__ __forceinline__ void cell_d(double ddiag, float up, float left, double x, double mu, const FillConsts &fc,
+                                       double lp_step, double lp_stay, float &score, bool &eu, bool &el, double &dup) {
     const double d = x - mu;
     const double q = d * fc.rsigma;                       // exact (x - mu) / sigma via FMA-corrected reciprocal
     const double rem = fma(-q, fc.sigma, d);
@@ -115,40 +119,16 @@ __device__ __forceinline__ void cell(float diag, float up, float left, double x,
     t = t * a;
     const float em = (float)(fc.C + (double)t);           // :135-136
     const double emd = (double)em;
-    const float sd = (float)(((double)diag + lp_step) + emd);   // :296
-    const float su = (float)(((double)up + lp_stay) + emd);     // :297
-    const float sl = (float)((double)left + fc.lp_skip);        // :298
-    // :300-306  max = d; if (u > max) max = u; from = (max == u) ? U : D; then the same for l: the result is the
-    // maximum of the three with ties resolved L over U over D (scores are never NaN), i.e. one v_max3 + two compares.
-    float mx;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(sd), "v"(su), "v"(sl));
-    unsigned f = (su == mx) ? 1u : 0u;
-    f = (sl == mx) ? 2u : f;
-    score = mx; from = f;
-}
-
-// the same cell with the diagonal operand already widened: "diag" of band b is "up" of band b - 1, whose (double) conversion
-// band b - 1 computed anyway -- k2_fill6 carries it over instead of converting the same float twice
-__device__ __forceinline__ void cell_d(double ddiag, float up, float left, double x, double mu, const FillConsts &fc,
-                                       double lp_step, double lp_stay, float &score, unsigned &from, double &dup) {
-    const double d = x - mu;
-    const double q = d * fc.rsigma;
-    const double rem = fma(-q, fc.sigma, d);
-    const double ad = fma(rem, fc.rsigma, q);
-    const float a = (float)ad;                            // :133
-    float t = -0.5f * a;                                  // :135
-    t = t * a;
-    const float em = (float)(fc.C + (double)t);           // :135-136
-    const double emd = (double)em;
     dup = (double)up;
     const float sd = (float)((ddiag + lp_step) + emd);          // :296
     const float su = (float)((dup + lp_stay) + emd);            // :297
     const float sl = (float)((double)left + fc.lp_skip);        // :298
+    // :300-306  max = d; if (u > max) max = u; from = (max == u) ? U : D; then the same for l: the result is the maximum of
+    // the three with ties resolved L over U over D (scores are never NaN), i.e. one v_max3 + two compares.
     float mx;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(sd), "v"(su), "v"(sl));
-    unsigned f = (su == mx) ? 1u : 0u;
-    f = (sl == mx) ? 2u : f;
-    score = mx; from = f;
+    eu = su == mx; el = sl == mx;
+    score = mx;
 }
 
 // uniform (wave-wide) loads of the one new x / mu value a band needs go through the scalar unit (s_load, counted
@@ -157,159 +137,6 @@ __device__ __forceinline__ void cell_d(double ddiag, float up, float left, doubl
 // the constant address space promises.
 typedef const double __attribute__((address_space(4))) *cdptr_t;
 
-// ------------------------------------------------------------------------------------------------
-// k2_fill5: single wavefront per read, 2 cells per lane, written for what the stamped builds measured on a lone
-// wavefront: streamed VALU arithmetic costs ~3.5 cycles/instruction, but every scalar dependency chain, VALU->SALU hop
-// and taken branch costs tens of cycles (k2_fill4p: 54 cell instructions 187 cycles, the 10-instruction move branch 400).
-//   * the Suzuki move is a VALU mask; BOTH moves' neighbours / shifted x / shifted mu are formed with DPP and picked with
-//     v_cndmask: no branch on the move at all;
-//   * bands are processed in runs: the number of following bands that cannot touch a matrix edge, the trim column or the
-//     end column is computed once (each band moves the corner by exactly one), and that run executes a loop body with no
-//     edge test; only the first/last ~100 bands of a read take the general body.
-// ------------------------------------------------------------------------------------------------
-struct F5State {
-    float P0, P1, Q0, Q1;
-    double X0, X1, M0, M1;
-    int km;                  // lower-left kmer index of the last band; event index ev = b - 2 - km
-    unsigned long long pr;   // lane mask: previous move was "right"
-};
-
-template <bool FAST, int ABL>
-__device__ __forceinline__ void f5_band(F5State &st, const int b, const int E, const int K, const int lane, const bool inb,
-                                        const unsigned o0, const unsigned o1, const unsigned meta_shift, const unsigned meta_mask,
-                                        const cdptr_t xs_c, const cdptr_t mu_c, double &nx, double &nm, const FillConsts &fc,
-                                        const double lp_step, const double lp_stay, unsigned short *rows16, float &best, int &best_e,
-                                        int &found) {
-    const float NINF = neg_inf();
-    // ---- Suzuki-Kasahara move (:237-253) as a lane mask ----
-    const float lo = bcast_f(st.P0, 0), hi = bcast_f(st.P1, 49);
-    const bool ob = fmaxf(lo, hi) == NINF;                 // both edge cells out of band
-    const bool vright = (ABL & 2) ? ((b & 1) != 0) : (ob ? ((b & 1) != 0) : (lo < hi));
-    const unsigned long long r = __ballot(vright);         // all-ones or zero (uniform)
-    const bool R = r != 0ull, PR = st.pr != 0ull;
-    // ---- neighbours for both moves, then select ----
-    const float nP0 = from_next<true>(st.P0, NINF, lane), pP1 = from_prev<true>(st.P1, NINF, lane);
-    const float nQ0 = from_next<true>(st.Q0, NINF, lane), pQ1 = from_prev<true>(st.Q1, NINF, lane);
-    const float up0 = vright ? st.P1 : st.P0, lf0 = vright ? st.P0 : pP1;
-    const float up1 = vright ? nP0 : st.P1,   lf1 = vright ? st.P1 : st.P0;
-    const float dA0 = PR ? st.Q1 : st.Q0, dA1 = PR ? nQ0 : st.Q1;        // diagonal if this move is "right"
-    const float dB0 = PR ? st.Q0 : pQ1,   dB1 = PR ? st.Q1 : st.Q0;      // ... if it is "down"
-    float dg0 = vright ? dA0 : dB0, dg1 = vright ? dA1 : dB1;
-    float up0_ = up0, up1_ = up1, lf0_ = lf0, lf1_ = lf1;
-    if (ABL & 8) { dg0 = st.Q0; dg1 = st.Q1; up0_ = st.P0; up1_ = st.P1; lf0_ = st.P1; lf1_ = st.P0; }
-    // ---- x moves one cell on "down", mu on "right"; the entering value was prefetched by the scalar unit ----
-    double tX = from_prev_d<true>(st.X1, lane); tX = (lane == 0) ? nx : tX;
-    double tM = from_next_d<true>(st.M0, lane); tM = (lane == 49) ? nm : tM;
-    const double X0 = (ABL & 1) ? st.X0 : (vright ? st.X0 : tX), X1 = (ABL & 1) ? st.X1 : (vright ? st.X1 : st.X0);
-    const double M0 = (ABL & 1) ? st.M0 : (vright ? st.M1 : st.M0), M1 = (ABL & 1) ? st.M1 : (vright ? tM : st.M1);
-    st.X0 = X0; st.X1 = X1; st.M0 = M0; st.M1 = M1;
-    const int km = st.km + (R ? 1 : 0);
-    const int ev = b - 2 - km;
-    st.km = km; st.pr = r;
-    // scalar prefetch of the values entering the NEXT band (FAST: indices are in range by construction)
-    nx = xs_c[FAST ? ev + 1 : min(ev + 1, E - 1)];
-    nm = mu_c[FAST ? km + 100 : max(min(km + 100, K - 1), 0)];
-
-    float S0, S1; unsigned F0, F1;
-    if (ABL & 16) { S0 = up0_ + dg0 + (float)X0; S1 = up1_ + dg1 + (float)M1; F0 = lf0_ > S0; F1 = lf1_ > S1; }
-    else {
-        cell(dg0, up0_, lf0_, X0, M0, fc, lp_step, lp_stay, S0, F0);
-        cell(dg1, up1_, lf1_, X1, M1, fc, lp_step, lp_stay, S1, F1);
-    }
-    S0 = inb ? S0 : NINF;                                  // cell 100 (lane 50) is the only idle cell a band cell can read
-    if (!FAST) {
-        const unsigned e0 = (unsigned)ev - o0, e1 = (unsigned)ev - o1;
-        const bool ok0 = ((unsigned)km + o0 < (unsigned)K) && (e0 < (unsigned)E);    // :269-278
-        const bool ok1 = ((unsigned)km + o1 < (unsigned)K) && (e1 < (unsigned)E);
-        S0 = ok0 ? S0 : NINF; F0 = ok0 ? F0 : 0u;
-        S1 = ok1 ? S1 : NINF; F1 = ok1 ? F1 : 0u;
-        if (km <= -1) {                                    // trim column kmer == -1 (:256-265)
-            const bool t0 = ((unsigned)km + o0 == 0xffffffffu) && (e0 < (unsigned)E);
-            const bool t1 = ((unsigned)km + o1 == 0xffffffffu) && (e1 < (unsigned)E);
-            if (t0) { S0 = (float)(fc.lp_trim * (double)(e0 + 1u)); F0 = 1; }
-            if (t1) { S1 = (float)(fc.lp_trim * (double)(e1 + 1u)); F1 = 1; }
-        }
-        const int oe = K - 1 - km;                         // end column (:329-340)
-        if (oe >= 0 && oe < DN_W) {
-            const int ee = ev - oe;
-            if (ee >= 0 && ee < E) {
-                const float sv = bcast_f((oe & 1) ? S1 : S0, oe >> 1);
-                const float sc = (float)((double)sv + (double)(unsigned long long)(E - ee) * fc.lp_trim);
-                if (sc > best) { best = sc; best_e = ee; found = 1; }
-            }
-        }
-    }
-    // ---- one 128-byte row: 100 trace bytes (lanes 0..49) + the band's lower-left event index (lanes 52, 53) ----
-    const unsigned meta = ((unsigned)ev >> meta_shift) & meta_mask;
-    if (!(ABL & 4)) rows16[(size_t)b * (DN_TROW / 2) + lane] = (unsigned short)(inb ? (F0 | (F1 << 8)) : meta);
-    else asm volatile("" :: "v"(F0), "v"(F1), "v"(meta));
-    st.Q0 = st.P0; st.Q1 = st.P1; st.P0 = S0; st.P1 = S1;
-}
-
-template <int ABL>
-__global__ __launch_bounds__(64) void k2_fill5(BatchDev B, const BandConsts *bc, FillConsts fc) {
-    const int r = blockIdx.x;
-    const int lane = threadIdx.x;
-    ReadRes &R = B.res[r];
-    if (R.status != 0) return;
-    const int E = (int)R.n_events, K = (int)R.n_kq;
-    const int n_bands = E + K + 2;
-    const double lp_stay = bc[r].lp_stay, lp_step = bc[r].lp_step;
-    const double *xs = B.ev_x + B.ev_off[r];
-    const double *mus = B.mu_q + B.base_off[r];
-    const cdptr_t xs_c = (cdptr_t)(uintptr_t)xs;
-    const cdptr_t mu_c = (cdptr_t)(uintptr_t)mus;
-    uint8_t *rows = B.trace + B.trace_off[r] * DN_TROW;
-    unsigned short *rows16 = reinterpret_cast<unsigned short *>(rows);
-    const float NINF = neg_inf();
-    const bool inb = lane < 50;
-    const unsigned o0 = inb ? (unsigned)(2 * lane) : 0x40000000u, o1 = inb ? (unsigned)(2 * lane + 1) : 0x40000000u;
-    const unsigned meta_shift = (lane == 53) ? 16u : 0u;
-    const unsigned meta_mask = (lane == 52 || lane == 53) ? 0xffffu : 0u;
-    // ---- bands 0 and 1 (event_handling.cpp:213-228) ----
-    F5State st;
-    st.Q0 = (o0 == 50u) ? 0.0f : NINF; st.Q1 = NINF;
-    st.P0 = (o0 == 50u) ? (float)fc.lp_trim : NINF; st.P1 = NINF;
-    {
-        const unsigned short w1 = (o0 == 50u) ? 1u : 0u;
-        rows16[lane] = inb ? (unsigned short)0 : (unsigned short)((49u >> meta_shift) & meta_mask);
-        rows16[DN_TROW / 2 + lane] = inb ? w1 : (unsigned short)((50u >> meta_shift) & meta_mask);
-    }
-    auto ldx = [&](int e) -> double { return (e >= 0 && e < E) ? xs[e] : 0.0; };
-    auto ldm = [&](int k) -> double { return (k >= 0 && k < K) ? mus[k] : 0.0; };
-    const int ev1 = 50, km1 = -51;
-    st.X0 = ldx(ev1 - (int)o0); st.X1 = ldx(ev1 - (int)o1);
-    st.M0 = ldm(km1 + (int)o0); st.M1 = ldm(km1 + (int)o1);
-    st.km = km1; st.pr = 0ull;
-    double nx = xs_c[min(ev1 + 1, E - 1)];
-    double nm = mu_c[max(min(km1 + 100, K - 1), 0)];
-    float best = NINF; int best_e = 0; int found = 0;
-    __builtin_amdgcn_s_waitcnt(0x0F70);                    // retire the pre-loop vector loads once (not per band)
-
-    int b = 2;
-    while (b < n_bands) {
-        const int km = st.km, ev = b - 3 - km;             // corner of band b-1
-        // after j more moves: kmer corner <= km + j, event corner <= ev + j.  A band is "fast" when, after its move,
-        // 0 <= km', km' + 100 < K (no end column, mu prefetch in range), 99 <= ev' < E - 1 (x prefetch in range).
-        int run = 0;
-        if (km >= 0 && ev >= DN_W - 1) run = min(K - 101 - km, E - 2 - ev);
-        run = min(run, n_bands - b);
-        if (run > 0) {
-            const int bend = b + run;
-            for (; b < bend; b++)
-                f5_band<true, ABL>(st, b, E, K, lane, inb, o0, o1, meta_shift, meta_mask, xs_c, mu_c, nx, nm, fc, lp_step, lp_stay, rows16, best, best_e, found);
-        } else {
-            f5_band<false, ABL>(st, b, E, K, lane, inb, o0, o1, meta_shift, meta_mask, xs_c, mu_c, nx, nm, fc, lp_step, lp_stay, rows16, best, best_e, found);
-            b++;
-        }
-    }
-    if (lane == 0) {
-        R.n_bands = (unsigned)n_bands;
-        R.end_event = best_e;
-        R.end_score = best;
-        if (!found) R.status = 3;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // k2_fill6: event-keyed slots.  The 100 cells of a band are the events [ev - 99, ev]; cell (event e, kmer k = b - 2 - e)
@@ -361,11 +188,36 @@ __device__ __forceinline__ void writelane_pair_d(double &A, double &Bv, double v
     Bv = __longlong_as_double(((long long)bhi << 32) | (unsigned)blo);
 }
 
+// ---- trace rows.  Row b is 32 bytes: the 2-bit from-codes of the 128 slots, PLANAR -- four 64-bit lane masks
+//      {A0, A1, B0, B1}: bit l of A0 / A1 = low / high code bit of slot 2l (even events), B0 / B1 of slot 2l + 1.  Codes:
+//      0 diag, 1 up, 2 left, 3 = slot outside the band.  This is the form the compare results of the cell arithmetic have
+//      anyway (a v_cmp writes a lane mask into a scalar register pair), so the codes are never materialised per lane; the
+//      eight dwords of a row are dropped into lanes 8 (b & 7) .. + 7 of an accumulator register (v_writelane) and every
+//      eighth band the wavefront stores the accumulator: 256 contiguous bytes = 8 rows.  (The reference stores one byte per
+//      cell, event_handling.cpp:192-199; round 1 stored 128-byte rows.) ----
+template <int PH>
+__device__ __forceinline__ void put_row(int &acc, const int b, const unsigned long long A0, const unsigned long long A1,
+                                        const unsigned long long B0, const unsigned long long B1, unsigned *rows32, const int lane) {
+    const int d[8] = { (int)(unsigned)A0, (int)(A0 >> 32), (int)(unsigned)A1, (int)(A1 >> 32),
+                       (int)(unsigned)B0, (int)(B0 >> 32), (int)(unsigned)B1, (int)(B1 >> 32) };
+    if (PH >= 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(d[j]), "i"(8 * (PH < 0 ? 0 : PH) + j));   // lane select: inline constant
+        if (PH == 7) rows32[(size_t)(b >> 3) * 64 + lane] = (unsigned)acc;
+    } else {
+        const int base = 8 * (b & 7);
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc = writelane_(acc, d[j], base + j);
+        if ((b & 7) == 7) rows32[(size_t)(b >> 3) * 64 + lane] = (unsigned)acc;
+    }
+}
+
 struct F6State {
     float PA, PB;
     double DA, DB;           // the diagonal operands, kept widened (see cell_d)
     double XA, XB, MA, MB;
     int ev, km;              // lower-left corner of the last band
+    int acc;                 // trace rows of the current group of eight bands (put_row)
 };
 struct F6In { double x0, x1, m0, m1; };   // prefetched for the next band: x of an event pair (2j, 2j + 1), mu of kmers (kA - 1, kA)
 
@@ -390,10 +242,11 @@ __device__ __forceinline__ void f6_prefetch(F6In &in, int b_next, int ev, int E,
     }
 }
 
-template <bool FAST>
+// PH: b & 7 when it is known at compile time (the eight-band trips of the fast loop), -1 otherwise
+template <bool FAST, int PH>
 __device__ __forceinline__ void f6_band(F6State &st, const int b, const int E, const int K, const int lane2, const cdptr_t xs_c,
                                         const cdptr_t mu_c, F6In &in, const FillConsts &fc, const double lp_step,
-                                        const double lp_stay, unsigned short *rows16, float &best, int &best_e, int &found) {
+                                        const double lp_stay, unsigned *rows32, float &best, int &best_e, int &found) {
     const int NINF_BITS = (int)0xff800000;
     const float NINF = neg_inf();
     // Program order is chosen for a lone wavefront (in-order issue): the end scores of the previous band are read first,
@@ -415,9 +268,9 @@ __device__ __forceinline__ void f6_band(F6State &st, const int b, const int E, c
     writelane_pair_d(st.MA, st.MB, in.m1, in.m0, l_hi);
     // ---- operands: left = same slot, up = previous slot, diag = the previous band's up ----
     const float upA = ror_f(st.PB), upB = st.PA;
-    float SA, SB; unsigned FA, FB; double dupA, dupB;
-    cell_d(st.DA, upA, st.PA, st.XA, st.MA, fc, lp_step, lp_stay, SA, FA, dupA);
-    cell_d(st.DB, upB, st.PB, st.XB, st.MB, fc, lp_step, lp_stay, SB, FB, dupB);
+    float SA, SB; bool euA, elA, euB, elB; double dupA, dupB;
+    cell_d(st.DA, upA, st.PA, st.XA, st.MA, fc, lp_step, lp_stay, SA, euA, elA, dupA);
+    cell_d(st.DB, upB, st.PB, st.XB, st.MB, fc, lp_step, lp_stay, SB, euB, elB, dupB);
     // ---- Suzuki-Kasahara move (:237-253) from the end cells of the previous band: events ev (lower left) and ev - 99 ----
     const int lo = (ev0 & 1) ? loB : loA, hi = (el0 & 1) ? hiB : hiA;
     // integer 0/1 arithmetic (scalar unit, no branch): both end cells out of band -> alternate by parity, else ll < ur
@@ -429,16 +282,23 @@ __device__ __forceinline__ void f6_band(F6State &st, const int b, const int E, c
     f6_prefetch<FAST>(in, b + 1, ev, E, K, xs_c, mu_c);
     // ---- in-band slots: ((ev - event) & 127) < 100, a cyclic run of 50 lanes in each register.  With several batches in
     //      flight the vector unit is the scarce one, so the two masks are built on the scalar unit (rotate a 50-bit run) ----
-    const unsigned tA = (unsigned)(ev - lane2) & 127u;     // only the edge path below needs the per-lane distance
     const unsigned p0 = (unsigned)(ev - (DN_W - 1)) & 127u;
     const unsigned long long FIFTY = (1ull << 50) - 1ull;
-    const bool actA = __builtin_amdgcn_inverse_ballot_w64(rotl64_(FIFTY, ((p0 + 1u) >> 1) & 63u));
-    const bool actB = __builtin_amdgcn_inverse_ballot_w64(rotl64_(FIFTY, p0 >> 1));
+    const unsigned long long mA = rotl64_(FIFTY, ((p0 + 1u) >> 1) & 63u), mB = rotl64_(FIFTY, p0 >> 1);
+    const bool actA = __builtin_amdgcn_inverse_ballot_w64(mA);
+    const bool actB = __builtin_amdgcn_inverse_ballot_w64(mB);
+    unsigned long long A0, A1, B0, B1;
     if (FAST) {
         SA = actA ? SA : NINF; SB = actB ? SB : NINF;
+        // from-code = 2 if max == left, else 1 if max == up, else 0 (:300-306); 3 outside the band -- all on the scalar unit
+        const unsigned long long uA = __ballot(euA), lA = __ballot(elA), uB = __ballot(euB), lB = __ballot(elB);
+        A1 = lA | ~mA; A0 = (uA & ~lA) | ~mA;
+        B1 = lB | ~mB; B0 = (uB & ~lB) | ~mB;
     } else {
+        const unsigned tA = (unsigned)(ev - lane2) & 127u;     // per-lane distance of the even slot's event from the corner
         const int eA = ev - (int)tA, eB = ev - (int)((tA - 1u) & 127u);
         const int kA = b - 2 - eA, kB = b - 2 - eB;
+        unsigned FA = elA ? 2u : (euA ? 1u : 0u), FB = elB ? 2u : (euB ? 1u : 0u);
         const bool okA = actA && (unsigned)kA < (unsigned)K && (unsigned)eA < (unsigned)E;       // :269-278
         const bool okB = actB && (unsigned)kB < (unsigned)K && (unsigned)eB < (unsigned)E;
         SA = okA ? SA : NINF; FA = okA ? FA : 0u;
@@ -454,11 +314,16 @@ __device__ __forceinline__ void f6_band(F6State &st, const int b, const int E, c
             const float sc = (float)((double)sv + (double)(unsigned long long)(E - ee) * fc.lp_trim);
             if (sc > best) { best = sc; best_e = ee; found = 1; }
         }
+        FA = actA ? FA : 3u; FB = actB ? FB : 3u;
+        A0 = __ballot((FA & 1u) != 0u); A1 = __ballot((FA & 2u) != 0u);
+        B0 = __ballot((FB & 1u) != 0u); B1 = __ballot((FB & 2u) != 0u);
     }
-    FA = actA ? FA : 0xFFu; FB = actB ? FB : 0xFFu;
-    rows16[(size_t)b * (DN_TROW / 2) + (lane2 >> 1)] = (unsigned short)(FA | (FB << 8));
+    put_row<PH>(st.acc, b, A0, A1, B0, B1, rows32, lane2 >> 1);
     st.DA = dupA; st.DB = dupB; st.PA = SA; st.PB = SB;
 }
+
+#define F6_ARGS st, E, K, lane2, xs_c, mu_c, in, fc, lp_step, lp_stay, rows32, best, best_e, found
+#define F6_BAND(FAST_, PH_, b_) f6_band<FAST_, PH_>(st, (b_), E, K, lane2, xs_c, mu_c, in, fc, lp_step, lp_stay, rows32, best, best_e, found)
 
 __global__ __launch_bounds__(64) void k2_fill6(BatchDev B, const BandConsts *bc, FillConsts fc) {
     const int r = blockIdx.x;
@@ -472,11 +337,11 @@ __global__ __launch_bounds__(64) void k2_fill6(BatchDev B, const BandConsts *bc,
     const double *mus = B.mu_q + B.base_off[r];
     const cdptr_t xs_c = (cdptr_t)(uintptr_t)xs;
     const cdptr_t mu_c = (cdptr_t)(uintptr_t)mus;
-    unsigned short *rows16 = reinterpret_cast<unsigned short *>(B.trace + B.trace_off[r] * DN_TROW);
+    unsigned *rows32 = reinterpret_cast<unsigned *>(B.trace + B.trace_off[r] * DN_TROW);
     const float NINF = neg_inf();
     // ---- bands 0 and 1 (event_handling.cpp:213-228): corners (49, -51) and (50, -51) ----
     F6State st;
-    st.ev = 50; st.km = -51;
+    st.ev = 50; st.km = -51; st.acc = 0;
     // slot events as seen from band 1 (events -49 .. 50 are in the band; the other slots belong to the events that enter next)
     const int eA = 50 - (int)(((unsigned)(50 - lane2)) & 127u), eB = 50 - (int)(((unsigned)(50 - lane2 - 1)) & 127u);
     st.PA = (eA == 0) ? (float)fc.lp_trim : NINF; st.PB = NINF;          // band 1: cell (event 0, kmer -1) = lp_trim (:224-228)
@@ -488,10 +353,10 @@ __global__ __launch_bounds__(64) void k2_fill6(BatchDev B, const BandConsts *bc,
     {
         // rows 0 and 1: band 0 holds events -50 .. 49 (all from-codes 0), band 1 events -49 .. 50 (event 0: from U, :226)
         const int e0A = 49 - (int)(((unsigned)(49 - lane2)) & 127u), e0B = 49 - (int)(((unsigned)(49 - lane2 - 1)) & 127u);
-        const unsigned a0 = (e0A >= -50) ? 0u : 0xFFu, b0 = (e0B >= -50) ? 0u : 0xFFu;
-        const unsigned a1 = (eA >= -49) ? (eA == 0 ? 1u : 0u) : 0xFFu, b1 = (eB >= -49) ? 0u : 0xFFu;
-        rows16[lane] = (unsigned short)(a0 | (b0 << 8));
-        rows16[DN_TROW / 2 + lane] = (unsigned short)(a1 | (b1 << 8));
+        const unsigned a0 = (e0A >= -50) ? 0u : 3u, b0 = (e0B >= -50) ? 0u : 3u;
+        const unsigned a1 = (eA >= -49) ? (eA == 0 ? 1u : 0u) : 3u, b1 = (eB >= -49) ? 0u : 3u;
+        put_row<-1>(st.acc, 0, __ballot((a0 & 1u) != 0u), __ballot((a0 & 2u) != 0u), __ballot((b0 & 1u) != 0u), __ballot((b0 & 2u) != 0u), rows32, lane);
+        put_row<-1>(st.acc, 1, __ballot((a1 & 1u) != 0u), __ballot((a1 & 2u) != 0u), __ballot((b1 & 1u) != 0u), __ballot((b1 & 2u) != 0u), rows32, lane);
     }
     F6In in;
     f6_prefetch<false>(in, 2, st.ev, E, K, xs_c, mu_c);
@@ -508,16 +373,20 @@ __global__ __launch_bounds__(64) void k2_fill6(BatchDev B, const BandConsts *bc,
         run = min(run, n_bands - b);
         if (run > 0) {
             const int bend = b + run;
-            for (; b + 1 < bend; b += 2) {                 // two bands per trip: the rotating state is renamed instead of moved
-                f6_band<true>(st, b, E, K, lane2, xs_c, mu_c, in, fc, lp_step, lp_stay, rows16, best, best_e, found);
-                f6_band<true>(st, b + 1, E, K, lane2, xs_c, mu_c, in, fc, lp_step, lp_stay, rows16, best, best_e, found);
+            for (; b < bend && (b & 7); b++) F6_BAND(true, -1, b);
+            // eight bands per trip: b & 7 is a compile-time constant (row deposit with constant lane selects, one 256-byte store per
+            // trip), and the rotating state is renamed instead of moved
+            for (; b + 8 <= bend; b += 8) {
+                F6_BAND(true, 0, b);     F6_BAND(true, 1, b + 1); F6_BAND(true, 2, b + 2); F6_BAND(true, 3, b + 3);
+                F6_BAND(true, 4, b + 4); F6_BAND(true, 5, b + 5); F6_BAND(true, 6, b + 6); F6_BAND(true, 7, b + 7);
             }
-            if (b < bend) { f6_band<true>(st, b, E, K, lane2, xs_c, mu_c, in, fc, lp_step, lp_stay, rows16, best, best_e, found); b++; }
+            for (; b < bend; b++) F6_BAND(true, -1, b);
         } else {
-            f6_band<false>(st, b, E, K, lane2, xs_c, mu_c, in, fc, lp_step, lp_stay, rows16, best, best_e, found);
+            F6_BAND(false, -1, b);
             b++;
         }
     }
+    if (n_bands & 7) rows32[(size_t)((n_bands - 1) >> 3) * 64 + lane] = (unsigned)st.acc;     // the last, partial group of rows
     if (lane == 0) {
         R.n_bands = (unsigned)n_bands;
         R.end_event = best_e;
@@ -527,32 +396,44 @@ __global__ __launch_bounds__(64) void k2_fill6(BatchDev B, const BandConsts *bc,
 }
 
 // ------------------------------------------------------------------------------------------------
-// k2_chase: record the backtrack path.  aln arrays are filled from the back so they end up in forward order.
+// k2_chase: record the backtrack path (event_handling.cpp:356-412) as a stream of from-codes.
+// One wavefront per read; trace rows (32 B each) are staged through double-buffered LDS tiles of 256 rows (coalesced 16-byte
+// loads; the whole trace is read exactly once: the path visits every band or every other band).  The walk records ONLY the
+// from-codes, 2 bits per step, 32 steps per 64-bit word (written by lane 0 into the still-unused cleaned-signal workspace);
+// k2_expand turns the code stream into (event, kmer) pairs.  Four-step lookahead: lane L < 40 stands for a prefix of up to three
+// moves (1 + 3 + 9 + 27 nodes of the ternary tree of continuations); ONE 16-byte LDS read per lane fetches the two code planes
+// of its candidate cell and four dependent v_readlane walk the tree.  Away from the matrix edge a group of four steps needs no
+// per-step test: the position update is two popcounts of the packed codes (diag: e-1 k-1 b-2, up: e-1 b-1, left: k-1 b-1).
 // ------------------------------------------------------------------------------------------------
-#define CH_ROWS 64
+#define CH_ROWS 256
 
-template <bool SLOT>
-__global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
+__device__ __forceinline__ unsigned trace_code(const uint8_t *tile, int row, int ev) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const unsigned s = (unsigned)ev & 127u;
+    const u64x2 w = *reinterpret_cast<const u64x2 *>(tile + row * DN_TROW + (s & 1u) * 16u);    // {X0, X1} of the slot's register
+    const unsigned l = s >> 1;
+    return ((unsigned)(w[0] >> l) & 1u) | (((unsigned)(w[1] >> l) & 1u) << 1);
+}
+
+__global__ __launch_bounds__(64) void k2_chase(BatchDev B) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[2][CH_ROWS * DN_TROW];
     const int r = blockIdx.x;
     const int lane = threadIdx.x;
     ReadRes &R = B.res[r];
     if (R.status != 0) return;
-    const int E = (int)R.n_events, K = (int)R.n_kq;
-    (void)E;                                              // only the offset-keyed (SLOT == false) walk needs it
+    const int K = (int)R.n_kq;
     const uint8_t *rows = B.trace + B.trace_off[r] * DN_TROW;
     const uint64_t a0 = B.aln_off[r];
     const unsigned cap = (unsigned)(B.aln_off[r + 1] - a0);
-    unsigned *ae = B.aln_event + a0, *ak = B.aln_kmer + a0;
-    uint8_t *pf = path_from + a0;
 
     int e = R.end_event, k = K - 1;
     int b = e + k + 2;
-    // tile t covers bands [lo, lo + 63]; cur tile index 0/1
+    // a tile covers bands [lo, lo + CH_ROWS); rows below band 0 do not exist: tiles are clamped at 0 and always hold CH_ROWS rows
+    // starting at `lo` (the trace allocation of a read is padded by CH_ROWS rows)
     int lo = b - (CH_ROWS - 1); if (lo < 0) lo = 0;
     typedef int i32x4 __attribute__((ext_vector_type(4)));        // a native vector type: the HIP int4 struct array went to scratch
     auto load_tile = [&](int tlo, i32x4 (&regs)[8]) {
-        // 64 rows * 128 B = 512 pieces of 16 B; lane handles pieces lane, lane+64, ...
+        // 256 rows * 32 B = 512 pieces of 16 B; lane handles pieces lane, lane+64, ...
         const i32x4 *src = reinterpret_cast<const i32x4 *>(rows + (size_t)tlo * DN_TROW);
 #pragma unroll
         for (int i = 0; i < 8; i++) regs[i] = src[lane + 64 * i];
@@ -563,105 +444,37 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
         for (int i = 0; i < 8; i++) dst[lane + 64 * i] = regs[i];
     };
     i32x4 regs[8];
-    // note: rows below band 0 do not exist; tiles are clamped at 0 and always hold 64 rows starting at `lo`
-    // (rows above the read's last band are never addressed).  The trace allocation is padded by 64 rows.
     load_tile(lo, regs);
     store_tile(0, regs);
     int cur = 0;
     int nlo = lo - CH_ROWS; if (nlo < 0) nlo = 0;
-    const bool have_next0 = lo > 0;
-    if (have_next0) load_tile(nlo, regs);
+    if (lo > 0) load_tile(nlo, regs);
     __syncthreads();
-    // per-row lower-left event index of the current tile, one row per lane
-    auto row_ev = [&](int which) -> int {
-        const uint8_t *p = tile[which] + lane * DN_TROW + 104;
-        return (int)(*reinterpret_cast<const unsigned *>(p));
-    };
-    int evrow = SLOT ? 0 : row_ev(cur);
 
     unsigned step = 0;
     int bad = 0;
-    if (SLOT) {
-        // ---- slot rows: the walk records ONLY the from-codes, 2 bits per step, 32 steps per 64-bit word (written by lane 0
-        //      into the still-unused cleaned-signal workspace); k2_expand turns the code stream into (event, kmer) pairs with a
-        //      parallel scan.  Four-step lookahead: lane L < 40 stands for a prefix of up to three moves (1 + 3 + 9 + 27 nodes
-        //      of the ternary tree of continuations); ONE LDS read fetches the from-codes of all 40 candidate cells and four
-        //      dependent v_readlane walk the tree.  Away from the matrix edge a group of four steps needs no per-step test:
-        //      the position update is two popcounts of the packed codes (diag: e-1 k-1 b-2, up: e-1 b-1, left: k-1 b-1). ----
-        unsigned long long *words = reinterpret_cast<unsigned long long *>(B.cl_sig + a0);
-        unsigned long long acc = 0ull; unsigned nacc = 0, nword = 0;
-        int la_db = 0, la_de = 0;                          // band / event offset of this lane's node from the current cell
-        {
-            const int base[4] = {0, 1, 4, 13};
-            const int lvl = lane >= 13 ? 3 : (lane >= 4 ? 2 : (lane >= 1 ? 1 : 0));
-            int code = lane - base[lvl];
-            for (int j = 0; j < lvl; j++) {
-                const int m = code % 3; code /= 3;
-                la_db += 2 - ((m + 1) >> 1); la_de += ((m >> 1) ^ 1);
-            }
-            if (lane >= 40) { la_db = 0; la_de = 0; }
+    unsigned long long *words = reinterpret_cast<unsigned long long *>(B.cl_sig + a0);
+    unsigned long long acc = 0ull; unsigned nacc = 0, nword = 0;
+    int la_db = 0, la_de = 0;                          // band / event offset of this lane's node from the current cell
+    {
+        const int base[4] = {0, 1, 4, 13};
+        const int lvl = lane >= 13 ? 3 : (lane >= 4 ? 2 : (lane >= 1 ? 1 : 0));
+        int code = lane - base[lvl];
+        for (int j = 0; j < lvl; j++) {
+            const int m = code % 3; code /= 3;
+            la_db += 2 - ((m + 1) >> 1); la_de += ((m >> 1) ^ 1);
         }
-        auto push = [&](unsigned codes, unsigned cnt) {     // cnt codes of 2 bits, oldest in the low bits; cnt <= 4
-            acc |= (unsigned long long)codes << (2u * nacc);
-            const unsigned room = 32u - nacc;
-            if (cnt >= room) {
-                if (lane == 0) words[nword] = acc;
-                nword++;
-                acc = (cnt > room) ? ((unsigned long long)codes >> (2u * room)) : 0ull;
-                nacc = cnt - room;
-            } else nacc += cnt;
-        };
-        while ((k | e) >= 0) {
-            if (b < lo) {
-                cur ^= 1;
-                store_tile(cur, regs);
-                lo = nlo;
-                nlo = lo - CH_ROWS; if (nlo < 0) nlo = 0;
-                if (lo > 0) load_tile(nlo, regs);
-                __syncthreads();
-            }
-            const int bi = b - lo;
-            if (bi >= 6 && e >= 4 && k >= 4 && step + 4u <= cap) {
-                const unsigned v = tile[cur][(bi - la_db) * DN_TROW + ((e - la_de) & 127)];
-                const unsigned f0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
-                const unsigned f1 = (unsigned)__builtin_amdgcn_readlane((int)v, 1 + (int)(f0 & 3u));
-                const unsigned f2 = (unsigned)__builtin_amdgcn_readlane((int)v, 4 + 3 * (int)(f0 & 3u) + (int)(f1 & 3u));
-                const unsigned f3 = (unsigned)__builtin_amdgcn_readlane((int)v, 13 + 9 * (int)(f0 & 3u) + 3 * (int)(f1 & 3u) + (int)(f2 & 3u));
-                if (((f0 | f1 | f2 | f3) & 0xFCu) == 0u && f0 != 3u && f1 != 3u && f2 != 3u && f3 != 3u) {
-                    const unsigned p = f0 | (f1 << 2) | (f2 << 4) | (f3 << 6);
-                    push(p, 4u);
-                    const int de = 4 - __builtin_popcount(p & 0xAAu), dk = 4 - __builtin_popcount(p & 0x55u);
-                    e -= de; k -= dk; b -= de + dk;
-                    step += 4u;
-                    continue;
-                }
-            }
-            // single step (matrix edge, tile seam, or an invalid code ahead)
-            const unsigned from = (unsigned)__builtin_amdgcn_readfirstlane((int)tile[cur][bi * DN_TROW + (e & 127)]);
-            if (from > 2u || step >= cap) { bad = 1; break; }                  // reference: out-of-bounds read (UB)
-            push(from, 1u);
-            step++;
-            e -= (int)((from >> 1) ^ 1u);
-            k -= (int)((from & 1u) ^ 1u);
-            b -= 2 - (int)((from + 1u) >> 1);
-        }
-        if (nacc && lane == 0) words[nword] = acc;
-    } else {
-    unsigned rec_e = 0, rec_k = 0;                     // rec_e carries the from-code in its top two bits until the flush
-    auto take = [&](unsigned from) -> bool {
-        if (from == 0xFFu || step >= cap) { bad = 1; return false; }        // reference: out-of-bounds read (UB)
-        const bool mine = lane == (int)(step & 63u);
-        rec_e = mine ? ((unsigned)e | (from << 30)) : rec_e;
-        rec_k = mine ? (unsigned)k : rec_k;
-        step++;
-        if ((step & 63u) == 0u) {
-            const unsigned idx = cap - (step - 64u) - 1u - (unsigned)lane;     // step-64+lane -> slot cap-1-(step-64+lane)
-            ae[idx] = rec_e & 0x3fffffffu; ak[idx] = rec_k; pf[idx] = (uint8_t)(rec_e >> 30);
-        }
-        e -= (int)((from >> 1) ^ 1u);
-        k -= (int)((from & 1u) ^ 1u);
-        b -= 2 - (int)((from + 1u) >> 1);
-        return (k | e) >= 0;
+        if (lane >= 40) { la_db = 0; la_de = 0; }
+    }
+    auto push = [&](unsigned codes, unsigned cnt) {     // cnt codes of 2 bits, oldest in the low bits; cnt <= 4
+        acc |= (unsigned long long)codes << (2u * nacc);
+        const unsigned room = 32u - nacc;
+        if (cnt >= room) {
+            if (lane == 0) words[nword] = acc;
+            nword++;
+            acc = (cnt > room) ? ((unsigned long long)codes >> (2u * room)) : 0ull;
+            nacc = cnt - room;
+        } else nacc += cnt;
     };
     while ((k | e) >= 0) {
         if (b < lo) {
@@ -671,21 +484,35 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
             nlo = lo - CH_ROWS; if (nlo < 0) nlo = 0;
             if (lo > 0) load_tile(nlo, regs);
             __syncthreads();
-            evrow = row_ev(cur);
         }
         const int bi = b - lo;
-        const int ev_b = __builtin_amdgcn_readlane(evrow, bi);
-        const int off = ev_b - e;
-        if (off < 0 || off >= DN_W) { bad = 1; break; }                   // reference: out-of-bounds read (UB)
-        if (!take(tile[cur][bi * DN_TROW + off])) break;
+        if (bi >= 6 && e >= 4 && k >= 4 && step + 4u <= cap) {
+            const unsigned v = trace_code(tile[cur], bi - la_db, e - la_de);
+            const unsigned f0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+            const unsigned f1 = (unsigned)__builtin_amdgcn_readlane((int)v, 1 + (int)f0);
+            const unsigned f2 = (unsigned)__builtin_amdgcn_readlane((int)v, 4 + 3 * (int)f0 + (int)f1);
+            const unsigned f3 = (unsigned)__builtin_amdgcn_readlane((int)v, 13 + 9 * (int)f0 + 3 * (int)f1 + (int)f2);
+            // a code 3 (slot outside the band) makes the lane indices above meaningless, but every index stays below 64 and the
+            // group is discarded here
+            if (f0 != 3u && f1 != 3u && f2 != 3u && f3 != 3u) {
+                const unsigned p = f0 | (f1 << 2) | (f2 << 4) | (f3 << 6);
+                push(p, 4u);
+                const int de = 4 - __builtin_popcount(p & 0xAAu), dk = 4 - __builtin_popcount(p & 0x55u);
+                e -= de; k -= dk; b -= de + dk;
+                step += 4u;
+                continue;
+            }
+        }
+        // single step (matrix edge, tile seam, or an invalid code ahead)
+        const unsigned from = (unsigned)__builtin_amdgcn_readfirstlane((int)trace_code(tile[cur], bi, e));
+        if (from > 2u || step >= cap) { bad = 1; break; }                  // reference: out-of-bounds read (UB)
+        push(from, 1u);
+        step++;
+        e -= (int)((from >> 1) ^ 1u);
+        k -= (int)((from & 1u) ^ 1u);
+        b -= 2 - (int)((from + 1u) >> 1);
     }
-    const unsigned rem = step & 63u;
-    if (!bad && rem && (unsigned)lane < rem) {
-        const unsigned base = step - rem;
-        const unsigned idx = cap - (base + (unsigned)lane) - 1u;
-        ae[idx] = rec_e & 0x3fffffffu; ak[idx] = rec_k; pf[idx] = (uint8_t)(rec_e >> 30);
-    }
-    }
+    if (nacc && lane == 0) words[nword] = acc;
     if (lane == 0) {
         if (bad) { R.status = 3; R.n_aligned = 0; R.aln_begin = cap; }
         else { R.n_aligned = step; R.aln_begin = cap - step; }
@@ -693,12 +520,15 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B, uint8_t *path_from) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k2_expand: the from-code stream of k2_chase<true> (2 bits per walk step, step 0 = the end cell) -> alignment pairs.
+// k2_expand: the from-code stream of k2_chase (2 bits per walk step, step 0 = the end cell) -> alignment pairs.
 // The event / kmer of step i is the end cell minus the number of earlier steps that moved in that dimension: an exclusive
-// prefix sum over the codes (per 32-step word: two popcounts), done per read by one block.
+// prefix sum over the codes.  One block per read works on 8 192 steps at a time: 256 words are scanned (two popcounts per word),
+// then thread t takes steps t, t + 256, ... of the group, finds its own position with two more popcounts of the masked word,
+// and writes slot cap - 1 - step: consecutive threads write consecutive addresses (the arrays end up in forward order).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k2_expand(BatchDev B, uint8_t *path_from) {
     __shared__ unsigned s_e[256], s_k[256];
+    __shared__ unsigned long long s_w[256];
     __shared__ unsigned base_e, base_k;
     const int r = blockIdx.x, tid = threadIdx.x;
     const ReadRes &R = B.res[r];
@@ -718,10 +548,11 @@ __global__ __launch_bounds__(256) void k2_expand(BatchDev B, uint8_t *path_from)
         unsigned long long word = 0ull; unsigned cnt = 0;
         if (w < nw) { word = words[w]; cnt = min(32u, n - w * 32u); }
         const unsigned long long live = cnt >= 32u ? ~0ull : ((1ull << (2u * cnt)) - 1ull);
+        word &= live;
         // steps that decrement e have code 0 or 1 (high bit clear), steps that decrement k have code 0 or 2 (low bit clear)
-        const unsigned de = cnt - (unsigned)__popcll(word & live & 0xAAAAAAAAAAAAAAAAull);
-        const unsigned dk = cnt - (unsigned)__popcll(word & live & 0x5555555555555555ull);
-        s_e[tid] = de; s_k[tid] = dk;
+        const unsigned de = cnt - (unsigned)__popcll(word & 0xAAAAAAAAAAAAAAAAull);
+        const unsigned dk = cnt - (unsigned)__popcll(word & 0x5555555555555555ull);
+        s_e[tid] = de; s_k[tid] = dk; s_w[tid] = word;
         __syncthreads();
         for (int d = 1; d < 256; d <<= 1) {
             const unsigned te = tid >= d ? s_e[tid - d] : 0u, tk = tid >= d ? s_k[tid - d] : 0u;
@@ -729,18 +560,24 @@ __global__ __launch_bounds__(256) void k2_expand(BatchDev B, uint8_t *path_from)
             s_e[tid] += te; s_k[tid] += tk;
             __syncthreads();
         }
-        unsigned e = e_end - (base_e + s_e[tid] - de), k = k_end - (base_k + s_k[tid] - dk);
-        for (unsigned j = 0; j < cnt; j++) {
-            const unsigned from = (unsigned)(word >> (2u * j)) & 3u;
-            const unsigned idx = cap - 1u - (w * 32u + j);              // walk step -> slot: the arrays end up in forward order
-            ae[idx] = e; ak[idx] = k; pf[idx] = (uint8_t)from;
-            e -= (from >> 1) ^ 1u; k -= (from & 1u) ^ 1u;
+        const unsigned be = base_e, bk = base_k;
+        const unsigned gsteps = min(8192u, n - w0 * 32u);
+        for (unsigned li = tid; li < gsteps; li += 256) {
+            const unsigned wl = li >> 5, bit = li & 31u;
+            const unsigned long long wd = s_w[wl];
+            const unsigned long long below = wd & ((1ull << (2u * bit)) - 1ull);
+            const unsigned pe = wl ? s_e[wl - 1] : 0u, pk = wl ? s_k[wl - 1] : 0u;      // steps of the earlier words of the group
+            const unsigned e = e_end - (be + pe + bit - (unsigned)__popcll(below & 0xAAAAAAAAAAAAAAAAull));
+            const unsigned k = k_end - (bk + pk + bit - (unsigned)__popcll(below & 0x5555555555555555ull));
+            const unsigned idx = cap - 1u - (w0 * 32u + li);
+            ae[idx] = e; ak[idx] = k; pf[idx] = (uint8_t)((unsigned)(wd >> (2u * bit)) & 3u);
         }
         __syncthreads();
         if (tid == 255) { base_e += s_e[255]; base_k += s_k[255]; }
         __syncthreads();
     }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // k2_post: QC + cleaned pairs from the recorded path.  Path slot j (forward order) corresponds to walk step
@@ -879,21 +716,13 @@ int k2_selftest_run(hipStream_t st) {
     hipFree(d);
     return h;
 }
-int k2_fill_variant() {      // 6 = event-keyed slots (slot-indexed trace rows); anything else writes offset-indexed rows
-    static const int variant = getenv("DN_FILL_VARIANT") ? atoi(getenv("DN_FILL_VARIANT")) : 6;
-    return variant;
-}
-void k2_launch_fill(const BatchDev &B, const void *bc, const void *fc, bool dpp, hipStream_t st) {
-    (void)dpp;
+void k2_launch_fill(const BatchDev &B, const void *bc, const void *fc, hipStream_t st) {
     const FillConsts f = *reinterpret_cast<const FillConsts *>(fc);
-    if (k2_fill_variant() == 6) { hipLaunchKernelGGL(k2_fill6, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f); return; }
-    hipLaunchKernelGGL(k2_fill5<0>, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f);
+    hipLaunchKernelGGL(k2_fill6, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f);
 }
 void k2_launch_chase(const BatchDev &B, uint8_t *path_from, hipStream_t st) {
-    if (k2_fill_variant() == 6) {
-        hipLaunchKernelGGL(k2_chase<true>, dim3(B.n_reads), dim3(64), 0, st, B, path_from);
-        hipLaunchKernelGGL(k2_expand, dim3(B.n_reads), dim3(256), 0, st, B, path_from);
-    } else hipLaunchKernelGGL(k2_chase<false>, dim3(B.n_reads), dim3(64), 0, st, B, path_from);
+    hipLaunchKernelGGL(k2_chase, dim3(B.n_reads), dim3(64), 0, st, B);
+    hipLaunchKernelGGL(k2_expand, dim3(B.n_reads), dim3(256), 0, st, B, path_from);
 }
 void k2_launch_post(const BatchDev &B, const uint8_t *path_from, float *path_lp, const void *fc, hipStream_t st) {
     const FillConsts f = *reinterpret_cast<const FillConsts *>(fc);

@@ -25,7 +25,7 @@ struct VitConsts {           // alignment.cpp:199-204 (host libm), normalPDF con
     double c, d2, rd2, logc; // 1/sqrt(2 s^2 pi), 2 s^2, RN(1/(2 s^2)), log(c)
     double initD[VT_NS];     // D_prev[i] of alignment.cpp:241-251: M2D, then + D2D sequentially
 };
-struct VitRead { double iM2M, eM2M, eM2MorD, eOrI; };   // alignment.cpp:207-210, per read (host libm)
+struct VitRead { double iM2M, eM2M, eM2MorD, eOrI; int fail, pad; };   // alignment.cpp:207-210, per read (host libm); fail: NegativeLog
 
 struct EaDev {               // outputs, all at ref_off[r] (capacity = reference length of the read)
     unsigned *coord, *qidx, *ridx; int *indel; unsigned *nsig; float *sig /* x20 */, *core, *resid;
@@ -104,8 +104,12 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
     const int r = blockIdx.x;
     const int lane = threadIdx.x;
     ReadRes &R = B.res[r];
-    if (R.status != 0) { if (lane == 0) { R.n_positions = 0; R.n_windows = 0; } return; }
     const VitRead vr = vrs[r];
+    if (R.status == 0 && vr.fail) {                       // eln() of a negative number: the reference throws NegativeLog (probability.cpp:45)
+        if (lane == 0) { R.status = 4; R.n_positions = 0; R.n_windows = 0; }
+        return;
+    }
+    if (R.status != 0) { if (lane == 0) { R.n_positions = 0; R.n_windows = 0; } return; }
     const double NaN = qnan();
     const uint64_t f0 = B.ref_off[r];
     const int n_ref = (int)(B.ref_off[r + 1] - f0);

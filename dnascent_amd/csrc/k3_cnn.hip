@@ -56,9 +56,14 @@ __device__ __forceinline__ void gru_matvec(const float (&h)[16], cfptr_t W, floa
 // time steps as its longest position, and the lengths are spread from 3 to the cap of 20 (mean ~10), so sorted wavefronts run
 // half the steps of wavefronts of 64 consecutive positions.  Any order gives the same numbers: positions are independent.
 __global__ __launch_bounds__(64) void k3_encode(const float *core, const float *resid, const float *sig, const uint64_t *perm_src,
-                                                const unsigned *perm_row, unsigned n_total, uint8_t *valid_out, float *out,
+                                                const unsigned *perm_row, const unsigned *hist, uint8_t *valid_out, float *out,
                                                 const float *wts, dn_cnn_op op) {
+    // the grid covers the BOUND of the pass's positions (known on the host); how many there really are is the total of the
+    // length histogram the counting sort built (wave-uniform loads)
+    unsigned n_total = 0;
+    for (int b = 0; b < DN_RAWDEPTH_DEV + 1; b++) n_total += hist[b];
     const unsigned i = blockIdx.x * 64 + threadIdx.x;
+    if (blockIdx.x * 64 >= n_total) return;
     const bool live = i < n_total;
     cfptr_t K1 = (cfptr_t)(wts + op.aux[0]), R1 = (cfptr_t)(wts + op.aux[1]), b1 = (cfptr_t)(wts + op.aux[2]);
     cfptr_t K2 = (cfptr_t)(wts + op.aux[3]), R2 = (cfptr_t)(wts + op.aux[4]), b2 = (cfptr_t)(wts + op.aux[5]);
@@ -1013,7 +1018,7 @@ int k3_run(const CnnRun &c, hipStream_t st) {
                 hipLaunchKernelGGL(k3_encode_perm, dim3((c.max_pos + 255) / 256, c.rows.r1 - c.rows.r0), dim3(256), 0, st, c.rows, c.enc_len, c.enc_hist,
                                    c.enc_hist + ENC_BINS, c.perm_src, c.perm_row);
                 if (c.n_pass_pos)
-                    hipLaunchKernelGGL(k3_encode, dim3((c.n_pass_pos + 63) / 64), dim3(64), 0, st, c.core, c.resid, c.sig, c.perm_src, c.perm_row, c.n_pass_pos,
+                    hipLaunchKernelGGL(k3_encode, dim3((c.n_pass_pos + 63) / 64), dim3(64), 0, st, c.core, c.resid, c.sig, c.perm_src, c.perm_row, c.enc_hist,
                                        c.valid, pb[o.dst], c.wts, o);
                 break;
             case DN_CNN_CONV:

@@ -18,7 +18,7 @@ for _i, _n in enumerate(K_NAMES):
 
 # every symbol include/dnascent_hip.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = ["dn_abi_version", "dn_device_count", "dn_ctx_create", "dn_ctx_destroy", "dn_last_error", "dn_sync",
-           "dn_load_pore_model", "dn_batch_upload", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded",
+           "dn_load_pore_model", "dn_batch_upload", "dn_host_alloc", "dn_host_free", "dn_host_register", "dn_host_unregister", "dn_run_detect", "dn_collect", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded",
            "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_set_align_table", "dn_get_align_rows", "dn_get_align_table", "dn_load_cnn", "dn_cnn_set_math", "dn_cnn_range_escalations", "dn_run_cnn", "dn_get_probabilities", "dn_cnn_infer", "dn_load_fit_models", "dn_run_hmm", "dn_get_hmm_calls", "dn_get_summaries", "dn_get_prefix_sums",
            "dn_get_tstats", "dn_get_scrappie_events", "dn_get_events", "dn_get_kmer_ranks", "dn_get_alignment",
            "dn_get_cleaned", "dn_get_trace", "dn_get_positions", "dn_get_windows", "dn_profile_enable", "dn_profile_get",
@@ -30,6 +30,13 @@ class BatchDesc(C.Structure):
                 ("cal_scale", C.c_void_p), ("basecall", C.c_void_p), ("basecall_off", C.c_void_p), ("refseq", C.c_void_p),
                 ("refseq_off", C.c_void_p), ("ref2query", C.c_void_p), ("query2ref", C.c_void_p), ("ref2del", C.c_void_p),
                 ("ref_start", C.c_void_p), ("ref_end", C.c_void_p), ("is_reverse", C.c_void_p)]
+
+
+class ResultBatch(C.Structure):
+    """dn_result_batch"""
+    _fields_ = [("n_reads", C.c_uint32), ("summary", C.c_void_p), ("call_off", C.c_void_p), ("n_calls", C.c_uint64),
+                ("ref_coord", C.c_void_p), ("query_idx", C.c_void_p), ("ref_idx", C.c_void_p), ("p_edu", C.c_void_p),
+                ("p_brdu", C.c_void_p), ("kmer9", C.c_void_p)]
 
 
 class CnnOp(C.Structure):
@@ -91,7 +98,7 @@ def lib():
         L.dn_load_pore_model.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
         L.dn_batch_upload.argtypes = [C.c_void_p, C.POINTER(BatchDesc)]
         for n in ("dn_sync", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded", "dn_run_theilsen", "dn_run_normalise",
-                  "dn_run_eventalign", "dn_set_align_table", "dn_get_align_rows", "dn_get_align_table", "dn_profile_reset"):
+                  "dn_run_eventalign", "dn_run_detect", "dn_set_align_table", "dn_get_align_rows", "dn_get_align_table", "dn_profile_reset"):
             getattr(L, n).argtypes = [C.c_void_p]
         L.dn_load_cnn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32]
         L.dn_run_cnn.argtypes = [C.c_void_p]
@@ -103,6 +110,11 @@ def lib():
         L.dn_cnn_infer.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dn_get_probabilities.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.dn_get_summaries.argtypes = [C.c_void_p, C.c_void_p]
+        L.dn_collect.argtypes = [C.c_void_p, C.POINTER(ResultBatch)]
+        L.dn_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+        L.dn_host_free.argtypes = [C.c_void_p]
+        L.dn_host_register.argtypes = [C.c_void_p, C.c_size_t]
+        L.dn_host_unregister.argtypes = [C.c_void_p]
         L.dn_get_prefix_sums.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.dn_get_tstats.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.dn_get_scrappie_events.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -217,6 +229,21 @@ class Context:
         out = np.zeros(self.n_reads, SUMMARY_DTYPE)
         self._chk(lib().dn_get_summaries(self.h, out.ctypes.data), "dn_get_summaries")
         return out
+
+    def collect(self):
+        """dn_collect: the bulk result of the batch as numpy COPIES: summary [n_reads], call_off [n_reads + 1], and per call
+        ref_coord / query_idx / ref_idx / p_edu / p_brdu / kmer (S9)."""
+        rb = ResultBatch()
+        self._chk(lib().dn_collect(self.h, C.byref(rb)), "dn_collect")
+        n, k = int(rb.n_reads), int(rb.n_calls)
+
+        def arr(ptr, dtype, cnt):
+            if cnt == 0:
+                return np.zeros(0, dtype)
+            return np.frombuffer((C.c_char * (cnt * np.dtype(dtype).itemsize)).from_address(ptr), dtype=dtype).copy()
+        return dict(summary=arr(rb.summary, SUMMARY_DTYPE, n), call_off=arr(rb.call_off, np.uint64, n + 1 if n else 0),
+                    ref_coord=arr(rb.ref_coord, np.uint32, k), query_idx=arr(rb.query_idx, np.uint32, k), ref_idx=arr(rb.ref_idx, np.uint32, k),
+                    p_edu=arr(rb.p_edu, np.float32, k), p_brdu=arr(rb.p_brdu, np.float32, k), kmer=arr(rb.kmer9, "S9", k))
 
     # ---- taps -------------------------------------------------------------------------------
     def prefix_sums(self, r, n):

@@ -10,6 +10,12 @@ from . import hip as _hip
 _lib = None
 
 
+class StreamStats(C.Structure):
+    """DNAscent::StreamStats"""
+    _fields_ = [("seconds_total", C.c_double), ("seconds_upload", C.c_double), ("seconds_collect", C.c_double), ("seconds_emit", C.c_double),
+                ("reads", C.c_uint64), ("reads_ok", C.c_uint64), ("samples", C.c_uint64), ("calls", C.c_uint64), ("bytes_out", C.c_uint64)]
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -57,6 +63,14 @@ def lib():
         L.dnh_detect_header.restype = C.c_uint64
         L.dnh_detect_header.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_char_p, C.c_char_p,
                                         C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64]
+        L.dnh_batch_fill_synth.restype = C.c_int
+        L.dnh_batch_fill_synth.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.dnh_stream_detect.restype = C.c_int
+        L.dnh_stream_detect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(StreamStats), C.c_void_p]
+        L.dnh_keep_new.restype = C.c_void_p
+        L.dnh_keep_free.argtypes = [C.c_void_p]
+        L.dnh_keep_get.restype = C.c_uint64
+        L.dnh_keep_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.dnh_revcomp.restype = C.c_int
         L.dnh_revcomp.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         _lib = L
@@ -167,6 +181,12 @@ class ReadBatch:
             self.reads.append(sr)
         return rc
 
+    def fill_synth(self, model, seed0, n_reads, n_bases, noise_pa=1.6, sub_rate=0.002, ins_rate=0.001, del_rate=0.001):
+        """n_reads synthetic reads (seeds seed0 .., every odd one reverse), generated on all host cores inside the host library.
+        The batch does not keep SynthRead objects for them (self.reads stays as it was)."""
+        m = np.ascontiguousarray(model, np.float64)
+        return int(lib().dnh_batch_fill_synth(self.h, m.ctypes.data, seed0, n_reads, n_bases, noise_pa, sub_rate, ins_rate, del_rate))
+
     def add_container(self, path, first=0, count=1 << 62):
         """reads [first, first + count) of a binary read container; returns how many were accepted (-1: malformed file)"""
         return int(lib().dnh_container_load(self.h, path.encode(), first, count))
@@ -212,3 +232,33 @@ class ReadBatch:
         if rc < 0:
             raise _hip.DnError("dnh_detect_write failed (%d): %s" % (rc, _hip.lib().dn_last_error(ctx.h).decode()))
         return rc
+
+
+def stream_detect(ctxs, batches, emit=True, out_path=None, header=None, keep=False):
+    """DNAscent::streamDetect: the batches through len(ctxs) contexts in flight, driven by one host thread (this one, inside the
+    host library).  Returns StreamStats, or (StreamStats, dict of numpy arrays: read_calls / coord / p_edu / p_brdu of the whole
+    stream) with keep=True."""
+    hc = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    hb = (C.c_void_p * len(batches))(*[b.h for b in batches])
+    st = StreamStats()
+    kh = C.c_void_p(lib().dnh_keep_new()) if keep else None
+    try:
+        rc = lib().dnh_stream_detect(hc, len(ctxs), hb, len(batches), int(emit), out_path.encode() if out_path else None,
+                                     header.encode() if header is not None else None, C.byref(st), kh)
+        if rc != 0:
+            msgs = [_hip.lib().dn_last_error(c.h).decode() for c in ctxs]
+            raise _hip.DnError("dnh_stream_detect failed (%d): %s" % (rc, "; ".join(m for m in msgs if m)))
+        for i, b in enumerate(batches):
+            if i >= len(batches) - len(ctxs):
+                ctxs[i % len(ctxs)].n_reads = b.size()
+        if not keep:
+            return st
+        out = {}
+        for which, (name, dt) in enumerate((("read_calls", np.uint64), ("coord", np.uint32), ("p_edu", np.float32), ("p_brdu", np.float32))):
+            p = C.c_void_p()
+            n = int(lib().dnh_keep_get(kh, which, C.byref(p)))
+            out[name] = np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(p.value), dtype=dt).copy() if n else np.zeros(0, dt)
+        return st, out
+    finally:
+        if kh:
+            lib().dnh_keep_free(kh)

@@ -66,38 +66,53 @@ def reduce_max(dist, value, device="cpu"):
     return float(t.item())
 
 
+def gather_bytes(dist, blob, dst=0, device="cpu"):
+    """Variable-size byte blocks of every rank to the writer rank `dst`: a tiny all_gather of the lengths, then ONE grouped
+    send / recv (batch_isend_irecv) -- every rank sends its block straight to the writer, the writer posts one receive per peer, so
+    over RCCL all of its xGMI links are used at once and nobody receives what it does not need (a padded all_gather would move
+    world x max bytes to every rank).  blob: uint8 numpy array.  Returns the list of per-rank uint8 arrays on `dst`, None elsewhere."""
+    import torch
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [blob]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ln = torch.tensor([blob.shape[0]], dtype=torch.int64, device=device)
+    lens = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(lens, ln)
+    lens = [int(x.item()) for x in lens]
+    ops, bufs = [], {}
+    if rank == dst:
+        for r in range(world):
+            if r != dst and lens[r]:
+                bufs[r] = torch.empty(lens[r], dtype=torch.uint8, device=device)
+                ops.append(dist.P2POp(dist.irecv, bufs[r], r))
+    elif blob.shape[0]:
+        mine = torch.from_numpy(blob).to(device)
+        ops.append(dist.P2POp(dist.isend, mine, dst))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if rank != dst:
+        return None
+    return [blob if r == dst else (bufs[r].cpu().numpy() if r in bufs else np.zeros(0, np.uint8)) for r in range(world)]
+
+
 def gather_records(dist, ordinals, records, dst=0, device="cpu"):
     """Gather per-read byte records to rank `dst`, returned there sorted by input ordinal (None elsewhere).
-
-    Each rank sends ONE buffer: [n, (ordinal, length)*n, payload].  all_gather of the buffer lengths, then padded
-    all_gather of the buffers (gloo and RCCL both support it; the payload of a 1000-read batch is a few MB).
-    """
-    import torch
+    Each rank sends ONE block: [n, (ordinal, length) * n, payload] (gather_bytes)."""
     assert len(ordinals) == len(records)
     head = np.zeros(1 + 2 * len(records), dtype=np.int64)
     head[0] = len(records)
     for j, (o, rec) in enumerate(zip(ordinals, records)):
         head[1 + 2 * j] = int(o)
         head[2 + 2 * j] = len(rec)
-    blob = head.tobytes() + b"".join(records)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        blobs = [blob]
-        rank = 0
-    else:
-        world, rank = dist.get_world_size(), dist.get_rank()
-        ln = torch.tensor([len(blob)], dtype=torch.int64, device=device)
-        lens = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-        dist.all_gather(lens, ln)
-        mx = int(max(int(x.item()) for x in lens))
-        buf = torch.zeros(mx, dtype=torch.uint8, device=device)
-        buf[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
-        bufs = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(world)]
-        dist.all_gather(bufs, buf)
-        blobs = [bytes(b[:int(l.item())].cpu().numpy().tobytes()) for b, l in zip(bufs, lens)]
-    if rank != dst:
+    blob = np.frombuffer(head.tobytes() + b"".join(records), dtype=np.uint8)
+    blobs = gather_bytes(dist, blob, dst=dst, device=device)
+    if blobs is None:
         return None
     merged = []
-    for bl in blobs:
+    for b in blobs:
+        bl = b.tobytes()
         n = int(np.frombuffer(bl[:8], dtype=np.int64)[0])
         hd = np.frombuffer(bl[8:8 + 16 * n], dtype=np.int64).reshape(n, 2)
         pos = 8 + 16 * n
@@ -106,3 +121,26 @@ def gather_records(dist, ordinals, records, dst=0, device="cpu"):
             pos += int(l)
     merged.sort(key=lambda t: t[0])
     return merged
+
+
+def gather_calls(dist, read_calls, coord, p_edu, p_brdu, dst=0, device="cpu"):
+    """The binary per-call results of a rank's reads -- calls per read (uint64), and per call the reference coordinate (uint32),
+    P(EdU), P(BrdU) (float32): 12 bytes per call, SURVEY s8e -- to the writer rank.  Returns there a list of per-rank tuples
+    (read_calls, coord, p_edu, p_brdu), None elsewhere."""
+    rc = np.ascontiguousarray(read_calls, np.uint64); c = np.ascontiguousarray(coord, np.uint32)
+    e = np.ascontiguousarray(p_edu, np.float32); b = np.ascontiguousarray(p_brdu, np.float32)
+    head = np.array([rc.shape[0], c.shape[0]], dtype=np.uint64)
+    blob = np.concatenate([x.view(np.uint8) for x in (head, rc, c, e, b)])
+    blobs = gather_bytes(dist, blob, dst=dst, device=device)
+    if blobs is None:
+        return None
+    out = []
+    for bl in blobs:
+        nr, nc = (int(x) for x in bl[:16].view(np.uint64))
+        o = 16
+        r_ = bl[o:o + 8 * nr].view(np.uint64); o += 8 * nr
+        c_ = bl[o:o + 4 * nc].view(np.uint32); o += 4 * nc
+        e_ = bl[o:o + 4 * nc].view(np.float32); o += 4 * nc
+        b_ = bl[o:o + 4 * nc].view(np.float32)
+        out.append((r_, c_, e_, b_))
+    return out

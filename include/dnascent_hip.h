@@ -8,7 +8,11 @@
  *
  * Conventions: int return codes (0 = DN_OK, <0 = error, text via dn_last_error), caller-owned host
  * buffers, library-owned device memory, no exceptions and no torch / HIP types across the boundary.
- * A context is single-producer; stages of one batch are stream-ordered on the context's HIP stream.
+ * A context holds ONE batch and is single-producer; the stages of the batch are stream-ordered on the context's HIP
+ * stream and every dn_run_* only ENQUEUES (no host synchronisation: the per-read constants the reference takes from libm
+ * are computed by stream-ordered host functions on page-locked mirrors).  dn_collect / dn_sync / the dn_get_* taps wait.
+ * Throughput comes from several contexts in flight, driven by one host thread:
+ *     for each slot:  dn_collect(slot) -> write records;  dn_batch_upload(slot, next batch);  dn_run_detect(slot)
  * There is NO CPU fallback: every dn_run_* fails with DN_ERR_NO_DEVICE when no gfx950 device is usable.
  */
 #ifndef DNASCENT_HIP_H
@@ -21,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 1
+#define DN_ABI_VERSION 2
 #define DN_KMER 9            /* config.h:45 */
 #define DN_NKMER 262144      /* 4^9, data_IO.cpp:177 */
 #define DN_BANDWIDTH 100     /* config.h:41 AdaptiveBanded_Params.bandwidth */
@@ -43,7 +47,9 @@ enum {
     DN_READ_FAIL_SCALING = 2,     /* event_handling.cpp:90-95,604 */
     DN_READ_FAIL_NO_END_CELL = 3, /* path left the band / no end cell: undefined behaviour in the reference */
     DN_READ_FAIL_NEGATIVE_LOG = 4,/* probability.cpp:45 NegativeLog */
-    DN_READ_FAIL_TOO_SHORT = 5
+    DN_READ_FAIL_TOO_SHORT = 5,
+    DN_READ_FAIL_WINDOW_EVENTS = 6/* more than 512 events inside one eventalign window (alignment.cpp:611-632 has no limit; a 50-base
+                                     window holds ~120): the device lattice is sized for 512, the read is reported failed */
 };
 
 typedef struct dn_ctx dn_ctx;
@@ -76,7 +82,15 @@ typedef struct {
     const uint8_t *is_reverse;                                    /* r.isReverse */
 } dn_batch_desc;
 
-int dn_batch_upload(dn_ctx *ctx, const dn_batch_desc *batch);    /* H2D; sizes every workspace */
+/* H2D; sizes every workspace (bounds only: nothing waits for a result).  Waits for the previous batch of the context first.
+ * With page-locked input arrays (dn_host_alloc / dn_host_register) the copies themselves are asynchronous too and the arrays
+ * must stay untouched until the next dn_sync / dn_collect of this context; with pageable arrays the call returns after the copies. */
+int dn_batch_upload(dn_ctx *ctx, const dn_batch_desc *batch);
+/* page-locked host memory for the input arrays: hipHostMalloc / hipHostRegister behind a C signature */
+int dn_host_alloc(size_t bytes, void **p);
+void dn_host_free(void *p);
+int dn_host_register(void *p, size_t bytes);
+int dn_host_unregister(void *p);
 
 /* ---- stages (stream-ordered; each works on the uploaded batch) ---- */
 int dn_run_segment(dn_ctx *ctx);        /* detect_events (scrappie/event_detection.c:268) + event build + k-mer ranks (event_handling.cpp:546-592) */
@@ -85,6 +99,7 @@ int dn_run_banded(dn_ctx *ctx);         /* adaptive_banded_simple_event_align (e
 int dn_run_theilsen(dn_ctx *ctx);       /* estimateScaling_theilSen (event_handling.cpp:24) + eventsPerBase (:606) */
 int dn_run_normalise(dn_ctx *ctx);      /* normaliseEvents (event_handling.h:13) == the four stages above */
 int dn_run_eventalign(dn_ctx *ctx);     /* eventalign (alignment.h:22): windowed Viterbi + feature fill + tensor packing (reads.h:305-372) */
+int dn_run_detect(dn_ctx *ctx);         /* the body of the reference's per-read loop (detect.cpp:876-896): dn_run_normalise + dn_run_eventalign + dn_run_cnn */
 
 /* ---- CNN (replaces model_load_*_twoInputs + TF_SessionRun, tensor.cpp:12-106, detect.cpp:577-675) ----
  * The network is DATA: an ordered op list over `n_buffers` activation buffers + one fp32 weight blob
@@ -163,6 +178,24 @@ typedef struct {
 } dn_read_summary;
 
 int dn_get_summaries(dn_ctx *ctx, dn_read_summary *out /* [n_reads] */);
+
+/* ---- bulk result of a batch: what runCNN leaves on every read (detect.cpp:677-731), one transfer per array ----
+ * A "call" is a position whose strand 9-mer has 'T' in the middle -- the only positions runCNN reports, in the .detect text
+ * (detect.cpp:690) and in the modbam tags (:704-707) alike.  Calls of read r are [call_off[r], call_off[r + 1]) in eventalign's
+ * creation order (sequencing direction); failed reads have none.  All pointers are page-locked memory owned by the context,
+ * valid until its next dn_batch_upload.  dn_collect waits for the batch (after dn_run_cnn / dn_run_detect). */
+typedef struct {
+    uint32_t n_reads;
+    const dn_read_summary *summary;   /* [n_reads]: status, shift, scale, events_per_base, n_positions, ... */
+    const uint64_t *call_off;         /* [n_reads + 1] */
+    uint64_t n_calls;                 /* == call_off[n_reads] */
+    const uint32_t *ref_coord;        /* reference coordinate of the position (alignment.cpp:648-650) */
+    const uint32_t *query_idx;        /* refToQuery of its reference index (modbam key, detect.cpp:705) */
+    const uint32_t *ref_idx;          /* index of the 9-mer's middle base in referenceSeqMappedTo (refToDel lookup, detect.cpp:704) */
+    const float *p_edu, *p_brdu;      /* class 2 / class 1 of the network output (detect.cpp:695) */
+    const char *kmer9;                /* [n_calls * 9] strand 9-mer, not NUL-terminated */
+} dn_result_batch;
+int dn_collect(dn_ctx *ctx, dn_result_batch *out);
 
 /* ---- intermediate taps (parity tests; sizes from dn_read_summary; NULL pointers are skipped) ---- */
 int dn_get_prefix_sums(dn_ctx *ctx, uint32_t read, double *sum /* [n+1] */, double *sumsq /* [n+1] */);

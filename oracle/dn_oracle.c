@@ -1077,3 +1077,29 @@ int dno_parse_cigar(const uint32_t *ops, const uint32_t *lens, size_t n_ops, int
     }
     return rp;
 }
+
+
+/* ---- bench.py cpu_baseline: the reference's per-read loop (detect.cpp:852: #pragma omp parallel for schedule(dynamic)) over an
+ *      array of reads, one read per thread: normaliseEvents and, if do_align, eventalign.  Returns the wall time; per-read
+ *      statuses and position counts come back for the caller's bookkeeping.  Test / measurement infrastructure only. ---- */
+#include <omp.h>
+double dno_bench_reads(const dno_model *m, const dno_read *reads, size_t n, int do_align, int n_threads, int *status, uint64_t *n_pos) {
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+    const double t0 = omp_get_wtime();
+#pragma omp parallel for schedule(dynamic)
+    for (long i = 0; i < (long)n; i++) {
+        dno_norm nm; memset(&nm, 0, sizeof nm);
+        int st = dno_normalise(m, &reads[i], &nm);
+        uint64_t np = 0;
+        if (st == 0 && do_align) {
+            dno_align al; memset(&al, 0, sizeof al);
+            st = dno_eventalign(m, &reads[i], &nm, &al);
+            np = st == 0 ? (uint64_t)al.n_pos : 0;
+            dno_align_free(&al);
+        }
+        dno_norm_free(&nm);
+        if (status) status[i] = st;
+        if (n_pos) n_pos[i] = np;
+    }
+    return omp_get_wtime() - t0;
+}

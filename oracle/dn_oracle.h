@@ -201,4 +201,7 @@ int dno_parse_cigar(const uint32_t *ops, const uint32_t *lens, size_t n_ops, int
 #ifdef __cplusplus
 }
 #endif
+/* OpenMP driver for bench.py's cpu_baseline: the reference's per-read loop (detect.cpp:852) over an array of reads */
+double dno_bench_reads(const dno_model *m, const dno_read *reads, size_t n, int do_align, int n_threads, int *status, uint64_t *n_pos);
+
 #endif

@@ -360,3 +360,17 @@ def viterbi(model_mean, obs, seq, shift, scale, epb, sigma=0.14):
     n = oracle().dno_viterbi(C.byref(m), obs.ctypes.data, T, seq if isinstance(seq, bytes) else seq.encode(), len(seq),
                              shift, scale, epb, C.byref(sc), st.ctypes.data, ps.ctypes.data, C.byref(err))
     return sc.value, st[:n].copy(), ps[:n].copy(), err.value
+
+
+def bench_reads(synth_reads, model_mean, full, threads):
+    """dno_bench_reads: the reference's OpenMP loop (one read per thread, schedule(dynamic)) over the given reads.
+    Returns (seconds, samples, positions, reads passing)."""
+    ors = [OracleRead(r, model_mean) for r in synth_reads]          # int16 -> pA and CIGAR flattening happen here, outside the timing
+    arr = (Read * len(ors))(*[o.c for o in ors])
+    st = (C.c_int * len(ors))()
+    npos = (C.c_uint64 * len(ors))()
+    L = oracle()
+    L.dno_bench_reads.restype = C.c_double
+    L.dno_bench_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    secs = L.dno_bench_reads(C.byref(ors[0].model), arr, len(ors), int(full), int(threads), st, npos)
+    return float(secs), sum(r.n_samples() for r in synth_reads), int(sum(npos)), int(sum(1 for x in st if x == 0))

@@ -1,0 +1,138 @@
+"""GPU: the bulk boundary.  dn_collect (one device-to-host transfer per output array for the whole batch, calls compacted on
+the device) against the per-read taps; DNAscent::streamDetect (several contexts in flight driven by one host thread, records
+written in input order) against the oracle's records byte for byte; the stages only ENQUEUE (a batch run stage by stage with a
+sync after each gives the same bits as dn_run_detect enqueued in one go)."""
+import os
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+from dnascent_amd import cnn_model, hip, host, synth
+
+pytestmark = pytest.mark.gpu
+
+SPECS = [
+    (401, 3000, dict()),
+    (402, 4000, dict(is_reverse=True)),
+    (403, 3500, dict(sub_rate=0.003, ins_rate=0.001, del_rate=0.001)),
+    (404, 3000, dict(noise_pa=6.5)),                                    # fails the banded QC: no calls, not written
+    (405, 3200, dict(is_reverse=True, sub_rate=0.003, ins_rate=0.002, del_rate=0.002, soft_clip_head=25, soft_clip_tail=40)),
+    (406, 4000, dict(n_unknown=3)),
+]
+
+
+def _ctx(model):
+    ctx = hip.Context(0)
+    ctx.load_pore_model(model, 0.14)
+    desc, blob, _ = cnn_model.default_model()
+    ctx.load_cnn(desc, blob)
+    return ctx
+
+
+def _batch(model, specs):
+    reads = [synth.make_read(seed, n, model=model, **kw) for seed, n, kw in specs]
+    b = host.ReadBatch()
+    for r in reads:
+        assert b.add_synth(r) >= 0
+    return b, reads
+
+
+def _same(ra, rc):
+    for k in ra:
+        if k == "summary":
+            for f in ra[k].dtype.names:                    # field by field: the structs carry padding bytes
+                assert np.asarray(ra[k][f]).tobytes() == np.asarray(rc[k][f]).tobytes(), f
+        else:
+            assert ra[k].tobytes() == rc[k].tobytes(), k
+
+
+def test_collect_equals_the_taps(model):
+    ctx = _ctx(model)
+    b, reads = _batch(model, SPECS)
+    b.upload(ctx)
+    ctx.run("detect")                                  # normalise + eventalign + CNN, enqueued without a host synchronisation
+    res = ctx.collect()
+    s = ctx.summaries()
+    for f in s.dtype.names:                                # field by field: the structs carry padding bytes
+        assert np.asarray(res["summary"][f]).tobytes() == np.asarray(s[f]).tobytes(), f
+    assert res["call_off"][0] == 0 and res["call_off"][-1] == res["kmer"].shape[0]
+    assert s["status"][3] != 0 and res["call_off"][4] == res["call_off"][3]       # the failed read has no calls
+    for r in range(len(reads)):
+        lo, hi = int(res["call_off"][r]), int(res["call_off"][r + 1])
+        if s["status"][r] != 0:
+            assert hi == lo
+            continue
+        n = int(s["n_positions"][r])
+        pos = ctx.positions(r, n)
+        pr = ctx.probabilities(r, n)
+        t = np.array([k[4:5] == b"T" for k in pos["kmer"]])                        # detect.cpp:690
+        assert hi - lo == int(t.sum()) > 100
+        assert np.array_equal(res["ref_coord"][lo:hi], pos["coord"][t]) and np.array_equal(res["query_idx"][lo:hi], pos["query_idx"][t])
+        assert np.array_equal(res["ref_idx"][lo:hi], pos["ref_idx"][t]) and np.array_equal(res["kmer"][lo:hi], pos["kmer"][t])
+        assert res["p_edu"][lo:hi].tobytes() == pr[t, 2].tobytes() and res["p_brdu"][lo:hi].tobytes() == pr[t, 1].tobytes()   # :695
+    ctx.close()
+
+
+def test_enqueued_pipeline_equals_stage_by_stage(model):
+    """dn_run_detect enqueues every stage back to back (per-read libm constants come from stream-ordered host functions);
+    running the stages one at a time with a host synchronisation after each must give the same bits."""
+    b, reads = _batch(model, SPECS)
+    a = _ctx(model); b.upload(a); a.run("detect"); ra = a.collect()
+    c = _ctx(model); b.upload(c)
+    for st in ("segment", "rough_scaling", "banded", "theilsen", "eventalign", "cnn"):
+        c.run(st); c.sync()
+    rc = c.collect()
+    _same(ra, rc)
+    a.close(); c.close()
+
+
+def test_stream_detect_file_matches_oracle_records(model, tmp_path):
+    """Five batches through three contexts in flight, one host thread; the .detect file is the oracle's records of the passing
+    reads in input order, byte for byte (CNN probabilities taken from the device: the text path is what is compared)."""
+    ctxs = [_ctx(model) for _ in range(3)]
+    batches, all_reads = [], []
+    for j in range(5):
+        specs = [(500 + 10 * j + i, 2500 + 300 * i, dict(is_reverse=bool((i + j) & 1), sub_rate=0.002, ins_rate=0.001, del_rate=0.001,
+                                                         noise_pa=6.5 if (i == 2 and j == 1) else 1.6)) for i in range(4)]
+        b, reads = _batch(model, specs)
+        batches.append(b); all_reads.append(reads)
+    path = str(tmp_path / "stream.detect")
+    st, kept = host.stream_detect(ctxs, batches, emit=True, out_path=path, header="#hdr\n", keep=True)
+    assert st.reads == 20 and st.reads_ok == 19 and st.bytes_out + 5 == os.path.getsize(path)
+    assert int(kept["read_calls"].sum()) == st.calls == kept["coord"].shape[0]
+    got = open(path, "rb").read()
+    # the same batches one by one on one context, records formatted by the oracle from the device's probabilities
+    ref = _ctx(model)
+    want = b"#hdr\n"
+    calls = []
+    for b, reads in zip(batches, all_reads):
+        b.upload(ref); ref.run("detect"); ref.sync()
+        s = ref.summaries()
+        for r, sr in enumerate(reads):
+            if s["status"][r] != 0:
+                calls.append(0)
+                continue
+            n = int(s["n_positions"][r])
+            o = po.OracleRead(sr, model)
+            assert o.normalise() == 0 and o.eventalign() == 0
+            rec = o.format_detect(ref.probabilities(r, n))
+            want += rec
+            calls.append(rec.count(b"\n") - 1)
+            o.free()
+    assert got == want
+    assert kept["read_calls"].tolist() == calls
+    for c in ctxs + [ref]:
+        c.close()
+
+
+def test_dalloc_exact_size_retry(model, monkeypatch):
+    """when the generous slab cannot be had, the allocator retries with exactly what is needed and must record THAT
+    capacity.  DN_SLAB_MIN_MB makes the first request absurd (so it fails) on every new slab; the batch must still run and give
+    the same bits as a context with default slabs."""
+    b, reads = _batch(model, SPECS[:3])
+    a = _ctx(model); b.upload(a); a.run("detect"); ra = a.collect()
+    monkeypatch.setenv("DN_SLAB_MIN_MB", str(1 << 24))           # 16 TiB: hipMalloc fails, the exact-size retry succeeds
+    c = _ctx(model); b.upload(c); c.run("detect"); rc = c.collect()
+    _same(ra, rc)
+    a.close(); c.close()

@@ -104,3 +104,20 @@ def test_align_record_matches_oracle(aligned, model):
         assert len(f) == 5 and len(f[1]) == 9 and len(f[3]) == 9 and len(f[2].split(".")[1]) == 6
         ins = [l for l in lines[1:] if l.endswith("NNNNNNNNN\t0")]
         assert len(ins) == int((t["kind"] == 1).sum())
+
+
+def test_fast_probability_format_equals_printf():
+    """The record formatter prints probabilities without snprintf (p * 1e6 is exact in double for a float p, so rint() is
+    glibc's correctly rounded "%f").  Every float next to a 6-decimal rounding boundary, random floats and the special values
+    (negative zero, out of range, NaN, inf) must give the same text as printf("%f")."""
+    import ctypes as C
+    L = host.lib()
+    L.dnh_check_prob_format.restype = C.c_uint64
+    L.dnh_check_prob_format.argtypes = [C.c_void_p, C.c_uint64]
+    rng = np.random.default_rng(1)
+    near = ((np.arange(0, 1000001) + 0.5) * 1e-6).astype(np.float32)          # every boundary k + 0.5 ppm, and its float neighbours
+    cand = np.concatenate([near, np.nextafter(near, np.float32(0)), np.nextafter(near, np.float32(2)), rng.random(1000000, dtype=np.float32),
+                           np.array([0, 1, -0.0, 1e-7, 5e-7, 4.9999997e-7, 0.9999995, 0.99999994, 1.0000001, 2.5, -1, np.nan, np.inf, 1e-30,
+                                     0.5, 0.1234565, 0.0000005, 0.0000015, 0.0000025], np.float32)])
+    cand = np.ascontiguousarray(cand)
+    assert L.dnh_check_prob_format(cand.ctypes.data, cand.shape[0]) == 0

@@ -1,5 +1,5 @@
 """GPU: the alternative kernel forms kept behind environment switches must give bit-identical results to the defaults:
-DN_FILL_VARIANT=5 (offset-keyed band fill), DN_SCAN4=0 (one read per wavefront in the prefix scan), DN_CNN_BM256=0 (128-row
+DN_SCAN4=0 (one read per wavefront in the prefix scan), DN_CNN_BM256=0 (128-row
 workgroups on the long-K convolutions), DN_CNN_SEP_WS=0 (single-role fused separable kernel for the 17-tap layers), DN_TS_FULL=1
 (Theil-Sen: the general first-level histogram path that a median slope outside [0.5, 2) takes).
 Each variant runs in its own process (the switches are read once per process)."""
@@ -43,7 +43,7 @@ def run(env):
 base = run({})
 print("default        ", base)
 ok = True
-for name, env in (("fill5", {"DN_FILL_VARIANT": "5"}), ("scan1", {"DN_SCAN4": "0"}), ("conv BM=128", {"DN_CNN_BM256": "0"}),
+for name, env in (("scan1", {"DN_SCAN4": "0"}), ("conv BM=128", {"DN_CNN_BM256": "0"}),
                   ("sep no-ws", {"DN_CNN_SEP_WS": "0"}), ("sep unfused", {"DN_CNN_FUSE": "0"}), ("theilsen full", {"DN_TS_FULL": "1"})):
     d = run(env)
     print("%-15s" % name, d, "same" if d == base else "DIFFERENT")
