@@ -78,6 +78,63 @@ def make_detect_line(line, chromosome):                      # utils/dnascent2be
     return int(s[0]), float(s[2]), float(s[1])               # pos, BrdU, EdU
 
 
+def detect_text_for_fixture(model):
+    """The .detect text of the committed fixture (tests/golden/bedgraph_input.detect): header + the records of SPECS as the host
+    writer formats them from the oracle's positions and seeded probabilities.  Deterministic; CPU only."""
+    text = host.detect_header("aln.bam", "genome.fa", "index.dnascent", 4, 20, 1000, False, "2026-01-01 00:00:00", "/opt/dnascent", "4.1.1", "deadbeef").decode()
+    for seed, n, kw in SPECS:
+        sr = synth.make_read(seed, n, model=model, **kw)
+        o = po.OracleRead(sr, model)
+        assert o.normalise() == 0 and o.eventalign() == 0
+        pr = np.random.default_rng(seed).dirichlet((1.0, 1.0, 1.0), int(o.align.n_pos)).astype(np.float32)
+        pos = o.positions()
+        text += host.format_detect(sr.read_id, sr.contig, sr.ref_start, sr.ref_end, sr.is_reverse, pos["coord"], pos["kmer"], pr).decode()
+        o.free()
+    return text
+
+
+def bedgraphs_restated(text):
+    """utils/dnascent2bedgraph.py parseBaseFile (:107-260) for a detect file with default arguments: per read two bedgraph files
+    (BrdU, EdU) in directory 1, a track line + one line per data line: chromosome pos pos+1 probability (Python float repr)."""
+    files, cur, cid, chrom = {}, None, None, None
+
+    def flush():
+        if cid is None:
+            return
+        head = 'track type=bedGraph name="%s" description="BedGraph format" visibility=full color=%s altColor=0,100,200 priority=20 viewLimits=0.0:1.0\n'
+        files["1/%s.BrdUdetect.bedgraph" % cid] = head % (cid, "200,100,0") + "".join(l[0] for l in cur)
+        files["1/%s.EdUdetect.bedgraph" % cid] = head % (cid, "93,197,186") + "".join(l[1] for l in cur)
+    for line in text.split("\n"):
+        if not line.rstrip() or line[0] == "#":
+            continue
+        if line[0] == ">":
+            flush()
+            cols = line.rstrip().split(" ")
+            cid, chrom, cur = cols[0][1:], cols[1], []
+            continue
+        pos, bd, ed = make_detect_line(line, chrom)
+        cur.append(("%s %d %d %s\n" % (chrom, pos, pos + 1, str(bd)), "%s %d %d %s\n" % (chrom, pos, pos + 1, str(ed))))
+    flush()
+    return files
+
+
+def test_bedgraphs_match_what_the_reference_script_extracted(model):
+    """tests/golden/bedgraph_expected.json holds every file the REFERENCE's utils/dnascent2bedgraph.py wrote when it was run (in
+    the build container, tests/golden/make_bedgraph_golden.py) on tests/golden/bedgraph_input.detect -- a file written by this
+    framework's host layer.  Here: the writer still produces that file byte for byte, and the restated parser extracts exactly
+    what the reference's parser extracted."""
+    import json
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    committed = open(os.path.join(g, "bedgraph_input.detect")).read()
+    assert detect_text_for_fixture(model) == committed
+    want = json.load(open(os.path.join(g, "bedgraph_expected.json")))["files"]
+    got = bedgraphs_restated(committed)
+    assert sorted(got) == sorted(want) and len(want) == 2 * len(SPECS)
+    for k in want:
+        assert got[k] == want[k], k
+
+
 def test_detect_file_round_trips_through_the_reference_consumers(model, tmp_path):
     text = host.detect_header("aln.bam", "genome.fa", "index.dnascent", 4, 20, 1000, False, "2026-01-01 00:00:00", "/opt/dnascent", "4.1.1", "deadbeef").decode()
     truth = []
