@@ -47,6 +47,7 @@ struct EaDevH { unsigned *coord, *qidx, *ridx; int *indel; unsigned *nsig; float
                 unsigned *win_ref, *win_len, *win_T; double *win_score;
                 unsigned *al_coord, *al_rpos; double *al_val; unsigned char *al_kind; const unsigned long long *al_off; unsigned *al_n; };
 void k2b_rowcap_launch(const BatchDev &, unsigned long long *, hipStream_t);
+void k2b_emission_tap_launch(const double *, const double *, double *, unsigned, const void *, hipStream_t);
 // k_collect.hip: per-read call counts (centre base T), their exclusive scan, ordered compaction of the per-call outputs
 struct CollectDev { const unsigned *coord, *qidx, *ridx; const float *probs; unsigned *cnt; unsigned long long *off;
                     unsigned *o_coord, *o_qidx, *o_ridx; float *o_edu, *o_brdu; char *o_kmer; };
@@ -635,6 +636,22 @@ int dn_run_eventalign(dn_ctx *c) {
     HIPCHK(c, hipGetLastError());
     c->stage = 6;
     return DN_OK;
+}
+
+int dn_debug_emission(dn_ctx *c, uint32_t n, const double *x, const double *mu, double *out) {
+    if (!c || !x || !mu || !out) return DN_ERR_ARG;
+    if (!c->have_model) return fail(c, DN_ERR_STATE, "dn_load_pore_model must be called first");
+    if (n == 0) return DN_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    double *d = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, (size_t)n * 3 * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(d, x, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + n, mu, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) { k2b_emission_tap_launch(d, d + n, d + 2 * (size_t)n, n, &c->vc, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d + 2 * (size_t)n, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    return e == hipSuccess ? DN_OK : fail(c, DN_ERR_HIP, "dn_debug_emission: %s", hipGetErrorString(e));
 }
 
 int dn_set_align_table(dn_ctx *c, int on) {

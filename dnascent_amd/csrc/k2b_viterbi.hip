@@ -437,6 +437,17 @@ void k2b_rowcap_launch(const BatchDev &B, unsigned long long *cap, hipStream_t s
     hipLaunchKernelGGL(k2b_rowcap, dim3(B.n_reads), dim3(256), 0, st, B, cap);
 }
 
+// tap: the emission term exactly as the lattice evaluates it, for a list of (observation, level) pairs (dn_debug_emission)
+__global__ __launch_bounds__(64) void k2b_emission_tap(const double *x, const double *mu, double *out, unsigned n, VitConsts vc) {
+    const unsigned i = blockIdx.x * 64 + threadIdx.x;
+    const bool live = i < n;
+    const double e = emission(live ? x[i] : 0.0, live ? mu[i] : 0.0, vc);     // every lane calls it: it holds a wave-level vote
+    if (live) out[i] = (e == qnan()) ? real_nan() : e;                         // log 0 leaves the kernel as NaN, like the window score
+}
+void k2b_emission_tap_launch(const double *x, const double *mu, double *out, unsigned n, const void *vc, hipStream_t st) {
+    hipLaunchKernelGGL(k2b_emission_tap, dim3((n + 63) / 64), dim3(64), 0, st, x, mu, out, n, *reinterpret_cast<const VitConsts *>(vc));
+}
+
 void k2b_launch(const BatchDev &B, const void *ea, const void *vr, const void *vc, unsigned max_ref, hipStream_t st) {
     const EaDev O = *reinterpret_cast<const EaDev *>(ea);
     const VitConsts V = *reinterpret_cast<const VitConsts *>(vc);

@@ -186,7 +186,10 @@ __device__ __forceinline__ void for_each_slope(const double *x, const double *y,
             const unsigned b = b0 + lane;
             const bool act = b < np;
             const double s = act ? (ya - y[b]) / (xa - x[b]) : 0.0;   // event_handling.cpp:70-73, IEEE fp64 division
-            f(dkey(s), act);
+            // 0 / 0 (two points with equal signal AND equal level) is NaN, on which std::sort is undefined; the oracle and this
+            // kernel define it as sorting LAST.  The sign of that NaN is the hardware's business (the division here returns it with
+            // the sign bit set, whose order-preserving key would sort FIRST and shift every rank by one), so the key is forced.
+            f(s != s ? ~0ull : dkey(s), act);
         }
     }
 }

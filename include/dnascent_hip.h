@@ -212,6 +212,11 @@ int dn_get_positions(dn_ctx *ctx, uint32_t read, uint32_t *coord, uint32_t *quer
                      char *kmer9, uint32_t *n_signal, float *signal20, float *core, float *residual);
 int dn_get_windows(dn_ctx *ctx, uint32_t read, uint32_t *ref_index, uint32_t *window_len, uint32_t *n_obs, double *score);
 
+/* the emission term of builtinViterbi as the device lattice evaluates it -- eln(normalPDF(mu, sigma, x)), alignment.cpp:273,347 with
+ * probability.cpp:35-47,145-148; sigma of dn_load_pore_model -- for n (observation, level) pairs; log 0 comes back as NaN.
+ * Parity tap: tests compare it with values the reference's own probability.cpp produced (tests/golden/ref_emission.npz). */
+int dn_debug_emission(dn_ctx *ctx, uint32_t n, const double *x, const double *mu, double *out);
+
 /* ---- measurement ---- */
 enum { DN_K_SCAN = 0, DN_K_TSTAT, DN_K_DETECT, DN_K_EVENTS, DN_K_RANKS, DN_K_QUANTILE, DN_K_PREP, DN_K_BAND_FILL,
        DN_K_BAND_TRACE, DN_K_THEILSEN, DN_K_VITERBI, DN_K_CNN, DN_K_HMM, DN_K_COUNT };

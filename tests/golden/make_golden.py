@@ -11,6 +11,7 @@ Files:
                          mean, stdv) with the reference's default detector parameters (event_detection.h:19-25)
   ref_common.npz         IUPAC sequences -> reference reverseComplement; fp64 vectors -> reference vectorMean (common.h)
   ref_logspace.npz       argument grids -> reference eexp / eln / lnSum / lnProd / lnGreaterThan / normalPDF (bit patterns)
+  ref_emission.npz       (level, observation) pairs -> reference eln(normalPDF(level, 0.14, observation)): builtinViterbi's emission
 """
 import ctypes as C
 import os
@@ -64,6 +65,18 @@ def main():
     npdf = np.array([ref.ref_normalPDF(float(m), 0.14, float(v)) for m, v in zip(mu, x)])
     np.savez_compressed(os.path.join(HERE, "ref_logspace.npz"), xs=xs, eexp=eexp, eln=np.array(eln), eln_neg=np.array(eln_neg, np.int8),
                         a=a, b=b, lnsum=lnsum, lnprod=lnprod, lngt=lngt, mu=mu, x=x, npdf=npdf)
+    # emission term of builtinViterbi (alignment.cpp:273,347): eln(normalPDF(mu, 0.14, x)) from the reference's probability.cpp,
+    # on levels like the pore table's and observations from the mode out to where exp() underflows (+- 40 sigma and beyond)
+    rng2 = np.random.default_rng(20251003)                  # its own stream: the draws below must not shift the other fixtures
+    emu = rng2.normal(0, 1, 6000)
+    dev = np.concatenate([rng2.normal(0, 0.14, 2000), rng2.normal(0, 0.6, 2000), rng2.uniform(-6.0, 6.0, 1500),
+                          rng2.uniform(5.0, 5.6, 250) * rng2.choice([-1, 1], 250), rng2.uniform(-60, 60, 250)])
+    ex = emu + dev
+    eem = []
+    for m, v in zip(emu, ex):
+        neg = C.c_int(0)
+        eem.append(ref.ref_eln(ref.ref_normalPDF(float(m), 0.14, float(v)), C.byref(neg)))
+    np.savez_compressed(os.path.join(HERE, "ref_emission.npz"), mu=emu, x=ex, emission=np.array(eem))
     # common.h: reverseComplement over the IUPAC alphabet the reference accepts, vectorMean on buffers of event means
     alpha = np.frombuffer(b"ATGCUYRKMBDHVNWS", np.uint8)
     seqs = [bytes(alpha[rng.integers(0, 16, n)]) for n in (0, 1, 9, 33, 250)] + [b"ATGCATGCN", b"TTTTTTTTT"]
@@ -74,7 +87,7 @@ def main():
                         **{"seq_%d" % i: np.frombuffer(q, np.uint8) for i, q in enumerate(seqs)},
                         **{"rc_%d" % i: np.frombuffer(q, np.uint8) for i, q in enumerate(rc)},
                         **{"vm_in_%d" % i: v for i, v in enumerate(vm_in)})
-    for f in ("ref_segmentation.npz", "ref_logspace.npz", "ref_common.npz"):
+    for f in ("ref_segmentation.npz", "ref_logspace.npz", "ref_emission.npz", "ref_common.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

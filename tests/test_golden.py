@@ -47,6 +47,43 @@ def test_oracle_logspace_matches_reference_goldens():
     assert np.array_equal(_bits(got), _bits(g["npdf"]))
 
 
+def test_oracle_emission_matches_reference_goldens():
+    """builtinViterbi's emission eln(normalPDF(mu, 0.14, x)) (alignment.cpp:273,347): the oracle's restatement against values the
+    reference's probability.cpp produced (tests/golden/ref_emission.npz, 6 000 pairs from the mode out to the exp() underflow)."""
+    g = np.load(os.path.join(G, "ref_emission.npz"))
+    o = po.oracle()
+    got = []
+    for m, v in zip(g["mu"], g["x"]):
+        neg = C.c_int(0)
+        got.append(o.dno_eln(o.dno_normalPDF(float(m), 0.14, float(v)), C.byref(neg)))
+    assert np.array_equal(_bits(np.array(got)), _bits(g["emission"]))
+    assert 100 < np.isnan(g["emission"]).sum() < 1000 and np.nanmax(g["emission"]) > 1.04          # log 0 and the mode are both covered
+
+
+@pytest.mark.gpu
+def test_hip_emission_matches_reference_goldens(model):
+    """The emission term as the DEVICE lattice evaluates it (dn_debug_emission: log c + arg where exp(arg) is a normal number,
+    the literal exp -> log chain below that) against the reference's own values.  Where exp() is normal the two agree to a few
+    ulps of the result (1e-12 relative: glibc vs the device library); in the band where the reference's exp() is subnormal
+    (|x - mu| > 37 sigma) a one-ulp difference of a subnormal is a large relative difference, so the bar there is 0.5 absolute on
+    a value near -720; log 0 (NaN) must appear for the same pairs except within that band's last 5 units."""
+    from dnascent_amd import hip
+    g = np.load(os.path.join(G, "ref_emission.npz"))
+    ctx = hip.Context(0)
+    ctx.load_pore_model(model, 0.14)
+    got, want = ctx.debug_emission(g["x"], g["mu"]), g["emission"]
+    ctx.close()
+    normal = np.isfinite(want) & (want > -700.0)
+    assert normal.sum() > 5000
+    rel = np.abs(got[normal] - want[normal]) / np.maximum(1.0, np.abs(want[normal]))
+    assert rel.max() < 1e-12, rel.max()
+    edge = np.isfinite(want) & ~normal
+    assert np.all(np.isfinite(got[edge]) | (want[edge] < -740.0)) and np.nanmax(np.abs(got[edge] - want[edge])) < 0.5
+    zero = np.isnan(want)
+    assert np.all(np.isnan(got[zero]) | (got[zero] < -740.0))
+    print("emission: max relative difference %.2e over %d pairs; %d subnormal-band pairs; %d log-0 pairs" % (rel.max(), normal.sum(), edge.sum(), zero.sum()))
+
+
 @pytest.mark.gpu
 def test_hip_segmentation_matches_reference_goldens(model):
     """The device segmentation (through the C-ABI) against the reference's own detect_events output."""
