@@ -174,6 +174,19 @@ bool ReadContainerReader::open(const std::string &path) {
     f = fp; seen = 0; bad = false;
     return true;
 }
+bool ReadContainerReader::skip(uint64_t *nSamples) {     // the next record's sample count; its payload is seeked over, not read
+    FILE *fp = (FILE *)f; if (!fp || seen >= n) return false;
+    auto skipStr = [&](uint32_t limit) { uint32_t k; return get(fp, k) && k <= limit && fseek(fp, (long)k, SEEK_CUR) == 0; };
+    uint32_t nc = 0; uint64_t na = 0;
+    bool ok = skipStr(1u << 16) && skipStr(1u << 16) && fseek(fp, 4 + 4 + 4 + 4 + 4 + 1 + 1 + 4, SEEK_CUR) == 0 && skipStr(1u << 30) && skipStr(1u << 30) &&
+              get(fp, nc) && nc <= (1u << 28) && fseek(fp, (long)nc * 8, SEEK_CUR) == 0 && get(fp, na) && na <= (1ull << 33) &&
+              fseek(fp, (long)(na * 2), SEEK_CUR) == 0;
+    if (ok) { const int c = fgetc(fp); if (c == EOF) { if (seen + 1 < n) ok = false; } else ungetc(c, fp); }   // a truncated payload shows at the next read
+    if (!ok) { bad = true; return false; }
+    if (nSamples) *nSamples = na;
+    seen++;
+    return true;
+}
 bool ReadContainerReader::next(OwnedRead &o) {
     FILE *fp = (FILE *)f; if (!fp || seen >= n) return false;
     ReadInput &in = o.in;
@@ -349,6 +362,7 @@ int streamDetect(dn_ctx **ctxs, int n_ctx, ReadBatch **batches, int n_batches, b
             for (uint32_t r = 0; r < res.n_reads; r++) S.reads_ok += res.summary[r].status == DN_READ_OK;
             if (keep) {
                 for (uint32_t r = 0; r < res.n_reads; r++) keep->read_calls.push_back(res.call_off[r + 1] - res.call_off[r]);
+                keep->record_bytes.resize(keep->read_calls.size(), 0);     // filled below when records are formatted
                 keep->coord.insert(keep->coord.end(), res.ref_coord, res.ref_coord + res.n_calls);
                 keep->p_edu.insert(keep->p_edu.end(), res.p_edu, res.p_edu + res.n_calls);
                 keep->p_brdu.insert(keep->p_brdu.end(), res.p_brdu, res.p_brdu + res.n_calls);
@@ -357,6 +371,7 @@ int streamDetect(dn_ctx **ctxs, int n_ctx, ReadBatch **batches, int n_batches, b
                 formatCalls(B, res, true, calls);
                 for (size_t r = 0; r < calls.size(); r++) {
                     if (res.summary[r].status != DN_READ_OK) continue;
+                    if (keep) keep->record_bytes[keep->record_bytes.size() - calls.size() + r] = calls[r].humanReadable_detectOut.size();
                     S.bytes_out += calls[r].humanReadable_detectOut.size();
                     if (f) fwrite(calls[r].humanReadable_detectOut.data(), 1, calls[r].humanReadable_detectOut.size(), f);
                 }
@@ -576,6 +591,31 @@ int64_t dnh_container_load(void *b, const char *path, uint64_t first, uint64_t c
     return accepted;
 }
 
+// stored sample count of every read of a container (its records are seeked over: cheap); returns the read count or -1
+int64_t dnh_container_sizes(const char *path, uint64_t *out, uint64_t cap) {
+    DNAscent::ReadContainerReader r;
+    if (!r.open(path)) return -1;
+    uint64_t i = 0, ns = 0;
+    while (r.skip(&ns)) { if (i < cap) out[i] = ns; i++; }
+    return r.failed() ? -1 : (int64_t)i;
+}
+// adds the reads with the given ASCENDING ordinals to the batch (the others are seeked over); returns how many were accepted or -1
+int64_t dnh_container_load_list(void *b, const char *path, const uint64_t *ordinals, uint64_t n_ord) {
+    DNAscent::ReadContainerReader r;
+    if (!r.open(path)) return -1;
+    DNAscent::OwnedRead o;
+    int64_t accepted = 0;
+    uint64_t at = 0;
+    for (uint64_t j = 0; j < n_ord; j++) {
+        if (ordinals[j] < at || ordinals[j] >= r.count()) return -1;
+        while (at < ordinals[j]) { if (!r.skip(nullptr)) return -1; at++; }
+        if (!r.next(o)) return -1;
+        at++;
+        if (((ReadBatch *)b)->add(o.in) >= 0) accepted++;
+    }
+    return accepted;
+}
+
 void dnh_batch_desc(void *b, dn_batch_desc *out) { *out = ((ReadBatch *)b)->desc(); }
 
 // flattened CIGAR maps of read i (for host-logic tests)
@@ -689,7 +729,7 @@ int dnh_stream_detect(void **ctxs, int n_ctx, void **batches, int n_batches, int
 }
 void *dnh_keep_new(void) { return new DNAscent::StreamKeep(); }
 void dnh_keep_free(void *k) { delete (DNAscent::StreamKeep *)k; }
-// which: 0 read_calls (u64), 1 coord (u32), 2 p_edu (f32), 3 p_brdu (f32); returns the element count, *p the data
+// which: 0 read_calls (u64), 1 coord (u32), 2 p_edu (f32), 3 p_brdu (f32), 4 record_bytes (u64); returns the element count, *p the data
 uint64_t dnh_keep_get(void *k, int which, const void **p) {
     DNAscent::StreamKeep *K = (DNAscent::StreamKeep *)k;
     switch (which) {
@@ -697,6 +737,7 @@ uint64_t dnh_keep_get(void *k, int which, const void **p) {
         case 1: *p = K->coord.data(); return K->coord.size();
         case 2: *p = K->p_edu.data(); return K->p_edu.size();
         case 3: *p = K->p_brdu.data(); return K->p_brdu.size();
+        case 4: *p = K->record_bytes.data(); return K->record_bytes.size();
     }
     *p = nullptr; return 0;
 }

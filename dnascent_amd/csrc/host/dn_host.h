@@ -85,6 +85,7 @@ public:
     bool open(const std::string &path);                                    // false: missing file / bad magic / version
     uint64_t count() const { return n; }
     bool next(OwnedRead &out);                                             // false at the end or on a truncated record
+    bool skip(uint64_t *nSamples);                                         // seek over the next record, reporting its sample count
     bool failed() const { return bad; }
     void close();
     ~ReadContainerReader() { close(); }
@@ -127,6 +128,7 @@ void formatCalls(const ReadBatch &batch, const dn_result_batch &res, bool humanR
 // order, to outPath (nullptr: formatted and counted, not written).  Every context needs its pore model and CNN loaded.
 struct StreamKeep {                     // optional: the binary per-call results of the whole stream, kept for the gather to the writer rank
     std::vector<uint64_t> read_calls;  // calls of every read, in stream order (0 for failed reads)
+    std::vector<uint64_t> record_bytes;// length of every read's .detect record in the output (0: failed read / emit off)
     std::vector<uint32_t> coord; std::vector<float> p_edu, p_brdu;
 };
 struct StreamStats {

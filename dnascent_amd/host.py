@@ -56,6 +56,10 @@ def lib():
         L.dnh_container_close.argtypes = [C.c_void_p]
         L.dnh_container_count.restype = C.c_int64
         L.dnh_container_count.argtypes = [C.c_char_p]
+        L.dnh_container_sizes.restype = C.c_int64
+        L.dnh_container_sizes.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64]
+        L.dnh_container_load_list.restype = C.c_int64
+        L.dnh_container_load_list.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
         L.dnh_container_load.restype = C.c_int64
         L.dnh_container_load.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64]
         L.dnh_hmm_write.restype = C.c_int
@@ -152,6 +156,18 @@ def container_count(path):
     return int(lib().dnh_container_count(path.encode()))
 
 
+def container_sizes(path):
+    """stored sample count of every read of a container (uint64 array); the records are seeked over, not read"""
+    n = container_count(path)
+    if n < 0:
+        raise IOError(path)
+    out = np.zeros(max(n, 1), np.uint64)
+    got = int(lib().dnh_container_sizes(path.encode(), out.ctypes.data, n))
+    if got != n:
+        raise IOError("%s: malformed container" % path)
+    return out[:n]
+
+
 class ReadBatch:
     """DNAscent::ReadBatch: reads packed as SoA, ready for dn_batch_upload."""
 
@@ -190,6 +206,11 @@ class ReadBatch:
     def add_container(self, path, first=0, count=1 << 62):
         """reads [first, first + count) of a binary read container; returns how many were accepted (-1: malformed file)"""
         return int(lib().dnh_container_load(self.h, path.encode(), first, count))
+
+    def add_container_list(self, path, ordinals):
+        """the reads with the given ascending ordinals of a container; returns how many were accepted (-1: malformed / bad list)"""
+        o = np.ascontiguousarray(ordinals, np.uint64)
+        return int(lib().dnh_container_load_list(self.h, path.encode(), o.ctypes.data, o.shape[0]))
 
     def size(self):
         return int(lib().dnh_batch_size(self.h))
@@ -254,7 +275,8 @@ def stream_detect(ctxs, batches, emit=True, out_path=None, header=None, keep=Fal
         if not keep:
             return st
         out = {}
-        for which, (name, dt) in enumerate((("read_calls", np.uint64), ("coord", np.uint32), ("p_edu", np.float32), ("p_brdu", np.float32))):
+        for which, (name, dt) in enumerate((("read_calls", np.uint64), ("coord", np.uint32), ("p_edu", np.float32), ("p_brdu", np.float32),
+                                             ("record_bytes", np.uint64))):
             p = C.c_void_p()
             n = int(lib().dnh_keep_get(kh, which, C.byref(p)))
             out[name] = np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(p.value), dtype=dt).copy() if n else np.zeros(0, dt)

@@ -1,0 +1,46 @@
+"""GPU: the product path end to end across ranks: container in, .detect out.  `python -m dnascent_amd.run_detect` with one
+rank, and under torch.distributed.run with two ranks sharing the one GPU (gloo; the 8-GPU node runs the same code over RCCL):
+partition (assign_reads) -> length-bucketed batches -> streamed pipeline -> grouped send / recv of the per-read records to the
+writer -> ordered write.  The two files must be byte-identical, and equal to a plain single-context run of the same reads."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from dnascent_amd import cnn_model, hip, host, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_write_the_same_file_as_one(model, tmp_path):
+    reads = [synth.make_read(8800 + i, 2000 + 700 * (i % 5), model=model, is_reverse=bool(i & 1), sub_rate=0.002, ins_rate=0.001, del_rate=0.001,
+                             noise_pa=6.5 if i == 4 else 1.6) for i in range(14)]
+    cont = str(tmp_path / "reads.dnrc")
+    host.write_container(cont, reads)
+    assert host.container_sizes(cont).tolist() == [r.n_samples() for r in reads]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    one = str(tmp_path / "one.detect"); two = str(tmp_path / "two.detect")
+    common = ["--container", cont, "--batch-samples", "60000", "--inflight", "2", "--header", "#hdr\n"]
+    r = subprocess.run([sys.executable, "-m", "dnascent_amd.run_detect", "--out", one] + common, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "dnascent_amd.run_detect", "--out", two, "--backend", "gloo"] + common,
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    a, b = open(one, "rb").read(), open(two, "rb").read()
+    assert a == b and a.startswith(b"#hdr\n") and a.count(b">") == 13                  # the noisy read fails the QC and is not written
+    # and both equal one plain batch on one context, records in input order
+    ctx = hip.Context(0); ctx.load_pore_model(model, 0.14)
+    desc, blob, _ = cnn_model.default_model(); ctx.load_cnn(desc, blob)
+    bt = host.ReadBatch()
+    for rd in reads:
+        assert bt.add_synth(rd) >= 0
+    bt.upload(ctx); ctx.run("normalise"); ctx.run("eventalign"); ctx.sync()
+    ref = str(tmp_path / "ref.detect")
+    assert bt.detect_write(ctx, ref, header="#hdr\n") == 13
+    assert open(ref, "rb").read() == a
+    ctx.close()
