@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -66,6 +67,30 @@ struct ProfRec { int k; hipEvent_t a, b; };
 
 }  // namespace
 
+// The CNN LANE of a device.  The network's kernels fill the whole GPU on their own; two networks running side by side (two
+// contexts that reached dn_run_cnn at the same time) only evict each other's activations from L2 / MALL and double the activation
+// memory.  All contexts of a process on one device therefore run their CNN passes on ONE extra stream, in submission order, with
+// ONE set of activation buffers: a context hands its batch over with an event, the lane's last kernel hands it back.  Meanwhile the
+// latency-bound stages of the other contexts (one wavefront per read) run beside the network on their own streams.
+struct CnnLane {
+    hipStream_t stream = nullptr;
+    std::mutex mu;                                       // enqueue order == execution order
+    DevBuf buf[8], valid, enclen, enchist, permsrc, permrow;
+    size_t bytes = 0;
+};
+#define DN_MAX_LANES 16
+static std::mutex g_lane_mu;
+static CnnLane *g_lane[64][DN_MAX_LANES] = { { nullptr } };
+static unsigned g_ctx_seq = 0;
+// how many lanes a device has (DN_CNN_LANES, default 2): contexts are dealt to them round-robin.  One lane serialises every
+// network of the process (least memory); measured on 4 x 500 x 50 kb in flight, two lanes are faster -- the other lane's kernels fill the
+// gaps a lone network leaves while the CUs' LDS is held by the one-wavefront-per-read stages
+static unsigned lane_count() {
+    const char *e = getenv("DN_CNN_LANES");
+    const unsigned v = e ? (unsigned)strtoul(e, nullptr, 10) : 2u;
+    return std::min<unsigned>(std::max<unsigned>(v, 1u), DN_MAX_LANES);
+}
+
 struct dn_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -104,7 +129,9 @@ struct dn_ctx {
     FillConstsH fc{};
     std::vector<int64_t> cnn_wb_off, cnn_wh_off; uint16_t *d_cnn_wb = nullptr, *d_cnn_wh = nullptr; size_t cnn_nwb = 0, cnn_nwh = 0; int cnn_math = DN_CNN_MATH_F16X3;
     std::vector<float> cnn_post, cnn_one; unsigned *d_cnn_flag = nullptr; uint64_t cnn_escalations = 0; bool cnn_f16_off = false;
-    std::vector<dn_cnn_op> cnn_ops; float *d_cnn_w = nullptr; size_t cnn_nw = 0; int cnn_nbuf = 0; DevBuf cnn_buf[8], cnn_valid, cnn_rowoff, cnn_npos, cnn_iooff, cnn_in[3], cnn_out, cnn_enclen, cnn_enchist, cnn_permsrc, cnn_permrow;
+    std::vector<dn_cnn_op> cnn_ops; float *d_cnn_w = nullptr; size_t cnn_nw = 0; int cnn_nbuf = 0; DevBuf cnn_rowoff, cnn_npos, cnn_iooff, cnn_in[3], cnn_out;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;    // hand-over to / from the device's CNN lane
+    unsigned lane_id = 0;
     float *d_probs = nullptr;
     double4 *d_fit[2] = { nullptr, nullptr }; bool have_fit = false, hmm_done = false;
     DevBuf hmm_poi, hmm_npoi, hmm_nev, hmm_ok, hmm_la, hmm_lt, hmm_reads;
@@ -188,14 +215,38 @@ static const char *KNAMES[DN_K_COUNT] = { "k1_scan", "k1_tstat", "k1_detect", "k
                                           "k2_fill", "k2_chase+k2_post", "k_theilsen", "k2b_viterbi", "k3_cnn", "k_hmm" };
 
 struct Timed {
-    dn_ctx *c; int k; hipEvent_t a = nullptr, b = nullptr;
-    Timed(dn_ctx *c_, int k_) : c(c_), k(k_) {
-        if (c->prof) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
+    dn_ctx *c; int k; hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
+    Timed(dn_ctx *c_, int k_, hipStream_t st_ = nullptr) : c(c_), k(k_), st(st_ ? st_ : c_->stream) {
+        if (c->prof) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); }
     }
     ~Timed() {
-        if (c->prof) { hipEventRecord(b, c->stream); c->pending.push_back({k, a, b}); }
+        if (c->prof) { hipEventRecord(b, st); c->pending.push_back({k, a, b}); }
     }
 };
+
+static int lane_grow(dn_ctx *c, CnnLane *L, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return DN_OK;
+    // hipFree waits for the device, so a buffer another context's pass is still using is never pulled from under it; growth only
+    // happens while the first batches of a run establish the sizes
+    if (b.p) { hipFree(b.p); L->bytes -= b.cap; }
+    b.p = nullptr; b.cap = 0;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(c, DN_ERR_HIP, "hipMalloc(%zu) for the CNN lane: %s", bytes, hipGetErrorString(e)); }
+    b.cap = bytes; L->bytes += bytes;
+    return DN_OK;
+}
+static CnnLane *lane_get(dn_ctx *c) {
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    if (c->device < 0 || c->device >= 64) return nullptr;
+    if (!g_lane[c->device][c->lane_id]) {
+        CnnLane *L = new CnnLane();
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = numerically largest = lowest priority
+        if (hipStreamCreateWithPriority(&L->stream, hipStreamNonBlocking, lo) != hipSuccess) { delete L; return nullptr; }
+        g_lane[c->device][c->lane_id] = L;
+    }
+    return g_lane[c->device][c->lane_id];
+}
 
 static void prof_collect(dn_ctx *c) {
     if (c->pending.empty()) return;
@@ -253,10 +304,21 @@ int dn_ctx_create(int device, void *hip_stream, dn_ctx **out) {
     }
     dn_ctx *c = new dn_ctx();
     c->device = device;
+    { std::lock_guard<std::mutex> lk(g_lane_mu); c->lane_id = (g_ctx_seq++) % lane_count(); }
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
     else {
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DN_ERR_HIP; }
+        // the per-batch stages are latency-bound chains of small launches: they get the highest stream priority so that their
+        // workgroups are placed as soon as they are ready, beside the CNN lane's (lowest priority) big grids
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const char *pe = getenv("DN_STREAM_PRIO");
+        const bool prio = !(pe && pe[0] == '0');
+        if ((prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return DN_ERR_HIP; }
         c->own_stream = true;
+    }
+    if (hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) {
+        if (c->own_stream) hipStreamDestroy(c->stream);
+        delete c; return DN_ERR_HIP;
     }
     const int st = k2_selftest_run(c->stream);
     if (st != 1) {
@@ -302,10 +364,9 @@ void dn_ctx_destroy(dn_ctx *c) {
     for (auto *p : c->d_fit) if (p) hipFree(p);
     for (DevBuf *b : { &c->hmm_poi, &c->hmm_npoi, &c->hmm_nev, &c->hmm_ok, &c->hmm_la, &c->hmm_lt, &c->hmm_reads, &c->al_coord, &c->al_rpos,
                        &c->al_val, &c->al_kind, &c->al_off, &c->al_n }) if (b->p) hipFree(b->p);
-    for (auto &b : c->cnn_buf) if (b.p) hipFree(b.p);
-    if (c->cnn_valid.p) hipFree(c->cnn_valid.p);
-    for (DevBuf *b : { &c->cnn_rowoff, &c->cnn_npos, &c->cnn_iooff, &c->cnn_in[0], &c->cnn_in[1], &c->cnn_in[2], &c->cnn_out, &c->cnn_enclen,
-                       &c->cnn_enchist, &c->cnn_permsrc, &c->cnn_permrow }) if (b->p) hipFree(b->p);
+    for (DevBuf *b : { &c->cnn_rowoff, &c->cnn_npos, &c->cnn_iooff, &c->cnn_in[0], &c->cnn_in[1], &c->cnn_in[2], &c->cnn_out }) if (b->p) hipFree(b->p);
+    if (c->ev_ready) hipEventDestroy(c->ev_ready);
+    if (c->ev_done) hipEventDestroy(c->ev_done);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1095,28 +1156,36 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned
         max_pos = std::max(max_pos, np);
     }
     { const uint64_t rr = (rows + 255) / 256 * 256; passes.push_back({ r0, n, (unsigned)rr, max_pos, pass_pos }); max_rows = std::max(max_rows, rr); }
+    CnnLane *L = lane_get(c);
+    if (!L) return fail(c, DN_ERR_HIP, "cannot create the CNN lane of device %d", c->device);
+    std::lock_guard<std::mutex> lane_lock(L->mu);
     for (int b = 0; b < c->cnn_nbuf; b++)
-        if ((rc = dgrow(c, c->cnn_buf[b], (size_t)max_rows * 256 * sizeof(float)))) return rc;
-    if ((rc = dgrow(c, c->cnn_enclen, (size_t)max_rows)) || (rc = dgrow(c, c->cnn_enchist, 64 * sizeof(unsigned))) ||
-        (rc = dgrow(c, c->cnn_permsrc, (size_t)max_rows * sizeof(uint64_t))) || (rc = dgrow(c, c->cnn_permrow, (size_t)max_rows * sizeof(unsigned)))) return rc;
-    if ((rc = dgrow(c, c->cnn_valid, (size_t)max_rows)) || (rc = dgrow(c, c->cnn_rowoff, n * sizeof(unsigned))) ||
-        (rc = dgrow(c, c->cnn_iooff, n * sizeof(uint64_t)))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->cnn_rowoff.p, row_off, n * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->cnn_iooff.p, c->p_cnn_iooff, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        if ((rc = lane_grow(c, L, L->buf[b], (size_t)max_rows * 256 * sizeof(float)))) return rc;
+    if ((rc = lane_grow(c, L, L->enclen, (size_t)max_rows)) || (rc = lane_grow(c, L, L->enchist, 64 * sizeof(unsigned))) ||
+        (rc = lane_grow(c, L, L->permsrc, (size_t)max_rows * sizeof(uint64_t))) || (rc = lane_grow(c, L, L->permrow, (size_t)max_rows * sizeof(unsigned))) ||
+        (rc = lane_grow(c, L, L->valid, (size_t)max_rows))) return rc;
+    if ((rc = dgrow(c, c->cnn_rowoff, n * sizeof(unsigned))) || (rc = dgrow(c, c->cnn_iooff, n * sizeof(uint64_t)))) return rc;
     if (!c->p_cnn_flag) HIPCHK(c, hipHostMalloc((void **)&c->p_cnn_flag, sizeof(unsigned), hipHostMallocDefault));
-    Timed t(c, DN_K_CNN);
+    // hand the batch over to the lane: everything the context's stream has enqueued so far (eventalign, the position counts)
+    hipStream_t st = L->stream;
+    HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_ready, 0));
+    HIPCHK(c, hipMemcpyAsync(c->cnn_rowoff.p, row_off, n * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->cnn_iooff.p, c->p_cnn_iooff, n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    {
+    Timed t(c, DN_K_CNN, st);
     for (const Pass &ps : passes) {
-        HIPCHK(c, hipMemsetAsync(c->cnn_valid.p, 0, (size_t)ps.rows, c->stream));
+        HIPCHK(c, hipMemsetAsync(L->valid.p, 0, (size_t)ps.rows, st));
         CnnRun run{};
         run.ops = c->cnn_ops.data(); run.n_ops = (int)c->cnn_ops.size(); run.wts = c->d_cnn_w;
-        for (int b = 0; b < c->cnn_nbuf; b++) run.buf[b] = (float *)c->cnn_buf[b].p;
+        for (int b = 0; b < c->cnn_nbuf; b++) run.buf[b] = (float *)L->buf[b].p;
         run.n_buf = c->cnn_nbuf;
-        run.rows.row_off = (const unsigned *)c->cnn_rowoff.p; run.rows.valid = (const uint8_t *)c->cnn_valid.p; run.rows.rows = ps.rows;
+        run.rows.row_off = (const unsigned *)c->cnn_rowoff.p; run.rows.valid = (const uint8_t *)L->valid.p; run.rows.rows = ps.rows;
         run.rows.r0 = ps.r0; run.rows.r1 = ps.r1;
         run.rows.n_pos = d_npos; run.rows.io_off = (const uint64_t *)c->cnn_iooff.p;
-        run.valid = (uint8_t *)c->cnn_valid.p;
-        run.n_pass_pos = ps.n_pos; run.enc_len = (uint8_t *)c->cnn_enclen.p; run.enc_hist = (unsigned *)c->cnn_enchist.p;
-        run.perm_src = (uint64_t *)c->cnn_permsrc.p; run.perm_row = (unsigned *)c->cnn_permrow.p;
+        run.valid = (uint8_t *)L->valid.p;
+        run.n_pass_pos = ps.n_pos; run.enc_len = (uint8_t *)L->enclen.p; run.enc_hist = (unsigned *)L->enchist.p;
+        run.perm_src = (uint64_t *)L->permsrc.p; run.perm_row = (unsigned *)L->permrow.p;
         run.core = d_core; run.resid = d_resid; run.sig = d_sig; run.probs = d_probs; run.max_pos = ps.max_pos;
         // fp16 pieces are only valid while every activation fits fp16: the kernels raise range_flag otherwise and the pass is
         // repeated with bf16 pieces (same result contract, 2x the matrix work) -- never a silently wrong answer
@@ -1126,18 +1195,22 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned
             run.pieces = math == DN_CNN_MATH_F16X3 ? 2 : 3;
             run.post = math == DN_CNN_MATH_F16X3 ? c->cnn_post.data() : c->cnn_one.data();
             run.range_flag = c->d_cnn_flag;
-            if (k3_run(run, c->stream)) return fail(c, DN_ERR_ARG, "unsupported op in the CNN description");
+            if (k3_run(run, st)) return fail(c, DN_ERR_ARG, "unsupported op in the CNN description");
             if (math != DN_CNN_MATH_F16X3 || !check_now) break;
-            HIPCHK(c, hipMemcpyAsync(c->p_cnn_flag, c->d_cnn_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->p_cnn_flag, c->d_cnn_flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
             if (!*c->p_cnn_flag) break;
-            HIPCHK(c, hipMemsetAsync(c->d_cnn_flag, 0, sizeof(unsigned), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_cnn_flag, 0, sizeof(unsigned), st));
             c->cnn_escalations++;
             c->cnn_f16_off = true;                          // this model's activations do not fit: stay on bf16 pieces from now on
             math = DN_CNN_MATH_BF16X6;
         }
     }
-    if (!check_now) HIPCHK(c, hipMemcpyAsync(c->p_cnn_flag, c->d_cnn_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (!check_now) HIPCHK(c, hipMemcpyAsync(c->p_cnn_flag, c->d_cnn_flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    // ... and back: the context's stream continues (dn_collect's compaction, the taps) when the lane's last operation is done
+    HIPCHK(c, hipEventRecord(c->ev_done, st));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
     HIPCHK(c, hipGetLastError());
     return DN_OK;
 }

@@ -498,6 +498,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
 // ds_read_b128 (MI355X_MICROARCH.md, LDS) then cover all 64 banks once.
 // ---------------------------------------------------------------------------------------------------------
 #define SEP_XP 40                                           // floats per raw-tile row
+#define SEP_XPW 36                                          // ... of the wave-specialised kernel's raw slices (see its depthwise)
 template <int BN, int KW, bool ADD, int NP>
 __global__ __launch_bounds__(256) void k3_sep_split(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wd,
                                                     const uint16_t *__restrict__ Wb, const float *__restrict__ scale,
@@ -674,7 +675,7 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
                                                  unsigned *range_flag) {
     constexpr int SROWS = 32 + KW - 1;                     // raw rows a producer wave needs for its 32 output rows
     constexpr int NLD = (SROWS * 8 + 63) / 64;             // float4 loads per lane for one raw slice
-    __shared__ __attribute__((aligned(16))) float Xr[4][SROWS * SEP_XP];
+    __shared__ __attribute__((aligned(16))) float Xr[4][SROWS * SEP_XPW];
     __shared__ __attribute__((aligned(16))) float Wl[2][KW * 32];
     __shared__ __attribute__((aligned(16))) uint16_t As[2][NP][CNN_BM * CNN_BP];
     __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NP][BN * CNN_BP];
@@ -693,7 +694,7 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     u32x4 rb[NP][NBQ];
     // ---- producer state ----
     const int pw = wave & 3;                               // slice: output rows 32 pw .. 32 pw + 31 of the tile
-    const int dq = lane & 7, dr = (lane >> 3) * 4;         // channels 4 dq .. 4 dq + 3, rows dr .. dr + 3 of the slice
+    const int cp = (lane & 15) * 2, dr = (lane >> 4) * 8;  // channel pair cp, cp + 1; output rows dr .. dr + 7 of the slice
     f32x4 rx[NLD]; bool pin[NLD];
     f32x4 rw = {0.f, 0.f, 0.f, 0.f};
     float amax = 0.0f;
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
 #pragma unroll
         for (int p = 0; p < NLD; p++) {
             const int f = lane + 64 * p, rr = f >> 3, q = f & 7;
-            if (rr < SROWS) *reinterpret_cast<f32x4 *>(&Xs[rr * SEP_XP + q * 4]) = pin[p] ? rx[p] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rr < SROWS) *reinterpret_cast<f32x4 *>(&Xs[rr * SEP_XPW + q * 4]) = pin[p] ? rx[p] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (ct < KW * 8) *reinterpret_cast<f32x4 *>(&Wl[wbuf][(ct >> 3) * 32 + (ct & 7) * 4]) = rw;
     };
@@ -732,49 +733,54 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
 #pragma unroll
             for (int q = 0; q < NBQ; q++) *reinterpret_cast<u32x4 *>(&Bs[buf][pc][(q * 64 + l_r) * CNN_BP + l_k]) = rb[pc][q];
     };
+    // Depthwise filter of one producer wavefront: 32 output rows x 32 channels per channel block.  A lane owns a PAIR of adjacent
+    // channels and 8 consecutive output rows: its 24 input rows and its 17 taps are each read ONCE from LDS as 8-byte pairs
+    // (ds_read_b64; the first version re-read every input row 5 times and the taps per 4-row strip as 16-byte quads: 37 KB of LDS
+    // reads per wavefront and channel block, now 21 KB) and the filter runs as packed fp32 FMAs (v_pk_fma_f32: the two channels of
+    // the pair in one instruction, half the vector instructions), taps in ascending order -- bit-identical to k3_dwconv.
+    // Raw-slice pitch 36 floats: the two 16-lane row groups of a 32-lane LDS pass start 8 rows = 1152 B = half a bank window apart.
     auto depthwise = [&](int abuf, int wbuf) {
-        f32x4 o[4], w[4];
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 o[8], w[KW];
 #pragma unroll
-        for (int i = 0; i < 4; i++) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < KW; t++) w[t] = *reinterpret_cast<const f32x2 *>(&Wl[wbuf][t * 32 + cp]);
 #pragma unroll
-        for (int j = 0; j < KW + 3; j++) {
-            const f32x4 x = *reinterpret_cast<const f32x4 *>(&Xs[(dr + j) * SEP_XP + dq * 4]);
-            if (j < KW) w[j & 3] = *reinterpret_cast<const f32x4 *>(&Wl[wbuf][j * 32 + dq * 4]);
+        for (int i = 0; i < 8; i++) o[i] = f32x2{0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int t = j - i;                       // tap of output row dr + i that input row dr + j meets
-                if (t >= 0 && t < KW) {
+        for (int j = 0; j < KW + 7; j++) {
+            const f32x2 x = *reinterpret_cast<const f32x2 *>(&Xs[(dr + j) * SEP_XPW + cp]);
 #pragma unroll
-                    for (int e = 0; e < 4; e++) o[i][e] = __builtin_fmaf(x[e], w[t & 3][e], o[i][e]);
-                }
+            for (int i = 0; i < 8; i++) {
+                const int t = j - i;                       // tap of output row dr + i that input row dr + j meets (ascending per output)
+                if (t >= 0 && t < KW) o[i] = __builtin_elementwise_fma(x, w[t], o[i]);
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int off = (32 * pw + dr + i) * CNN_BP + dq * 4;
+        for (int i = 0; i < 8; i++) {
+            const int off = (32 * pw + dr + i) * CNN_BP + cp;
             if (NP == 3) {
-                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                bf16x4 h, m, l;
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                bf16x2 h, m, l;
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
+                for (int e = 0; e < 2; e++) {
                     const float x = o[i][e];
                     const __bf16 hh = (__bf16)x; const float r1 = x - (float)hh;
                     const __bf16 mm = (__bf16)r1; const float r2 = r1 - (float)mm;
                     h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
                 }
-                *reinterpret_cast<bf16x4 *>(&As[abuf][0][off]) = h; *reinterpret_cast<bf16x4 *>(&As[abuf][1][off]) = m;
-                *reinterpret_cast<bf16x4 *>(&As[abuf][NP - 1][off]) = l;
+                *reinterpret_cast<bf16x2 *>(&As[abuf][0][off]) = h; *reinterpret_cast<bf16x2 *>(&As[abuf][1][off]) = m;
+                *reinterpret_cast<bf16x2 *>(&As[abuf][NP - 1][off]) = l;
             } else {
-                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-                f16x4 h, l;
+                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                f16x2 h, l;
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
+                for (int e = 0; e < 2; e++) {
                     const float x = o[i][e];
                     amax = fmaxf(amax, fabsf(x));
                     const _Float16 hh = (_Float16)x;
                     h[e] = hh; l[e] = (_Float16)(x - (float)hh);
                 }
-                *reinterpret_cast<f16x4 *>(&As[abuf][0][off]) = h; *reinterpret_cast<f16x4 *>(&As[abuf][1][off]) = l;
+                *reinterpret_cast<f16x2 *>(&As[abuf][0][off]) = h; *reinterpret_cast<f16x2 *>(&As[abuf][1][off]) = l;
             }
         }
     };
