@@ -124,6 +124,7 @@ struct dn_ctx {
     DevBuf col_dev; void *col_host = nullptr; size_t col_host_cap = 0;
     unsigned long long *p_call_off = nullptr; dn_read_summary *p_summary = nullptr;
     bool upload_pinned = false;
+    bool keep_k1 = false;                               // dn_debug_keep_k1
     size_t n_ref_T = 0; char *d_col = nullptr;
     unsigned *p_cnn_rowoff = nullptr; uint64_t *p_cnn_iooff = nullptr; size_t cnn_meta_cap = 0; unsigned *p_cnn_flag = nullptr; bool cnn_pending = false;
     FillConstsH fc{};
@@ -500,8 +501,9 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     UP(trace_off, c->h_trace_off.data(), n + 1);
 #undef UP
 #define AL(field, cnt) if ((rc = dalloc(c, &B.field, (size_t)(cnt)))) return rc
-    AL(psum, S); AL(t1, S); AL(t2, S);
-    AL(chunk_npk, NCH); AL(chunk_peaks, NCH * DN_SEG_PEAKCAP); AL(chunk_in, NCH); AL(chunk_out, NCH);
+    AL(carry, 4 * NCH + n);
+    if (c->keep_k1) { AL(psum, S); AL(t1, S); AL(t2, S); }      // parity taps only: every prefix sum and both t-statistics in HBM
+    AL(chunk_npk, NCH); AL(chunk_peaks, NCH * DN_SEG_PEAKCAP); AL(chunk_psum, NCH * DN_SEG_PEAKCAP); AL(chunk_in, NCH); AL(chunk_out, NCH);
     AL(et_start, NEV); AL(et_mean, NEV); AL(ev_mean, NEV); AL(ev_start, NEV); AL(ev_len, NEV); AL(ev_x, NEV);
     AL(rank_q, NB); AL(rank_r, NR); AL(mu_q, NB);
     AL(aln_event, NAL); AL(aln_kmer, NAL); AL(cl_sig, NAL); AL(cl_rank, NAL);
@@ -563,7 +565,7 @@ int dn_run_segment(dn_ctx *c) {
     int rc = need(c, 1, "dn_run_segment"); if (rc) return rc;
     if (c->B.n_reads == 0) { c->stage = std::max(c->stage, 2); return DN_OK; }
     { Timed t(c, DN_K_SCAN);   k1_launch_scan(c->B, c->stream); }
-    { Timed t(c, DN_K_TSTAT);  k1_launch_tstat(c->B, c->max_samples, c->stream); }
+    if (c->B.psum) { Timed t(c, DN_K_TSTAT); k1_launch_tstat(c->B, c->max_samples, c->stream); }      // taps only
     { Timed t(c, DN_K_DETECT); k1_launch_detect(c->B, c->max_chunks, c->stream); }
     { Timed t(c, DN_K_EVENTS); k1_launch_events(c->B, c->stream); }
     { Timed t(c, DN_K_RANKS);  ks_launch_ranks(c->B, c->max_len, c->stream); }
@@ -861,8 +863,15 @@ int dn_host_unregister(void *p) { return (p && hipHostUnregister(p) == hipSucces
     int rc = need(c, stage_, name_); if (rc) return rc;              \
     if (read >= (uint32_t)c->B.n_reads) return DN_ERR_ARG;
 
+int dn_debug_keep_k1(dn_ctx *c, int on) {
+    if (!c) return DN_ERR_ARG;
+    c->keep_k1 = on != 0;
+    return DN_OK;
+}
+
 int dn_get_prefix_sums(dn_ctx *c, uint32_t read, double *sum, double *sumsq) {
     CHECK_READ(2, "dn_get_prefix_sums");
+    if (!c->B.psum) return fail(c, DN_ERR_STATE, "dn_debug_keep_k1(ctx, 1) must precede dn_batch_upload: prefix sums do not leave the kernels otherwise");
     const uint64_t s0 = c->h_samp_off[read]; const size_t n = (size_t)(c->h_samp_off[read + 1] - s0);
     std::vector<double2> tmp(n);
     if ((rc = d2h(c, tmp.data(), c->B.psum + s0, n))) return rc;
@@ -873,6 +882,7 @@ int dn_get_prefix_sums(dn_ctx *c, uint32_t read, double *sum, double *sumsq) {
 
 int dn_get_tstats(dn_ctx *c, uint32_t read, float *a, float *b) {
     CHECK_READ(2, "dn_get_tstats");
+    if (!c->B.t1) return fail(c, DN_ERR_STATE, "dn_debug_keep_k1(ctx, 1) must precede dn_batch_upload: t-statistics do not leave the kernels otherwise");
     const uint64_t s0 = c->h_samp_off[read]; const size_t n = (size_t)(c->h_samp_off[read + 1] - s0);
     if ((rc = d2h(c, a, c->B.t1 + s0, n))) return rc;
     return d2h(c, b, c->B.t2 + s0, n);

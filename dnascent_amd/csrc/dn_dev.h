@@ -19,6 +19,7 @@ struct DetState {           // one scrappie Detector (event_detection.c:10-21)
     float peak_val;
     int valid;
 };
+#define DN_SEG_CARRY 256    // k1_carry keeps the exact running sums {sum, sumsq} at every 256th sample (and at the read's end)
 struct SegState { DetState s, l; };
 
 struct ReadRes {            // per-read scalars produced on device (mirrors dn_read_summary)
@@ -52,11 +53,13 @@ struct BatchDev {
     const unsigned *model_pos;     // [4^9] position of each 9-mer's level in the sorted table (ties: any order, equal values)
     const double *model_sorted;    // [4^9] the levels in ascending order
     // ---- K1 workspace ----
-    double2 *psum;           // [samples]  psum[i] = {sum[i+1], sumsq[i+1]}  (sum[0] = 0 is implicit)
-    float *t1, *t2;          // [samples]
+    double2 *carry;          // [4 * chunks + n_reads] exact {sum[256 j], sumsq[256 j]} of read r at 4 * chunk_off[r] + r + j; the last one is {sum[n], sumsq[n]}
+    double2 *psum;           // TAPS ONLY (dn_debug_keep_k1; else null): [samples] psum[i] = {sum[i+1], sumsq[i+1]}
+    float *t1, *t2;          // TAPS ONLY: [samples] the two t-statistics
     const uint64_t *chunk_off;   // [n+1] detector chunk offsets
     unsigned *chunk_npk;     // [chunks]
-    unsigned *chunk_peaks;   // [chunks * DN_SEG_PEAKCAP]
+    unsigned *chunk_peaks;   // [chunks * DN_SEG_PEAKCAP] peak positions ...
+    double *chunk_psum;      // [chunks * DN_SEG_PEAKCAP] ... and the exact prefix sum sum[peak] that goes with each (event means need nothing else)
     SegState *chunk_in, *chunk_out;   // [chunks]
     // scrappie events + DNAscent events; capacity per read = ev_off[r+1]-ev_off[r]
     const uint64_t *ev_off;  // [n+1]

@@ -3,125 +3,38 @@
 // Replaces detect_events (scrappie/event_detection.c:268-319) and the event build of normaliseEvents
 // (event_handling.cpp:546-575) with results bit-identical to the reference:
 //
-//   k1_scan     serial fp64 prefix sums of x and x*x (event_detection.c:42-47).  Rounding of a running fp64
-//               sum depends on the order of the additions, so the order is kept; one wavefront per read does the
-//               conversion (int16 -> pA in fp32, widened, pod5.cpp:60), squares and stores 64 wide and only the
-//               two dependent adds per sample serially, through LDS.
-//   k1_tstat    the two windowed t-statistics (event_detection.c:60-115), one thread per sample; the mixed
-//               float/double expression order of the reference is written out cast by cast.
-//   k1_detect   the short/long peak detector (event_detection.c:122-198) is a serial state machine.  It is run
-//               SPECULATIVELY: one lane per DN_SEG_CHUNK-sample chunk starts DN_SEG_WARM samples early from the default
-//               state; after a common emitted peak the state no longer depends on history, so the state at the
-//               chunk start is almost always the true one.
-//   k1_events   verifies every chunk hand-off exactly (state in == previous state out), recomputes the rare
-//               chunk whose speculation missed (so the result is exact, never approximate), compacts the peaks,
-//               forms event means from the prefix sums (event_detection.c:213-266) and applies the event-build
-//               quirks of event_handling.cpp:549-575 (first mean 0.0, last event dropped, mean <= 0 merged).
+//   k1_carry    serial fp64 prefix sums of x and x*x (event_detection.c:42-47).  Rounding of a running fp64 sum depends on the
+//               order of the additions, so the order is kept: four reads per wavefront, the two dependent adds per sample run by 16
+//               lanes with EXEC narrowed per sample.  Only the running sums at every 256th sample (and at the read's end) leave
+//               the kernel: 16 bytes per 256 samples.  (Round 1 stored all of them: 16 bytes per sample, read back three times.)
+//   k1_detect   ONE pass over the signal for everything else: a lane owns a 1024-sample chunk, restarts the exact chain from the
+//               stored carry 256 samples before it (64 independent chains per wavefront, all lanes busy), forms both t-statistics
+//               (event_detection.c:60-115; the mixed float/double expression order written out cast by cast) from a register
+//               window of 28 prefix sums, and steps the short/long peak detector (event_detection.c:122-198) on them -- neither
+//               the prefix sums nor the t-statistics ever touch HBM.  The detector is a serial state machine and is run
+//               SPECULATIVELY: it starts 192 samples before the chunk from the default state; after a common emitted peak the
+//               state no longer depends on history, so the state at the chunk start is almost always the true one.  Every peak
+//               is recorded with the exact prefix sum at its position, which is all the event means need.
+//   k1_events   verifies every chunk hand-off exactly (state in == previous state out), recomputes the rare chunk whose
+//               speculation missed (so the result is exact, never approximate), compacts the peaks, forms event means from the
+//               recorded sums (event_detection.c:213-266) and applies the event-build quirks of event_handling.cpp:549-575
+//               (first mean 0.0, last event dropped, mean <= 0 merged).
+//   (taps)      k1_scan4<true> / k1_tstat write every prefix sum and both t-statistics to HBM when dn_debug_keep_k1 asked for
+//               them (parity tests); same arithmetic functions as the product kernels.
 #include "dn_dev.h"
 #include <float.h>
 
-// ------------------------------------------------------------------------------------------------
-// k1_scan: one wavefront per read.
-// The running fp64 sums must be accumulated strictly left to right (their rounding depends on the order), so per
-// sample there is an irreducible serial part: s += x; q += x*x.  Everything else is done 64 lanes wide: a chunk of
-// 256 samples is loaded coalesced (4 per lane), converted int16 -> pA (fp32, pod5.cpp:60) -> fp64, squared, and
-// parked in LDS as {x, x*x}; the serial pass then costs one broadcast ds_read_b128, two dependent adds and one
-// ds_write_b128 per sample (executed wave-uniformly), and the {sum, sumsq} pairs leave LDS through coalesced
-// 16-byte stores (1 KiB per wavefront store).
-// ------------------------------------------------------------------------------------------------
 #define SCAN_CHUNK 256
-
-// eight order-exact steps s += x, q += y of k1_scan with EXEC = lanes j..15 for step j (lanes 0..15 are active on entry)
-#define SCAN_ADD8(v, o, m0, m1, m2, m3, m4, m5, m6, m7)                                                                          \
-    {                                                                                                                             \
-        unsigned long long sv_;                                                                                                   \
-        asm volatile("s_mov_b64 %2, exec\n\t"                                                                                     \
-                     "s_mov_b64 exec, " m0 "\n\tv_add_f64 %0, %0, %3\n\tv_add_f64 %1, %1, %4\n\t"                                \
-                     "s_mov_b64 exec, " m1 "\n\tv_add_f64 %0, %0, %5\n\tv_add_f64 %1, %1, %6\n\t"                                \
-                     "s_mov_b64 exec, " m2 "\n\tv_add_f64 %0, %0, %7\n\tv_add_f64 %1, %1, %8\n\t"                                \
-                     "s_mov_b64 exec, " m3 "\n\tv_add_f64 %0, %0, %9\n\tv_add_f64 %1, %1, %10\n\t"                               \
-                     "s_mov_b64 exec, " m4 "\n\tv_add_f64 %0, %0, %11\n\tv_add_f64 %1, %1, %12\n\t"                              \
-                     "s_mov_b64 exec, " m5 "\n\tv_add_f64 %0, %0, %13\n\tv_add_f64 %1, %1, %14\n\t"                              \
-                     "s_mov_b64 exec, " m6 "\n\tv_add_f64 %0, %0, %15\n\tv_add_f64 %1, %1, %16\n\t"                              \
-                     "s_mov_b64 exec, " m7 "\n\tv_add_f64 %0, %0, %17\n\tv_add_f64 %1, %1, %18\n\t"                              \
-                     "s_mov_b64 exec, %2"                                                                                         \
-                     : "+v"(s), "+v"(q), "=&s"(sv_)                                                                               \
-                     : "v"(v[o + 0].x), "v"(v[o + 0].y), "v"(v[o + 1].x), "v"(v[o + 1].y), "v"(v[o + 2].x), "v"(v[o + 2].y),        \
-                       "v"(v[o + 3].x), "v"(v[o + 3].y), "v"(v[o + 4].x), "v"(v[o + 4].y), "v"(v[o + 5].x), "v"(v[o + 5].y),        \
-                       "v"(v[o + 6].x), "v"(v[o + 6].y), "v"(v[o + 7].x), "v"(v[o + 7].y));                                        \
-    }
-
 #define LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")   /* one wavefront per block: LDS ops are in order */
 
-__global__ __launch_bounds__(64) void k1_scan(BatchDev B) {
-    __shared__ double2 buf[SCAN_CHUNK];
-    const int r = blockIdx.x;
-    const int lane = threadIdx.x;
-    const uint64_t s0 = B.samp_off[r];
-    const unsigned n = (unsigned)(B.samp_off[r + 1] - s0);
-    const int16_t *a = B.adc + s0;
-    double2 *out = B.psum + s0;
-    const float off = B.cal_off[r], sc = B.cal_scale[r];
-    double s = 0.0, q = 0.0;
-    // samples of the next chunk are fetched while the current one is summed
-    int16_t nxt[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { const unsigned i = (unsigned)lane * 4u + j; nxt[j] = i < n ? a[i] : (int16_t)0; }
-    for (unsigned base = 0; base < n; base += SCAN_CHUNK) {
-        const unsigned cnt = min((unsigned)SCAN_CHUNK, n - base);
-        // ---- parallel: convert + square, 4 consecutive samples per lane ----
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float v = ((float)nxt[j] + off) * sc;            // pod5.cpp:60
-            const double x = (double)v;
-            buf[lane * 4 + j] = make_double2(x, x * x);
-        }
-        {
-            const unsigned nb = base + SCAN_CHUNK;
-#pragma unroll
-            for (int j = 0; j < 4; j++) { const unsigned i = nb + (unsigned)lane * 4u + j; nxt[j] = i < n ? a[i] : (int16_t)0; }
-        }
-        LDS_FENCE();
-        // ---- serial, order-exact (event_detection.c:45-46).  A single-lane ds_write_b128 costs ~50 cycles, so the chain is
-        //      run by 16 lanes at once (broadcast LDS reads; same instruction count as one lane): lane j stops adding after
-        //      sample g + j (the adds of sample i execute only on lanes >= i), so it ends the group holding the running
-        //      sums after ITS sample; one 16-lane store puts the 16 results back and lane 15's sums carry on. ----
-        if (lane < 16) {
-            const unsigned full = cnt & ~15u;
-            for (unsigned g = 0; g < full; g += 16) {
-                double2 v[16];
-#pragma unroll
-                for (int j = 0; j < 16; j++) v[j] = buf[g + j];
-                // the adds of sample j run on lanes j..15 only: EXEC is narrowed by hand (the compiler would turn an `if` into
-                // four v_cndmask per sample inside the dependency chain); both blocks restore it before they end
-                SCAN_ADD8(v, 0, "0xffff", "0xfffe", "0xfffc", "0xfff8", "0xfff0", "0xffe0", "0xffc0", "0xff80")
-                SCAN_ADD8(v, 8, "0xff00", "0xfe00", "0xfc00", "0xf800", "0xf000", "0xe000", "0xc000", "0x8000")
-                buf[g + lane] = make_double2(s, q);
-                s = bcast_d(s, 15); q = bcast_d(q, 15);
-            }
-            for (unsigned i = full; i < cnt; i++) {
-                const double2 v = buf[i];
-                s = s + v.x;
-                q = q + v.y;
-                if (lane == 0) buf[i] = make_double2(s, q);
-            }
-        }
-        LDS_FENCE();
-        // ---- parallel: coalesced write-out (1 KiB per wavefront store) ----
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const unsigned i = (unsigned)j * 64u + (unsigned)lane;
-            if (i < cnt) out[base + i] = buf[i];
-        }
-        LDS_FENCE();
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// k1_scan4: the same scan with FOUR reads per wavefront.  The order-exact chain is two dependent fp64 adds per sample, issued as
-// whole-wavefront instructions whatever the number of active lanes; k1_scan keeps 16 lanes busy with them (one read), so with
-// eight batches in flight -- when the vector issue slots, not the latency of one chain, are what is scarce -- three quarters of
-// every such instruction are wasted.  Here each 16-lane row of the wavefront runs the chain of its own read (EXEC narrowed with
+// k1_scan4 (k1_carry): the order-exact running sums s += x, q += x * x of FOUR reads per wavefront.  The sums must be accumulated
+// strictly left to right (their rounding depends on the order), so per sample there is an irreducible serial part of two dependent
+// fp64 adds; everything else is 64 lanes wide: a chunk of 256 samples per read is loaded coalesced, converted int16 -> pA (fp32,
+// pod5.cpp:60) -> fp64, squared and parked in LDS as {x, x * x}.  A single-lane LDS store costs ~50 cycles, so the chain is run by 16
+// lanes at once (broadcast LDS reads; lane j stops adding after sample g + j, so it ends a group of 16 holding the running sums
+// after ITS sample) -- and since those adds are whole-wavefront instructions whatever the number of active lanes, each 16-lane row
+// of the wavefront runs the chain of its own read (EXEC narrowed with
 // the 16-bit pattern replicated four times: two 32-bit scalar moves, s_mov_b64 takes no 64-bit literal), so a batch costs a quarter of the vector instructions for the same chain latency.
 // Reads of different lengths: a finished (or absent) read keeps adding +0.0, which is exact (the running sums are never -0.0:
 // they start at +0.0 and round-to-nearest never produces -0.0 from a sum with a +0.0 or non-zero operand), and writes nothing.
@@ -146,6 +59,7 @@ __global__ __launch_bounds__(64) void k1_scan(BatchDev B) {
                        "v"(v[o + 6].x), "v"(v[o + 6].y), "v"(v[o + 7].x), "v"(v[o + 7].y));                                        \
     }
 
+template <bool FULL>
 __global__ __launch_bounds__(64) void k1_scan4(BatchDev B) {
     __shared__ double2 buf[4][SCAN_CHUNK];
     const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
@@ -154,7 +68,9 @@ __global__ __launch_bounds__(64) void k1_scan4(BatchDev B) {
     const uint64_t s0 = have ? B.samp_off[r] : 0ull;
     const unsigned n = have ? (unsigned)(B.samp_off[r + 1] - s0) : 0u;
     const int16_t *a = B.adc + s0;
-    double2 *out = B.psum + s0;
+    double2 *out = FULL ? B.psum + s0 : nullptr;
+    double2 *carry = B.carry + (have ? 4ull * B.chunk_off[r] + (unsigned)r : 0ull);      // {sum[256 j], sumsq[256 j]}, j = 0 .. ceil(n / 256)
+    if (have && l == 0) carry[0] = make_double2(0.0, 0.0);
     const float off = have ? B.cal_off[r] : 0.0f, sc = have ? B.cal_scale[r] : 0.0f;
     unsigned nmax = n;
     nmax = max(nmax, (unsigned)__shfl_xor((int)nmax, 16)); nmax = max(nmax, (unsigned)__shfl_xor((int)nmax, 32));
@@ -196,11 +112,15 @@ __global__ __launch_bounds__(64) void k1_scan4(BatchDev B) {
             s = c.x; q = c.y;
         }
         LDS_FENCE();
-        // ---- parallel: write-out, 256 contiguous bytes per row and store ----
+        // the running sums after this chunk (a finished read kept adding +0.0: they are sum[n]); the last carry of a read is its total
+        if (cnt && l == 0) carry[base / SCAN_CHUNK + 1] = make_double2(s, q);
+        if (FULL) {
+            // ---- taps: parallel write-out of every prefix sum, 256 contiguous bytes per row and store ----
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const unsigned i = (unsigned)(j * 16 + l);
-            if (i < cnt) out[base + i] = mybuf[i];
+            for (int j = 0; j < 16; j++) {
+                const unsigned i = (unsigned)(j * 16 + l);
+                if (i < cnt) out[base + i] = mybuf[i];
+            }
         }
         LDS_FENCE();
     }
@@ -253,16 +173,12 @@ template <bool EXACT> __device__ __forceinline__ float tstat_ratio(float dm, flo
     return (float)y;
 }
 
+// one t-statistic from the three prefix pairs it needs: a = {sum, sumsq}[i - w], b = [i], c = [i + w] (event_detection.c:89-111)
 template <unsigned W, bool EXACT>
-__device__ __forceinline__ float tstat_at(const double2 *P, unsigned n, unsigned i, bool &bad) {
-    constexpr unsigned w = W;
-    const bool valid = n >= 2 * w && i >= w && i <= n - w;       // :76-86, loop bound :89 is inclusive; elsewhere the statistic is 0
-    const unsigned ii = valid ? i : w;                           // a position whose loads are in range whenever n >= 2 w
+__device__ __forceinline__ float tstat_from(const double2 a, const double2 b, const double2 c, const bool valid, bool &bad) {
     constexpr float wf = (float)W;
     constexpr float rwf = 1.0f / wf;                             // RN(1 / w), folded by the compiler exactly as IEEE division
     constexpr double wd = (double)wf, rwd = 1.0 / wd;
-    const double2 z = make_double2(0.0, 0.0);
-    const double2 a = n >= 2 * w ? prefix_at(P, ii - w) : z, b = n >= 2 * w ? prefix_at(P, ii) : z, c = n >= 2 * w ? prefix_at(P, ii + w) : z;
     bool mybad = false;
     const double sum1 = b.x - a.x, sumsq1 = b.y - a.y;           // :90-95 (sum[0] == 0, so i == w is the same expression)
     const float sum2 = (float)(c.x - b.x);                       // :96
@@ -280,6 +196,16 @@ __device__ __forceinline__ float tstat_at(const double2 *P, unsigned n, unsigned
     return valid ? t : 0.0f;
 }
 
+template <unsigned W, bool EXACT>
+__device__ __forceinline__ float tstat_at(const double2 *P, unsigned n, unsigned i, bool &bad) {
+    constexpr unsigned w = W;
+    const bool valid = n >= 2 * w && i >= w && i <= n - w;       // :76-86, loop bound :89 is inclusive; elsewhere the statistic is 0
+    const unsigned ii = valid ? i : w;                           // a position whose loads are in range whenever n >= 2 w
+    const double2 z = make_double2(0.0, 0.0);
+    const double2 a = n >= 2 * w ? prefix_at(P, ii - w) : z, b = n >= 2 * w ? prefix_at(P, ii) : z, c = n >= 2 * w ? prefix_at(P, ii + w) : z;
+    return tstat_from<W, EXACT>(a, b, c, valid, bad);
+}
+
 __global__ __launch_bounds__(256) void k1_tstat(BatchDev B) {
     const int r = blockIdx.y;
     const uint64_t s0 = B.samp_off[r];
@@ -295,6 +221,7 @@ __global__ __launch_bounds__(256) void k1_tstat(BatchDev B) {
     B.t2[s0 + i] = t2;
 }
 
+
 // ------------------------------------------------------------------------------------------------
 // peak detector state machine (event_detection.c:136-195), shared by the speculative pass and the exact redo
 // ------------------------------------------------------------------------------------------------
@@ -305,24 +232,26 @@ __device__ __forceinline__ SegState seg_initial() {
     return st;
 }
 
+// one sample of both detectors.  cur: the prefix sum sum[i]; a detector that moves its peak to i remembers it (ss / ls), and an
+// emitted peak is stored together with that sum -- create_event needs nothing else of the signal (event_detection.c:224-226)
 template <bool EMIT>
-__device__ __forceinline__ void seg_step(SegState &st, int i, float v1, float v2, unsigned *pk, unsigned &npk) {
+__device__ __forceinline__ void seg_step(SegState &st, double &ss, double &ls, int i, float v1, float v2, double cur, unsigned *pk, double *pks, unsigned &npk) {
     const float peak_height = 0.2f;
     // short detector: window 3, threshold 1.4
     if (!(st.s.masked_to >= i)) {                                 // :140
         const float v = v1;
         if (st.s.peak_pos == -1) {
             if (v < st.s.peak_val) st.s.peak_val = v;
-            else if (v - st.s.peak_val > peak_height) { st.s.peak_val = v; st.s.peak_pos = i; }
+            else if (v - st.s.peak_val > peak_height) { st.s.peak_val = v; st.s.peak_pos = i; ss = cur; }
         } else {
-            if (v > st.s.peak_val) { st.s.peak_val = v; st.s.peak_pos = i; }
+            if (v > st.s.peak_val) { st.s.peak_val = v; st.s.peak_pos = i; ss = cur; }
             if (st.s.peak_val > 1.4f) {                           // :166-176 short dominates long
                 st.l.masked_to = st.s.peak_pos + 3;
                 st.l.peak_pos = -1; st.l.peak_val = FLT_MAX; st.l.valid = 0;
             }
             if (st.s.peak_val - v > peak_height && st.s.peak_val > 1.4f) st.s.valid = 1;
             if (st.s.valid && (i - st.s.peak_pos) > 1) {          // window_length / 2 == 1
-                if (EMIT) { if (npk < DN_SEG_PEAKCAP) pk[npk] = (unsigned)st.s.peak_pos; npk++; }
+                if (EMIT) { if (npk < DN_SEG_PEAKCAP) { pk[npk] = (unsigned)st.s.peak_pos; pks[npk] = ss; } npk++; }
                 st.s.peak_pos = -1; st.s.peak_val = v; st.s.valid = 0;
             }
         }
@@ -332,12 +261,12 @@ __device__ __forceinline__ void seg_step(SegState &st, int i, float v1, float v2
         const float v = v2;
         if (st.l.peak_pos == -1) {
             if (v < st.l.peak_val) st.l.peak_val = v;
-            else if (v - st.l.peak_val > peak_height) { st.l.peak_val = v; st.l.peak_pos = i; }
+            else if (v - st.l.peak_val > peak_height) { st.l.peak_val = v; st.l.peak_pos = i; ls = cur; }
         } else {
-            if (v > st.l.peak_val) { st.l.peak_val = v; st.l.peak_pos = i; }
+            if (v > st.l.peak_val) { st.l.peak_val = v; st.l.peak_pos = i; ls = cur; }
             if (st.l.peak_val - v > peak_height && st.l.peak_val > 9.0f) st.l.valid = 1;
             if (st.l.valid && (i - st.l.peak_pos) > 3) {          // window_length / 2 == 3
-                if (EMIT) { if (npk < DN_SEG_PEAKCAP) pk[npk] = (unsigned)st.l.peak_pos; npk++; }
+                if (EMIT) { if (npk < DN_SEG_PEAKCAP) { pk[npk] = (unsigned)st.l.peak_pos; pks[npk] = ls; } npk++; }
                 st.l.peak_pos = -1; st.l.peak_val = v; st.l.valid = 0;
             }
         }
@@ -352,71 +281,114 @@ __device__ __forceinline__ bool seg_equal(const SegState &a, const SegState &b, 
            __float_as_int(a.l.peak_val) == __float_as_int(b.l.peak_val) && a.l.valid == b.l.valid;
 }
 
-struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };   // 16-byte load that only needs 4-byte alignment
+// ------------------------------------------------------------------------------------------------
+// The chunk walker: chain -> t-statistics -> detector for one 1024-sample chunk per lane.
+//   stream      sample index i = chunk * 1024 - 256 + p, p = 0 .. 1299 (25 tiles of 52): the chain restarts from the carry k1_carry
+//               left at chunk * 1024 - 256 (a multiple of 256) -- for chunk 0 from 0 with the samples "before the read" as exact
+//               zeros (adding +0.0 leaves the sums untouched), likewise beyond the read's end;
+//   tile        64 rows (lanes) x 52 samples, int16 -> pA in fp32 (pod5.cpp:60) on the way into LDS, read back one row per lane
+//               (row stride 53 words: conflict-free);
+//   body        13 samples at a time, fully unrolled, over a RING of 13 prefix pairs held in registers: sample j's sums overwrite
+//               slot j (the oldest), and the statistic of sample i0 = i - 5 finds the pairs at i0 - 6, - 3, 0, + 3, + 6 in slots
+//               j + 1, + 4, + 7, + 10, + 13 (mod 13) -- static indices, no copying.  The detector so runs 5 samples behind the chain;
+//   detector    speculative mode: default state from 192 samples before the chunk (peaks recorded from the chunk start on, the state
+//               AT the chunk start is saved for k1_events' exact hand-off check); redo mode: every lane walks the SAME chunk from
+//               the given true state (wave-uniform; every lane stores the same values).
+// ------------------------------------------------------------------------------------------------
+#define SEG_BODY 13
+#define SEG_TILE (4 * SEG_BODY)
+#define SEG_PITCH (SEG_TILE + 1)
+#define SEG_PRE DN_SEG_CARRY                                  // chain warm-up = distance to the carry the stream starts from
+#define SEG_TILES ((SEG_PRE + DN_SEG_CHUNK + 5 + SEG_TILE - 1) / SEG_TILE)
 
-#define SEG_TILE 32                      // samples per lane per LDS tile
-#define SEG_STREAM (DN_SEG_WARM + DN_SEG_CHUNK)
+__device__ __forceinline__ void seg_body13(const float *row, const int A /* sample index of row[0] */, const int n, const int det_lo, const int det_hi,
+                                           const int emit_lo, SegState *save_at_emit_lo, double &S, double &Q, double (&rs)[13], double (&rq)[13],
+                                           SegState &st, double &ss, double &ls, unsigned *pk, double *pks, unsigned &npk) {
+#pragma unroll
+    for (int j = 0; j < SEG_BODY; j++) {
+        const double x = (double)row[j];
+        S = S + x; Q = Q + x * x;                             // the order-exact chain (event_detection.c:45-46): {sum, sumsq}[A + j + 1]
+        rs[j] = S; rq[j] = Q;                                 // overwrites {sum, sumsq}[A + j - 12]: the ring now holds [A + j - 11, A + j + 1]
+        const int i0 = A + j - 5;                             // the sample whose windows are complete: needs sum[i0 - 6 .. i0 + 6]
+        const bool on = i0 >= det_lo && i0 < det_hi;
+        if (!__any(on)) continue;
+        const unsigned un = (unsigned)n, ui = (unsigned)i0;
+        const bool v3 = un >= 6u && ui >= 3u && ui <= un - 3u, v6 = un >= 12u && ui >= 6u && ui <= un - 6u;   // :76-89
+#define RING(d) make_double2(rs[(j + 1 + (d)) % SEG_BODY], rq[(j + 1 + (d)) % SEG_BODY])      /* {sum, sumsq}[i0 - 6 + d] */
+        const double2 p0 = RING(0), p3 = RING(3), p6 = RING(6), p9 = RING(9), p12 = RING(12);
+#undef RING
+        bool bad = false;
+        float t1 = tstat_from<3, false>(p3, p6, p9, v3 && on, bad);          // event_detection.h:19-25
+        float t2 = tstat_from<6, false>(p0, p6, p12, v6 && on, bad);
+        if (__builtin_expect(__any(bad), 0)) { bool x2 = false; t1 = tstat_from<3, true>(p3, p6, p9, v3, x2); t2 = tstat_from<6, true>(p0, p6, p12, v6, x2); }
+        if (save_at_emit_lo && i0 == emit_lo) *save_at_emit_lo = st;         // wave-uniform position: the state at the chunk start
+        if (on) {
+            if (i0 >= emit_lo) seg_step<true>(st, ss, ls, i0, t1, t2, p6.x, pk, pks, npk);
+            else { unsigned none = 0; seg_step<false>(st, ss, ls, i0, t1, t2, p6.x, pk, pks, none); }
+        }
+    }
+}
 
-__global__ __launch_bounds__(64) void k1_detect(BatchDev B) {
-    // One wavefront = 64 consecutive chunks of one read, one chunk per lane.  Lane l walks samples
-    // [c*CHUNK - WARM, c*CHUNK + CHUNK): a stream strided by CHUNK samples between lanes.  The two t-statistic streams
-    // are staged through LDS in tiles of 64 rows x 32 samples, loaded with coalesced 16-byte loads (8 lanes cover one
-    // row's 128 bytes) and read back one row per lane (row stride 33 words: conflict-free).
-    __shared__ float tile1[64 * 33], tile2[64 * 33];
-    const int r = blockIdx.y;
+// walks chunk `c` of read r on every lane that `have`s one.  REDO: all lanes walk the same chunk from state `st`.
+template <bool REDO>
+__device__ __forceinline__ void seg_walk(const BatchDev &B, float *tile /* [64 * SEG_PITCH] */, const int r, const int cbase, const int c, const bool have,
+                                         SegState &st, unsigned &npk) {
     const int lane = threadIdx.x;
     const uint64_t s0 = B.samp_off[r];
     const int n = (int)(B.samp_off[r + 1] - s0);
+    const uint64_t c0 = B.chunk_off[r];
+    const int16_t *adc = B.adc + s0;
+    const float off = B.cal_off[r], sc = B.cal_scale[r];
+    const int cc = have ? c : 0;
+    const int my0 = cc * DN_SEG_CHUNK - SEG_PRE;                // sample index of stream position 0
+    // carry {sum, sumsq} at my0 (k1_carry): index my0 / 256 of the read's carries; chunk 0 starts from the zeros before the read
+    double S = 0.0, Q = 0.0;
+    if (have && my0 > 0) { const double2 cy = B.carry[4ull * c0 + (unsigned)r + (unsigned)(my0 / DN_SEG_CARRY)]; S = cy.x; Q = cy.y; }
+    double rs[13], rq[13];
+#pragma unroll
+    for (int k = 0; k < 13; k++) { rs[k] = S; rq[k] = Q; }       // never read by a live statistic: the detector starts >= 64 samples in
+    double ss = 0.0, ls = 0.0;
+    unsigned *pk = B.chunk_peaks + (c0 + cc) * DN_SEG_PEAKCAP;
+    double *pks = B.chunk_psum + (c0 + cc) * DN_SEG_PEAKCAP;
+    const int chunk_lo = cc * DN_SEG_CHUNK;
+    const int det_hi = have ? min(n, chunk_lo + DN_SEG_CHUNK) : 0;
+    const int det_lo = REDO ? chunk_lo : max(1, chunk_lo - DN_SEG_WARM);     // sample 0 is always masked (:140)
+    SegState *save = (!REDO && have) ? &B.chunk_in[c0 + cc] : nullptr;
+    for (int t = 0; t < SEG_TILES; t++) {
+        __syncthreads();
+        // tile: row = the lane that will read it; 52 samples per row = 13 groups of 4; thread handles (row, group) pairs round-robin
+        for (int f = lane; f < 64 * (SEG_TILE / 4); f += 64) {
+            const int row = f / (SEG_TILE / 4), g = f % (SEG_TILE / 4);
+            const int rc = REDO ? c : cbase + row;                // the chunk this row's lane walks
+            const int idx = rc * DN_SEG_CHUNK - SEG_PRE + t * SEG_TILE + 4 * g;
+            float *d = tile + row * SEG_PITCH + 4 * g;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = idx + e;
+                d[e] = (i >= 0 && i < n) ? ((float)adc[i] + off) * sc : 0.0f;    // pod5.cpp:60; outside the read: an exact zero
+            }
+        }
+        __syncthreads();
+        const float *rowp = tile + lane * SEG_PITCH;
+#pragma unroll 1
+        for (int h = 0; h < SEG_TILE / SEG_BODY; h++)
+            seg_body13(rowp + SEG_BODY * h, my0 + t * SEG_TILE + SEG_BODY * h, n, det_lo, det_hi, chunk_lo, save, S, Q, rs, rq, st, ss, ls, pk, pks, npk);
+    }
+}
+
+__global__ __launch_bounds__(64) void k1_detect(BatchDev B) {
+    __shared__ float tile[64 * SEG_PITCH];
+    const int r = blockIdx.y;
+    const int lane = threadIdx.x;
     const uint64_t c0 = B.chunk_off[r];
     const int nch = (int)(B.chunk_off[r + 1] - c0);
     const int cbase = blockIdx.x * 64;
     if (cbase >= nch) return;
     const int c = cbase + lane;
     const bool have = c < nch;
-    const float *t1 = B.t1 + s0, *t2 = B.t2 + s0;
     SegState st = seg_initial();
-    unsigned *pk = B.chunk_peaks + (c0 + (have ? c : 0)) * DN_SEG_PEAKCAP;
     unsigned npk = 0;
-    const int my0 = c * DN_SEG_CHUNK - DN_SEG_WARM;              // sample index of stream position 0 of this lane
-    const int lrow = lane >> 3, lcol = (lane & 7) * 4;
-    for (int t = 0; t < SEG_STREAM / SEG_TILE; t++) {
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < 8; p++) {
-            const int row = p * 8 + lrow;
-            const int idx = (cbase + row) * DN_SEG_CHUNK - DN_SEG_WARM + t * SEG_TILE + lcol;
-            f4u a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-            if (idx >= 0 && idx + 3 < n) {
-                a = *reinterpret_cast<const f4u *>(t1 + idx);
-                b = *reinterpret_cast<const f4u *>(t2 + idx);
-            } else {
-                float ta[4], tb[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) { const int i = idx + q; const bool ok = i >= 0 && i < n; ta[q] = ok ? t1[i] : 0.f; tb[q] = ok ? t2[i] : 0.f; }
-                a.x = ta[0]; a.y = ta[1]; a.z = ta[2]; a.w = ta[3]; b.x = tb[0]; b.y = tb[1]; b.z = tb[2]; b.w = tb[3];
-            }
-            float *d1 = tile1 + row * 33 + lcol, *d2 = tile2 + row * 33 + lcol;
-            d1[0] = a.x; d1[1] = a.y; d1[2] = a.z; d1[3] = a.w;
-            d2[0] = b.x; d2[1] = b.y; d2[2] = b.z; d2[3] = b.w;
-        }
-        __syncthreads();
-        if (t * SEG_TILE == DN_SEG_WARM && have) B.chunk_in[c0 + c] = st;       // state at the chunk start
-        const bool emit = t * SEG_TILE >= DN_SEG_WARM;
-        const float *r1 = tile1 + lane * 33, *r2 = tile2 + lane * 33;
-        if (emit) {
-#pragma unroll 8
-            for (int j = 0; j < SEG_TILE; j++) {
-                const int i = my0 + t * SEG_TILE + j;
-                if (i >= 1 && i < n) seg_step<true>(st, i, r1[j], r2[j], pk, npk);
-            }
-        } else {
-#pragma unroll 8
-            for (int j = 0; j < SEG_TILE; j++) {
-                const int i = my0 + t * SEG_TILE + j;
-                if (i >= 1 && i < n) seg_step<false>(st, i, r1[j], r2[j], nullptr, npk);   // sample 0 is always masked (:140)
-            }
-        }
-    }
+    seg_walk<false>(B, tile, r, cbase, c, have, st, npk);
     if (have) {
         B.chunk_npk[c0 + c] = npk;
         B.chunk_out[c0 + c] = st;
@@ -436,6 +408,8 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
 }
 
 __global__ __launch_bounds__(64) void k1_events(BatchDev B, unsigned *scratch_u32 /* aliases cl_rank: kept-index list */) {
+    __shared__ float tile[64 * SEG_PITCH];                        // the exact redo's signal tile
+    __shared__ unsigned pre[4096];                                // exclusive prefix of peaks per chunk (<= 4M samples / read)
     const int r = blockIdx.x;
     const int lane = threadIdx.x;
     const uint64_t s0 = B.samp_off[r];
@@ -444,8 +418,6 @@ __global__ __launch_bounds__(64) void k1_events(BatchDev B, unsigned *scratch_u3
     const int nch = (int)(B.chunk_off[r + 1] - c0);
     const uint64_t e0 = B.ev_off[r];
     const unsigned ecap = (unsigned)(B.ev_off[r + 1] - e0);
-    const float *t1 = B.t1 + s0, *t2 = B.t2 + s0;
-    const double2 *P = B.psum + s0;
     ReadRes &R = B.res[r];
 
     // ---- 1. exact verification of the speculative hand-offs ----
@@ -456,26 +428,16 @@ __global__ __launch_bounds__(64) void k1_events(BatchDev B, unsigned *scratch_u3
     }
     unsigned rechecks = 0;
     if (__any(any_bad)) {
-        // slow path (rare): walk the chain, redo every chunk whose assumed start state was wrong
+        // slow path (rare): walk the chain of chunks, redo every chunk whose assumed start state was wrong -- the whole wavefront
+        // walks that one chunk from the true state (wave-uniform; every lane computes and stores the same values)
         SegState tru = B.chunk_out[c0];
         for (int c = 1; c < nch; c++) {
             const SegState in = B.chunk_in[c0 + c];
             if (seg_equal(tru, in, c * DN_SEG_CHUNK)) { tru = B.chunk_out[c0 + c]; continue; }
             SegState st = tru;
-            const int beg = c * DN_SEG_CHUNK, end = min(beg + DN_SEG_CHUNK, n);
-            unsigned *pk = B.chunk_peaks + (c0 + c) * DN_SEG_PEAKCAP;
             unsigned npk = 0;
-            // lane 0 redoes the chunk from the true state and stores; its end state is broadcast below
-            if (lane == 0) {
-                for (int i = beg; i < end; i++) seg_step<true>(st, i, t1[i], t2[i], pk, npk);
-                B.chunk_npk[c0 + c] = npk;
-                B.chunk_out[c0 + c] = st;
-            }
-            // broadcast lane 0's end state
-            st.s.masked_to = __shfl(st.s.masked_to, 0); st.s.peak_pos = __shfl(st.s.peak_pos, 0);
-            st.s.peak_val = __shfl(st.s.peak_val, 0);   st.s.valid = __shfl(st.s.valid, 0);
-            st.l.masked_to = __shfl(st.l.masked_to, 0); st.l.peak_pos = __shfl(st.l.peak_pos, 0);
-            st.l.peak_val = __shfl(st.l.peak_val, 0);   st.l.valid = __shfl(st.l.valid, 0);
+            seg_walk<true>(B, tile, r, 0, c, true, st, npk);
+            if (lane == 0) { B.chunk_npk[c0 + c] = npk; B.chunk_out[c0 + c] = st; }
             tru = st;
             rechecks++;
         }
@@ -483,10 +445,10 @@ __global__ __launch_bounds__(64) void k1_events(BatchDev B, unsigned *scratch_u3
     }
     __syncthreads();
 
-    // ---- 2. compact the peaks: et_start[0] = 0, et_start[1 + j] = j-th peak ----
-    __shared__ unsigned pre[4096];                                // exclusive prefix of peaks per chunk (<= 4M samples / read)
+    // ---- 2. compact the peaks: et_start[0] = 0, et_start[1 + j] = j-th peak; their prefix sums alongside ----
     unsigned *et_start = B.et_start + e0;
     float *et_mean = B.et_mean + e0;
+    double *et_sum = B.ev_x + e0;                                 // sum[et_start[e]]; ev_x is free until k_prep writes it
     unsigned running = 0;
     int overflow = nch > 4096;
     for (int cb = 0; cb < nch && cb < 4096; cb += 64) {
@@ -502,25 +464,27 @@ __global__ __launch_bounds__(64) void k1_events(BatchDev B, unsigned *scratch_u3
         const unsigned base = pre[c];
         const unsigned cnt = ((c + 1 < nch && c + 1 < 4096) ? pre[c + 1] : running) - base;
         const unsigned *pk = B.chunk_peaks + (c0 + c) * DN_SEG_PEAKCAP;
+        const double *pks = B.chunk_psum + (c0 + c) * DN_SEG_PEAKCAP;
         for (unsigned j = lane; j < cnt; j += 64) {
             const unsigned slot = 1 + base + j;
-            if (slot < ecap) et_start[slot] = pk[j];
+            if (slot < ecap) { et_start[slot] = pk[j]; et_sum[slot] = pks[j]; }
         }
     }
-    if (lane == 0) et_start[0] = 0;
+    if (lane == 0) { et_start[0] = 0; et_sum[0] = 0.0; }
     unsigned n_et = 1 + running;                                  // create_events :242-247 (every recorded peak satisfies 0 < p < n)
     if (n_et > ecap) { overflow = 1; n_et = ecap; }
     overflow = __any(overflow);
     __threadfence_block();
     __syncthreads();
 
-    // ---- 3. scrappie event means (create_event :224-226) ----
+    // ---- 3. scrappie event means (create_event :224-226): (float)(sum[end] - sum[start]) / length ----
+    const double total = B.carry[4ull * c0 + (unsigned)r + (unsigned)((n + DN_SEG_CARRY - 1) / DN_SEG_CARRY)].x;     // sum[n]
     for (unsigned e = lane; e < n_et; e += 64) {
         const unsigned st = et_start[e];
         const unsigned en = (e + 1 < n_et) ? et_start[e + 1] : (unsigned)n;
-        const double2 a = prefix_at(P, st), b = prefix_at(P, en);
+        const double a = et_sum[e], b = (e + 1 < n_et) ? et_sum[e + 1] : total;
         const float length = (float)(unsigned long long)((unsigned long long)en - (unsigned long long)st);
-        et_mean[e] = (float)(b.x - a.x) / length;
+        et_mean[e] = (float)(b - a) / length;
     }
     __threadfence_block();
     __syncthreads();
@@ -565,12 +529,12 @@ __global__ __launch_bounds__(64) void k1_events(BatchDev B, unsigned *scratch_u3
 // launch helpers (called from dn_capi.hip)
 // ------------------------------------------------------------------------------------------------
 void k1_launch_scan(const BatchDev &B, hipStream_t st) {
-    static const bool scan4 = !(getenv("DN_SCAN4") && atoi(getenv("DN_SCAN4")) == 0);
-    if (scan4) hipLaunchKernelGGL(k1_scan4, dim3((B.n_reads + 3) / 4), dim3(64), 0, st, B);
-    else hipLaunchKernelGGL(k1_scan, dim3(B.n_reads), dim3(64), 0, st, B);
+    // taps requested (B.psum != null): the same kernel also writes every prefix sum
+    if (B.psum) hipLaunchKernelGGL(k1_scan4<true>, dim3((B.n_reads + 3) / 4), dim3(64), 0, st, B);
+    else hipLaunchKernelGGL(k1_scan4<false>, dim3((B.n_reads + 3) / 4), dim3(64), 0, st, B);
 }
-void k1_launch_tstat(const BatchDev &B, unsigned max_samples, hipStream_t st) {
-    hipLaunchKernelGGL(k1_tstat, dim3((max_samples + 255) / 256, B.n_reads), dim3(256), 0, st, B);
+void k1_launch_tstat(const BatchDev &B, unsigned max_samples, hipStream_t st) {      // taps only
+    if (B.psum && B.t1) hipLaunchKernelGGL(k1_tstat, dim3((max_samples + 255) / 256, B.n_reads), dim3(256), 0, st, B);
 }
 void k1_launch_detect(const BatchDev &B, unsigned max_chunks, hipStream_t st) {
     hipLaunchKernelGGL(k1_detect, dim3((max_chunks + 63) / 64, B.n_reads), dim3(64), 0, st, B);

@@ -18,7 +18,7 @@ for _i, _n in enumerate(K_NAMES):
 
 # every symbol include/dnascent_hip.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = ["dn_abi_version", "dn_device_count", "dn_ctx_create", "dn_ctx_destroy", "dn_last_error", "dn_sync",
-           "dn_load_pore_model", "dn_batch_upload", "dn_host_alloc", "dn_host_free", "dn_host_register", "dn_host_unregister", "dn_run_detect", "dn_collect", "dn_debug_emission", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded",
+           "dn_load_pore_model", "dn_batch_upload", "dn_host_alloc", "dn_host_free", "dn_host_register", "dn_host_unregister", "dn_run_detect", "dn_collect", "dn_debug_emission", "dn_debug_keep_k1", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded",
            "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_set_align_table", "dn_get_align_rows", "dn_get_align_table", "dn_load_cnn", "dn_cnn_set_math", "dn_cnn_range_escalations", "dn_run_cnn", "dn_get_probabilities", "dn_cnn_infer", "dn_load_fit_models", "dn_run_hmm", "dn_get_hmm_calls", "dn_get_summaries", "dn_get_prefix_sums",
            "dn_get_tstats", "dn_get_scrappie_events", "dn_get_events", "dn_get_kmer_ranks", "dn_get_alignment",
            "dn_get_cleaned", "dn_get_trace", "dn_get_positions", "dn_get_windows", "dn_profile_enable", "dn_profile_get",
@@ -112,6 +112,7 @@ def lib():
         L.dn_get_summaries.argtypes = [C.c_void_p, C.c_void_p]
         L.dn_collect.argtypes = [C.c_void_p, C.POINTER(ResultBatch)]
         L.dn_debug_emission.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dn_debug_keep_k1.argtypes = [C.c_void_p, C.c_int]
         L.dn_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
         L.dn_host_free.argtypes = [C.c_void_p]
         L.dn_host_register.argtypes = [C.c_void_p, C.c_size_t]
@@ -245,6 +246,10 @@ class Context:
         return dict(summary=arr(rb.summary, SUMMARY_DTYPE, n), call_off=arr(rb.call_off, np.uint64, n + 1 if n else 0),
                     ref_coord=arr(rb.ref_coord, np.uint32, k), query_idx=arr(rb.query_idx, np.uint32, k), ref_idx=arr(rb.ref_idx, np.uint32, k),
                     p_edu=arr(rb.p_edu, np.float32, k), p_brdu=arr(rb.p_brdu, np.float32, k), kmer=arr(rb.kmer9, "S9", k))
+
+    def keep_k1(self, on=True):
+        """prefix sums / t-statistics also go to HBM for the batches uploaded from now on (taps prefix_sums() / tstats())"""
+        self._chk(lib().dn_debug_keep_k1(self.h, int(on)), "dn_debug_keep_k1")
 
     def debug_emission(self, x, mu):
         x = np.ascontiguousarray(x, np.float64); mu = np.ascontiguousarray(mu, np.float64)

@@ -198,6 +198,9 @@ typedef struct {
 int dn_collect(dn_ctx *ctx, dn_result_batch *out);
 
 /* ---- intermediate taps (parity tests; sizes from dn_read_summary; NULL pointers are skipped) ---- */
+/* prefix sums and t-statistics live only in registers / LDS of the segmentation kernels; dn_debug_keep_k1(ctx, 1) BEFORE
+ * dn_batch_upload makes the next batches also write them to HBM (24 bytes per sample) so that the two taps below work */
+int dn_debug_keep_k1(dn_ctx *ctx, int on);
 int dn_get_prefix_sums(dn_ctx *ctx, uint32_t read, double *sum /* [n+1] */, double *sumsq /* [n+1] */);
 int dn_get_tstats(dn_ctx *ctx, uint32_t read, float *t_short, float *t_long /* [n_samples] */);
 int dn_get_scrappie_events(dn_ctx *ctx, uint32_t read, uint32_t *start, float *length, float *mean /* [n_scrappie] */);

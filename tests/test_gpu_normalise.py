@@ -32,6 +32,7 @@ SPECS = [
 def ctx(model):
     c = hip.Context(0)
     c.load_pore_model(model, 0.14)
+    c.keep_k1(True)        # prefix sums / t-statistics normally never leave the segmentation kernels: ask for the taps
     yield c
     c.close()
 

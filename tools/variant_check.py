@@ -1,5 +1,5 @@
 """GPU: the alternative kernel forms kept behind environment switches must give bit-identical results to the defaults:
-DN_SCAN4=0 (one read per wavefront in the prefix scan), DN_CNN_BM256=0 (128-row
+DN_CNN_BM256=0 (128-row
 workgroups on the long-K convolutions), DN_CNN_SEP_WS=0 (single-role fused separable kernel for the 17-tap layers), DN_TS_FULL=1
 (Theil-Sen: the general first-level histogram path that a median slope outside [0.5, 2) takes).
 Each variant runs in its own process (the switches are read once per process)."""
@@ -15,7 +15,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     from dnascent_amd import cnn_model, hip, host, synth
     model = synth.pore_model()
     desc, blob, _ = cnn_model.default_model()
-    ctx = hip.Context(0); ctx.load_pore_model(model, 0.14); ctx.load_cnn(desc, blob)
+    ctx = hip.Context(0); ctx.load_pore_model(model, 0.14); ctx.load_cnn(desc, blob); ctx.keep_k1(True)
     b = host.ReadBatch()
     for seed, n, kw in SPECS:
         assert b.add_synth(synth.make_read(seed, n, model=model, **kw)) >= 0
@@ -43,7 +43,7 @@ def run(env):
 base = run({})
 print("default        ", base)
 ok = True
-for name, env in (("scan1", {"DN_SCAN4": "0"}), ("conv BM=128", {"DN_CNN_BM256": "0"}),
+for name, env in (("conv BM=128", {"DN_CNN_BM256": "0"}),
                   ("sep no-ws", {"DN_CNN_SEP_WS": "0"}), ("sep unfused", {"DN_CNN_FUSE": "0"}), ("theilsen full", {"DN_TS_FULL": "1"})):
     d = run(env)
     print("%-15s" % name, d, "same" if d == base else "DIFFERENT")
