@@ -529,7 +529,9 @@ __global__ __launch_bounds__(64) void k1_events(BatchDev B, unsigned *scratch_u3
 // launch helpers (called from dn_capi.hip)
 // ------------------------------------------------------------------------------------------------
 void k1_launch_scan(const BatchDev &B, hipStream_t st) {
-    // taps requested (B.psum != null): the same kernel also writes every prefix sum
+    // taps requested (B.psum != null): the same kernel also writes every prefix sum.  (A one-read-per-lane carry kernel -- no
+    // EXEC narrowing, 64 chains per wavefront -- was tried: with 16 wavefronts for 1 000 reads its uncoalesced 2-byte tile loads
+    // were fully exposed, 51 ms against 4.4.)
     if (B.psum) hipLaunchKernelGGL(k1_scan4<true>, dim3((B.n_reads + 3) / 4), dim3(64), 0, st, B);
     else hipLaunchKernelGGL(k1_scan4<false>, dim3((B.n_reads + 3) / 4), dim3(64), 0, st, B);
 }
