@@ -232,10 +232,36 @@ __device__ __forceinline__ SegState seg_initial() {
     return st;
 }
 
+// Where a lane's emitted peaks go: position + exact prefix sum.  HBM writes are write-through at 32-byte granularity, so a lane
+// that stored every peak on its own (4 + 8 bytes) would write 64 bytes for 12; peaks are parked in the lane's column of a small
+// LDS block and leave eight at a time as full 32- / 64-byte pieces.
+struct PeakSink {
+    unsigned *pk; double *pks;           // the chunk's slots in HBM (DN_SEG_PEAKCAP each, 32-byte aligned)
+    unsigned *bpos; double *bsum;        // this lane's column of the LDS block: entry k at [k * 64]
+    __device__ __forceinline__ void put(unsigned pos, double sum, unsigned &npk) {
+        const unsigned k = npk & 7u;
+        bpos[k * 64] = pos; bsum[k * 64] = sum;
+        npk++;
+        if ((npk & 7u) == 0u && npk <= DN_SEG_PEAKCAP) {
+            typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+            u32x4_ a = { bpos[0], bpos[64], bpos[128], bpos[192] }, b = { bpos[256], bpos[320], bpos[384], bpos[448] };
+            u32x4_ *dp = reinterpret_cast<u32x4_ *>(pk + (npk - 8u));
+            dp[0] = a; dp[1] = b;
+            double2 *ds = reinterpret_cast<double2 *>(pks + (npk - 8u));
+#pragma unroll
+            for (int q = 0; q < 4; q++) ds[q] = make_double2(bsum[(2 * q) * 64], bsum[(2 * q + 1) * 64]);
+        }
+    }
+    __device__ __forceinline__ void flush(unsigned npk) {                    // the last, partial group of eight
+        const unsigned m = min(npk, (unsigned)DN_SEG_PEAKCAP);
+        for (unsigned j = m & ~7u; j < m; j++) { pk[j] = bpos[(j & 7u) * 64]; pks[j] = bsum[(j & 7u) * 64]; }
+    }
+};
+
 // one sample of both detectors.  cur: the prefix sum sum[i]; a detector that moves its peak to i remembers it (ss / ls), and an
-// emitted peak is stored together with that sum -- create_event needs nothing else of the signal (event_detection.c:224-226)
+// emitted peak is recorded together with that sum -- create_event needs nothing else of the signal (event_detection.c:224-226)
 template <bool EMIT>
-__device__ __forceinline__ void seg_step(SegState &st, double &ss, double &ls, int i, float v1, float v2, double cur, unsigned *pk, double *pks, unsigned &npk) {
+__device__ __forceinline__ void seg_step(SegState &st, double &ss, double &ls, int i, float v1, float v2, double cur, PeakSink &sink, unsigned &npk) {
     const float peak_height = 0.2f;
     // short detector: window 3, threshold 1.4
     if (!(st.s.masked_to >= i)) {                                 // :140
@@ -251,7 +277,7 @@ __device__ __forceinline__ void seg_step(SegState &st, double &ss, double &ls, i
             }
             if (st.s.peak_val - v > peak_height && st.s.peak_val > 1.4f) st.s.valid = 1;
             if (st.s.valid && (i - st.s.peak_pos) > 1) {          // window_length / 2 == 1
-                if (EMIT) { if (npk < DN_SEG_PEAKCAP) { pk[npk] = (unsigned)st.s.peak_pos; pks[npk] = ss; } npk++; }
+                if (EMIT) sink.put((unsigned)st.s.peak_pos, ss, npk);
                 st.s.peak_pos = -1; st.s.peak_val = v; st.s.valid = 0;
             }
         }
@@ -266,7 +292,7 @@ __device__ __forceinline__ void seg_step(SegState &st, double &ss, double &ls, i
             if (v > st.l.peak_val) { st.l.peak_val = v; st.l.peak_pos = i; ls = cur; }
             if (st.l.peak_val - v > peak_height && st.l.peak_val > 9.0f) st.l.valid = 1;
             if (st.l.valid && (i - st.l.peak_pos) > 3) {          // window_length / 2 == 3
-                if (EMIT) { if (npk < DN_SEG_PEAKCAP) { pk[npk] = (unsigned)st.l.peak_pos; pks[npk] = ls; } npk++; }
+                if (EMIT) sink.put((unsigned)st.l.peak_pos, ls, npk);
                 st.l.peak_pos = -1; st.l.peak_val = v; st.l.valid = 0;
             }
         }
@@ -303,7 +329,7 @@ __device__ __forceinline__ bool seg_equal(const SegState &a, const SegState &b, 
 
 __device__ __forceinline__ void seg_body13(const float *row, const int A /* sample index of row[0] */, const int n, const int det_lo, const int det_hi,
                                            const int emit_lo, SegState *save_at_emit_lo, double &S, double &Q, double (&rs)[13], double (&rq)[13],
-                                           SegState &st, double &ss, double &ls, unsigned *pk, double *pks, unsigned &npk) {
+                                           SegState &st, double &ss, double &ls, PeakSink &sink, unsigned &npk) {
 #pragma unroll
     for (int j = 0; j < SEG_BODY; j++) {
         const double x = (double)row[j];
@@ -323,16 +349,16 @@ __device__ __forceinline__ void seg_body13(const float *row, const int A /* samp
         if (__builtin_expect(__any(bad), 0)) { bool x2 = false; t1 = tstat_from<3, true>(p3, p6, p9, v3, x2); t2 = tstat_from<6, true>(p0, p6, p12, v6, x2); }
         if (save_at_emit_lo && i0 == emit_lo) *save_at_emit_lo = st;         // wave-uniform position: the state at the chunk start
         if (on) {
-            if (i0 >= emit_lo) seg_step<true>(st, ss, ls, i0, t1, t2, p6.x, pk, pks, npk);
-            else { unsigned none = 0; seg_step<false>(st, ss, ls, i0, t1, t2, p6.x, pk, pks, none); }
+            if (i0 >= emit_lo) seg_step<true>(st, ss, ls, i0, t1, t2, p6.x, sink, npk);
+            else { unsigned none = 0; seg_step<false>(st, ss, ls, i0, t1, t2, p6.x, sink, none); }
         }
     }
 }
 
 // walks chunk `c` of read r on every lane that `have`s one.  REDO: all lanes walk the same chunk from state `st`.
 template <bool REDO>
-__device__ __forceinline__ void seg_walk(const BatchDev &B, float *tile /* [64 * SEG_PITCH] */, const int r, const int cbase, const int c, const bool have,
-                                         SegState &st, unsigned &npk) {
+__device__ __forceinline__ void seg_walk(const BatchDev &B, float *tile /* [64 * SEG_PITCH] */, unsigned *lds_pos /* [8 * 64] */, double *lds_sum /* [8 * 64] */,
+                                         const int r, const int cbase, const int c, const bool have, SegState &st, unsigned &npk) {
     const int lane = threadIdx.x;
     const uint64_t s0 = B.samp_off[r];
     const int n = (int)(B.samp_off[r + 1] - s0);
@@ -348,8 +374,7 @@ __device__ __forceinline__ void seg_walk(const BatchDev &B, float *tile /* [64 *
 #pragma unroll
     for (int k = 0; k < 13; k++) { rs[k] = S; rq[k] = Q; }       // never read by a live statistic: the detector starts >= 64 samples in
     double ss = 0.0, ls = 0.0;
-    unsigned *pk = B.chunk_peaks + (c0 + cc) * DN_SEG_PEAKCAP;
-    double *pks = B.chunk_psum + (c0 + cc) * DN_SEG_PEAKCAP;
+    PeakSink sink{ B.chunk_peaks + (c0 + cc) * DN_SEG_PEAKCAP, B.chunk_psum + (c0 + cc) * DN_SEG_PEAKCAP, lds_pos + lane, lds_sum + lane };
     const int chunk_lo = cc * DN_SEG_CHUNK;
     const int det_hi = have ? min(n, chunk_lo + DN_SEG_CHUNK) : 0;
     const int det_lo = REDO ? chunk_lo : max(1, chunk_lo - DN_SEG_WARM);     // sample 0 is always masked (:140)
@@ -372,12 +397,15 @@ __device__ __forceinline__ void seg_walk(const BatchDev &B, float *tile /* [64 *
         const float *rowp = tile + lane * SEG_PITCH;
 #pragma unroll 1
         for (int h = 0; h < SEG_TILE / SEG_BODY; h++)
-            seg_body13(rowp + SEG_BODY * h, my0 + t * SEG_TILE + SEG_BODY * h, n, det_lo, det_hi, chunk_lo, save, S, Q, rs, rq, st, ss, ls, pk, pks, npk);
+            seg_body13(rowp + SEG_BODY * h, my0 + t * SEG_TILE + SEG_BODY * h, n, det_lo, det_hi, chunk_lo, save, S, Q, rs, rq, st, ss, ls, sink, npk);
     }
+    if (have) sink.flush(npk);
 }
 
 __global__ __launch_bounds__(64) void k1_detect(BatchDev B) {
     __shared__ float tile[64 * SEG_PITCH];
+    __shared__ unsigned lds_pos[8 * 64];
+    __shared__ double lds_sum[8 * 64];
     const int r = blockIdx.y;
     const int lane = threadIdx.x;
     const uint64_t c0 = B.chunk_off[r];
@@ -388,7 +416,7 @@ __global__ __launch_bounds__(64) void k1_detect(BatchDev B) {
     const bool have = c < nch;
     SegState st = seg_initial();
     unsigned npk = 0;
-    seg_walk<false>(B, tile, r, cbase, c, have, st, npk);
+    seg_walk<false>(B, tile, lds_pos, lds_sum, r, cbase, c, have, st, npk);
     if (have) {
         B.chunk_npk[c0 + c] = npk;
         B.chunk_out[c0 + c] = st;
@@ -408,7 +436,9 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
 }
 
 __global__ __launch_bounds__(64) void k1_events(BatchDev B, unsigned *scratch_u32 /* aliases cl_rank: kept-index list */) {
-    __shared__ float tile[64 * SEG_PITCH];                        // the exact redo's signal tile
+    __shared__ float tile[64 * SEG_PITCH];                        // the exact redo's signal tile ...
+    __shared__ unsigned lds_pos[8 * 64];                          // ... and peak staging
+    __shared__ double lds_sum[8 * 64];
     __shared__ unsigned pre[4096];                                // exclusive prefix of peaks per chunk (<= 4M samples / read)
     const int r = blockIdx.x;
     const int lane = threadIdx.x;
@@ -436,7 +466,7 @@ __global__ __launch_bounds__(64) void k1_events(BatchDev B, unsigned *scratch_u3
             if (seg_equal(tru, in, c * DN_SEG_CHUNK)) { tru = B.chunk_out[c0 + c]; continue; }
             SegState st = tru;
             unsigned npk = 0;
-            seg_walk<true>(B, tile, r, 0, c, true, st, npk);
+            seg_walk<true>(B, tile, lds_pos, lds_sum, r, 0, c, true, st, npk);
             if (lane == 0) { B.chunk_npk[c0 + c] = npk; B.chunk_out[c0 + c] = st; }
             tru = st;
             rechecks++;
