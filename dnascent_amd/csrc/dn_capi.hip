@@ -82,12 +82,13 @@ struct CnnLane {
 static std::mutex g_lane_mu;
 static CnnLane *g_lane[64][DN_MAX_LANES] = { { nullptr } };
 static unsigned g_ctx_seq = 0;
-// how many lanes a device has (DN_CNN_LANES, default 2): contexts are dealt to them round-robin.  One lane serialises every
-// network of the process (least memory); measured on 4 x 500 x 50 kb in flight, two lanes are faster -- the other lane's kernels fill the
-// gaps a lone network leaves while the CUs' LDS is held by the one-wavefront-per-read stages
+// how many lanes a device has (DN_CNN_LANES, default 4): contexts are dealt to them round-robin.  One lane serialises every
+// network of the process (least memory: one set of activation buffers); measured with 4 x 500 x 50 kb reads in flight on one box:
+// 1 lane 466, 2 lanes 478, 4 lanes 493 Msamples/s -- a second network's kernels fill the gaps a lone one leaves while the CUs' LDS
+// is held by the one-wavefront-per-read stages of the other batches
 static unsigned lane_count() {
     const char *e = getenv("DN_CNN_LANES");
-    const unsigned v = e ? (unsigned)strtoul(e, nullptr, 10) : 2u;
+    const unsigned v = e ? (unsigned)strtoul(e, nullptr, 10) : 4u;
     return std::min<unsigned>(std::max<unsigned>(v, 1u), DN_MAX_LANES);
 }
 
@@ -1182,6 +1183,8 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_ready, 0));
     HIPCHK(c, hipMemcpyAsync(c->cnn_rowoff.p, row_off, n * sizeof(unsigned), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->cnn_iooff.p, c->p_cnn_iooff, n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    // (the two small copies above execute after the hand-over wait; the profiling event below is recorded behind them, so the
+    // measured duration is the network's own and does not include the wait for the batch's eventalign or for the lane)
     {
     Timed t(c, DN_K_CNN, st);
     for (const Pass &ps : passes) {
