@@ -1043,6 +1043,8 @@ int k3_run(const CnnRun &c, hipStream_t st) {
 #define CONV_GO_BF(BN_, ADD_) do { if (c.pieces == 3) CONV_GO_SP(BN_, ADD_, 3); else if (BN_ == 128 && o.k >= 9 && o.cin >= 128 && rows % 256 == 0 && k3_bm256_enabled()) CONV_GO_BM(128, ADD_); \
         else CONV_GO_SP(BN_, ADD_, 2); } while (0)
                 if (c.wts_split) {
+                    // (256-column workgroups -- each wavefront 64 rows x 128 columns, 12 LDS fragment reads per 24 MFMAs instead of 8 per 12 --
+                    // were measured: 308-356 VGPRs, one workgroup per CU, 17 x 128 -> 256: 4.37 ms against 3.58; not kept)
                     if (o.cout % 128 == 0) { if (add) CONV_GO_BF(128, true); else CONV_GO_BF(128, false); }
                     else { if (add) CONV_GO_BF(64, true); else CONV_GO_BF(64, false); }
                 } else if (o.cout % 128 == 0) { if (add) CONV_GO(128, 2, true); else CONV_GO(128, 2, false); }
