@@ -46,7 +46,8 @@ struct VitConstsH { double D2D, D2M, I2M, M2D, M2I, I2I; double c, d2, rd2, logc
 struct VitReadH { double iM2M, eM2M, eM2MorD, eOrI; int fail, pad; };   // fail: eln() of a negative number (the reference throws NegativeLog)
 struct EaDevH { unsigned *coord, *qidx, *ridx; int *indel; unsigned *nsig; float *sig, *core, *resid;
                 unsigned *win_ref, *win_len, *win_T; double *win_score;
-                unsigned *al_coord, *al_rpos; double *al_val; unsigned char *al_kind; const unsigned long long *al_off; unsigned *al_n; };
+                unsigned *al_coord, *al_rpos; double *al_val; unsigned char *al_kind; const unsigned long long *al_off; unsigned *al_n;
+                unsigned char *redo; };
 void k2b_rowcap_launch(const BatchDev &, unsigned long long *, hipStream_t);
 void k2b_emission_tap_launch(const double *, const double *, double *, unsigned, const void *, hipStream_t);
 // k_collect.hip: per-read call counts (centre base T), their exclusive scan, ordered compaction of the per-call outputs
@@ -237,6 +238,22 @@ static int lane_grow(dn_ctx *c, CnnLane *L, DevBuf &b, size_t bytes) {
     b.cap = bytes; L->bytes += bytes;
     return DN_OK;
 }
+// CU partition (DN_FRONT_CUS = n, 0 = off).  The per-batch stages before the CNN are latency-bound chains with one wavefront (or one
+// small workgroup) per read: they need few CUs but hold LDS for a long time (k2b_eventalign: 50 KB per wavefront for ~90 ms), which
+// keeps the network's large workgroups (k3_sep_ws: 155 KB) off every CU they sit on.  With a CU mask the contexts' streams are
+// confined to n CUs (spread over the XCDs) and the CNN lanes to the others.
+static unsigned front_cus() {
+    const char *e = getenv("DN_FRONT_CUS");
+    const unsigned v = e ? (unsigned)strtoul(e, nullptr, 10) : 0u;
+    return std::min(v, 192u);
+}
+static void front_mask(uint32_t (&m)[8], bool complement) {
+    for (int i = 0; i < 8; i++) m[i] = 0u;
+    const unsigned n = front_cus();
+    for (unsigned k = 0; k < n; k++) { const unsigned bit = (k % 8u) * 32u + (k / 8u); m[bit >> 5] |= 1u << (bit & 31u); }
+    if (complement) for (int i = 0; i < 8; i++) m[i] = ~m[i];
+}
+
 static CnnLane *lane_get(dn_ctx *c) {
     std::lock_guard<std::mutex> lk(g_lane_mu);
     if (c->device < 0 || c->device >= 64) return nullptr;
@@ -244,7 +261,13 @@ static CnnLane *lane_get(dn_ctx *c) {
         CnnLane *L = new CnnLane();
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = numerically largest = lowest priority
-        if (hipStreamCreateWithPriority(&L->stream, hipStreamNonBlocking, lo) != hipSuccess) { delete L; return nullptr; }
+        bool made = false;
+        if (front_cus()) {
+            uint32_t m[8]; front_mask(m, true);
+            made = hipExtStreamCreateWithCUMask(&L->stream, 8, m) == hipSuccess;
+            if (!made) (void)hipGetLastError();
+        }
+        if (!made && hipStreamCreateWithPriority(&L->stream, hipStreamNonBlocking, lo) != hipSuccess) { delete L; return nullptr; }
         g_lane[c->device][c->lane_id] = L;
     }
     return g_lane[c->device][c->lane_id];
@@ -315,7 +338,13 @@ int dn_ctx_create(int device, void *hip_stream, dn_ctx **out) {
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         const char *pe = getenv("DN_STREAM_PRIO");
         const bool prio = !(pe && pe[0] == '0');
-        if ((prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return DN_ERR_HIP; }
+        bool made = false;
+        if (front_cus()) {
+            uint32_t m[8]; front_mask(m, false);
+            made = hipExtStreamCreateWithCUMask(&c->stream, 8, m) == hipSuccess;
+            if (!made) { (void)hipGetLastError(); fprintf(stderr, "dnascent_hip: CU-masked stream unavailable, using a plain one\n"); }
+        }
+        if (!made && (prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return DN_ERR_HIP; }
         c->own_stream = true;
     }
     if (hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) {
@@ -536,7 +565,7 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
         (rc = dalloc(c, &c->ea.indel, (size_t)NR)) || (rc = dalloc(c, &c->ea.nsig, (size_t)NR)) || (rc = dalloc(c, &c->ea.sig, (size_t)NR * DN_RAWDEPTH)) ||
         (rc = dalloc(c, &c->ea.core, (size_t)NR)) || (rc = dalloc(c, &c->ea.resid, (size_t)NR)) || (rc = dalloc(c, &c->ea.win_ref, (size_t)NR)) ||
         (rc = dalloc(c, &c->ea.win_len, (size_t)NR)) || (rc = dalloc(c, &c->ea.win_T, (size_t)NR)) || (rc = dalloc(c, &c->ea.win_score, (size_t)NR)) ||
-        (rc = dalloc(c, &c->d_vitread, (size_t)n)) || (rc = dalloc(c, &c->d_probs, (size_t)NR * 3))) return rc;
+        (rc = dalloc(c, &c->d_vitread, (size_t)n)) || (rc = dalloc(c, &c->d_probs, (size_t)NR * 3)) || (rc = dalloc(c, &c->ea.redo, (size_t)n))) return rc;
     c->max_ref = 0;
     for (uint32_t r = 0; r < n; r++) c->max_ref = std::max<unsigned>(c->max_ref, (unsigned)(c->h_ref_off[r + 1] - c->h_ref_off[r]));
     HIPCHK(c, hipMemsetAsync(B.res, 0, n * sizeof(ReadRes), c->stream));

@@ -17,7 +17,11 @@
 // arg-max decisions are compared exactly.
 #include "dn_dev.h"
 
-#define VT_TMAX 512          // observations per window held in LDS (a window spans <= 65 positions, ~2.2 events each)
+#define VT_TMAX 512          // observations per window the lattice is sized for at most (a window spans <= 65 positions, ~2.2 events each)
+#define VT_TFAST 224         // ... and in the first pass: a window of the synthetic workloads holds 110-160.  The backtrace block is
+                             // (T + 1) x 66 bytes of LDS per wavefront: 34 KB at 512 kept the occupancy at 3 wavefronts per CU and
+                             // the CNN's large workgroups off every CU an eventalign wavefront sat on; at 224 it is 15 KB (22 KB in
+                             // all).  A read with a longer window is redone by a second launch of the 512 variant.
 #define VT_NS 66             // backtrace row stride (positions per window <= 65)
 
 struct VitConsts {           // alignment.cpp:199-204 (host libm), normalPDF constants, deletion chain before the first event
@@ -33,6 +37,7 @@ struct EaDev {               // outputs, all at ref_off[r] (capacity = reference
     // `DNAscent align` table (alignment.cpp:697-733), optional (al_val == nullptr: not requested): one row per raw sample of
     // every event labelled M and of every event labelled I before the window's last match; rows of read r start at al_off[r]
     unsigned *al_coord, *al_rpos; double *al_val; unsigned char *al_kind; const unsigned long long *al_off; unsigned *al_n;
+    unsigned char *redo;     // [n_reads] set by the VT_TFAST pass for reads that need the VT_TMAX pass
 };
 
 // log(0) is NaN in the reference (probability.cpp) and every use of it is one of: NaN + x = NaN, and lnGreaterThan
@@ -93,16 +98,18 @@ __device__ __forceinline__ double emission(double x, double mu, const VitConsts 
     return e;
 }
 
+template <int TMAX>
 __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const VitRead *vrs, VitConsts vc) {
-    __shared__ double xs[VT_TMAX];                        // scaled observations of the window
-    __shared__ unsigned tk_start[VT_TMAX], tk_len[VT_TMAX];   // raw span of each taken event (event.raw, reads.h:68-72)
-    __shared__ unsigned ev_slot[VT_TMAX], ev_cnt0[VT_TMAX];   // label pass: position slot of an M-labelled event / samples before it
+    __shared__ double xs[TMAX];                           // scaled observations of the window
+    __shared__ unsigned tk_start[TMAX], tk_len[TMAX];     // raw span of each taken event (event.raw, reads.h:68-72)
+    __shared__ unsigned ev_slot[TMAX], ev_cnt0[TMAX];     // label pass: position slot of an M-labelled event / samples before it
     __shared__ unsigned ps_p[VT_NS], ps_cnt[VT_NS];           // positions created by this window: lattice position, sample count
-    __shared__ unsigned short evlab[VT_TMAX];             // label of the state that emitted observation t: state << 8 | position
-    __shared__ unsigned char bt[(VT_TMAX + 1) * VT_NS];   // backtrace codes: I 2 bits | M 3 bits | D 2 bits
-    __shared__ unsigned ev_aoff[VT_TMAX];                 // align table: first row of each printed event (0xffffffff: not printed)
+    __shared__ unsigned short evlab[TMAX];                // label of the state that emitted observation t: state << 8 | position
+    __shared__ unsigned char bt[(TMAX + 1) * VT_NS];      // backtrace codes: I 2 bits | M 3 bits | D 2 bits
+    __shared__ unsigned ev_aoff[TMAX];                    // align table: first row of each printed event (0xffffffff: not printed)
     const int r = blockIdx.x;
     const int lane = threadIdx.x;
+    if (TMAX == VT_TMAX && !O.redo[r]) return;            // second pass: only the reads the first one handed over
     ReadRes &R = B.res[r];
     const VitRead vr = vrs[r];
     if (R.status == 0 && vr.fail) {                       // eln() of a negative number: the reference throws NegativeLog (probability.cpp:45)
@@ -172,13 +179,16 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             const bool take = inw && (0. < mean) && (mean < 250.);      // :624
             const unsigned long long tm = __ballot(take);
             const unsigned p = nt + (unsigned)__popcll(tm & ((1ull << lane) - 1ull));
-            if (take && p < VT_TMAX) { tk_start[p] = ev_start[e_idx]; tk_len[p] = ev_len[e_idx]; xs[p] = (mean - shift) / scale; }
+            if (take && p < (unsigned)TMAX) { tk_start[p] = ev_start[e_idx]; tk_len[p] = ev_len[e_idx]; xs[p] = (mean - shift) / scale; }
             nt += (unsigned)__popcll(tm);
             if (stopm) break;
         }
         const int indel = (int)(qhi - qlo) - (int)(W - DN_K + 1);       // :635-638
         if (nt < 2) { ri += W; continue; }                // :641
-        if (nt > VT_TMAX) { fail = 6; break; }
+        if (nt > (unsigned)TMAX) {
+            if (TMAX < VT_TMAX) { if (lane == 0) O.redo[r] = 1; return; }     // wave-uniform: the whole read again in the large variant
+            fail = 6; break;
+        }
         const int T = (int)nt;
         __syncthreads();
         const int coord0 = is_rev ? (ref_end - ri - DN_K / 2) : (ref_start + ri + DN_K / 2);
@@ -451,6 +461,8 @@ void k2b_emission_tap_launch(const double *x, const double *mu, double *out, uns
 void k2b_launch(const BatchDev &B, const void *ea, const void *vr, const void *vc, unsigned max_ref, hipStream_t st) {
     const EaDev O = *reinterpret_cast<const EaDev *>(ea);
     const VitConsts V = *reinterpret_cast<const VitConsts *>(vc);
-    hipLaunchKernelGGL(k2b_eventalign, dim3(B.n_reads), dim3(64), 0, st, B, O, (const VitRead *)vr, V);
+    hipMemsetAsync(O.redo, 0, (size_t)B.n_reads, st);
+    hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, dim3(B.n_reads), dim3(64), 0, st, B, O, (const VitRead *)vr, V);
+    hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), 0, st, B, O, (const VitRead *)vr, V);
     hipLaunchKernelGGL(k2b_features, dim3((max_ref + 255) / 256, B.n_reads), dim3(256), 0, st, B, O);
 }
