@@ -298,14 +298,32 @@ def main():
                 "reads_per_step": rps, "bases_per_read": bases, "reads_per_gpu": args.steps * rps, "samples_per_gpu": int(st.samples),
                 "reads_passing_qc_per_gpu": int(st.reads_ok), "calls_per_gpu": int(st.calls),
                 "parallelism": "reads sharded, %d rank(s), %d batches in flight per GPU, one host thread per rank" % (world, nctx)}
-            out["roofline"] = {"bound": "mfma", "kernel": "k3_cnn (all layers of one batch)", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": None, "algorithmic_flops_per_launch": flops, "mean_launch_ms": cnn_ms / max(cnn_n, 1),
-                               "issued_frac": ach * issued / peak,
-                               "note": "achieved = algorithmic fp32 flops (2 x MACs x positions) / launch time; every fp32 product is issued as %g "
-                                       "16-bit MFMA products (issued_frac counts those)" % issued}
+            # ---- the dominant kernel of the run: k3_sep_ws, the 17-tap separable layers 128 -> 256 and 5 x 256 -> 256 (most kernel time
+            #      in profiles/r02_kernel_stats.csv).  Algorithmic flops of ALL its launches in the timed region = 2 x (17 cin + cin cout)
+            #      x positions, summed over those layers; divided by the summed HIP-event durations of those launches.
+            ws = [(o, cnn_desc["ops"][i + 1]) for i, o in enumerate(cnn_desc["ops"]) if o["op"] == "dwconv" and o["k"] == 17 and cnn_desc["ops"][i + 1]["cout"] == 256]
+            ws_flops = 2.0 * sum(d["k"] * d["c"] + p["cin"] * p["cout"] for d, p in ws) * float(st.positions)
+            ws_ms, ws_n = prof.get("k3_sep_ws", (0.0, 0))
+            if cnn_math == "f16x3" and ws_n:
+                ws_ach = ws_flops / (ws_ms / 1e3) / 1e12
+                out["roofline"] = {"bound": "mfma", "kernel": "k3_sep_ws<256, 17> (SeparableConv1D 17 taps -> 256 channels, depthwise fused into the pointwise GEMM)",
+                                   "achieved": ws_ach, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s", "frac": ws_ach / MFMA_F16_PEAK, "traffic": None,
+                                   "launches": ws_n, "mean_launch_ms": ws_ms / ws_n, "algorithmic_flops_per_launch": ws_flops / ws_n,
+                                   "issued_frac": ws_ach * 3.0 / MFMA_F16_PEAK,
+                                   "note": "achieved = algorithmic fp32 flops of the layer / launch time (HIP events around every launch, on the CNN lane's "
+                                           "stream); every fp32 product is issued as 3 fp16 MFMA products (issued_frac counts those); the layer's "
+                                           "activation I/O (2 KB per position, fp32) bounds it at ~0.5 ms per 1.2 M positions from HBM"}
+            roof_net = {"bound": "mfma", "kernel": "k3_cnn (all layers of one batch = one dn_run_cnn)", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                        "frac": ach / peak, "traffic": None, "algorithmic_flops_per_launch": flops, "mean_launch_ms": cnn_ms / max(cnn_n, 1),
+                        "issued_frac": ach * issued / peak,
+                        "note": "achieved = algorithmic fp32 flops (2 x MACs x positions) / launch time; every fp32 product is issued as %g "
+                                "16-bit MFMA products (issued_frac counts those)" % issued}
             if "k3_cnn" in solo:
-                out["roofline"]["solo_launch_ms"] = solo["k3_cnn"]
-                out["roofline"]["solo_frac"] = flops / (solo["k3_cnn"] / 1e3) / 1e12 / peak
+                roof_net["solo_launch_ms"] = solo["k3_cnn"]
+                roof_net["solo_frac"] = flops / (solo["k3_cnn"] / 1e3) / 1e12 / peak
+            out["roofline_network"] = roof_net
+            if "roofline" not in out:
+                out["roofline"] = roof_net
             out["roofline_banded"] = roof_banded
             out["host"] = {"datagen_s": t_gen, "upload_s": st.seconds_upload, "collect_wait_s": st.seconds_collect, "emit_s": st.seconds_emit,
                            "gather_s": gather_s, "emission": {"records_per_s": st.calls / st.seconds_emit if st.seconds_emit > 0 else None,

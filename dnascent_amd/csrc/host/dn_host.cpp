@@ -359,7 +359,7 @@ int streamDetect(dn_ctx **ctxs, int n_ctx, ReadBatch **batches, int n_batches, b
             S.seconds_collect += b - a;
             S.reads += res.n_reads; S.calls += res.n_calls; S.samples += B.totalSamples();
             B.summary.assign(res.summary, res.summary + res.n_reads);
-            for (uint32_t r = 0; r < res.n_reads; r++) S.reads_ok += res.summary[r].status == DN_READ_OK;
+            for (uint32_t r = 0; r < res.n_reads; r++) if (res.summary[r].status == DN_READ_OK) { S.reads_ok++; S.positions += res.summary[r].n_positions; }
             if (keep) {
                 for (uint32_t r = 0; r < res.n_reads; r++) keep->read_calls.push_back(res.call_off[r + 1] - res.call_off[r]);
                 keep->record_bytes.resize(keep->read_calls.size(), 0);     // filled below when records are formatted

@@ -133,7 +133,7 @@ struct StreamKeep {                     // optional: the binary per-call results
 };
 struct StreamStats {
     double seconds_total, seconds_upload, seconds_collect, seconds_emit;   // wall time of the call / spent inside uploads, collects, emission
-    uint64_t reads, reads_ok, samples, calls, bytes_out;
+    uint64_t reads, reads_ok, samples, calls, bytes_out, positions;        // positions: r.refCoordToAP entries of the passing reads (CNN rows)
 };
 int streamDetect(dn_ctx **ctxs, int n_ctx, ReadBatch **batches, int n_batches, bool emit, const char *outPath, const char *header,
                  StreamStats *st, StreamKeep *keep = nullptr);

@@ -99,6 +99,11 @@ __global__ __launch_bounds__(256) void kc_pack(BatchDev B, CollectDev C) {
     }
 }
 
+__global__ void kc_nop() {}
+// an empty kernel: a profiling event recorded behind it carries the time at which the stream really got past a preceding
+// hipStreamWaitEvent (a bare event record after the wait is stamped early)
+void kc_launch_nop(hipStream_t st) { hipLaunchKernelGGL(kc_nop, dim3(1), dim3(1), 0, st); }
+
 void kc_launch_npos(const BatchDev &B, unsigned *npos, hipStream_t st) {
     hipLaunchKernelGGL(kc_npos, dim3((B.n_reads + 255) / 256), dim3(256), 0, st, B, npos);
 }
