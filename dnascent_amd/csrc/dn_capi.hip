@@ -34,7 +34,8 @@ struct CnnRun { const dn_cnn_op *ops; int n_ops; const float *wts; float *buf[8]
                  const float *core, *resid, *sig; float *probs; unsigned max_pos; const uint16_t *wts_split; const int64_t *wb_off;
                  int pieces; const float *post; unsigned *range_flag;
                  unsigned n_pass_pos; uint8_t *enc_len; unsigned *enc_hist; uint64_t *perm_src; unsigned *perm_row;
-                 void (*mark)(void *who, int begin, hipStream_t st); void *mark_who; };
+                 void (*mark)(void *who, int begin, hipStream_t st); void *mark_who;
+                 unsigned *row_off_w; int *live; };
 int k3_run(const CnnRun &, hipStream_t);
 struct HmmConstsH { double D2D, D2M, I2M, M2D, M2I, I2I, ln025, ln05; };
 struct HmmReadH { double iM2M, eM2M, endM; };
@@ -78,7 +79,7 @@ struct ProfRec { int k; hipEvent_t a, b; };
 struct CnnLane {
     hipStream_t stream = nullptr;
     std::mutex mu;                                       // enqueue order == execution order
-    DevBuf buf[8], valid, enclen, enchist, permsrc, permrow;
+    DevBuf buf[8], valid, enclen, enchist, permsrc, permrow, live;
     size_t bytes = 0;
 };
 #define DN_MAX_LANES 16
@@ -1212,15 +1213,14 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned
         if ((rc = lane_grow(c, L, L->buf[b], (size_t)max_rows * 256 * sizeof(float)))) return rc;
     if ((rc = lane_grow(c, L, L->enclen, (size_t)max_rows)) || (rc = lane_grow(c, L, L->enchist, 64 * sizeof(unsigned))) ||
         (rc = lane_grow(c, L, L->permsrc, (size_t)max_rows * sizeof(uint64_t))) || (rc = lane_grow(c, L, L->permrow, (size_t)max_rows * sizeof(unsigned))) ||
-        (rc = lane_grow(c, L, L->valid, (size_t)max_rows))) return rc;
+        (rc = lane_grow(c, L, L->valid, (size_t)max_rows)) || (rc = lane_grow(c, L, L->live, 256))) return rc;
     if ((rc = dgrow(c, c->cnn_rowoff, n * sizeof(unsigned))) || (rc = dgrow(c, c->cnn_iooff, n * sizeof(uint64_t)))) return rc;
     if (!c->p_cnn_flag) HIPCHK(c, hipHostMalloc((void **)&c->p_cnn_flag, sizeof(unsigned), hipHostMallocDefault));
     // hand the batch over to the lane: everything the context's stream has enqueued so far (eventalign, the position counts)
     hipStream_t st = L->stream;
     HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_ready, 0));
-    HIPCHK(c, hipMemcpyAsync(c->cnn_rowoff.p, row_off, n * sizeof(unsigned), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->cnn_iooff.p, c->p_cnn_iooff, n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->cnn_iooff.p, c->p_cnn_iooff, n * sizeof(uint64_t), hipMemcpyHostToDevice, st));     // (row offsets: k3_layout, on the device)
     if (c->prof) kc_launch_nop(st);     // the profiling event below must be stamped AFTER the hand-over wait: behind a kernel it is
     {
     Timed t(c, DN_K_CNN, st);
@@ -1238,6 +1238,7 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned
         run.perm_src = (uint64_t *)L->permsrc.p; run.perm_row = (unsigned *)L->permrow.p;
         run.core = d_core; run.resid = d_resid; run.sig = d_sig; run.probs = d_probs; run.max_pos = ps.max_pos;
         run.mark = c->prof ? cnn_mark : nullptr; run.mark_who = c;
+        run.row_off_w = (unsigned *)c->cnn_rowoff.p; run.live = (int *)L->live.p;
         // fp16 pieces are only valid while every activation fits fp16: the kernels raise range_flag otherwise and the pass is
         // repeated with bf16 pieces (same result contract, 2x the matrix work) -- never a silently wrong answer
         for (int math = (c->cnn_math == DN_CNN_MATH_F16X3 && c->cnn_f16_off) ? DN_CNN_MATH_BF16X6 : c->cnn_math;;) {

@@ -33,6 +33,25 @@ struct CnnRows {             // per batch
     const uint64_t *io_off;  // [n_seq] first position of each sequence in the input tensors / the probability output
 };
 
+// Row layout of one pass, computed ON THE DEVICE from the live position counts: sequence r owns n_pos[r] rows + CNN_PAD zero rows, the
+// sequences of the pass lie end to end behind CNN_PAD leading rows, and the live row count (rounded up to 256) goes to *live.  The host
+// only knows the BOUND of every count (it sizes the buffers and the grids from it); workgroups beyond the live rows return at once.
+// One wavefront; a pass holds at most a few thousand sequences.
+__global__ __launch_bounds__(64) void k3_layout(unsigned *row_off, const unsigned *n_pos, unsigned r0, unsigned r1, int *live) {
+    const int lane = threadIdx.x;
+    unsigned rows = CNN_PAD;
+    for (unsigned b = r0; b < r1; b += 64) {
+        const unsigned r = b + lane;
+        const unsigned mine = r < r1 ? n_pos[r] + CNN_PAD : 0u;
+        unsigned incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        if (r < r1) row_off[r] = rows + incl - mine;
+        rows += __shfl(incl, 63);
+    }
+    if (lane == 0) *live = (int)((rows + 255u) / 256u * 256u);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // v_exp_f32 / v_rcp_f32 are 1-ulp instructions: |error| of the gates ~2e-7, far inside the 1e-4 bar on the probabilities
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
@@ -231,8 +250,9 @@ static inline unsigned conv_grid(unsigned rows, int cout, int BN, int BM = CNN_B
 template <int BN, int NBUF, bool ADD>
 __global__ __launch_bounds__(256) void k3_conv(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wt,
                                                   const float *__restrict__ scale, const float *__restrict__ shift,
-                                                  const float *__restrict__ Add, const uint8_t *__restrict__ valid, int rows, int k,
+                                                  const float *__restrict__ Add, const uint8_t *__restrict__ valid, int rows, const int *__restrict__ live, int k,
                                                   int cin, int cout, int relu) {
+    rows = min(rows, *live);                              // the grid covers the BOUND of the pass's rows; the live count is on the device
     __shared__ __attribute__((aligned(16))) float As[NBUF][CNN_BM * CNN_PITCH];
     __shared__ __attribute__((aligned(16))) float Bs[NBUF][BN * CNN_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -367,8 +387,9 @@ template <int NP> __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32
 template <int BN, bool ADD, int NP, int BM = CNN_BM>
 __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const float *__restrict__ X, float *__restrict__ Y, const uint16_t *__restrict__ Wb,
                                                      const float *__restrict__ scale, const float *__restrict__ shift,
-                                                     const float *__restrict__ Add, const uint8_t *__restrict__ valid, int rows, int k,
+                                                     const float *__restrict__ Add, const uint8_t *__restrict__ valid, int rows, const int *__restrict__ live, int k,
                                                      int cin, int cout, int relu, float post, unsigned *range_flag) {
+    rows = min(rows, *live);
     __shared__ __attribute__((aligned(16))) uint16_t As[NP][(BM + 16) * CNN_BP];
     __shared__ __attribute__((aligned(16))) uint16_t Bs[NP][BN * CNN_BP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -503,8 +524,9 @@ template <int BN, int KW, bool ADD, int NP>
 __global__ __launch_bounds__(256) void k3_sep_split(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wd,
                                                     const uint16_t *__restrict__ Wb, const float *__restrict__ scale,
                                                     const float *__restrict__ shift, const float *__restrict__ Add,
-                                                    const uint8_t *__restrict__ valid, int rows, int cin, int cout, int relu, float post,
+                                                    const uint8_t *__restrict__ valid, int rows, const int *__restrict__ live, int cin, int cout, int relu, float post,
                                                     unsigned *range_flag) {
+    rows = min(rows, *live);
     constexpr int XROWS = CNN_BM + KW - 1;
     constexpr int NLD = (XROWS * 8 + 255) / 256;           // float4 loads per thread for one raw tile
     __shared__ __attribute__((aligned(16))) float Xr[XROWS * SEP_XP];
@@ -671,8 +693,9 @@ template <int BN, int KW, bool ADD, int NP>
 __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wd,
                                                  const uint16_t *__restrict__ Wb, const float *__restrict__ scale,
                                                  const float *__restrict__ shift, const float *__restrict__ Add,
-                                                 const uint8_t *__restrict__ valid, int rows, int cin, int cout, int relu, float post,
+                                                 const uint8_t *__restrict__ valid, int rows, const int *__restrict__ live, int cin, int cout, int relu, float post,
                                                  unsigned *range_flag) {
+    rows = min(rows, *live);
     constexpr int SROWS = 32 + KW - 1;                     // raw rows a producer wave needs for its 32 output rows
     constexpr int NLD = (SROWS * 8 + 63) / 64;             // float4 loads per lane for one raw slice
     __shared__ __attribute__((aligned(16))) float Xr[4][SROWS * SEP_XPW];
@@ -852,7 +875,8 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
 #define DW_ROWS 16
 template <int KW>
 __global__ __launch_bounds__(256) void k3_dwconv(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wt,
-                                                 const uint8_t *__restrict__ valid, int rows, int c) {
+                                                 const uint8_t *__restrict__ valid, int rows, const int *__restrict__ live, int c) {
+    rows = min(rows, *live);
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int c4 = c >> 2;
     const long r0 = (long)(idx / c4) * DW_ROWS;
@@ -884,9 +908,10 @@ __global__ __launch_bounds__(256) void k3_dwconv(const float *__restrict__ X, fl
     }
 }
 
-__global__ __launch_bounds__(256) void k3_add_relu(const float *__restrict__ A, const float *__restrict__ Bv, float *__restrict__ Y, size_t n4) {
+__global__ __launch_bounds__(256) void k3_add_relu(const float *__restrict__ A, const float *__restrict__ Bv, float *__restrict__ Y, size_t n4,
+                                                   const int *__restrict__ live, int c4) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
+    if (i >= n4 || i >= (size_t)*live * (size_t)c4) return;
     const float4 a = reinterpret_cast<const float4 *>(A)[i], b = reinterpret_cast<const float4 *>(Bv)[i];
     reinterpret_cast<float4 *>(Y)[i] = make_float4(fmaxf(a.x + b.x, 0.f), fmaxf(a.y + b.y, 0.f), fmaxf(a.z + b.z, 0.f), fmaxf(a.w + b.w, 0.f));
 }
@@ -947,6 +972,7 @@ struct CnnRun {
     uint8_t *enc_len; unsigned *enc_hist; uint64_t *perm_src; unsigned *perm_row;   // device scratch of the encoder's counting sort
     // profiling (null = off): HIP event pairs around every launch of the network's dominant kernel, the 17-tap separable layer
     void (*mark)(void *who, int begin, hipStream_t st); void *mark_who;
+    unsigned *row_off_w; int *live;   // device: this pass's row offsets (written by k3_layout) and its live row count
 };
 
 static bool k3_sep_ws_enabled() { static const bool on = !(getenv("DN_CNN_SEP_WS") && atoi(getenv("DN_CNN_SEP_WS")) == 0); return on; }
@@ -977,7 +1003,7 @@ template <int BN, bool ADD, int NP>
 static int k3_launch_sep(const CnnRun &c, int i, const float *in, float *out, const float *add, hipStream_t st) {
     const dn_cnn_op &d = c.ops[i], &o = c.ops[i + 1];
     const unsigned rows = c.rows.rows;
-#define SEP_ARGS in, out, c.wts + d.w, c.wts_split + c.wb_off[i + 1], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, \
+#define SEP_ARGS in, out, c.wts + d.w, c.wts_split + c.wb_off[i + 1], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, c.live, \
         o.cin, o.cout, o.relu, c.post[i + 1], c.range_flag
 #define SEP_GO(KW_) hipLaunchKernelGGL((k3_sep_split<BN, KW_, ADD, NP>), dim3(conv_grid(rows, o.cout, BN)), dim3(256), 0, st, SEP_ARGS)
     if (NP == 2 && d.k == 17 && o.cout % 256 == 0 && k3_sep_ws_enabled()) {
@@ -1022,6 +1048,7 @@ int k3_run(const CnnRun &c, hipStream_t st) {
         }
         switch (o.op) {
             case DN_CNN_ENCODE_GRU:
+                hipLaunchKernelGGL(k3_layout, dim3(1), dim3(64), 0, st, c.row_off_w, c.rows.n_pos, c.rows.r0, c.rows.r1, c.live);
                 hipMemsetAsync(pb[o.dst], 0, (size_t)rows * 64 * sizeof(float), st);
                 hipMemsetAsync(c.enc_hist, 0, 2 * ENC_BINS * sizeof(unsigned), st);
                 hipLaunchKernelGGL(k3_encode_len, dim3((c.max_pos + 255) / 256, c.rows.r1 - c.rows.r0), dim3(256), 0, st, c.sig, c.rows, c.enc_len, c.enc_hist);
@@ -1037,12 +1064,12 @@ int k3_run(const CnnRun &c, hipStream_t st) {
             {
                 const float *add = o.op == DN_CNN_CONV_ADD ? pb[o.a] : nullptr;          // fused residual join: y = act(conv + buf[a])
 #define CONV_GO(BN_, NBUF_, ADD_) hipLaunchKernelGGL((k3_conv<BN_, NBUF_, ADD_>), dim3(conv_grid(rows, o.cout, BN_)), dim3(256), 0, st, \
-        pb[o.src], pb[o.dst], c.wts + o.w, c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu)
+        pb[o.src], pb[o.dst], c.wts + o.w, c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, c.live, o.k, o.cin, o.cout, o.relu)
 #define CONV_GO_SP(BN_, ADD_, NP_) hipLaunchKernelGGL((k3_conv_split<BN_, ADD_, NP_>), dim3(conv_grid(rows, o.cout, BN_)), dim3(256), 0, st, \
-        pb[o.src], pb[o.dst], c.wts_split + c.wb_off[i], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu, \
+        pb[o.src], pb[o.dst], c.wts_split + c.wb_off[i], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, c.live, o.k, o.cin, o.cout, o.relu, \
         c.post[i], c.range_flag)
 #define CONV_GO_BM(BN_, ADD_) hipLaunchKernelGGL((k3_conv_split<BN_, ADD_, 2, 256>), dim3(conv_grid(rows, o.cout, BN_, 256)), dim3(512), 0, st, \
-        pb[o.src], pb[o.dst], c.wts_split + c.wb_off[i], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, o.k, o.cin, o.cout, o.relu, \
+        pb[o.src], pb[o.dst], c.wts_split + c.wb_off[i], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, c.live, o.k, o.cin, o.cout, o.relu, \
         c.post[i], c.range_flag)
 #define CONV_GO_BF(BN_, ADD_) do { if (c.pieces == 3) CONV_GO_SP(BN_, ADD_, 3); else if (BN_ == 128 && o.k >= 9 && o.cin >= 128 && rows % 256 == 0 && k3_bm256_enabled()) CONV_GO_BM(128, ADD_); \
         else CONV_GO_SP(BN_, ADD_, 2); } while (0)
@@ -1062,14 +1089,14 @@ int k3_run(const CnnRun &c, hipStream_t st) {
             case DN_CNN_DWCONV: {
                 const size_t n = (size_t)((rows + DW_ROWS - 1) / DW_ROWS) * (o.cin / 4);
                 const dim3 g((unsigned)((n + 255) / 256));
-#define DW_CASE(KW) case KW: hipLaunchKernelGGL(k3_dwconv<KW>, g, dim3(256), 0, st, pb[o.src], pb[o.dst], c.wts + o.w, c.valid, (int)rows, o.cin); break;
+#define DW_CASE(KW) case KW: hipLaunchKernelGGL(k3_dwconv<KW>, g, dim3(256), 0, st, pb[o.src], pb[o.dst], c.wts + o.w, c.valid, (int)rows, c.live, o.cin); break;
                 switch (o.k) { DW_CASE(3) DW_CASE(5) DW_CASE(7) DW_CASE(9) DW_CASE(17) default: return -1; }
 #undef DW_CASE
                 break;
             }
             case DN_CNN_ADD_RELU: {
                 const size_t n4 = (size_t)rows * o.cin / 4;
-                hipLaunchKernelGGL(k3_add_relu, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, pb[o.a], pb[o.b], pb[o.dst], n4);
+                hipLaunchKernelGGL(k3_add_relu, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, pb[o.a], pb[o.b], pb[o.dst], n4, c.live, o.cin / 4);
                 break;
             }
             case DN_CNN_DENSE_SOFTMAX:
