@@ -515,6 +515,9 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
 //     pointwise  the 1-tap step of k3_conv_split on those planes
 //   Two barriers per block: [A planes complete / raw tile free] -> next raw tile + taps to LDS, MFMAs -> [planes and B free] ->
 //   next B tile to LDS, next depthwise.  A workgroup does not overlap its own depthwise with its own MFMAs; the 2 workgroups of a CU do.
+// (Round 2: taking the B fragments straight from L2 instead of an LDS tile cuts the kernel's LDS from 64 to 43 KB for 128 channels,
+// enough for three workgroups per CU -- but the fragments' registers push it to 244 VGPRs (two workgroups again, 3.35 ms against 3.19
+// for the eleven 9-tap layers), and capping the registers at 168 spills: 10.8 ms.  Not kept.)
 // The raw-tile pitch (160 B) makes 4 rows advance the bank window by half (640 mod 256 = 128): the four 16-lane groups of a
 // ds_read_b128 (MI355X_MICROARCH.md, LDS) then cover all 64 banks once.
 // ---------------------------------------------------------------------------------------------------------
@@ -701,7 +704,6 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     __shared__ __attribute__((aligned(16))) float Xr[4][SROWS * SEP_XPW];
     __shared__ __attribute__((aligned(16))) float Wl[2][KW * 32];
     __shared__ __attribute__((aligned(16))) uint16_t As[2][NP][CNN_BM * CNN_BP];
-    __shared__ __attribute__((aligned(16))) uint16_t Bs[2][NP][BN * CNN_BP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;                       // wave-uniform
     int m0, n0;
@@ -713,48 +715,36 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     // ---- consumer state ----
     const int cw = wave & 3, wm = cw >> 1, wn = cw & 1;
     const int ct = tid & 255;
-    const int l_r = ct >> 2, l_k = (ct & 3) * 8;          // B loader (consumer threads): 64 rows x 4 chunks of 8 elements per pass
-    u32x4 rb[NP][NBQ];
     // ---- producer state ----
     const int pw = wave & 3;                               // slice: output rows 32 pw .. 32 pw + 31 of the tile
     const int cp = (lane & 15) * 2, dr = (lane >> 4) * 8;  // channel pair cp, cp + 1; output rows dr .. dr + 7 of the slice
-    f32x4 rx[NLD]; bool pin[NLD];
-    f32x4 rw = {0.f, 0.f, 0.f, 0.f};
+    // Two register sets of raw rows + taps in flight: a slice is stored to LDS TWO iterations after its loads were issued.  With one
+    // set the loads had exactly one iteration to land, so an iteration could not be shorter than the HBM latency under load (~3 us
+    // against ~0.7 us of MFMA work per channel block: the kernel ran at the memory LATENCY, not at any bandwidth).
+    struct RawSet { f32x4 rx[NLD]; bool pin[NLD]; f32x4 rw; };
+    RawSet S0, S1;
+    S0.rw = f32x4{0.f, 0.f, 0.f, 0.f}; S1.rw = S0.rw;
     float amax = 0.0f;
     float *Xs = Xr[pw];
-    auto gloadX = [&](int cb) {
+    auto gloadX = [&](RawSet &S, int cb) {
 #pragma unroll
         for (int p = 0; p < NLD; p++) {
             const int f = lane + 64 * p, rr = f >> 3, q = f & 7;
             const int src = m0 + 32 * pw - half + rr;
             const bool in = rr < SROWS && src >= 0 && src < rows;
-            rx[p] = *reinterpret_cast<const f32x4 *>(X + (size_t)(in ? src : m0) * cin + (cb << 5) + q * 4);
-            pin[p] = in;
+            S.rx[p] = *reinterpret_cast<const f32x4 *>(X + (size_t)(in ? src : m0) * cin + (cb << 5) + q * 4);
+            S.pin[p] = in;
         }
         const int wt = ct;                                 // taps: KW x 8 float4, spread over the 256 producer threads
-        if (wt < KW * 8) rw = *reinterpret_cast<const f32x4 *>(Wd + (size_t)(wt >> 3) * cin + (cb << 5) + (wt & 7) * 4);
+        if (wt < KW * 8) S.rw = *reinterpret_cast<const f32x4 *>(Wd + (size_t)(wt >> 3) * cin + (cb << 5) + (wt & 7) * 4);
     };
-    auto lstoreX = [&](int wbuf) {
+    auto lstoreX = [&](RawSet &S, int wbuf) {
 #pragma unroll
         for (int p = 0; p < NLD; p++) {
             const int f = lane + 64 * p, rr = f >> 3, q = f & 7;
-            if (rr < SROWS) *reinterpret_cast<f32x4 *>(&Xs[rr * SEP_XPW + q * 4]) = pin[p] ? rx[p] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rr < SROWS) *reinterpret_cast<f32x4 *>(&Xs[rr * SEP_XPW + q * 4]) = S.pin[p] ? S.rx[p] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (ct < KW * 8) *reinterpret_cast<f32x4 *>(&Wl[wbuf][(ct >> 3) * 32 + (ct & 7) * 4]) = rw;
-    };
-    auto gloadB = [&](int cb) {
-#pragma unroll
-        for (int pc = 0; pc < NP; pc++) {
-            const uint16_t *wb = Wb + ((size_t)(cb * NP + pc) * cout + n0) * 32;
-#pragma unroll
-            for (int q = 0; q < NBQ; q++) rb[pc][q] = *reinterpret_cast<const u32x4 *>(wb + (size_t)(q * 64 + l_r) * 32 + l_k);
-        }
-    };
-    auto lstoreB = [&](int buf) {
-#pragma unroll
-        for (int pc = 0; pc < NP; pc++)
-#pragma unroll
-            for (int q = 0; q < NBQ; q++) *reinterpret_cast<u32x4 *>(&Bs[buf][pc][(q * 64 + l_r) * CNN_BP + l_k]) = rb[pc][q];
+        if (ct < KW * 8) *reinterpret_cast<f32x4 *>(&Wl[wbuf][(ct >> 3) * 32 + (ct & 7) * 4]) = S.rw;
     };
     // Depthwise filter of one producer wavefront: 32 output rows x 32 channels per channel block.  A lane owns a PAIR of adjacent
     // channels and 8 consecutive output rows: its 24 input rows and its 17 taps are each read ONCE from LDS as 8-byte pairs
@@ -810,17 +800,17 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     // The two roles run their own loops (the accumulators exist only on the consumer side, the filter window only on the producer
     // side: the register allocation is the larger of the two, not the sum).  Every wavefront executes the same number of barriers.
     if (producer) {
-        gloadX(0); lstoreX(0); gloadX(min(1, cblocks - 1));
+        // block b's raw slice travels in set S1 for even b >= 2, S0 for odd b (and for blocks 0, 1 of the prologue); cblocks is even
+        gloadX(S0, 0); lstoreX(S0, 0); gloadX(S0, min(1, cblocks - 1)); gloadX(S1, min(2, cblocks - 1));
         __syncthreads();
-        depthwise(0, 0); lstoreX(1); gloadX(min(2, cblocks - 1));
+        depthwise(0, 0); lstoreX(S0, 1); gloadX(S0, min(3, cblocks - 1));
         __syncthreads();
-        for (int cb = 0; cb < cblocks; cb++) {
-            const int cur = cb & 1, nxt = cur ^ 1;
-            if (cb + 1 < cblocks) {
-                depthwise(nxt, nxt);                       // block cb + 1: its raw slice and taps were stored during block cb - 1
-                lstoreX(cur);                              // raw slice + taps of block cb + 2 (this wave is done reading its slice)
-                gloadX(min(cb + 3, cblocks - 1));
-            }
+        for (int cb = 0; cb < cblocks; cb += 2) {
+            // even iteration: filter block cb + 1 (stored during iteration cb - 1), store block cb + 2 (set S1, loaded two iterations ago)
+            if (cb + 1 < cblocks) { depthwise(1, 1); lstoreX(S1, 0); gloadX(S1, min(cb + 4, cblocks - 1)); }
+            __syncthreads();
+            // odd iteration cb + 1: filter block cb + 2, store block cb + 3 (set S0)
+            if (cb + 2 < cblocks) { depthwise(0, 0); lstoreX(S0, 1); gloadX(S0, min(cb + 5, cblocks - 1)); }
             __syncthreads();
         }
         if (NP == 2 && __any(amax > 65504.0f) && lane == 0) atomicOr(range_flag, 1u);
@@ -833,38 +823,51 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
         for (int j = 0; j < NJ; j++)
 #pragma unroll
             for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
-    gloadB(0); lstoreB(0); gloadB(min(1, cblocks - 1));
-    __syncthreads();
-    __syncthreads();
+    // B fragments come STRAIGHT from L2 into registers (pre-split weights [channel block][piece][cout][32]: a fragment is one
+    // 16-byte load, 64-byte rows of consecutive lanes coalesce): no B tile in LDS -- that tile was 82 of the kernel's 155 KB, which
+    // kept this workgroup off every CU where a per-read stage of another batch held some LDS, and half of its LDS traffic.
+    // Double-buffered per k16 step: the loads of step s + 1 are in flight during the MFMAs of step s.
     const int fm = lane & 31, fk = (lane >> 5) * 8;
-    for (int cb = 0; cb < cblocks; cb++) {
-        const int cur = cb & 1, nxt = cur ^ 1;
-        lstoreB(nxt);                                      // B tile of block cb + 1 (registers loaded during block cb - 1)
-        gloadB(min(cb + 2, cblocks - 1));
-        __builtin_amdgcn_sched_barrier(0);
+    const uint16_t *wlane = Wb + ((size_t)(n0 + wn * (BN / 2) + fm)) * 32 + fk;
+    auto loadB = [&](u32x4 (&b)[NJ][NP], int step) {            // step = 2 * cb + k16
+        const int cb = min(step >> 1, cblocks - 1), k16 = step & 1;
 #pragma unroll
-        for (int k16 = 0; k16 < 2; k16++) {
-            u32x4 a[2][NP], b[NJ][NP];
+        for (int pc = 0; pc < NP; pc++)
 #pragma unroll
-            for (int pc = 0; pc < NP; pc++) {
+            for (int j = 0; j < NJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(wlane + ((size_t)(cb * NP + pc) * cout + j * 32) * 32 + k16 * 16);
+    };
+    u32x4 b0[NJ][NP], b1[NJ][NP];
+    loadB(b0, 0);
+    __syncthreads();
+    __syncthreads();
+    auto mma = [&](int cur, int k16, u32x4 (&b)[NJ][NP]) {
+        u32x4 a[2][NP];
 #pragma unroll
-                for (int i = 0; i < 2; i++) a[i][pc] = *reinterpret_cast<const u32x4 *>(&As[cur][pc][(wm * 64 + i * 32 + fm) * CNN_BP + k16 * 16 + fk]);
+        for (int pc = 0; pc < NP; pc++)
 #pragma unroll
-                for (int j = 0; j < NJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(&Bs[cur][pc][(wn * (BN / 2) + j * 32 + fm) * CNN_BP + k16 * 16 + fk]);
-            }
-            constexpr int NT = NP == 3 ? 6 : 3;
+            for (int i = 0; i < 2; i++) a[i][pc] = *reinterpret_cast<const u32x4 *>(&As[cur][pc][(wm * 64 + i * 32 + fm) * CNN_BP + k16 * 16 + fk]);
+        constexpr int NT = NP == 3 ? 6 : 3;
 #pragma unroll
-            for (int t = 0; t < NT; t++) {
-                constexpr int PA3[6] = {1, 2, 0, 1, 0, 0}, PB3[6] = {1, 0, 2, 0, 1, 0};
-                constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
-                const int pa = NP == 3 ? PA3[t] : PA2[t % 3], pb = NP == 3 ? PB3[t] : PB2[t % 3];
+        for (int t = 0; t < NT; t++) {
+            constexpr int PA3[6] = {1, 2, 0, 1, 0, 0}, PB3[6] = {1, 0, 2, 0, 1, 0};
+            constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
+            const int pa = NP == 3 ? PA3[t] : PA2[t % 3], pb = NP == 3 ? PB3[t] : PB2[t % 3];
 #pragma unroll
-                for (int i = 0; i < 2; i++)
+            for (int i = 0; i < 2; i++)
 #pragma unroll
-                    for (int j = 0; j < NJ; j++)
-                        acc[i][j] = mfma16<NP>(a[i][pa], b[j][pb], acc[i][j]);
-            }
+                for (int j = 0; j < NJ; j++)
+                    acc[i][j] = mfma16<NP>(a[i][pa], b[j][pb], acc[i][j]);
         }
+    };
+    for (int cb = 0; cb < cblocks; cb++) {
+        const int cur = cb & 1;
+        loadB(b1, 2 * cb + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(cur, 0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        loadB(b0, 2 * cb + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(cur, 1, b1);
         __syncthreads();
     }
     conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, m0, n0, wm, wn, lane, cout, relu, post);
@@ -1006,7 +1009,7 @@ static int k3_launch_sep(const CnnRun &c, int i, const float *in, float *out, co
 #define SEP_ARGS in, out, c.wts + d.w, c.wts_split + c.wb_off[i + 1], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, c.live, \
         o.cin, o.cout, o.relu, c.post[i + 1], c.range_flag
 #define SEP_GO(KW_) hipLaunchKernelGGL((k3_sep_split<BN, KW_, ADD, NP>), dim3(conv_grid(rows, o.cout, BN)), dim3(256), 0, st, SEP_ARGS)
-    if (NP == 2 && d.k == 17 && o.cout % 256 == 0 && k3_sep_ws_enabled()) {
+    if (NP == 2 && d.k == 17 && o.cout % 256 == 0 && o.cin % 64 == 0 && k3_sep_ws_enabled()) {
         if (c.mark) c.mark(c.mark_who, 1, st);
         hipLaunchKernelGGL((k3_sep_ws<256, 17, ADD, 2>), dim3(conv_grid(rows, o.cout, 256)), dim3(512), 0, st, SEP_ARGS);
         if (c.mark) c.mark(c.mark_who, 0, st);

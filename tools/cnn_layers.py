@@ -6,7 +6,7 @@ from dnascent_amd import cnn_model
 desc, _, _ = cnn_model.default_model()
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k3_" in r["Kernel_Name"]]
 sort_us = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "k3_encode_" in r["Kernel_Name"])
-rows = [r for r in rows if "k3_encode_" not in r["Kernel_Name"]]      # the encoder's counting sort (two small kernels) is reported on its own line
+rows = [r for r in rows if "k3_encode_" not in r["Kernel_Name"] and "k3_layout" not in r["Kernel_Name"]]      # the encoder's counting sort (two small kernels) is reported on its own line
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 npos = int(sys.argv[2]); ops = desc["ops"]
 # kernels of one run: walk the op list backwards from the end of the trace
