@@ -76,6 +76,29 @@ def build_host(force=False):
     return HOST_SO
 
 
+def build_io(force=False):
+    """OPTIONAL: BAM / POD5 ingestion through htslib and libpod5 (csrc/host/dn_io_htslib.cpp) -> lib/libdnascent_io.so.  Built only
+    where the headers exist: DN_HTSLIB_INC / DN_POD5_INC (or /usr/include/htslib/sam.h, /usr/include/pod5_format/c_api.h).  Neither
+    library is in this image; the function then returns None and the binary read container remains the ingestion path."""
+    hts = os.environ.get("DN_HTSLIB_INC") or ("/usr/include" if os.path.exists("/usr/include/htslib/sam.h") else None)
+    pod = os.environ.get("DN_POD5_INC") or ("/usr/include" if os.path.exists("/usr/include/pod5_format/c_api.h") else None)
+    if not hts and not pod:
+        return None
+    out = os.path.join(LIB, "libdnascent_io.so")
+    src = os.path.join(CSRC, "host", "dn_io_htslib.cpp")
+    if not force and not _newer(out, [src]):
+        return out
+    build_host(False)
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", out, src]
+    if hts:
+        cmd += ["-DDN_WITH_HTSLIB", "-I", hts]
+    if pod:
+        cmd += ["-DDN_WITH_POD5", "-I", pod]
+    cmd += ["-L", LIB, "-ldnascent_host", "-Wl,-rpath,$ORIGIN"] + (["-lhts"] if hts else []) + (["-lpod5_format"] if pod else [])
+    _run(cmd)
+    return out
+
+
 def build_oracle():
     _run(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
 
@@ -83,6 +106,7 @@ def build_oracle():
 def build_all(force=False):
     build_hip(force)
     build_host(force)
+    build_io(force)          # no-op where htslib / libpod5 are absent (this image)
     build_oracle()
 
 
