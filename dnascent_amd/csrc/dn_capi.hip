@@ -542,9 +542,9 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
 #undef UP
 #define AL(field, cnt) if ((rc = dalloc(c, &B.field, (size_t)(cnt)))) return rc
     AL(carry, 4 * NCH + n);
-    if (c->keep_k1) { AL(psum, S); AL(t1, S); AL(t2, S); }      // parity taps only: every prefix sum and both t-statistics in HBM
+    if (c->keep_k1) { AL(psum, S); AL(t1, S); AL(t2, S); AL(et_start, NEV); AL(et_mean, NEV); }      // parity taps only: every prefix sum and both t-statistics in HBM
     AL(chunk_npk, NCH); AL(chunk_peaks, NCH * DN_SEG_PEAKCAP); AL(chunk_psum, NCH * DN_SEG_PEAKCAP); AL(chunk_in, NCH); AL(chunk_out, NCH);
-    AL(et_start, NEV); AL(et_mean, NEV); AL(ev_mean, NEV); AL(ev_start, NEV); AL(ev_len, NEV); AL(ev_x, NEV);
+    AL(ev_mean, NEV); AL(ev_start, NEV); AL(ev_len, NEV); AL(ev_x, NEV);
     AL(rank_q, NB); AL(rank_r, NR); AL(mu_q, NB);
     AL(aln_event, NAL); AL(aln_kmer, NAL); AL(cl_sig, NAL); AL(cl_rank, NAL);
     AL(res, n);
@@ -930,6 +930,7 @@ int dn_get_tstats(dn_ctx *c, uint32_t read, float *a, float *b) {
 
 int dn_get_scrappie_events(dn_ctx *c, uint32_t read, uint32_t *start, float *length, float *mean) {
     CHECK_READ(2, "dn_get_scrappie_events");
+    if (!c->B.et_start) return fail(c, DN_ERR_STATE, "dn_debug_keep_k1(ctx, 1) must precede dn_batch_upload: the scrappie event table does not leave the kernels otherwise");
     if ((rc = fetch_res(c))) return rc;
     const size_t n = c->h_res[read].n_scrappie; const uint64_t e0 = c->h_ev_off[read];
     std::vector<uint32_t> st(n);

@@ -63,7 +63,7 @@ struct BatchDev {
     SegState *chunk_in, *chunk_out;   // [chunks]
     // scrappie events + DNAscent events; capacity per read = ev_off[r+1]-ev_off[r]
     const uint64_t *ev_off;  // [n+1]
-    unsigned *et_start; float *et_mean;     // scrappie event_t (start, mean); length = start[i+1]-start[i]
+    unsigned *et_start; float *et_mean;     // TAP ONLY (null unless keep_k1): scrappie event_t (start, mean); length = start[i+1]-start[i]
     double *ev_mean; unsigned *ev_start, *ev_len;   // r.events
     double *ev_x;            // (mean - shift)/scale with the rough scaling
     // ---- k-mer ranks ----

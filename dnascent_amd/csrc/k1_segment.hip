@@ -16,11 +16,12 @@
 //               state no longer depends on history, so the state at the chunk start is almost always the true one.  Every peak
 //               is recorded with the exact prefix sum at its position, which is all the event means need.
 //   k1_events   verifies every chunk hand-off exactly (state in == previous state out), recomputes the rare chunk whose
-//               speculation missed (so the result is exact, never approximate), compacts the peaks, forms event means from the
-//               recorded sums (event_detection.c:213-266) and applies the event-build quirks of event_handling.cpp:549-575
-//               (first mean 0.0, last event dropped, mean <= 0 merged).
-//   (taps)      k1_scan4<true> / k1_tstat write every prefix sum and both t-statistics to HBM when dn_debug_keep_k1 asked for
-//               them (parity tests); same arithmetic functions as the product kernels.
+//               speculation missed (so the result is exact, never approximate), then streams the recorded peaks ONCE through an
+//               LDS tile: event means from the recorded sums (event_detection.c:213-266) and the event-build quirks of
+//               event_handling.cpp:549-575 (first mean 0.0, last event dropped, mean <= 0 merged) in the same pass -- it reads
+//               12 bytes per peak and writes 16 per event, the scrappie table itself never exists in HBM.
+//   (taps)      k1_scan4<true> / k1_tstat write every prefix sum and both t-statistics, k1_events the scrappie table, to HBM when
+//               dn_debug_keep_k1 asked for them (parity tests); same arithmetic functions / same registers as the product path.
 #include "dn_dev.h"
 #include <float.h>
 
@@ -234,27 +235,29 @@ __device__ __forceinline__ SegState seg_initial() {
 
 // Where a lane's emitted peaks go: position + exact prefix sum.  HBM writes are write-through at 32-byte granularity, so a lane
 // that stored every peak on its own (4 + 8 bytes) would write 64 bytes for 12; peaks are parked in the lane's column of a small
-// LDS block and leave eight at a time as full 32- / 64-byte pieces.
+// LDS block and leave SINK_N at a time as full 32- / 64-byte pieces.  (16 at a time: WRITE_SIZE unchanged -- 583 against 602 MiB for
+// 45 M peaks of 12 bytes, i.e. the pieces of eight already leave whole -- and k1_detect 3.5 -> 4.7 ms: eight it is.)
+#define SINK_N 8
 struct PeakSink {
-    unsigned *pk; double *pks;           // the chunk's slots in HBM (DN_SEG_PEAKCAP each, 32-byte aligned)
+    unsigned *pk; double *pks;           // the chunk's slots in HBM (DN_SEG_PEAKCAP each, 64-byte aligned)
     unsigned *bpos; double *bsum;        // this lane's column of the LDS block: entry k at [k * 64]
     __device__ __forceinline__ void put(unsigned pos, double sum, unsigned &npk) {
-        const unsigned k = npk & 7u;
+        const unsigned k = npk & (SINK_N - 1u);
         bpos[k * 64] = pos; bsum[k * 64] = sum;
         npk++;
-        if ((npk & 7u) == 0u && npk <= DN_SEG_PEAKCAP) {
+        if ((npk & (SINK_N - 1u)) == 0u && npk <= DN_SEG_PEAKCAP) {
             typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-            u32x4_ a = { bpos[0], bpos[64], bpos[128], bpos[192] }, b = { bpos[256], bpos[320], bpos[384], bpos[448] };
-            u32x4_ *dp = reinterpret_cast<u32x4_ *>(pk + (npk - 8u));
-            dp[0] = a; dp[1] = b;
-            double2 *ds = reinterpret_cast<double2 *>(pks + (npk - 8u));
+            u32x4_ *dp = reinterpret_cast<u32x4_ *>(pk + (npk - SINK_N));
 #pragma unroll
-            for (int q = 0; q < 4; q++) ds[q] = make_double2(bsum[(2 * q) * 64], bsum[(2 * q + 1) * 64]);
+            for (int q = 0; q < SINK_N / 4; q++) { const u32x4_ a = { bpos[(4 * q) * 64], bpos[(4 * q + 1) * 64], bpos[(4 * q + 2) * 64], bpos[(4 * q + 3) * 64] }; dp[q] = a; }
+            double2 *ds = reinterpret_cast<double2 *>(pks + (npk - SINK_N));
+#pragma unroll
+            for (int q = 0; q < SINK_N / 2; q++) ds[q] = make_double2(bsum[(2 * q) * 64], bsum[(2 * q + 1) * 64]);
         }
     }
-    __device__ __forceinline__ void flush(unsigned npk) {                    // the last, partial group of eight
+    __device__ __forceinline__ void flush(unsigned npk) {                    // the last, partial group
         const unsigned m = min(npk, (unsigned)DN_SEG_PEAKCAP);
-        for (unsigned j = m & ~7u; j < m; j++) { pk[j] = bpos[(j & 7u) * 64]; pks[j] = bsum[(j & 7u) * 64]; }
+        for (unsigned j = m & ~(SINK_N - 1u); j < m; j++) { pk[j] = bpos[(j & (SINK_N - 1u)) * 64]; pks[j] = bsum[(j & (SINK_N - 1u)) * 64]; }
     }
 };
 
@@ -357,7 +360,7 @@ __device__ __forceinline__ void seg_body13(const float *row, const int A /* samp
 
 // walks chunk `c` of read r on every lane that `have`s one.  REDO: all lanes walk the same chunk from state `st`.
 template <bool REDO>
-__device__ __forceinline__ void seg_walk(const BatchDev &B, float *tile /* [64 * SEG_PITCH] */, unsigned *lds_pos /* [8 * 64] */, double *lds_sum /* [8 * 64] */,
+__device__ __forceinline__ void seg_walk(const BatchDev &B, float *tile /* [64 * SEG_PITCH] */, unsigned *lds_pos /* [SINK_N * 64] */, double *lds_sum /* [SINK_N * 64] */,
                                          const int r, const int cbase, const int c, const bool have, SegState &st, unsigned &npk) {
     const int lane = threadIdx.x;
     const uint64_t s0 = B.samp_off[r];
@@ -404,8 +407,8 @@ __device__ __forceinline__ void seg_walk(const BatchDev &B, float *tile /* [64 *
 
 __global__ __launch_bounds__(64) void k1_detect(BatchDev B) {
     __shared__ float tile[64 * SEG_PITCH];
-    __shared__ unsigned lds_pos[8 * 64];
-    __shared__ double lds_sum[8 * 64];
+    __shared__ unsigned lds_pos[SINK_N * 64];
+    __shared__ double lds_sum[SINK_N * 64];
     const int r = blockIdx.y;
     const int lane = threadIdx.x;
     const uint64_t c0 = B.chunk_off[r];
@@ -435,11 +438,16 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
     return v;
 }
 
-__global__ __launch_bounds__(64) void k1_events(BatchDev B, unsigned *scratch_u32 /* aliases cl_rank: kept-index list */) {
+#define EV_TILE 512
+__global__ __launch_bounds__(64) void k1_events(BatchDev B) {
     __shared__ float tile[64 * SEG_PITCH];                        // the exact redo's signal tile ...
-    __shared__ unsigned lds_pos[8 * 64];                          // ... and peak staging
-    __shared__ double lds_sum[8 * 64];
-    __shared__ unsigned pre[4096];                                // exclusive prefix of peaks per chunk (<= 4M samples / read)
+    __shared__ unsigned lds_pos[SINK_N * 64];                          // ... and peak staging
+    __shared__ double lds_sum[SINK_N * 64];
+    __shared__ unsigned pre[4096];                                // peaks per chunk (<= 4M samples / read)
+    __shared__ unsigned t_pos[EV_TILE + DN_SEG_PEAKCAP + 1];      // the streaming tile: start and prefix sum of consecutive scrappie events
+    __shared__ double t_sum[EV_TILE + DN_SEG_PEAKCAP + 1];
+    __shared__ float k_mean[65];                                  // kept events of one 64-wide step, slot 0 = the previous kept one
+    __shared__ unsigned k_start[65];
     const int r = blockIdx.x;
     const int lane = threadIdx.x;
     const uint64_t s0 = B.samp_off[r];
@@ -475,76 +483,100 @@ __global__ __launch_bounds__(64) void k1_events(BatchDev B, unsigned *scratch_u3
     }
     __syncthreads();
 
-    // ---- 2. compact the peaks: et_start[0] = 0, et_start[1 + j] = j-th peak; their prefix sums alongside ----
-    unsigned *et_start = B.et_start + e0;
-    float *et_mean = B.et_mean + e0;
-    double *et_sum = B.ev_x + e0;                                 // sum[et_start[e]]; ev_x is free until k_prep writes it
+    // ---- 2. one streaming pass over the peaks, chunk after chunk, through an LDS tile: scrappie events -> DNAscent events ----
+    // scrappie event e (create_events :242-247): start[0] = 0, start[1 + j] = j-th peak (every recorded peak has 0 < p < n);
+    // mean[e] = (float)(sum[start[e + 1]] - sum[start[e]]) / length (create_event :224-226), the last one ends at n.
+    // DNAscent event build (event_handling.cpp:549-575): kept scrappie indices are e > 0 && mean[e] > 0; event j carries mean and
+    // rawStart of the PREVIOUS kept index (0.0 / 0 for the first) and the raw span up to start[kept_j] - 1.  Nothing but the
+    // recorded peaks is read and nothing but the events is written (the scrappie table itself only as a parity tap).
     unsigned running = 0;
     int overflow = nch > 4096;
-    for (int cb = 0; cb < nch && cb < 4096; cb += 64) {
+    const int nchc = min(nch, 4096);
+    for (int cb = 0; cb < nchc; cb += 64) {
         const int c = cb + lane;
-        unsigned cnt = (c < nch) ? B.chunk_npk[c0 + c] : 0u;
+        unsigned cnt = (c < nchc) ? B.chunk_npk[c0 + c] : 0u;
         if (cnt > DN_SEG_PEAKCAP) { overflow = 1; cnt = DN_SEG_PEAKCAP; }
-        const unsigned incl = wave_incl_scan(cnt, lane);
-        if (c < nch && c < 4096) pre[c] = running + incl - cnt;
-        running += __shfl(incl, 63);
+        if (c < nchc) pre[c] = cnt;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+        running += cnt;
     }
-    __syncthreads();
-    for (int c = 0; c < nch && c < 4096; c++) {                   // one chunk at a time, lanes copy its peaks coalesced
-        const unsigned base = pre[c];
-        const unsigned cnt = ((c + 1 < nch && c + 1 < 4096) ? pre[c + 1] : running) - base;
-        const unsigned *pk = B.chunk_peaks + (c0 + c) * DN_SEG_PEAKCAP;
-        const double *pks = B.chunk_psum + (c0 + c) * DN_SEG_PEAKCAP;
-        for (unsigned j = lane; j < cnt; j += 64) {
-            const unsigned slot = 1 + base + j;
-            if (slot < ecap) { et_start[slot] = pk[j]; et_sum[slot] = pks[j]; }
-        }
-    }
-    if (lane == 0) { et_start[0] = 0; et_sum[0] = 0.0; }
-    unsigned n_et = 1 + running;                                  // create_events :242-247 (every recorded peak satisfies 0 < p < n)
+    unsigned n_et = 1 + running;
     if (n_et > ecap) { overflow = 1; n_et = ecap; }
     overflow = __any(overflow);
-    __threadfence_block();
-    __syncthreads();
-
-    // ---- 3. scrappie event means (create_event :224-226): (float)(sum[end] - sum[start]) / length ----
     const double total = B.carry[4ull * c0 + (unsigned)r + (unsigned)((n + DN_SEG_CARRY - 1) / DN_SEG_CARRY)].x;     // sum[n]
-    for (unsigned e = lane; e < n_et; e += 64) {
-        const unsigned st = et_start[e];
-        const unsigned en = (e + 1 < n_et) ? et_start[e + 1] : (unsigned)n;
-        const double a = et_sum[e], b = (e + 1 < n_et) ? et_sum[e + 1] : total;
-        const float length = (float)(unsigned long long)((unsigned long long)en - (unsigned long long)st);
-        et_mean[e] = (float)(b - a) / length;
-    }
-    __threadfence_block();
-    __syncthreads();
-
-    // ---- 4. DNAscent event build (event_handling.cpp:549-575) ----
-    // kept scrappie indices: i > 0 && et[i].mean > 0.  Event j: mean/rawStart of the PREVIOUS kept index
-    // (0.0 / 0 for the first), raw span up to et[kept_j].start - 1.
-    unsigned kept_total = 0;
-    for (unsigned eb = 0; eb < n_et; eb += 64) {
-        const unsigned e = eb + lane;
-        const int keep = (e < n_et) && (e > 0) && ((double)et_mean[e] > 0.);
-        const unsigned long long m = __ballot(keep);
-        const unsigned pos = kept_total + __popcll(m & ((1ull << lane) - 1ull));
-        if (keep) scratch_u32[e0 + pos] = e;
-        kept_total += __popcll(m);
-    }
-    __threadfence_block();
-    __syncthreads();
+    unsigned *tap_start = B.et_start ? B.et_start + e0 : nullptr;
+    float *tap_mean = B.et_mean ? B.et_mean + e0 : nullptr;
     double *ev_mean = B.ev_mean + e0;
     unsigned *ev_start = B.ev_start + e0, *ev_len = B.ev_len + e0;
-    for (unsigned j = lane; j < kept_total; j += 64) {
-        const unsigned i = scratch_u32[e0 + j];
-        double mean = 0.;
-        unsigned rs = 0;
-        if (j > 0) { const unsigned ip = scratch_u32[e0 + j - 1]; mean = (double)et_mean[ip]; rs = et_start[ip]; }
-        unsigned last = et_start[i] - 1u;                         // :563 (et[i].start >= 1 for i > 0)
-        if (last > (unsigned)n - 1u) last = (unsigned)n - 1u;
-        ev_mean[j] = mean;
-        ev_start[j] = rs;
-        ev_len[j] = (last >= rs) ? (last - rs + 1u) : 0u;
+    if (lane == 0) { t_pos[0] = 0u; t_sum[0] = 0.0; }
+    unsigned fill = 1;                      // entries in the tile: scrappie events E0 .. E0 + fill - 1
+    unsigned E0 = 0, taken = 1;             // taken: scrappie events placed in the tile so far (of n_et)
+    unsigned kept_total = 0;
+    float prev_mean = 0.0f; unsigned prev_start = 0u;             // the previous kept scrappie event (wave-uniform)
+    LDS_FENCE();
+    __syncthreads();
+    for (int c = 0; c < max(nchc, 1); c++) {
+        if (c < nchc) {
+            const unsigned cnt = min(pre[c], n_et - taken);
+            const unsigned *pk = B.chunk_peaks + (c0 + c) * DN_SEG_PEAKCAP;
+            const double *pks = B.chunk_psum + (c0 + c) * DN_SEG_PEAKCAP;
+            for (unsigned j = lane; j < cnt; j += 64) { t_pos[fill + j] = pk[j]; t_sum[fill + j] = pks[j]; }
+            fill += cnt; taken += cnt;
+            if (fill < EV_TILE && c + 1 < nchc) continue;
+        }
+        const bool last = c + 1 >= nchc;
+        if (!last && fill < 2) continue;
+        LDS_FENCE();
+        __syncthreads();
+        const unsigned proc = last ? fill : fill - 1;             // the newest entry waits for its successor
+        for (unsigned ib = 0; ib < proc; ib += 64) {
+            const unsigned i = ib + lane;
+            const bool on = i < proc;
+            unsigned st = 0; float mean = 0.0f;
+            if (on) {
+                st = t_pos[i];
+                const bool more = i + 1 < fill;
+                const unsigned en = more ? t_pos[i + 1] : (unsigned)n;
+                const double a = t_sum[i], b = more ? t_sum[i + 1] : total;
+                const float length = (float)(unsigned long long)((unsigned long long)en - (unsigned long long)st);
+                mean = (float)(b - a) / length;
+                if (tap_start) { tap_start[E0 + i] = st; tap_mean[E0 + i] = mean; }
+            }
+            const bool keep = on && (E0 + i > 0u) && ((double)mean > 0.);
+            const unsigned long long m = __ballot(keep);
+            if (m == 0ull) continue;
+            const unsigned q = (unsigned)__popcll(m & ((1ull << lane) - 1ull)), k = (unsigned)__popcll(m);
+            if (lane == 0) { k_mean[0] = prev_mean; k_start[0] = prev_start; }
+            if (keep) { k_mean[q + 1] = mean; k_start[q + 1] = st; }
+            LDS_FENCE();
+            if (keep) {
+                const unsigned j = kept_total + q;
+                const double pm = (double)k_mean[q];
+                const unsigned rs = k_start[q];
+                unsigned lastS = st - 1u;                          // :563 (start >= 1 for e > 0)
+                if (lastS > (unsigned)n - 1u) lastS = (unsigned)n - 1u;
+                // (staging these in LDS to leave as 64-entry aligned blocks was measured: WRITE_SIZE identical -- the runs of one
+                // step are contiguous and the L2 merges them -- and the kernel 12 % slower)
+                ev_mean[j] = j > 0 ? pm : 0.;
+                ev_start[j] = rs;
+                ev_len[j] = (lastS >= rs) ? (lastS - rs + 1u) : 0u;
+            }
+            prev_mean = k_mean[k]; prev_start = k_start[k];
+            kept_total += k;
+            LDS_FENCE();
+        }
+        E0 += proc;
+        if (last) break;
+        {
+            const unsigned kp = t_pos[fill - 1]; const double ks = t_sum[fill - 1];
+            LDS_FENCE();
+            __syncthreads();
+            if (lane == 0) { t_pos[0] = kp; t_sum[0] = ks; }
+            fill = 1;
+            LDS_FENCE();
+            __syncthreads();
+        }
     }
     if (lane == 0) {
         R.n_samples = (unsigned)n;
@@ -572,5 +604,5 @@ void k1_launch_detect(const BatchDev &B, unsigned max_chunks, hipStream_t st) {
     hipLaunchKernelGGL(k1_detect, dim3((max_chunks + 63) / 64, B.n_reads), dim3(64), 0, st, B);
 }
 void k1_launch_events(const BatchDev &B, hipStream_t st) {
-    hipLaunchKernelGGL(k1_events, dim3(B.n_reads), dim3(64), 0, st, B, B.cl_rank);
+    hipLaunchKernelGGL(k1_events, dim3(B.n_reads), dim3(64), 0, st, B);
 }

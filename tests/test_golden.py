@@ -98,17 +98,33 @@ def test_hip_segmentation_matches_reference_goldens(model):
     for i, r in enumerate(reads):
         assert np.array_equal(r.adc, g["adc_%d" % i])
         b.add_synth(r)
-    ctx = hip.Context(0)
-    ctx.load_pore_model(model)
-    b.upload(ctx)
-    ctx.run("segment")
-    s = ctx.summaries()
-    for i in range(n):
-        st, ln, mn = ctx.scrappie_events(i, int(s["n_scrappie"][i]))
-        assert np.array_equal(st, g["start_%d" % i])
-        assert np.array_equal(_bits(ln), _bits(g["length_%d" % i]))
-        assert np.array_equal(_bits(mn), _bits(g["mean_%d" % i]))
-    ctx.close()
+    for taps in (True, False):
+        ctx = hip.Context(0)
+        ctx.load_pore_model(model)
+        ctx.keep_k1(taps)                  # the scrappie table itself leaves the kernel only as a tap (same registers, one more store)
+        b.upload(ctx)
+        ctx.run("segment")
+        s = ctx.summaries()
+        for i in range(n):
+            gs, gm = g["start_%d" % i], g["mean_%d" % i]
+            assert s["n_scrappie"][i] == gs.shape[0]
+            if taps:
+                st, ln, mn = ctx.scrappie_events(i, int(s["n_scrappie"][i]))
+                assert np.array_equal(st, gs)
+                assert np.array_equal(_bits(ln), _bits(g["length_%d" % i]))
+                assert np.array_equal(_bits(mn), _bits(gm))
+            # what the product path keeps: the DNAscent events built from the reference's table (event_handling.cpp:549-575:
+            # kept = index > 0 and mean > 0; an event carries mean / start of the previous kept index, 0.0 / 0 for the first)
+            kept = np.flatnonzero((np.arange(gs.shape[0]) > 0) & (gm.astype(np.float64) > 0))
+            prev = np.concatenate([[-1], kept[:-1]])
+            want_mean = np.where(prev >= 0, gm[np.maximum(prev, 0)].astype(np.float64), 0.0)
+            want_start = np.where(prev >= 0, gs[np.maximum(prev, 0)], 0).astype(np.uint32)
+            last = np.minimum(gs[kept].astype(np.int64) - 1, int(s["n_samples"][i]) - 1)
+            want_len = np.maximum(last - want_start.astype(np.int64) + 1, 0).astype(np.uint32)
+            assert s["n_events"][i] == kept.shape[0]
+            em, es, el = ctx.events(i, int(s["n_events"][i]))
+            assert np.array_equal(_bits(em), _bits(want_mean)) and np.array_equal(es, want_start) and np.array_equal(el, want_len)
+        ctx.close()
 
 
 def test_common_helpers_match_reference_goldens():
