@@ -207,33 +207,56 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][BN / 64], float *
                                               const float *__restrict__ shift, const float *__restrict__ Add,
                                               const uint8_t *__restrict__ valid, int m0, int n0, int wm, int wn, int lane, int cout, int relu,
                                               float post = 1.0f) {
+    // y = max(acc * scale + shift (+ residual), floor), zero on padding rows.  An accumulator register q of row block i holds row
+    // 32 i + 8 (q >> 2) + (q & 3) + 4 (lane >> 5): the row is wave-uniform up to the lane half, so per (i, q) the row's base
+    // address and its padding mask are SCALAR (one SGPR pair each: the select is a v_cndmask on that pair, the address an SGPR
+    // base + one lane offset computed once); the NJ column tiles of the row are 128 bytes apart (immediate offsets).  The first
+    // version computed a 64-bit address and a shifted mask bit per element in the vector unit: ~10 vector instructions per
+    // element, 6.8 k ticks per 128 x 256 tile -- a seventh of the 17-tap layer's time and the whole of the short layers' tail.
     constexpr int NJ = BN / 64;
     const unsigned long long vmask = __ballot(valid[m0 + wm * 64 + lane] != 0);
     const float floor_ = relu ? 0.0f : -3.402823466e38f;
+    const int colb = n0 + wn * (BN / 2) + (lane & 31);
+    float sc[NJ], sh[NJ];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int j = 0; j < NJ; j++) { sc[j] = scale[colb + j * 32] * post; sh[j] = shift[colb + j * 32]; }   // post: a power of two (exact), 1 except on the fp16 path
+    // buffer addressing: descriptor = the wavefront's 64 rows of Y (and of the residual), voffset = the lane's part (bytes),
+    // soffset = the row's part (scalar), immediate = the column tile
+    auto uniform_ptr = [](const void *p) {
+        const unsigned long long v = (unsigned long long)p;
+        return (void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+    };
+    const size_t wbase = (size_t)(m0 + wm * 64) * cout;
+    const int wbytes = 64 * cout * 4;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(Y + wbase), 0, wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float *>(ADD ? Add + wbase : Y + wbase)), 0, wbytes, 0x00020000);
+    const int voff = (4 * (lane >> 5) * cout + colb) * 4;
 #pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-            const float sc = scale[col] * post, sh = shift[col];     // post: a power of two (exact), 1 except on the fp16 path
-            const int rbase = i * 32 + 4 * (lane >> 5);
-            float *yp = Y + (size_t)(m0 + wm * 64 + rbase) * cout + col;
-            float addv[16];
-            if (ADD) {
-                const float *ap = Add + (size_t)(m0 + wm * 64 + rbase) * cout + col;
-#pragma unroll
-                for (int q = 0; q < 16; q++) addv[q] = ap[(size_t)((q & 3) + 8 * (q >> 2)) * cout];
-            }
+    for (int i = 0; i < 2; i++) {
+        float addv[16][NJ];
+        if (ADD) {                                          // all residual loads of the row block first: the stores below may not pass them
 #pragma unroll
             for (int q = 0; q < 16; q++) {
-                const int ro = (q & 3) + 8 * (q >> 2);
-                float y = __builtin_fmaf(acc[i][j][q], sc, sh);
-                if (ADD) y += addv[q];
-                y = fmaxf(y, floor_);
-                y = ((vmask >> (rbase + ro)) & 1ull) ? y : 0.0f;
-                yp[(size_t)ro * cout] = y;
+                const int soff = __builtin_amdgcn_readfirstlane((i * 32 + (q & 3) + 8 * (q >> 2)) * cout * 4);
+#pragma unroll
+                for (int j = 0; j < NJ; j++) addv[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, voff + j * 128, soff, 0));
             }
         }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int row = i * 32 + (q & 3) + 8 * (q >> 2);                   // + 4 for the upper lane half
+            const int soff = __builtin_amdgcn_readfirstlane(row * cout * 4);
+            const unsigned long long keep = (((vmask >> row) & 1ull) ? 0x00000000ffffffffull : 0ull) | (((vmask >> (row + 4)) & 1ull) ? 0xffffffff00000000ull : 0ull);
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                float y = __builtin_fmaf(acc[i][j][q], sc[j], sh[j]);
+                if (ADD) y += addv[q][j];
+                y = fmaxf(y, floor_);
+                asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(y) : "v"(y), "s"(keep));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), ry, voff + j * 128, soff, 0);
+            }
+        }
+    }
 }
 
 // Workgroup numbering of the conv kernels (1-D grid): consecutive workgroup ids go round-robin to the 8 XCDs, each with its own
@@ -681,6 +704,15 @@ __global__ __launch_bounds__(256) void k3_sep_split(const float *__restrict__ X,
     conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, m0, n0, wm, wn, lane, cout, relu, post);
 }
 
+#ifdef DN_WS_TRACE       /* experiment build only (tools/ws_trace.py): shader-clock stamps of one workgroup's phases */
+__device__ unsigned long long ws_trace[8][64];
+#define WS_T(i) do { if (blockIdx.x == DN_WS_TRACE && lane == 0) ws_trace[wave][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define WS_TRACE_TILE 2                                   /* the workgroup's third tile: steady state */
+extern "C" int dn_debug_ws_trace(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ws_trace), sizeof(ws_trace)); }
+#else
+#define WS_T(i) do { } while (0)
+#define WS_TRACE_TILE (-1)
+#endif
 // ---------------------------------------------------------------------------------------------------------
 // k3_sep_ws: the fused SeparableConv1D with WAVE SPECIALISATION.  In k3_sep_split a workgroup alternates between its
 // depthwise phase (vector unit + LDS) and its pointwise phase (matrix cores); the two never overlap inside the workgroup, and
@@ -706,12 +738,20 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     __shared__ __attribute__((aligned(16))) uint16_t As[2][NP][CNN_BM * CNN_BP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;                       // wave-uniform
-    int m0, n0;
-    if (!conv_tile(cout, BN, rows, m0, n0)) return;
+    // PERSISTENT workgroup: it takes the row tiles blockIdx.x, + gridDim.x, ... (BN == cout: one column tile) and runs their channel
+    // blocks as ONE stream of `nb` steps.  The producers are always one step ahead, so while the consumers write a tile's results
+    // (6.8 k ticks of the 47 k a one-tile workgroup took) the producers already filter the next tile's first block, and only the
+    // first tile of a workgroup waits for its first planes (8.3 k ticks) -- tools/ws_trace.py.
+    const int ntiles = (rows + CNN_BM - 1) / CNN_BM;
+    const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    if (my_tiles == 0) return;
+    const int n0 = 0;
     constexpr int NJ = BN / 64;
     constexpr int NBQ = BN / 64;
     constexpr int half = (KW - 1) / 2;
     const int cblocks = cin >> 5;
+    const int nb = my_tiles * cblocks;                     // steps of this workgroup (even: cblocks is)
+    auto tile_m0 = [&](int it) { return ((int)blockIdx.x + it * (int)gridDim.x) * CNN_BM; };
     // ---- consumer state ----
     const int cw = wave & 3, wm = cw >> 1, wn = cw & 1;
     const int ct = tid & 255;
@@ -721,12 +761,17 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     // Two register sets of raw rows + taps in flight: a slice is stored to LDS TWO iterations after its loads were issued.  With one
     // set the loads had exactly one iteration to land, so an iteration could not be shorter than the HBM latency under load (~3 us
     // against ~0.7 us of MFMA work per channel block: the kernel ran at the memory LATENCY, not at any bandwidth).
-    struct RawSet { f32x4 rx[NLD]; bool pin[NLD]; f32x4 rw; };
+    struct RawSet { f32x4 rx[NLD]; bool pin[NLD]; f32x4 rw; bool edge; };
     RawSet S0, S1;
     S0.rw = f32x4{0.f, 0.f, 0.f, 0.f}; S1.rw = S0.rw;
     float amax = 0.0f;
     float *Xs = Xr[pw];
-    auto gloadX = [&](RawSet &S, int cb) {
+    auto gloadX = [&](RawSet &S, int step) {               // step: clamped to the last one (loads past the end are harmless)
+        step = min(step, nb - 1);
+        const int it = step / cblocks, cb = step - it * cblocks, m0 = tile_m0(it);
+        // rows outside [0, rows) read as zeros ('same' padding at the ends of the pass); only the first and the last row tile have
+        // any, so the 24 selects per slice sit behind a wave-uniform branch (the vector unit is what this kernel is short of)
+        S.edge = m0 - half < 0 || m0 + CNN_BM + half > rows;
 #pragma unroll
         for (int p = 0; p < NLD; p++) {
             const int f = lane + 64 * p, rr = f >> 3, q = f & 7;
@@ -739,10 +784,14 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
         if (wt < KW * 8) S.rw = *reinterpret_cast<const f32x4 *>(Wd + (size_t)(wt >> 3) * cin + (cb << 5) + (wt & 7) * 4);
     };
     auto lstoreX = [&](RawSet &S, int wbuf) {
+        if (S.edge) {
+#pragma unroll
+            for (int p = 0; p < NLD; p++) S.rx[p] = S.pin[p] ? S.rx[p] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int p = 0; p < NLD; p++) {
             const int f = lane + 64 * p, rr = f >> 3, q = f & 7;
-            if (rr < SROWS) *reinterpret_cast<f32x4 *>(&Xs[rr * SEP_XPW + q * 4]) = S.pin[p] ? S.rx[p] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rr < SROWS) *reinterpret_cast<f32x4 *>(&Xs[rr * SEP_XPW + q * 4]) = S.rx[p];
         }
         if (ct < KW * 8) *reinterpret_cast<f32x4 *>(&Wl[wbuf][(ct >> 3) * 32 + (ct & 7) * 4]) = S.rw;
     };
@@ -759,13 +808,21 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
         for (int t = 0; t < KW; t++) w[t] = *reinterpret_cast<const f32x2 *>(&Wl[wbuf][t * 32 + cp]);
 #pragma unroll
         for (int i = 0; i < 8; i++) o[i] = f32x2{0.f, 0.f};
+        // All input rows first, then per input row one GROUP of up to 8 independent FMAs (one per output row it meets), in exactly
+        // this order: the FMAs are volatile asm statements, which keep their relative order.  Left to the compiler this became 8
+        // serial chains of 17 dependent v_pk_fma_f32 with a hazard nop after each (a dependent vector instruction issues every
+        // ~8.5 ticks, an independent one every ~5.5: tools/ubench_coissue.hip, profiles/r01_valu_issue_microbench.txt);
+        // __builtin_amdgcn_sched_barrier between the groups did not help, the chains are formed before the scheduler sees them.
+        // The phase trace (tools/ws_trace.py) shows the producers' filter, not the matrix work, setting the pace of the workgroup.
+        f32x2 x[KW + 7];
+#pragma unroll
+        for (int j = 0; j < KW + 7; j++) x[j] = *reinterpret_cast<const f32x2 *>(&Xs[(dr + j) * SEP_XPW + cp]);
 #pragma unroll
         for (int j = 0; j < KW + 7; j++) {
-            const f32x2 x = *reinterpret_cast<const f32x2 *>(&Xs[(dr + j) * SEP_XPW + cp]);
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int t = j - i;                       // tap of output row dr + i that input row dr + j meets (ascending per output)
-                if (t >= 0 && t < KW) o[i] = __builtin_elementwise_fma(x, w[t], o[i]);
+                if (t >= 0 && t < KW) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(o[i]) : "v"(x[j]), "v"(w[t]));
             }
         }
 #pragma unroll
@@ -784,15 +841,12 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
                 *reinterpret_cast<bf16x2 *>(&As[abuf][0][off]) = h; *reinterpret_cast<bf16x2 *>(&As[abuf][1][off]) = m;
                 *reinterpret_cast<bf16x2 *>(&As[abuf][NP - 1][off]) = l;
             } else {
+                // the pair at once: packed round-to-nearest conversions, packed subtraction (same values as element by element)
                 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-                f16x2 h, l;
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const float x = o[i][e];
-                    amax = fmaxf(amax, fabsf(x));
-                    const _Float16 hh = (_Float16)x;
-                    h[e] = hh; l[e] = (_Float16)(x - (float)hh);
-                }
+                amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(o[i][0]), __builtin_fabsf(o[i][1])));
+                const f16x2 h = __builtin_convertvector(o[i], f16x2);
+                const f32x2 rest = o[i] - __builtin_convertvector(h, f32x2);
+                const f16x2 l = __builtin_convertvector(rest, f16x2);
                 *reinterpret_cast<f16x2 *>(&As[abuf][0][off]) = h; *reinterpret_cast<f16x2 *>(&As[abuf][1][off]) = l;
             }
         }
@@ -801,28 +855,35 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     // side: the register allocation is the larger of the two, not the sum).  Every wavefront executes the same number of barriers.
     if (producer) {
         // block b's raw slice travels in set S1 for even b >= 2, S0 for odd b (and for blocks 0, 1 of the prologue); cblocks is even
-        gloadX(S0, 0); lstoreX(S0, 0); gloadX(S0, min(1, cblocks - 1)); gloadX(S1, min(2, cblocks - 1));
+        // step b's raw slice travels in set S1 for even b >= 2, S0 for odd b (and for steps 0, 1 of the prologue)
+        gloadX(S0, 0); lstoreX(S0, 0); gloadX(S0, 1); gloadX(S1, 2);
         __syncthreads();
-        depthwise(0, 0); lstoreX(S0, 1); gloadX(S0, min(3, cblocks - 1));
+        depthwise(0, 0); lstoreX(S0, 1); gloadX(S0, 3);
         __syncthreads();
-        for (int cb = 0; cb < cblocks; cb += 2) {
-            // even iteration: filter block cb + 1 (stored during iteration cb - 1), store block cb + 2 (set S1, loaded two iterations ago)
-            if (cb + 1 < cblocks) { depthwise(1, 1); lstoreX(S1, 0); gloadX(S1, min(cb + 4, cblocks - 1)); }
+        // The steady-state loop has NO conditional around its loads: with `if (b + 2 < nb)` around the second half, the two paths
+        // into the loop head carried different numbers of outstanding loads, the compiler's wait insertion took the conservative
+        // one and put s_waitcnt vmcnt(0) in front of the first use of the OLDER set.  The last pair of steps is peeled instead.
+        for (int b = 0; b + 2 < nb; b += 2) {
+            const bool tr = b / cblocks == WS_TRACE_TILE; const int c4 = 4 * (b % cblocks); (void)tr; (void)c4;
+            // even step: filter step b + 1 (stored during step b - 1), store step b + 2 (set S1, loaded two steps ago)
+            if (tr) WS_T(3 + c4);
+            depthwise(1, 1); if (tr) WS_T(4 + c4); lstoreX(S1, 0); gloadX(S1, b + 4);
+            if (tr) WS_T(5 + c4);
             __syncthreads();
-            // odd iteration cb + 1: filter block cb + 2, store block cb + 3 (set S0)
-            if (cb + 2 < cblocks) { depthwise(0, 0); lstoreX(S0, 1); gloadX(S0, min(cb + 5, cblocks - 1)); }
+            if (tr) WS_T(6 + c4);
+            // odd step b + 1: filter step b + 2, store step b + 3 (set S0)
+            depthwise(0, 0); if (tr) WS_T(7 + c4); lstoreX(S0, 1); gloadX(S0, b + 5);
+            if (tr) WS_T(8 + c4);
             __syncthreads();
+            if (tr) WS_T(9 + c4);
         }
+        depthwise(1, 1);                                   // the last step (nb - 1, odd)
+        __syncthreads();
+        __syncthreads();
         if (NP == 2 && __any(amax > 65504.0f) && lane == 0) atomicOr(range_flag, 1u);
         return;
     }
     f32x16 acc[2][NJ];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < NJ; j++)
-#pragma unroll
-            for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
     // B fragments come STRAIGHT from L2 into registers (pre-split weights [channel block][piece][cout][32]: a fragment is one
     // 16-byte load, 64-byte rows of consecutive lanes coalesce): no B tile in LDS -- that tile was 82 of the kernel's 155 KB, which
     // kept this workgroup off every CU where a per-read stage of another batch held some LDS, and half of its LDS traffic.
@@ -830,7 +891,7 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     const int fm = lane & 31, fk = (lane >> 5) * 8;
     const uint16_t *wlane = Wb + ((size_t)(n0 + wn * (BN / 2) + fm)) * 32 + fk;
     auto loadB = [&](u32x4 (&b)[NJ][NP], int step) {            // step = 2 * cb + k16
-        const int cb = min(step >> 1, cblocks - 1), k16 = step & 1;
+        const int cb = (step >> 1) % cblocks, k16 = step & 1;          // the weights of a step depend on its channel block only
 #pragma unroll
         for (int pc = 0; pc < NP; pc++)
 #pragma unroll
@@ -841,6 +902,9 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     __syncthreads();
     __syncthreads();
     auto mma = [&](int cur, int k16, u32x4 (&b)[NJ][NP]) {
+#ifdef DN_WS_NOMMA
+        return;
+#endif
         u32x4 a[2][NP];
 #pragma unroll
         for (int pc = 0; pc < NP; pc++)
@@ -859,18 +923,32 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
                     acc[i][j] = mfma16<NP>(a[i][pa], b[j][pb], acc[i][j]);
         }
     };
-    for (int cb = 0; cb < cblocks; cb++) {
-        const int cur = cb & 1;
-        loadB(b1, 2 * cb + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(cur, 0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        loadB(b0, 2 * cb + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(cur, 1, b1);
-        __syncthreads();
+    for (int it = 0; it < my_tiles; it++) {
+        const bool tr = it == WS_TRACE_TILE; (void)tr;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
+        if (tr) WS_T(3);
+        for (int cb = 0; cb < cblocks; cb++) {
+            const int cur = cb & 1, step = it * cblocks + cb;
+            loadB(b1, 2 * step + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(cur, 0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tr) WS_T(4 + 3 * cb);
+            loadB(b0, 2 * step + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(cur, 1, b1);
+            if (tr) WS_T(5 + 3 * cb);
+            __syncthreads();
+            if (tr) WS_T(6 + 3 * cb);
+        }
+        conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, tile_m0(it), n0, wm, wn, lane, cout, relu, post);
+        if (tr) WS_T(40);
     }
-    conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, m0, n0, wm, wn, lane, cout, relu, post);
 }
 
 // depthwise part of SeparableConv1D: each thread owns 4 channels of DW_ROWS consecutive rows and slides a register window
@@ -978,6 +1056,10 @@ struct CnnRun {
     unsigned *row_off_w; int *live;   // device: this pass's row offsets (written by k3_layout) and its live row count
 };
 
+static unsigned k3_cu_count() {                            // persistent kernels: one workgroup per CU of the current device
+    static const unsigned n = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return (unsigned)v; }();
+    return n;
+}
 static bool k3_sep_ws_enabled() { static const bool on = !(getenv("DN_CNN_SEP_WS") && atoi(getenv("DN_CNN_SEP_WS")) == 0); return on; }
 static bool k3_bm256_enabled() { static const bool on = !(getenv("DN_CNN_BM256") && atoi(getenv("DN_CNN_BM256")) == 0); return on; }
 static bool k3_fuse_enabled() { static const bool on = !(getenv("DN_CNN_FUSE") && atoi(getenv("DN_CNN_FUSE")) == 0); return on; }
@@ -1009,9 +1091,9 @@ static int k3_launch_sep(const CnnRun &c, int i, const float *in, float *out, co
 #define SEP_ARGS in, out, c.wts + d.w, c.wts_split + c.wb_off[i + 1], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, c.live, \
         o.cin, o.cout, o.relu, c.post[i + 1], c.range_flag
 #define SEP_GO(KW_) hipLaunchKernelGGL((k3_sep_split<BN, KW_, ADD, NP>), dim3(conv_grid(rows, o.cout, BN)), dim3(256), 0, st, SEP_ARGS)
-    if (NP == 2 && d.k == 17 && o.cout % 256 == 0 && o.cin % 64 == 0 && k3_sep_ws_enabled()) {
+    if (NP == 2 && d.k == 17 && o.cout == 256 && o.cin % 64 == 0 && k3_sep_ws_enabled()) {      // BN == cout: one column tile
         if (c.mark) c.mark(c.mark_who, 1, st);
-        hipLaunchKernelGGL((k3_sep_ws<256, 17, ADD, 2>), dim3(conv_grid(rows, o.cout, 256)), dim3(512), 0, st, SEP_ARGS);
+        hipLaunchKernelGGL((k3_sep_ws<256, 17, ADD, 2>), dim3(min(conv_grid(rows, o.cout, 256), k3_cu_count())), dim3(512), 0, st, SEP_ARGS);
         if (c.mark) c.mark(c.mark_who, 0, st);
         return 0;
     }
