@@ -215,6 +215,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][BN / 64], float *
     // element, 6.8 k ticks per 128 x 256 tile -- a seventh of the 17-tap layer's time and the whole of the short layers' tail.
     constexpr int NJ = BN / 64;
     const unsigned long long vmask = __ballot(valid[m0 + wm * 64 + lane] != 0);
+    const bool all_valid = vmask == ~0ull;                 // wave-uniform
     const float floor_ = relu ? 0.0f : -3.402823466e38f;
     const int colb = n0 + wn * (BN / 2) + (lane & 31);
     float sc[NJ], sh[NJ];
@@ -242,18 +243,26 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][BN / 64], float *
                 for (int j = 0; j < NJ; j++) addv[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, voff + j * 128, soff, 0));
             }
         }
+        // rows in pairs (q, q + 1): packed FMA and packed add; the padding select only where the wavefront's rows have padding at all
+        // (a tile in 140 on the 20 kb workload)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int row = i * 32 + (q & 3) + 8 * (q >> 2);                   // + 4 for the upper lane half
-            const int soff = __builtin_amdgcn_readfirstlane(row * cout * 4);
-            const unsigned long long keep = (((vmask >> row) & 1ull) ? 0x00000000ffffffffull : 0ull) | (((vmask >> (row + 4)) & 1ull) ? 0xffffffff00000000ull : 0ull);
+        for (int q = 0; q < 16; q += 2) {
+            const int row = i * 32 + (q & 3) + 8 * (q >> 2);                   // + 4 for the upper lane half; q + 1: the next row
+            const int soff0 = __builtin_amdgcn_readfirstlane(row * cout * 4), soff1 = __builtin_amdgcn_readfirstlane((row + 1) * cout * 4);
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
-                float y = __builtin_fmaf(acc[i][j][q], sc[j], sh[j]);
-                if (ADD) y += addv[q][j];
-                y = fmaxf(y, floor_);
-                asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(y) : "v"(y), "s"(keep));
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), ry, voff + j * 128, soff, 0);
+                f32x2 y = __builtin_elementwise_fma(f32x2{acc[i][j][q], acc[i][j][q + 1]}, f32x2{sc[j], sc[j]}, f32x2{sh[j], sh[j]});
+                if (ADD) y += f32x2{addv[q][j], addv[q + 1][j]};
+                float y0 = fmaxf(y[0], floor_), y1 = fmaxf(y[1], floor_);
+                if (!all_valid) {
+                    const unsigned long long k0 = (((vmask >> row) & 1ull) ? 0x00000000ffffffffull : 0ull) | (((vmask >> (row + 4)) & 1ull) ? 0xffffffff00000000ull : 0ull);
+                    const unsigned long long k1 = (((vmask >> (row + 1)) & 1ull) ? 0x00000000ffffffffull : 0ull) | (((vmask >> (row + 5)) & 1ull) ? 0xffffffff00000000ull : 0ull);
+                    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(y0) : "v"(y0), "s"(k0));
+                    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(y1) : "v"(y1), "s"(k1));
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y0), ry, voff + j * 128, soff0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y1), ry, voff + j * 128, soff1, 0);
             }
         }
     }
@@ -766,22 +775,43 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     S0.rw = f32x4{0.f, 0.f, 0.f, 0.f}; S1.rw = S0.rw;
     float amax = 0.0f;
     float *Xs = Xr[pw];
-    auto gloadX = [&](RawSet &S, int step) {               // step: clamped to the last one (loads past the end are harmless)
-        step = min(step, nb - 1);
-        const int it = step / cblocks, cb = step - it * cblocks, m0 = tile_m0(it);
-        // rows outside [0, rows) read as zeros ('same' padding at the ends of the pass); only the first and the last row tile have
-        // any, so the 24 selects per slice sit behind a wave-uniform branch (the vector unit is what this kernel is short of)
-        S.edge = m0 - half < 0 || m0 + CNN_BM + half > rows;
+    // The raw slices are fetched in step order, one call per step: the position of the load stream (tile, channel block) is kept
+    // incrementally (no division per call); past the last step it stays on the last one (loads past the end are harmless).
+    // Interior tiles use buffer addressing: descriptor = the wavefront's SROWS rows, voffset = the lane's (row, float4) inside
+    // them (six lane constants), soffset = the channel block -- no 64-bit address arithmetic in the vector unit, which is what
+    // this kernel is short of.  The taps likewise; lanes beyond the KW x 8 float4 of a block fall outside the descriptor and
+    // read zeros, so there is no branch around that load and the count of loads in flight is the same on every path.
+    int ld_cb = 0, ld_it = 0;
+    auto uniform_ptr = [](const void *p) {
+        const unsigned long long v = (unsigned long long)p;
+        return (void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+    };
+    int xoff[NLD];
 #pragma unroll
-        for (int p = 0; p < NLD; p++) {
-            const int f = lane + 64 * p, rr = f >> 3, q = f & 7;
-            const int src = m0 + 32 * pw - half + rr;
-            const bool in = rr < SROWS && src >= 0 && src < rows;
-            S.rx[p] = *reinterpret_cast<const f32x4 *>(X + (size_t)(in ? src : m0) * cin + (cb << 5) + q * 4);
-            S.pin[p] = in;
+    for (int p = 0; p < NLD; p++) { const int f = lane + 64 * p; xoff[p] = ((f >> 3) * cin + (f & 7) * 4) * 4; }
+    const int woff = ((ct >> 3) * cin + (ct & 7) * 4) * 4;
+    const __amdgpu_buffer_rsrc_t rtap = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float *>(Wd)), 0, KW * cin * 4, 0x00020000);
+    auto gloadX = [&](RawSet &S) {
+        const int cb = ld_cb, m0 = tile_m0(ld_it);
+        if (ld_cb + 1 < cblocks) ld_cb++; else if (ld_it + 1 < my_tiles) { ld_cb = 0; ld_it++; }
+        // rows outside [0, rows) read as zeros ('same' padding at the ends of the pass); only the first and the last row tile have
+        // any: they take the clamped-address path and 24 selects per slice (lstoreX), behind wave-uniform branches
+        S.edge = m0 - half < 0 || m0 + CNN_BM + half > rows;
+        if (S.edge) {
+#pragma unroll
+            for (int p = 0; p < NLD; p++) {
+                const int f = lane + 64 * p, rr = f >> 3, q = f & 7;
+                const int src = m0 + 32 * pw - half + rr;
+                const bool in = rr < SROWS && src >= 0 && src < rows;
+                S.rx[p] = *reinterpret_cast<const f32x4 *>(X + (size_t)(in ? src : m0) * cin + (cb << 5) + q * 4);
+                S.pin[p] = in;
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float *>(X + (size_t)(m0 + 32 * pw - half) * cin)), 0, SROWS * cin * 4, 0x00020000);
+#pragma unroll
+            for (int p = 0; p < NLD; p++) S.rx[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsl, xoff[p], cb << 7, 0));
         }
-        const int wt = ct;                                 // taps: KW x 8 float4, spread over the 256 producer threads
-        if (wt < KW * 8) S.rw = *reinterpret_cast<const f32x4 *>(Wd + (size_t)(wt >> 3) * cin + (cb << 5) + (wt & 7) * 4);
+        S.rw = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rtap, woff, cb << 7, 0));
     };
     auto lstoreX = [&](RawSet &S, int wbuf) {
         if (S.edge) {
@@ -856,23 +886,23 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     if (producer) {
         // block b's raw slice travels in set S1 for even b >= 2, S0 for odd b (and for blocks 0, 1 of the prologue); cblocks is even
         // step b's raw slice travels in set S1 for even b >= 2, S0 for odd b (and for steps 0, 1 of the prologue)
-        gloadX(S0, 0); lstoreX(S0, 0); gloadX(S0, 1); gloadX(S1, 2);
+        gloadX(S0); lstoreX(S0, 0); gloadX(S0); gloadX(S1);
         __syncthreads();
-        depthwise(0, 0); lstoreX(S0, 1); gloadX(S0, 3);
+        depthwise(0, 0); lstoreX(S0, 1); gloadX(S0);
         __syncthreads();
         // The steady-state loop has NO conditional around its loads: with `if (b + 2 < nb)` around the second half, the two paths
         // into the loop head carried different numbers of outstanding loads, the compiler's wait insertion took the conservative
         // one and put s_waitcnt vmcnt(0) in front of the first use of the OLDER set.  The last pair of steps is peeled instead.
         for (int b = 0; b + 2 < nb; b += 2) {
-            const bool tr = b / cblocks == WS_TRACE_TILE; const int c4 = 4 * (b % cblocks); (void)tr; (void)c4;
+            const bool tr = WS_TRACE_TILE >= 0 && b / cblocks == WS_TRACE_TILE; const int c4 = WS_TRACE_TILE >= 0 ? 4 * (b % cblocks) : 0; (void)tr; (void)c4;
             // even step: filter step b + 1 (stored during step b - 1), store step b + 2 (set S1, loaded two steps ago)
             if (tr) WS_T(3 + c4);
-            depthwise(1, 1); if (tr) WS_T(4 + c4); lstoreX(S1, 0); gloadX(S1, b + 4);
+            depthwise(1, 1); if (tr) WS_T(4 + c4); lstoreX(S1, 0); gloadX(S1);
             if (tr) WS_T(5 + c4);
             __syncthreads();
             if (tr) WS_T(6 + c4);
             // odd step b + 1: filter step b + 2, store step b + 3 (set S0)
-            depthwise(0, 0); if (tr) WS_T(7 + c4); lstoreX(S0, 1); gloadX(S0, b + 5);
+            depthwise(0, 0); if (tr) WS_T(7 + c4); lstoreX(S0, 1); gloadX(S0);
             if (tr) WS_T(8 + c4);
             __syncthreads();
             if (tr) WS_T(9 + c4);
