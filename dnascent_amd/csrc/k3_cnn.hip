@@ -547,6 +547,9 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
 //     pointwise  the 1-tap step of k3_conv_split on those planes
 //   Two barriers per block: [A planes complete / raw tile free] -> next raw tile + taps to LDS, MFMAs -> [planes and B free] ->
 //   next B tile to LDS, next depthwise.  A workgroup does not overlap its own depthwise with its own MFMAs; the 2 workgroups of a CU do.
+// (Round 2: the vector-unit diet that helped k3_sep_ws -- packed FMAs in a fixed interleaved order, packed conversions, buffer
+// addressing, selects only on edge tiles -- was applied here too and measured A/B in one session: 5-tap layers unchanged, 9-tap layers
+// 3.5 % slower (240 VGPRs instead of 232); with two or three workgroups per CU this kernel is not short of vector issue.  Not kept.)
 // (Round 2: taking the B fragments straight from L2 instead of an LDS tile cuts the kernel's LDS from 64 to 43 KB for 128 channels,
 // enough for three workgroups per CU -- but the fragments' registers push it to 244 VGPRs (two workgroups again, 3.35 ms against 3.19
 // for the eleven 9-tap layers), and capping the registers at 168 spills: 10.8 ms.  Not kept.)
@@ -1086,8 +1089,13 @@ struct CnnRun {
     unsigned *row_off_w; int *live;   // device: this pass's row offsets (written by k3_layout) and its live row count
 };
 
-static unsigned k3_cu_count() {                            // persistent kernels: one workgroup per CU of the current device
-    static const unsigned n = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return (unsigned)v; }();
+static unsigned k3_cu_count() {                            // persistent kernels: one workgroup per CU of the current device (DN_CNN_WS_WGS overrides)
+    static const unsigned n = [] {
+        if (getenv("DN_CNN_WS_WGS") && atoi(getenv("DN_CNN_WS_WGS")) > 0) return (unsigned)atoi(getenv("DN_CNN_WS_WGS"));
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return (unsigned)v;
+    }();
     return n;
 }
 static bool k3_sep_ws_enabled() { static const bool on = !(getenv("DN_CNN_SEP_WS") && atoi(getenv("DN_CNN_SEP_WS")) == 0); return on; }
