@@ -87,18 +87,31 @@ def cpu_baseline(model, n_bases, seed0, full, budget_reads):
             "sample": "%d of the %d-base reads of the workload (%d pass QC); %s" % (n, n_bases, ok, what)}
 
 
+def _hbm_info():
+    """device memory in use at the end of the run (every context, every CNN lane allocated): hipMemGetInfo through ctypes"""
+    import ctypes
+    try:
+        rt = ctypes.CDLL("libamdhip64.so")
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        if rt.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) != 0:
+            return None
+        return {"used_GB": round((total.value - free.value) / 1e9, 1), "total_GB": round(total.value / 1e9, 1)}
+    except OSError:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scope", choices=["full", "banded"], default="full",
                     help="full = BASELINE configs[2] (default): streamed 50 kb reads, whole pipeline, H2D to results on host; "
                          "banded = configs[1]: 1 000 x 20 kb resident batch, normaliseEvents only (CNN stubbed)")
     ap.add_argument("--reads-per-step", type=int, default=None, help="reads per batch (default 500 full / 1000 banded)")
     ap.add_argument("--bases", type=int, default=None, help="bases per read (default 50000 full / 20000 banded)")
     ap.add_argument("--inflight", type=int, default=None,
-                    help="batches in flight per GPU, each on its own context / stream / workspace (default 4 full / 8 banded)")
+                    help="batches in flight per GPU, each on its own context / stream / workspace (default 6 full / 8 banded)")
     ap.add_argument("--emit", type=int, default=1, help="full scope: format + write the .detect records inside the timed region")
     ap.add_argument("--out", default=None, help="full scope: .detect output path (default: formatted and counted, not written)")
     ap.add_argument("--cnn-math", choices=["f16x3", "bf16x6", "fp32"], default=None)
@@ -107,7 +120,7 @@ def main():
     full = args.scope == "full"
     rps = args.reads_per_step or (500 if full else 1000)
     bases = args.bases or (50000 if full else 20000)
-    inflight = args.inflight or (4 if full else 8)
+    inflight = args.inflight or (6 if full else 8)         # full: 3 -> 548, 4 -> 587, 6 -> 617 Msamples/s in one session; 8 does not fit beside the CNN lanes
     os.environ.setdefault("DN_CNN_ROWS", str(4 << 20))      # activation rows resident per CNN pass and lane: 4 Mi rows = 16 GiB (2 Mi: -6 %, 8 Mi: -3 %)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -163,6 +176,11 @@ def main():
     gather_s = 0.0
     if full:
         warm, timed = batches[:args.warmup], batches[args.warmup:]
+        # set-up, not a step: every context the warm-up batches will not reach gets its workspace now (a first upload is a
+        # 10+ GB hipMalloc; with --warmup 2 and 4 contexts two of those used to land inside the timed region: 513 against 605)
+        for c in ctxs[len(warm):]:
+            batches[0].upload(c)
+            c.sync()
         if warm:
             host.stream_detect(ctxs, warm, emit=bool(args.emit), out_path=None)
         barrier()
@@ -325,6 +343,7 @@ def main():
             if "roofline" not in out:
                 out["roofline"] = roof_net
             out["roofline_banded"] = roof_banded
+            out["hbm"] = _hbm_info()
             out["host"] = {"datagen_s": t_gen, "upload_s": st.seconds_upload, "collect_wait_s": st.seconds_collect, "emit_s": st.seconds_emit,
                            "gather_s": gather_s, "emission": {"records_per_s": st.calls / st.seconds_emit if st.seconds_emit > 0 else None,
                                                               "MB_per_s": st.bytes_out / st.seconds_emit / 1e6 if st.seconds_emit > 0 else None,

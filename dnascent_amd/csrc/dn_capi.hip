@@ -106,6 +106,7 @@ struct dn_ctx {
     // per-batch workspaces come out of grow-only slabs: after the first batches no hipMalloc / hipFree happens per upload
     struct Slab { char *p; size_t cap, used; };
     std::vector<Slab> slabs; size_t slab_cur = 0;
+    bool measuring = false; size_t measured = 0;        // dn_batch_upload's first pass: sizes only (see fit_slab)
     // model
     double *d_model = nullptr; double sigma = 0.14; bool have_model = false;
     unsigned *d_model_pos = nullptr; double *d_model_sorted = nullptr;
@@ -177,6 +178,7 @@ static size_t slab_min_bytes() {
 template <class T>
 static int dalloc(dn_ctx *c, T **p, size_t n) {
     const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+    if (c->measuring) { c->measured += bytes; *p = nullptr; return DN_OK; }
     for (; c->slab_cur < c->slabs.size(); c->slab_cur++) {
         dn_ctx::Slab &s = c->slabs[c->slab_cur];
         if (s.used + bytes <= s.cap) { *p = (T *)(s.p + s.used); s.used += bytes; return DN_OK; }
@@ -206,6 +208,22 @@ static void dfree_all(dn_ctx *c) {                       // start of a new batch
 static void dfree_slabs(dn_ctx *c) {
     for (dn_ctx::Slab &s : c->slabs) hipFree(s.p);
     c->slabs.clear(); c->slab_cur = 0;
+}
+// The workspace of a batch is ONE slab sized from the batch itself: dn_batch_upload first runs its placement with dalloc only adding
+// up (every size follows from the batch's offsets), then makes sure a single slab of that size (+ 1/16 so that the next, slightly
+// larger batch still fits) exists, then places for real.  Growing slab by slab as the placements came (round 1) left a context
+// holding ~35 GB for a 500 x 50 kb batch that needs ~14: skipped tails of earlier slabs and geometric growth.
+static int fit_slab(dn_ctx *c, size_t need) {
+    if (c->slabs.size() == 1 && c->slabs[0].cap >= need) return DN_OK;
+    for (dn_ctx::Slab &s : c->slabs) { hipFree(s.p); c->dev_bytes -= s.cap; }
+    c->slabs.clear(); c->slab_cur = 0;
+    size_t cap = std::max(need + need / 16 + (1u << 20), slab_min_bytes());
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, cap);
+    if (e != hipSuccess) { (void)hipGetLastError(); cap = need; q = nullptr; e = hipMalloc(&q, cap); }   // memory is tight: exactly what is needed, and THAT capacity recorded
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(c, DN_ERR_HIP, "hipMalloc(%zu) for the batch workspace: %s", need, hipGetErrorString(e)); }
+    c->slabs.push_back({ (char *)q, cap, 0 }); c->dev_bytes += cap;
+    return DN_OK;
 }
 static int dgrow(dn_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap) return DN_OK;
@@ -299,7 +317,7 @@ static int upload(dn_ctx *c, const T **dst, const T *src, size_t n) {
     T *d = nullptr;
     int rc = dalloc(c, &d, n);
     if (rc) return rc;
-    if (n) HIPCHK(c, hipMemcpyAsync(d, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    if (n && !c->measuring) HIPCHK(c, hipMemcpyAsync(d, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
     *dst = d;
     return DN_OK;
 }
@@ -526,6 +544,23 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     }
     const uint64_t NCH = c->h_chunk_off[n], NEV = c->h_ev_off[n], NAL = c->h_aln_off[n];
     int rc;
+    {   // dn_collect's packed arrays: a call is a thymidine of referenceSeqMappedTo (detect.cpp:690), so their count is the bound
+        size_t nt = 0;
+        for (uint64_t i = 0; i < NR; i++) nt += d->refseq[i] == 'T';
+        c->n_ref_T = (nt + 3) & ~(size_t)3;
+    }
+    if (n > c->p_cap) {                                   // page-locked mirrors for the stream-ordered host functions
+        if (c->p_res) { hipHostFree(c->p_res); hipHostFree(c->p_bandc); hipHostFree(c->p_vit); hipHostFree(c->p_call_off); hipHostFree(c->p_summary); }
+        c->p_res = nullptr; c->p_bandc = nullptr; c->p_vit = nullptr; c->p_call_off = nullptr; c->p_summary = nullptr; c->p_cap = 0;
+        const size_t cap = (size_t)n + n / 4 + 16;
+        HIPCHK(c, hipHostMalloc((void **)&c->p_res, cap * sizeof(ReadRes), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->p_bandc, cap * sizeof(BandConstsH), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->p_vit, cap * sizeof(VitReadH), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->p_call_off, (cap + 1) * sizeof(unsigned long long), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->p_summary, cap * sizeof(dn_read_summary), hipHostMallocDefault));
+        c->p_cap = cap;
+    }
+    auto place = [&]() -> int {
 #define UP(field, src, cnt) if ((rc = upload(c, &B.field, src, (size_t)(cnt)))) return rc
     UP(adc, d->adc, S);                  UP(samp_off, c->h_samp_off.data(), n + 1);
     UP(cal_off, d->cal_offset, n);       UP(cal_scale, d->cal_scale, n);
@@ -554,28 +589,21 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     if ((rc = dalloc(c, &B.trace, (size_t)c->h_trace_off[n] * DN_TROW))) return rc;
     { BandConstsH *bcp = nullptr; if ((rc = dalloc(c, &bcp, (size_t)n))) return rc; c->d_bandc = bcp; }
     if ((rc = dalloc(c, &c->d_call_cnt, (size_t)n)) || (rc = dalloc(c, &c->d_call_off, (size_t)n + 1))) return rc;
-    {   // dn_collect's packed arrays: a call is a thymidine of referenceSeqMappedTo (detect.cpp:690), so their count is the bound
-        size_t nt = 0;
-        for (uint64_t i = 0; i < NR; i++) nt += d->refseq[i] == 'T';
-        c->n_ref_T = (nt + 3) & ~(size_t)3;
-        if ((rc = dalloc(c, &c->d_col, std::max<size_t>(c->n_ref_T, 4) * (5 * 4 + DN_KMER)))) return rc;
-    }
-    if (n > c->p_cap) {                                   // page-locked mirrors for the stream-ordered host functions
-        if (c->p_res) { hipHostFree(c->p_res); hipHostFree(c->p_bandc); hipHostFree(c->p_vit); hipHostFree(c->p_call_off); hipHostFree(c->p_summary); }
-        c->p_res = nullptr; c->p_bandc = nullptr; c->p_vit = nullptr; c->p_call_off = nullptr; c->p_summary = nullptr; c->p_cap = 0;
-        const size_t cap = (size_t)n + n / 4 + 16;
-        HIPCHK(c, hipHostMalloc((void **)&c->p_res, cap * sizeof(ReadRes), hipHostMallocDefault));
-        HIPCHK(c, hipHostMalloc((void **)&c->p_bandc, cap * sizeof(BandConstsH), hipHostMallocDefault));
-        HIPCHK(c, hipHostMalloc((void **)&c->p_vit, cap * sizeof(VitReadH), hipHostMallocDefault));
-        HIPCHK(c, hipHostMalloc((void **)&c->p_call_off, (cap + 1) * sizeof(unsigned long long), hipHostMallocDefault));
-        HIPCHK(c, hipHostMalloc((void **)&c->p_summary, cap * sizeof(dn_read_summary), hipHostMallocDefault));
-        c->p_cap = cap;
-    }
+    if ((rc = dalloc(c, &c->d_col, std::max<size_t>(c->n_ref_T, 4) * (5 * 4 + DN_KMER)))) return rc;
     if ((rc = dalloc(c, &c->ea.coord, (size_t)NR)) || (rc = dalloc(c, &c->ea.qidx, (size_t)NR)) || (rc = dalloc(c, &c->ea.ridx, (size_t)NR)) ||
         (rc = dalloc(c, &c->ea.indel, (size_t)NR)) || (rc = dalloc(c, &c->ea.nsig, (size_t)NR)) || (rc = dalloc(c, &c->ea.sig, (size_t)NR * DN_RAWDEPTH)) ||
         (rc = dalloc(c, &c->ea.core, (size_t)NR)) || (rc = dalloc(c, &c->ea.resid, (size_t)NR)) || (rc = dalloc(c, &c->ea.win_ref, (size_t)NR)) ||
         (rc = dalloc(c, &c->ea.win_len, (size_t)NR)) || (rc = dalloc(c, &c->ea.win_T, (size_t)NR)) || (rc = dalloc(c, &c->ea.win_score, (size_t)NR)) ||
         (rc = dalloc(c, &c->d_vitread, (size_t)n)) || (rc = dalloc(c, &c->d_probs, (size_t)NR * 3)) || (rc = dalloc(c, &c->ea.redo, (size_t)n))) return rc;
+        return DN_OK;
+    };
+    c->measuring = true; c->measured = 0;
+    rc = place();
+    c->measuring = false;
+    if (rc) return rc;
+    if ((rc = fit_slab(c, c->measured))) return rc;
+    dfree_all(c);
+    if ((rc = place())) return rc;
     c->max_ref = 0;
     for (uint32_t r = 0; r < n; r++) c->max_ref = std::max<unsigned>(c->max_ref, (unsigned)(c->h_ref_off[r + 1] - c->h_ref_off[r]));
     HIPCHK(c, hipMemsetAsync(B.res, 0, n * sizeof(ReadRes), c->stream));
