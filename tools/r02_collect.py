@@ -7,7 +7,12 @@ for n in ("bench_default", "bench_under_rocprof", "bench_banded", "bench_fp32"):
         shutil.copy("%s/%s.json" % (src, n), "profiles/r02_%s.json" % n)
 
 
-def per_kernel(d):
+for n in ("k3_layers.txt", "k3_math_modes.txt"):
+    if os.path.exists(src + "/" + n):
+        shutil.copy(src + "/" + n, "profiles/r02_" + n)
+
+
+def per_kernel(d, short=True):
     f = glob.glob(src + "/" + d + "/*counter_collection.csv")[0]
     agg = collections.defaultdict(float); n = collections.Counter(); seen = set()
     for r in csv.DictReader(open(f)):
@@ -42,3 +47,26 @@ print(open("profiles/r02_pmc_hbm_traffic.csv").read())
 for n in ("bench_default", "bench_banded", "bench_fp32"):
     d = json.load(open("profiles/r02_%s.json" % n))
     print(n, round(d["value"], 1), d["unit"], "| roofline", d["roofline"]["kernel"], round(d["roofline"]["frac"], 4), "| cpu", d.get("cpu_baseline", {}).get("value"))
+
+# ---- K3 alone (tools/gpu_cnn_time.py 64 20000: 1.2 M positions): HBM traffic per kernel, summed over the launches of ONE network pass ----
+if glob.glob(src + "/k3pmc_WRITE_SIZE/*counter_collection.csv"):
+    def per_kernel_sum(d):
+        f = glob.glob(src + "/" + d + "/*counter_collection.csv")[0]
+        agg = collections.defaultdict(float); n = collections.Counter(); seen = set()
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            if not k.startswith("k3_"):
+                continue
+            agg[k] += float(r["Counter_Value"])
+            if (k, r["Dispatch_Id"]) not in seen:
+                seen.add((k, r["Dispatch_Id"])); n[k] += 1
+        return agg, n
+    w3, n3 = per_kernel_sum("k3pmc_WRITE_SIZE"); f3, m3 = per_kernel_sum("k3pmc_FETCH_SIZE")
+    passes = 5.0            # gpu_cnn_time.py runs the network once to warm up and 4 more times (1 + 3 timed + 1 first)
+    with open("profiles/r02_pmc_k3_traffic.csv", "w") as o:
+        o.write("# rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes), tools/gpu_cnn_time.py 64 20000 f16x3: K3 alone, 1 200 057 positions per network pass\n")
+        o.write("# MB per launch (mean); FETCH corrected x 2 (gfx950); layer I/O = rows x (cin + cout) x 4 B\n")
+        o.write("kernel,launches,WRITE_MB_per_launch,FETCH_MB_per_launch_corrected\n")
+        for k in sorted(w3, key=lambda k: -(w3[k] + 2 * f3.get(k, 0))):
+            o.write("%s,%d,%.1f,%.1f\n" % (k, n3[k], w3[k] * 1024 / n3[k] / 1e6, 2 * f3.get(k, 0) * 1024 / max(1, m3.get(k, 1)) / 1e6))
+    print(open("profiles/r02_pmc_k3_traffic.csv").read())
