@@ -129,6 +129,10 @@ def main():
     dist = None
     torch = None
     if world > 1:
+        # the host side (read generation, record formatting) is OpenMP over reads: the ranks of a node share its cores
+        # (torch.distributed.run exports OMP_NUM_THREADS=1 for its workers: the per-rank share replaces that launcher default)
+        if os.environ.get("OMP_NUM_THREADS", "1") == "1":
+            os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // world))
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
