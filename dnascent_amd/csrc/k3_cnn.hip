@@ -61,14 +61,43 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builti
 // (s_load_dwordx16 rows) instead of occupying ~2.5k vector registers per lane.
 typedef const float __attribute__((address_space(4))) *cfptr_t;
 
-// h[16] (x) W[16][48] accumulated into z r g (16 each), row by row so that every s_load fetches one contiguous row
-__device__ __forceinline__ void gru_matvec(const float (&h)[16], cfptr_t W, float (&z)[16], float (&r)[16], float (&g)[16]) {
+// h[16] (x) W[16][48] accumulated into z r g (16 each).  The 768 weights arrive as SGPR operands of the FMAs; left to the compiler
+// all 48 s_load_dwordx16 of a product were hoisted to its top, which needs 768 live SGPRs of the ~100 there are: the loop body held
+// 878 v_readlane + 876 v_writelane + 660 s_mov of SGPR spill traffic beside its 2 400 arithmetic instructions.  Here the weights
+// come in chunks of 32 (two s_load_dwordx16 in asm), double-buffered: the chunk after next is requested before the 32 FMAs of the
+// current one, and waited for (SMEM returns out of order: lgkmcnt(0)) after them -- 64 SGPRs live, nothing spilled.
+typedef float sf32x16 __attribute__((ext_vector_type(16)));
+struct WChunk { sf32x16 a, b; };
+template <int CHUNK> __device__ __forceinline__ void gru_wload(WChunk &w, cfptr_t W) {
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4" : "=&s"(w.a), "=&s"(w.b) : "s"(W), "n"(CHUNK * 128), "n"(CHUNK * 128 + 64));
+}
+__device__ __forceinline__ void gru_wwait(WChunk &w) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w.a), "+s"(w.b)); }
+template <int CHUNK> __device__ __forceinline__ void gru_wfma(const WChunk &w, const float (&h)[16], float (&z)[16], float (&r)[16], float (&g)[16]) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const float hj = h[j];
-#pragma unroll
-        for (int u = 0; u < 16; u++) { z[u] = __builtin_fmaf(hj, W[j * 48 + u], z[u]); r[u] = __builtin_fmaf(hj, W[j * 48 + 16 + u], r[u]); g[u] = __builtin_fmaf(hj, W[j * 48 + 32 + u], g[u]); }
+    for (int e = 0; e < 32; e++) {
+        const int idx = CHUNK * 32 + e, j = idx / 48, v = idx % 48;          // weight W[j][v]: input j, output v (z 0-15, r 16-31, g 32-47)
+        const float wv = e < 16 ? w.a[e] : w.b[e - 16];
+        // asm, not __builtin_fmaf: the SLP vectoriser pairs the FMAs into v_pk_fma_f32 with SGPR PAIRS assembled from non-adjacent
+        // registers (s_mov shuffles, more spills than before); one scalar operand per v_fmac_f32 is what the weights' layout gives
+        float &acc = v < 16 ? z[v] : v < 32 ? r[v - 16] : g[v - 32];
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(wv), "v"(h[j]));
     }
+}
+template <int C> struct GruSteps {
+    static __device__ __forceinline__ void run(WChunk &cur, WChunk &nxt, cfptr_t W, const float (&h)[16], float (&z)[16], float (&r)[16], float (&g)[16]) {
+        if (C + 1 < 24) gru_wload<(C + 1 < 24 ? C + 1 : 23)>(nxt, W);
+        gru_wfma<C>(cur, h, z, r, g);
+        if (C + 1 < 24) { gru_wwait(nxt); GruSteps<C + 1>::run(nxt, cur, W, h, z, r, g); }
+    }
+};
+template <> struct GruSteps<24> {
+    static __device__ __forceinline__ void run(WChunk &, WChunk &, cfptr_t, const float (&)[16], float (&)[16], float (&)[16], float (&)[16]) {}
+};
+__device__ __forceinline__ void gru_matvec(const float (&h)[16], cfptr_t W, float (&z)[16], float (&r)[16], float (&g)[16]) {
+    WChunk w0, w1;
+    gru_wload<0>(w0, W);
+    gru_wwait(w0);
+    GruSteps<0>::run(w0, w1, W, h, z, r, g);
 }
 
 // Positions are visited in order of DESCENDING signal length (k3_encode_len / k3_encode_perm below): a wavefront runs as many
