@@ -72,32 +72,41 @@ template <int CHUNK> __device__ __forceinline__ void gru_wload(WChunk &w, cfptr_
     asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4" : "=&s"(w.a), "=&s"(w.b) : "s"(W), "n"(CHUNK * 128), "n"(CHUNK * 128 + 64));
 }
 __device__ __forceinline__ void gru_wwait(WChunk &w) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w.a), "+s"(w.b)); }
-template <int CHUNK> __device__ __forceinline__ void gru_wfma(const WChunk &w, const float (&h)[16], float (&z)[16], float (&r)[16], float (&g)[16]) {
+typedef float gf32x2 __attribute__((ext_vector_type(2)));
+// the 32 weights of a chunk are 16 adjacent (output v, v + 1) pairs of ONE input j or of two consecutive ones (48 outputs per input):
+// v_pk_fma_f32 with the SGPR pair as one operand and h[j] broadcast to both halves -- half the vector instructions of v_fmac_f32
+template <int CHUNK> __device__ __forceinline__ void gru_wfma(const WChunk &w, const gf32x2 (&hh)[16], gf32x2 (&acc)[24]) {
 #pragma unroll
-    for (int e = 0; e < 32; e++) {
-        const int idx = CHUNK * 32 + e, j = idx / 48, v = idx % 48;          // weight W[j][v]: input j, output v (z 0-15, r 16-31, g 32-47)
-        const float wv = e < 16 ? w.a[e] : w.b[e - 16];
-        // asm, not __builtin_fmaf: the SLP vectoriser pairs the FMAs into v_pk_fma_f32 with SGPR PAIRS assembled from non-adjacent
-        // registers (s_mov shuffles, more spills than before); one scalar operand per v_fmac_f32 is what the weights' layout gives
-        float &acc = v < 16 ? z[v] : v < 32 ? r[v - 16] : g[v - 32];
-        asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(wv), "v"(h[j]));
+    for (int e = 0; e < 32; e += 2) {
+        const int idx = CHUNK * 32 + e, j = idx / 48, v = idx % 48;          // weights W[j][v], W[j][v + 1]: input j, outputs v, v + 1 (z 0-15, r 16-31, g 32-47)
+        const gf32x2 wv = e < 16 ? gf32x2{w.a[e], w.a[e + 1]} : gf32x2{w.b[e - 16], w.b[e - 15]};
+        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[v / 2]) : "s"(wv), "v"(hh[j]));
     }
 }
 template <int C> struct GruSteps {
-    static __device__ __forceinline__ void run(WChunk &cur, WChunk &nxt, cfptr_t W, const float (&h)[16], float (&z)[16], float (&r)[16], float (&g)[16]) {
+    static __device__ __forceinline__ void run(WChunk &cur, WChunk &nxt, cfptr_t W, const gf32x2 (&hh)[16], gf32x2 (&acc)[24]) {
         if (C + 1 < 24) gru_wload<(C + 1 < 24 ? C + 1 : 23)>(nxt, W);
-        gru_wfma<C>(cur, h, z, r, g);
-        if (C + 1 < 24) { gru_wwait(nxt); GruSteps<C + 1>::run(nxt, cur, W, h, z, r, g); }
+        gru_wfma<C>(cur, hh, acc);
+        if (C + 1 < 24) { gru_wwait(nxt); GruSteps<C + 1>::run(nxt, cur, W, hh, acc); }
     }
 };
 template <> struct GruSteps<24> {
-    static __device__ __forceinline__ void run(WChunk &, WChunk &, cfptr_t, const float (&)[16], float (&)[16], float (&)[16], float (&)[16]) {}
+    static __device__ __forceinline__ void run(WChunk &, WChunk &, cfptr_t, const gf32x2 (&)[16], gf32x2 (&)[24]) {}
 };
 __device__ __forceinline__ void gru_matvec(const float (&h)[16], cfptr_t W, float (&z)[16], float (&r)[16], float (&g)[16]) {
+    gf32x2 hh[16], acc[24];
+#pragma unroll
+    for (int j = 0; j < 16; j++) hh[j] = gf32x2{h[j], h[j]};
+#pragma unroll
+    for (int q = 0; q < 8; q++) { acc[q] = gf32x2{z[2 * q], z[2 * q + 1]}; acc[8 + q] = gf32x2{r[2 * q], r[2 * q + 1]}; acc[16 + q] = gf32x2{g[2 * q], g[2 * q + 1]}; }
     WChunk w0, w1;
     gru_wload<0>(w0, W);
     gru_wwait(w0);
-    GruSteps<0>::run(w0, w1, W, h, z, r, g);
+    GruSteps<0>::run(w0, w1, W, hh, acc);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        z[2 * q] = acc[q][0]; z[2 * q + 1] = acc[q][1]; r[2 * q] = acc[8 + q][0]; r[2 * q + 1] = acc[8 + q][1]; g[2 * q] = acc[16 + q][0]; g[2 * q + 1] = acc[16 + q][1];
+    }
 }
 
 // Positions are visited in order of DESCENDING signal length (k3_encode_len / k3_encode_perm below): a wavefront runs as many
