@@ -56,6 +56,13 @@ __device__ __forceinline__ double shl_prev_d(double v, double fill, int lane) { 
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
+// The constants of the inner loop, held in VECTOR registers (every lane the same value).  As kernel-argument scalars they lost the
+// fight for the ~100 SGPRs against the ~60 pointers of BatchDev / EaDev that stay live across the lattice loop: the compiler kept them
+// spilled in VGPR lanes and fetched each one back with v_readlane before every use -- 65 v_readlane per lattice step beside its ~60
+// fp64 instructions.  fp64 vector instructions take VGPR operands just as well.
+struct VitHot { double I2I, M2I, I2M, M2D, D2D, D2M, eM2M, iM2M, rd2, d2, logc, c; };
+__device__ __forceinline__ double in_vgpr(double x) { asm volatile("" : "+v"(x)); return x; }
+
 // one lattice cell (alignment.cpp:278-285/:351-356 insertion, :305-310/:372-381 match, :326-328/:408-413 deletion).
 // Position 0 has no left neighbour and may come from START instead; it is expressed through the INPUTS so the cell has
 // no per-lane special case: for lane 0 the shifted-in left values are log(0), `s0` carries start_prev (0 at t == 0, log(0)
@@ -64,7 +71,7 @@ __device__ __forceinline__ double shl_prev_d(double v, double fill, int lane) { 
 // ("+ insProb" with insProb == 0.0 is dropped: it can only change the sign of an exact zero.)
 __device__ __forceinline__ void vit_cell(const double s0, const double l3, const double tr3, const double Ip, const double Mp,
                                          const double lI2, const double lM2, const double lM1, const double lD1, const double e,
-                                         const VitConsts &vc, const VitRead &vr, double &In, double &Mn, double &Dn, unsigned &code) {
+                                         const VitHot &vc, const VitHot &vr, double &In, double &Mn, double &Dn, unsigned &code) {
     double bi = Ip + vc.I2I; unsigned ci = 0;
     { const double v = Mp + vc.M2I; if (ln_gt(v, bi)) { bi = v; ci = 1; } }
     { const double v = s0 + vc.M2I; if (ln_gt(v, bi)) { bi = v; ci = 2; } }
@@ -78,7 +85,7 @@ __device__ __forceinline__ void vit_cell(const double s0, const double l3, const
     code = ci | (cm << 2) | (cd << 5);
 }
 
-__device__ __forceinline__ double emission(double x, double mu, const VitConsts &vc) {
+template <class C> __device__ __forceinline__ double emission(double x, double mu, const C &vc) {
     const double d = x - mu;
     const double sq = d * d;                              // pow(d, 2.0) as compiled in the reference
     const double n = -sq;
@@ -135,6 +142,8 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
     const int is_rev = B.is_rev[r], ref_start = B.ref_start[r], ref_end = B.ref_end[r];
     const double *model = B.model_mean;
 
+    const VitHot hot = { in_vgpr(vc.I2I), in_vgpr(vc.M2I), in_vgpr(vc.I2M), in_vgpr(vc.M2D), in_vgpr(vc.D2D), in_vgpr(vc.D2M), in_vgpr(vr.eM2M), in_vgpr(vr.iM2M),
+                         in_vgpr(vc.rd2), in_vgpr(vc.d2), in_vgpr(vc.logc), in_vgpr(vc.c) };
     unsigned readHead = 0; int ri = 0;
     unsigned npos = 0, nwin = 0;
     unsigned al_rows = 0;                                 // rows of the align table written so far
@@ -211,9 +220,9 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             if (tail) {
                 const int t64 = d - 64;
                 if (t64 >= 0 && t64 < T) {                 // uses lane 63's results of steps d-1 (time t64) and d-2 (time t64-1)
-                    const double e = emission(xs[t64], mu64, vc);
+                    const double e = emission(xs[t64], mu64, hot);
                     double In, Mn, Dn; unsigned code;
-                    vit_cell(NaN, oD2, vc.D2M, tI, tM, oI2, oM2, M1, D1, e, vc, vr, In, Mn, Dn, code);
+                    vit_cell(NaN, oD2, hot.D2M, tI, tM, oI2, oM2, M1, D1, e, hot, hot, In, Mn, Dn, code);
                     tI = In; tM = Mn; tD = Dn;
                     if (lane == 63) bt[(t64 + 1) * VT_NS + 64] = (unsigned char)code;
                 }
@@ -221,11 +230,11 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             }
             const int t = d - lane;
             const bool act = (t >= 0) && (t < T) && (lane < N);
-            const double e = emission(xs[act ? t : 0], mu, vc);
+            const double e = emission(xs[act ? t : 0], mu, hot);
             const double s0 = (is0 && t == 0) ? 0.0 : NaN;                          // start_prev (:235, :432), position 0 only
             const double l3 = is0 ? s0 : sD2;
             double a, b, c2; unsigned code;
-            vit_cell(s0, l3, tr3, I1, M1, sI2, sM2, sM1, sD1, e, vc, vr, a, b, c2, code);
+            vit_cell(s0, l3, tr3, I1, M1, sI2, sM2, sM1, sD1, e, hot, hot, a, b, c2, code);
             if (act) { bt[(t + 1) * VT_NS + lane] = (unsigned char)code; I1 = a; M1 = b; D1 = c2; }
             sI2 = sI1; sM2 = sM1; sD2 = sD1;
             sI1 = shl_prev_d(I1, NaN, lane); sM1 = shl_prev_d(M1, NaN, lane); sD1 = shl_prev_d(D1, NaN, lane);
