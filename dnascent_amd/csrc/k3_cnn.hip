@@ -484,41 +484,50 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
     const int steps = k * cblocks;
     const int arows = BM + k - 1;
     const int l_r = tid >> 2, l_k = (tid & 3) * 8;        // loader: 64 rows x 4 chunks of 8 elements per pass
-    f32x4 ra[3][2]; bool pin[3];
+    f32x4 ra[3][2];
     u32x4 rb[NP][NBQ];
     float amax = 0.0f;                                     // NP == 2: largest |activation| this thread has split
+    // Buffer addressing, one path for every tile: descriptor = the rows of [0, rows) the tile needs, starting at row
+    // max(m0 - half, 0); voffset = the lane's (row, chunk) minus the rows the first tile lacks -- a row before the pass wraps to
+    // a huge unsigned offset, a row past its end lies beyond num_records: both read as the zeros 'same' padding wants, without a
+    // select; soffset = the channel block / the step.  No 64-bit addresses in vector registers: the 256-row form lives under a
+    // 128-VGPR cap and used to spill two address pairs and two staged float4 to scratch INSIDE the step loop.
+    auto uniform_ptr = [](const void *p) {
+        const unsigned long long v = (unsigned long long)p;
+        return (void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+    };
+    const int row0 = max(m0 - half, 0), lack = row0 - (m0 - half), rows_here = min(rows, m0 + BM + half) - row0;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float *>(X + (size_t)row0 * cin)), 0, rows_here * cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<uint16_t *>(Wb)), 0, steps * NP * cout * 64, 0x00020000);
+    const int aoff = ((l_r - lack) * cin + l_k) * 4;       // + p * LR rows
+    const int boff = (l_r * 32 + l_k) * 2;                 // + q * LR rows of 64 bytes
     auto gloadA = [&](int cb) {
 #pragma unroll
         for (int p = 0; p < 3; p++) {
-            const int ar = p * LR + l_r;                   // row of the staged tile; global row = m0 - half + ar
-            const int src = m0 - half + ar;
-            const bool in = ar < arows && src >= 0 && src < rows;
-            const float *xp = X + (size_t)(in ? src : m0) * cin + (cb << 5) + l_k;
-            ra[p][0] = *reinterpret_cast<const f32x4 *>(xp); ra[p][1] = *reinterpret_cast<const f32x4 *>(xp + 4);
-            pin[p] = in;
+            ra[p][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, aoff + p * LR * cin * 4, cb << 7, 0));
+            ra[p][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, aoff + p * LR * cin * 4 + 16, cb << 7, 0));
         }
     };
     auto gloadB = [&](int s) {
 #pragma unroll
         for (int pc = 0; pc < NP; pc++) {
-            const uint16_t *wb = Wb + ((size_t)(s * NP + pc) * cout + n0) * 32;
+            const int so = ((s * NP + pc) * cout + n0) * 64;
 #pragma unroll
-            for (int q = 0; q < NBQ; q++) rb[pc][q] = *reinterpret_cast<const u32x4 *>(wb + (size_t)(q * LR + l_r) * 32 + l_k);
+            for (int q = 0; q < NBQ; q++) rb[pc][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, boff + q * LR * 64, so, 0));
         }
     };
     auto lstoreA = [&]() {
 #pragma unroll
         for (int p = 0; p < 3; p++) {
             if (p * LR + l_r < BM + 16) {
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 const int o = (p * LR + l_r) * CNN_BP + l_k;
                 if (NP == 3) {
                     bf16x8 h, m, l;
-                    split3(pin[p] ? ra[p][0] : z, pin[p] ? ra[p][1] : z, h, m, l);
+                    split3(ra[p][0], ra[p][1], h, m, l);
                     *reinterpret_cast<bf16x8 *>(&As[0][o]) = h; *reinterpret_cast<bf16x8 *>(&As[1][o]) = m; *reinterpret_cast<bf16x8 *>(&As[NP - 1][o]) = l;
                 } else {
                     f16x8 h, l;
-                    split2(pin[p] ? ra[p][0] : z, pin[p] ? ra[p][1] : z, h, l, amax);
+                    split2(ra[p][0], ra[p][1], h, l, amax);
                     *reinterpret_cast<f16x8 *>(&As[0][o]) = h; *reinterpret_cast<f16x8 *>(&As[1][o]) = l;
                 }
             }
