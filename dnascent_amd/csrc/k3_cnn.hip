@@ -597,6 +597,8 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
 //     pointwise  the 1-tap step of k3_conv_split on those planes
 //   Two barriers per block: [A planes complete / raw tile free] -> next raw tile + taps to LDS, MFMAs -> [planes and B free] ->
 //   next B tile to LDS, next depthwise.  A workgroup does not overlap its own depthwise with its own MFMAs; the 2 workgroups of a CU do.
+// (Round 2: buffer-descriptor loaders alone, which made every k3_conv_split layer 3-10 % faster, make this kernel 4-7 % SLOWER (A/B in
+// one session, twice); its loads are few and its address arithmetic is not what it waits for.  Not kept.)
 // (Round 2: the vector-unit diet that helped k3_sep_ws -- packed FMAs in a fixed interleaved order, packed conversions, buffer
 // addressing, selects only on edge tiles -- was applied here too and measured A/B in one session: 5-tap layers unchanged, 9-tap layers
 // 3.5 % slower (240 VGPRs instead of 232); with two or three workgroups per CU this kernel is not short of vector issue.  Not kept.)
