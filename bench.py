@@ -320,21 +320,42 @@ def main():
                 "reads_per_step": rps, "bases_per_read": bases, "reads_per_gpu": args.steps * rps, "samples_per_gpu": int(st.samples),
                 "reads_passing_qc_per_gpu": int(st.reads_ok), "calls_per_gpu": int(st.calls),
                 "parallelism": "reads sharded, %d rank(s), %d batches in flight per GPU, one host thread per rank" % (world, nctx)}
-            # ---- the dominant kernel of the run: k3_sep_ws, the 17-tap separable layers 128 -> 256 and 5 x 256 -> 256 (most kernel time
-            #      in profiles/r02_kernel_stats.csv).  Algorithmic flops of ALL its launches in the timed region = 2 x (17 cin + cin cout)
-            #      x positions, summed over those layers; divided by the summed HIP-event durations of those launches.
-            ws = [(o, cnn_desc["ops"][i + 1]) for i, o in enumerate(cnn_desc["ops"]) if o["op"] == "dwconv" and o["k"] == 17 and cnn_desc["ops"][i + 1]["cout"] == 256]
-            ws_flops = 2.0 * sum(d["k"] * d["c"] + p["cin"] * p["cout"] for d, p in ws) * float(st.positions)
-            ws_ms, ws_n = prof.get("k3_sep_ws", (0.0, 0))
-            if cnn_math == "f16x3" and ws_n:
-                ws_ach = ws_flops / (ws_ms / 1e3) / 1e12
-                out["roofline"] = {"bound": "mfma", "kernel": "k3_sep_ws<256, 17> (SeparableConv1D 17 taps -> 256 channels, depthwise fused into the pointwise GEMM)",
-                                   "achieved": ws_ach, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s", "frac": ws_ach / MFMA_F16_PEAK, "traffic": None,
-                                   "launches": ws_n, "mean_launch_ms": ws_ms / ws_n, "algorithmic_flops_per_launch": ws_flops / ws_n,
-                                   "issued_frac": ws_ach * 3.0 / MFMA_F16_PEAK,
-                                   "note": "achieved = algorithmic fp32 flops of the layer / launch time (HIP events around every launch, on the CNN lane's "
-                                           "stream); every fp32 product is issued as 3 fp16 MFMA products (issued_frac counts those); the layer's "
-                                           "activation I/O (2 KB per position, fp32) bounds it at ~0.5 ms per 1.2 M positions from HBM"}
+            # ---- the two largest kernels of the run (profiles/r02_kernel_stats.csv): k3_sep_split<128, 9> (the eleven 9-tap separable
+            #      layers 128 -> 128) and k3_sep_ws<256, 17> (the six 17-tap ones -> 256 channels).  HIP events bracket EVERY launch of
+            #      both on the CNN lane's stream; the one with the larger summed time is `roofline`, the other `roofline_second`.
+            #      A fused separable layer does 2 (k cin + cin cout) flops per position for 4 (cin + cout) bytes of activation I/O:
+            #      34 flop/B (9 x 128 -> 128) and 68 flop/B (17 x 256 -> 256) against a ridge of 104 at the f16x3 rate (833 TFLOP/s
+            #      over 8 TB/s) -- both sit on the HBM side of the roofline, so `bound` is "hbm" and `achieved` the layer I/O per
+            #      second (PMC: HBM traffic = 1.03-1.05 x that, profiles/r02_pmc_k3_traffic.csv); the matrix-core view is kept beside it.
+            ops = cnn_desc["ops"]
+            def sep_roofline(name, label, pairs):
+                ms, n = prof.get(name, (0.0, 0))
+                if not n or cnn_math != "f16x3":
+                    return None, 0.0
+                fl = 2.0 * sum(d["k"] * d["c"] + p["cin"] * p["cout"] for d, p in pairs) * float(st.positions)
+                by = 4.0 * sum(p["cin"] + p["cout"] + (p["cout"] if p.get("add", -1) >= 0 else 0) for d, p in pairs) * float(st.positions)   # + the residual read
+                gbs = by / (ms / 1e3) / 1e9
+                tf = fl / (ms / 1e3) / 1e12
+                r = {"bound": "hbm", "kernel": label, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "traffic": None, "launches": n, "mean_launch_ms": ms / n, "algorithmic_bytes_per_launch": by / n,
+                        "algorithmic_flops_per_launch": fl / n, "mfma_TFLOPs": tf, "mfma_frac": tf / MFMA_F16_PEAK, "mfma_issued_frac": 3.0 * tf / MFMA_F16_PEAK,
+                        "note": "achieved = activation I/O of the layer (4 B x (cin + cout [+ cout residual]) x positions) / launch time, HIP events around every launch "
+                                "in the timed region; a launch shares the chip with the other CNN lanes and the per-read stages of the batches in "
+                                "flight; mfma_*: the same launches as algorithmic fp32 flops against the dense fp16 MFMA peak (x 3 issued); "
+                                "solo_*: the same kernel in one batch that has the chip to itself (untimed pass after the run)"}
+                if name in solo and solo[name] > 0:
+                    r["solo_launch_ms"] = solo[name]
+                    r["solo_frac"] = (by / n) / (solo[name] / 1e3) / 1e9 / HBM_PEAK_GBS
+                return r, ms
+            ws_pairs = [(o, ops[i + 1]) for i, o in enumerate(ops) if o["op"] == "dwconv" and o["k"] == 17 and ops[i + 1]["cout"] == 256]
+            s9_pairs = [(o, ops[i + 1]) for i, o in enumerate(ops) if o["op"] == "dwconv" and o["k"] == 9 and o["c"] == 128 and ops[i + 1]["cout"] == 128]
+            r_ws, t_ws = sep_roofline("k3_sep_ws", "k3_sep_ws<256, 17> (SeparableConv1D 17 taps -> 256 channels, depthwise fused into the pointwise GEMM, persistent)", ws_pairs)
+            r_s9, t_s9 = sep_roofline("k3_sep9", "k3_sep_split<128, 9> (SeparableConv1D 9 taps 128 -> 128 channels, depthwise fused into the pointwise GEMM)", s9_pairs)
+            first, second = (r_s9, r_ws) if t_s9 >= t_ws else (r_ws, r_s9)
+            if first:
+                out["roofline"] = first
+            if second:
+                out["roofline_second"] = second
             roof_net = {"bound": "mfma", "kernel": "k3_cnn (all layers of one batch = one dn_run_cnn)", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                         "frac": ach / peak, "traffic": None, "algorithmic_flops_per_launch": flops, "mean_launch_ms": cnn_ms / max(cnn_n, 1),
                         "issued_frac": ach * issued / peak,

@@ -34,7 +34,7 @@ struct CnnRun { const dn_cnn_op *ops; int n_ops; const float *wts; float *buf[8]
                  const float *core, *resid, *sig; float *probs; unsigned max_pos; const uint16_t *wts_split; const int64_t *wb_off;
                  int pieces; const float *post; unsigned *range_flag;
                  unsigned n_pass_pos; uint8_t *enc_len; unsigned *enc_hist; uint64_t *perm_src; unsigned *perm_row;
-                 void (*mark)(void *who, int begin, hipStream_t st); void *mark_who;
+                 void (*mark)(void *who, int begin, int kind, hipStream_t st); void *mark_who;
                  unsigned *row_off_w; int *live; };
 int k3_run(const CnnRun &, hipStream_t);
 struct HmmConstsH { double D2D, D2M, I2M, M2D, M2I, I2I, ln025, ln05; };
@@ -236,7 +236,7 @@ static int dgrow(dn_ctx *c, DevBuf &b, size_t bytes) {
 }
 
 static const char *KNAMES[DN_K_COUNT] = { "k1_scan", "k1_tstat", "k1_detect", "k1_events", "k_ranks", "k_quantile", "k_prep",
-                                          "k2_fill", "k2_chase+k2_post", "k_theilsen", "k2b_viterbi", "k3_cnn", "k_hmm", "k3_sep_ws" };
+                                          "k2_fill", "k2_chase+k2_post", "k_theilsen", "k2b_viterbi", "k3_cnn", "k_hmm", "k3_sep_ws", "k3_sep9" };
 
 struct Timed {
     dn_ctx *c; int k; hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
@@ -294,10 +294,11 @@ static CnnLane *lane_get(dn_ctx *c) {
     return g_lane[c->device][c->lane_id];
 }
 
-// HIP event pairs around every launch of the network's dominant kernel (k3_sep_ws: the 17-tap separable layers), profiling only
-static void cnn_mark(void *who, int begin, hipStream_t st) {
+// HIP event pairs around every launch of the network's two largest kernels (kind 0: k3_sep_ws, the 17-tap separable layers; kind 1:
+// k3_sep_split<128, 9>, the 9-tap 128 -> 128 ones), profiling only
+static void cnn_mark(void *who, int begin, int kind, hipStream_t st) {
     dn_ctx *c = (dn_ctx *)who;
-    if (begin) { hipEvent_t a; hipEventCreate(&a); hipEventRecord(a, st); c->pending.push_back({DN_K_CNN_SEPWS, a, nullptr}); }
+    if (begin) { hipEvent_t a; hipEventCreate(&a); hipEventRecord(a, st); c->pending.push_back({kind ? DN_K_CNN_SEP9 : DN_K_CNN_SEPWS, a, nullptr}); }
     else if (!c->pending.empty() && !c->pending.back().b) { hipEvent_t b; hipEventCreate(&b); hipEventRecord(b, st); c->pending.back().b = b; }
 }
 

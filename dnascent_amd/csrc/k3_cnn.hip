@@ -1140,7 +1140,7 @@ struct CnnRun {
     unsigned n_pass_pos;              // positions of the sequences [r0, r1)
     uint8_t *enc_len; unsigned *enc_hist; uint64_t *perm_src; unsigned *perm_row;   // device scratch of the encoder's counting sort
     // profiling (null = off): HIP event pairs around every launch of the network's dominant kernel, the 17-tap separable layer
-    void (*mark)(void *who, int begin, hipStream_t st); void *mark_who;
+    void (*mark)(void *who, int begin, int kind, hipStream_t st); void *mark_who;
     unsigned *row_off_w; int *live;   // device: this pass's row offsets (written by k3_layout) and its live row count
 };
 
@@ -1185,12 +1185,15 @@ static int k3_launch_sep(const CnnRun &c, int i, const float *in, float *out, co
         o.cin, o.cout, o.relu, c.post[i + 1], c.range_flag
 #define SEP_GO(KW_) hipLaunchKernelGGL((k3_sep_split<BN, KW_, ADD, NP>), dim3(conv_grid(rows, o.cout, BN)), dim3(256), 0, st, SEP_ARGS)
     if (NP == 2 && d.k == 17 && o.cout == 256 && o.cin % 64 == 0 && k3_sep_ws_enabled()) {      // BN == cout: one column tile
-        if (c.mark) c.mark(c.mark_who, 1, st);
+        if (c.mark) c.mark(c.mark_who, 1, 0, st);
         hipLaunchKernelGGL((k3_sep_ws<256, 17, ADD, 2>), dim3(min(conv_grid(rows, o.cout, 256), k3_cu_count())), dim3(512), 0, st, SEP_ARGS);
-        if (c.mark) c.mark(c.mark_who, 0, st);
+        if (c.mark) c.mark(c.mark_who, 0, 0, st);
         return 0;
     }
+    const bool mark9 = c.mark && NP == 2 && BN == 128 && d.k == 9 && o.cin == 128;
+    if (mark9) c.mark(c.mark_who, 1, 1, st);
     switch (d.k) { case 3: SEP_GO(3); break; case 5: SEP_GO(5); break; case 9: SEP_GO(9); break; case 17: SEP_GO(17); break; default: return -1; }
+    if (mark9) c.mark(c.mark_who, 0, 1, st);
 #undef SEP_GO
 #undef SEP_ARGS
     return 0;

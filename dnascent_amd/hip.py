@@ -11,7 +11,7 @@ from . import build as _build
 
 DN_OK = 0
 K_NAMES = ["DN_K_SCAN", "DN_K_TSTAT", "DN_K_DETECT", "DN_K_EVENTS", "DN_K_RANKS", "DN_K_QUANTILE", "DN_K_PREP",
-           "DN_K_BAND_FILL", "DN_K_BAND_TRACE", "DN_K_THEILSEN", "DN_K_VITERBI", "DN_K_CNN", "DN_K_HMM", "DN_K_CNN_SEPWS"]
+           "DN_K_BAND_FILL", "DN_K_BAND_TRACE", "DN_K_THEILSEN", "DN_K_VITERBI", "DN_K_CNN", "DN_K_HMM", "DN_K_CNN_SEPWS", "DN_K_CNN_SEP9"]
 DN_K_COUNT = len(K_NAMES)
 for _i, _n in enumerate(K_NAMES):
     globals()[_n] = _i

@@ -223,7 +223,8 @@ int dn_debug_emission(dn_ctx *ctx, uint32_t n, const double *x, const double *mu
 /* ---- measurement ---- */
 enum { DN_K_SCAN = 0, DN_K_TSTAT, DN_K_DETECT, DN_K_EVENTS, DN_K_RANKS, DN_K_QUANTILE, DN_K_PREP, DN_K_BAND_FILL,
        DN_K_BAND_TRACE, DN_K_THEILSEN, DN_K_VITERBI, DN_K_CNN /* the whole network of a batch */, DN_K_HMM,
-       DN_K_CNN_SEPWS /* every single launch of the network's dominant kernel, the 17-tap separable layer */, DN_K_COUNT };
+       DN_K_CNN_SEPWS /* every single launch of the 17-tap separable layers (k3_sep_ws) */,
+       DN_K_CNN_SEP9 /* ... and of the 9-tap 128 -> 128 separable layers (k3_sep_split<128, 9>): the two largest kernels of the run */, DN_K_COUNT };
 int dn_profile_enable(dn_ctx *ctx, int on);     /* HIP events around every kernel launch on the context's stream */
 int dn_profile_get(dn_ctx *ctx, int kernel, double *total_ms, uint32_t *launches);
 int dn_profile_reset(dn_ctx *ctx);
