@@ -614,7 +614,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
 #define SEP_XP 40                                           // floats per raw-tile row
 #define SEP_XPW 36                                          // ... of the wave-specialised kernel's raw slices (see its depthwise)
 template <int BN, int KW, bool ADD, int NP>
-__global__ __launch_bounds__(256) void k3_sep_split(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wd,
+__global__ __launch_bounds__(256, 2) void k3_sep_split(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wd,
                                                     const uint16_t *__restrict__ Wb, const float *__restrict__ scale,
                                                     const float *__restrict__ shift, const float *__restrict__ Add,
                                                     const uint8_t *__restrict__ valid, int rows, const int *__restrict__ live, int cin, int cout, int relu, float post,
@@ -628,26 +628,36 @@ __global__ __launch_bounds__(256) void k3_sep_split(const float *__restrict__ X,
     __shared__ __attribute__((aligned(16))) uint16_t Bs[NP][BN * CNN_BP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int m0, n0;
-    if (!conv_tile(cout, BN, rows, m0, n0)) return;
+    // PERSISTENT where the layer has one column tile (cout == BN: every layer that takes this kernel by default): the grid is two
+    // workgroups per CU and a workgroup takes the row tiles blockIdx.x + k gridDim.x, running their channel blocks as ONE stream of
+    // steps.  The raw tile of step g + 2 is requested during step g ACROSS tile boundaries, so only a workgroup's first tile pays the
+    // two exposed load latencies of the prologue, and a tile's epilogue runs while the next tile's loads are in flight.  Phase trace
+    // of the one-tile-per-workgroup form (9 x 128 -> 128): 30 k cycles per tile = 7.0 k prologue + 4 x 3.9 k + 2.0 k drain + 5.0 k
+    // epilogue; its MFMAs are 4 k of that.  With several column tiles (DN_CNN_SEP_WS=0 on the 256-wide layers) the old numbering stays.
+    int m0f = 0, n0 = 0, t0 = 0, tstride = 1, my_tiles = 1;
+    if (cout == BN) {
+        const int ntiles = (rows + CNN_BM - 1) / CNN_BM;
+        t0 = (int)blockIdx.x; tstride = (int)gridDim.x;
+        my_tiles = t0 < ntiles ? (ntiles - t0 + tstride - 1) / tstride : 0;
+        if (my_tiles == 0) return;
+    } else if (!conv_tile(cout, BN, rows, m0f, n0)) return;
+    auto tile_m0 = [&](int it) { return cout == BN ? (t0 + it * tstride) * CNN_BM : m0f; };
     constexpr int NJ = BN / 64;
     constexpr int NBQ = BN / 64;
     constexpr int half = (KW - 1) / 2;
     f32x16 acc[2][NJ];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < NJ; j++)
-#pragma unroll
-            for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
     const int cblocks = cin >> 5;
+    const int nb = my_tiles * cblocks;                     // steps of this workgroup
     const int l_r = tid >> 2, l_k = (tid & 3) * 8;        // B loader: 64 rows x 4 chunks of 8 elements per pass
     const int dq = tid & 7, dr = (tid >> 3) * 4;          // depthwise: channels 4 dq .. 4 dq + 3, output rows dr .. dr + 3
     f32x4 rx[NLD]; bool pin[NLD];
     u32x4 rb[NP][NBQ];
     f32x4 rw = {0.f, 0.f, 0.f, 0.f};
     float amax = 0.0f;
-    auto gloadX = [&](int cb) {
+    int ld_it = 0, ld_cb = 0;                              // the raw tiles are requested in step order: position of that stream
+    auto gloadX = [&]() {                                   // past the last step it stays on the last one (harmless)
+        const int cb = ld_cb, m0 = tile_m0(ld_it);
+        if (ld_cb + 1 < cblocks) ld_cb++; else if (ld_it + 1 < my_tiles) { ld_cb = 0; ld_it++; }
 #pragma unroll
         for (int p = 0; p < NLD; p++) {
             const int f = tid + 256 * p, rr = f >> 3, q = f & 7;
@@ -725,50 +735,59 @@ __global__ __launch_bounds__(256) void k3_sep_split(const float *__restrict__ X,
             }
         }
     };
-    gloadX(0); gloadB(0);
+    gloadX(); gloadB(0);
     lstoreX(); lstoreB();
     __syncthreads();
-    gloadX(min(1, cblocks - 1)); gloadB(min(1, cblocks - 1));
+    gloadX(); gloadB(1 % cblocks);
     depthwise();
     const int fm = lane & 31, fk = (lane >> 5) * 8;
-    for (int cb = 0; cb < cblocks; cb++) {
-        __syncthreads();                                   // A planes of cb complete; the raw tile is free
-        lstoreX();                                         // raw tile of cb + 1 (loaded during the previous block)
-        gloadX(min(cb + 2, cblocks - 1));
-        __builtin_amdgcn_sched_barrier(0);
+    for (int it = 0; it < my_tiles; it++) {
 #pragma unroll
-        for (int k16 = 0; k16 < 2; k16++) {
-            u32x4 a[2][NP], b[NJ][NP];
+        for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int pc = 0; pc < NP; pc++) {
+            for (int j = 0; j < NJ; j++)
 #pragma unroll
-                for (int i = 0; i < 2; i++) a[i][pc] = *reinterpret_cast<const u32x4 *>(&As[pc][(wm * 64 + i * 32 + fm) * CNN_BP + k16 * 16 + fk]);
+                for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
+        for (int cb = 0; cb < cblocks; cb++) {
+            const int g = it * cblocks + cb;
+            __syncthreads();                               // A planes of step g complete; the raw tile is free
+            lstoreX();                                     // raw tile of step g + 1 (loaded during the previous step)
+            gloadX();                                      // ... of step g + 2
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < NJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(&Bs[pc][(wn * (BN / 2) + j * 32 + fm) * CNN_BP + k16 * 16 + fk]);
+            for (int k16 = 0; k16 < 2; k16++) {
+                u32x4 a[2][NP], b[NJ][NP];
+#pragma unroll
+                for (int pc = 0; pc < NP; pc++) {
+#pragma unroll
+                    for (int i = 0; i < 2; i++) a[i][pc] = *reinterpret_cast<const u32x4 *>(&As[pc][(wm * 64 + i * 32 + fm) * CNN_BP + k16 * 16 + fk]);
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(&Bs[pc][(wn * (BN / 2) + j * 32 + fm) * CNN_BP + k16 * 16 + fk]);
+                }
+                constexpr int NT = NP == 3 ? 6 : 3;
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    constexpr int PA3[6] = {1, 2, 0, 1, 0, 0}, PB3[6] = {1, 0, 2, 0, 1, 0};
+                    constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
+                    const int pa = NP == 3 ? PA3[t] : PA2[t % 3], pb = NP == 3 ? PB3[t] : PB2[t % 3];
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int j = 0; j < NJ; j++)
+                            acc[i][j] = mfma16<NP>(a[i][pa], b[j][pb], acc[i][j]);
+                }
             }
-            constexpr int NT = NP == 3 ? 6 : 3;
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                constexpr int PA3[6] = {1, 2, 0, 1, 0, 0}, PB3[6] = {1, 0, 2, 0, 1, 0};
-                constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
-                const int pa = NP == 3 ? PA3[t] : PA2[t % 3], pb = NP == 3 ? PB3[t] : PB2[t % 3];
-#pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int j = 0; j < NJ; j++)
-                        acc[i][j] = mfma16<NP>(a[i][pa], b[j][pb], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < nb) {                              // wave-uniform
+                __syncthreads();                           // every wavefront is done with the planes and the B tile; raw tile of g + 1 visible
+                lstoreB();
+                gloadB((g + 2) % cblocks);
+                depthwise();                               // A planes of step g + 1 (the next tile's first block after a tile's last)
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (cb + 1 < cblocks) {                            // wave-uniform
-            __syncthreads();                               // every wavefront is done with the planes and the B tile; raw tile of cb + 1 visible
-            lstoreB();
-            gloadB(min(cb + 2, cblocks - 1));
-            depthwise();
-        }
+        conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, tile_m0(it), n0, wm, wn, lane, cout, relu, post);
     }
     if (NP == 2 && __any(amax > 65504.0f) && lane == 0) atomicOr(range_flag, 1u);
-    conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, m0, n0, wm, wn, lane, cout, relu, post);
 }
 
 #ifdef DN_WS_TRACE       /* experiment build only (tools/ws_trace.py): shader-clock stamps of one workgroup's phases */
@@ -1153,6 +1172,10 @@ static unsigned k3_cu_count() {                            // persistent kernels
     }();
     return n;
 }
+static unsigned k3_sep_wgs(int bn) {                       // persistent k3_sep_split: workgroups per launch = what a CU holds (two of the 128-column
+    static const unsigned env = (getenv("DN_CNN_SEP_WGS") && atoi(getenv("DN_CNN_SEP_WGS")) > 0) ? (unsigned)atoi(getenv("DN_CNN_SEP_WGS")) : 0u;   // form, three of the 64-column one)
+    return env ? env : (bn == 64 ? 3u : 2u) * k3_cu_count();
+}
 static bool k3_sep_ws_enabled() { static const bool on = !(getenv("DN_CNN_SEP_WS") && atoi(getenv("DN_CNN_SEP_WS")) == 0); return on; }
 static bool k3_bm256_enabled() { static const bool on = !(getenv("DN_CNN_BM256") && atoi(getenv("DN_CNN_BM256")) == 0); return on; }
 static bool k3_fuse_enabled() { static const bool on = !(getenv("DN_CNN_FUSE") && atoi(getenv("DN_CNN_FUSE")) == 0); return on; }
@@ -1183,7 +1206,7 @@ static int k3_launch_sep(const CnnRun &c, int i, const float *in, float *out, co
     const unsigned rows = c.rows.rows;
 #define SEP_ARGS in, out, c.wts + d.w, c.wts_split + c.wb_off[i + 1], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, c.live, \
         o.cin, o.cout, o.relu, c.post[i + 1], c.range_flag
-#define SEP_GO(KW_) hipLaunchKernelGGL((k3_sep_split<BN, KW_, ADD, NP>), dim3(conv_grid(rows, o.cout, BN)), dim3(256), 0, st, SEP_ARGS)
+#define SEP_GO(KW_) hipLaunchKernelGGL((k3_sep_split<BN, KW_, ADD, NP>), dim3(o.cout == BN ? min(conv_grid(rows, o.cout, BN), k3_sep_wgs(BN)) : conv_grid(rows, o.cout, BN)), dim3(256), 0, st, SEP_ARGS)
     if (NP == 2 && d.k == 17 && o.cout == 256 && o.cin % 64 == 0 && k3_sep_ws_enabled()) {      // BN == cout: one column tile
         if (c.mark) c.mark(c.mark_who, 1, 0, st);
         hipLaunchKernelGGL((k3_sep_ws<256, 17, ADD, 2>), dim3(min(conv_grid(rows, o.cout, 256), k3_cu_count())), dim3(512), 0, st, SEP_ARGS);
