@@ -453,6 +453,9 @@ template <int NP> __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32
 // workgroups that stream alone takes ~2/3 of the L2 bandwidth on the long-K layers.  Measured: 17 taps x 128 channels -8 %,
 // 9 x 128 -6 %, but the 3-tap layers +8 % (two 512-thread workgroups per CU need <= 128 VGPRs: 44 bytes of scratch), so only
 // layers with >= 9 taps and >= 128 input channels take it.
+// (Round 2: the persistent form that pays for the separable kernels -- a workgroup walking the tile ids of its XCD -- makes this one
+// slower: 256-row layers +14 % alone, full pipeline 692 -> 668 Msamples/s, A/B in one session.  Its tiles are long (13 us and more) and
+// plentiful; the dispatcher balances them better than a static share.  Not kept.)
 // (Round 2: B fragments straight from L2 into registers -- no B tile in LDS, no barrier inside a channel block, half the LDS fragment
 // traffic -- measured on every 128-column layer: 17 x 128 -> 256 3.39 ms against 3.10 for the 256-row form below, the others within 2 %:
 // neither the barriers nor the LDS pipe is what the long-K layers wait for; halving the weight stream per flop (256 rows) is what pays.)
