@@ -253,6 +253,10 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             int i = N - 1, col = T;
             bool done = false;
             int guard = 3 * N * (T + 1) + 8;
+            // (Round 2 phase trace, 500 x 50 kb, cycles per window: event gather 9 k, lattice 103 k, termination + this walk 72 k, feature fill
+            // 15 k.  The walk is a serial chain of LDS look-ups, ~360 cycles per step; a version with the lattice row in a register, the next
+            // row prefetched and the walk on the scalar unit (v_readlane with the scalar position) was bit-identical and no faster alone
+            // (81.3 against 82.4 ms) or in the pipeline: the chain is LDS latency, which other wavefronts of the SIMD fill.  Not kept.)
             // labels are parked in registers (lane = observation & 63) and leave through ONE 64-lane LDS store per 64
             // observations: a single-lane LDS store per step costs ~50 cycles in this wave-uniform walk
             unsigned lab = 0u; int last_ob = -1;
