@@ -453,6 +453,8 @@ template <int NP> __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32
 // workgroups that stream alone takes ~2/3 of the L2 bandwidth on the long-K layers.  Measured: 17 taps x 128 channels -8 %,
 // 9 x 128 -6 %, but the 3-tap layers +8 % (two 512-thread workgroups per CU need <= 128 VGPRs: 44 bytes of scratch), so only
 // layers with >= 9 taps and >= 128 input channels take it.
+// (Round 2: a ping-pong form -- the workgroup's two halves half a step out of phase, one feeding the matrix pipe while the other does
+// the memory half-step -- is in tools/k3_conv_pp_experiment.hip: bit-identical, 17 x 128 -> 256 in 3.64 ms against 3.05.  Not kept.)
 // (Round 2: the persistent form that pays for the separable kernels -- a workgroup walking the tile ids of its XCD -- makes this one
 // slower: 256-row layers +14 % alone, full pipeline 692 -> 668 Msamples/s, A/B in one session.  Its tiles are long (13 us and more) and
 // plentiful; the dispatcher balances them better than a static share.  Not kept.)
