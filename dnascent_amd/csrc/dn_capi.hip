@@ -86,6 +86,29 @@ struct CnnLane {
 static std::mutex g_lane_mu;
 static CnnLane *g_lane[64][DN_MAX_LANES] = { { nullptr } };
 static unsigned g_ctx_seq = 0;
+static unsigned g_dev_ctx[64] = { 0 };                  // live contexts per device: the last one to go takes the device's lanes with it
+// caller holds g_lane_mu; no dn_run_* of the device may be in progress (contexts are single-producer, the last one is being destroyed
+// or the host called dn_shutdown between runs)
+static void lanes_free_device(int dev) {
+    if (dev < 0 || dev >= 64) return;
+    for (unsigned l = 0; l < DN_MAX_LANES; l++) {
+        CnnLane *L = g_lane[dev][l];
+        if (!L) continue;
+        (void)hipSetDevice(dev);
+        if (L->stream) { (void)hipStreamSynchronize(L->stream); (void)hipStreamDestroy(L->stream); }
+        for (DevBuf &b : L->buf) if (b.p) (void)hipFree(b.p);
+        for (DevBuf *b : { &L->valid, &L->enclen, &L->enchist, &L->permsrc, &L->permrow, &L->live }) if (b->p) (void)hipFree(b->p);
+        delete L;
+        g_lane[dev][l] = nullptr;
+    }
+}
+static size_t lanes_bytes_device(int dev) {
+    size_t n = 0;
+    if (dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    for (unsigned l = 0; l < DN_MAX_LANES; l++) if (g_lane[dev][l]) n += g_lane[dev][l]->bytes;
+    return n;
+}
 // how many lanes a device has (DN_CNN_LANES, default 4): contexts are dealt to them round-robin.  One lane serialises every
 // network of the process (least memory: one set of activation buffers); measured with 4 x 500 x 50 kb reads in flight on one box:
 // 1 lane 466, 2 lanes 478, 4 lanes 493 Msamples/s -- a second network's kernels fill the gaps a lone one leaves while the CUs' LDS
@@ -343,6 +366,19 @@ int dn_device_count(void) {
 
 const char *dn_kernel_name(int k) { return (k >= 0 && k < DN_K_COUNT) ? KNAMES[k] : "?"; }
 
+// one context less on its device; the last one frees the device's CNN lanes (round-2 advisor: lanes used to outlive every context)
+static void ctx_unregister(dn_ctx *c) {
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    if (c->device < 0 || c->device >= 64 || g_dev_ctx[c->device] == 0) return;
+    if (--g_dev_ctx[c->device] == 0) lanes_free_device(c->device);
+}
+
+int dn_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    for (int d = 0; d < 64; d++) lanes_free_device(d);
+    return DN_OK;
+}
+
 int dn_ctx_create(int device, void *hip_stream, dn_ctx **out) {
     if (!out) return DN_ERR_ARG;
     *out = nullptr;
@@ -358,7 +394,7 @@ int dn_ctx_create(int device, void *hip_stream, dn_ctx **out) {
     }
     dn_ctx *c = new dn_ctx();
     c->device = device;
-    { std::lock_guard<std::mutex> lk(g_lane_mu); c->lane_id = (g_ctx_seq++) % lane_count(); }
+    { std::lock_guard<std::mutex> lk(g_lane_mu); c->lane_id = (g_ctx_seq++) % lane_count(); if (device < 64) g_dev_ctx[device]++; }
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
     else {
         // the per-batch stages are latency-bound chains of small launches: they get the highest stream priority so that their
@@ -373,12 +409,12 @@ int dn_ctx_create(int device, void *hip_stream, dn_ctx **out) {
             made = hipExtStreamCreateWithCUMask(&c->stream, 8, m) == hipSuccess;
             if (!made) { (void)hipGetLastError(); fprintf(stderr, "dnascent_hip: CU-masked stream unavailable, using a plain one\n"); }
         }
-        if (!made && (prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return DN_ERR_HIP; }
+        if (!made && (prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { ctx_unregister(c); delete c; return DN_ERR_HIP; }
         c->own_stream = true;
     }
     if (hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) {
         if (c->own_stream) hipStreamDestroy(c->stream);
-        delete c; return DN_ERR_HIP;
+        ctx_unregister(c); delete c; return DN_ERR_HIP;
     }
     const int st = k2_selftest_run(c->stream);
     if (st != 1) {
@@ -387,7 +423,7 @@ int dn_ctx_create(int device, void *hip_stream, dn_ctx **out) {
         if (!(force && force[0] == '1')) {
             fprintf(stderr, "dnascent_hip: wave-shift DPP self-test failed (%d); set DN_FORCE_SHFL=1 to use ds_bpermute shifts\n", st);
             if (c->own_stream) hipStreamDestroy(c->stream);
-            delete c;
+            ctx_unregister(c); delete c;
             return DN_ERR_HIP;
         }
     }
@@ -428,6 +464,7 @@ void dn_ctx_destroy(dn_ctx *c) {
     if (c->ev_ready) hipEventDestroy(c->ev_ready);
     if (c->ev_done) hipEventDestroy(c->ev_done);
     if (c->own_stream) hipStreamDestroy(c->stream);
+    ctx_unregister(c);
     delete c;
 }
 
@@ -440,7 +477,7 @@ int dn_sync(dn_ctx *c) {
     return async_status(c);
 }
 
-size_t dn_device_bytes(const dn_ctx *c) { return c ? c->dev_bytes : 0; }
+size_t dn_device_bytes(const dn_ctx *c) { return c ? c->dev_bytes + lanes_bytes_device(c->device) : 0; }
 
 int dn_load_pore_model(dn_ctx *c, const double *mean, double sigma) {
     if (!c || !mean || !(sigma > 0.)) return DN_ERR_ARG;
@@ -500,6 +537,13 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     prof_collect(c);
     dfree_all(c);
     c->have_batch = false; c->stage = 0;
+    // a batch that raised the fp16 range flag and was never collected must not leave it to the next one (round-2 advisor)
+    if (c->cnn_pending) {
+        c->cnn_pending = false;
+        if (c->p_cnn_flag && *c->p_cnn_flag) { c->cnn_f16_off = true; c->cnn_escalations++; }      // the model does not fit fp16: remembered, the dropped batch is not repeated
+    }
+    if (c->p_cnn_flag) *c->p_cnn_flag = 0;
+    if (c->d_cnn_flag) HIPCHK(c, hipMemsetAsync(c->d_cnn_flag, 0, sizeof(unsigned), c->stream));
     const uint32_t n = d->n_reads;
     if (n == 0) {                                         // an empty buffer of reads is legal: every stage is a no-op
         memset(&c->B, 0, sizeof(c->B));
@@ -611,9 +655,17 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     // Page-locked input arrays (dn_host_alloc / dn_host_register) make the whole upload asynchronous; with pageable memory the
     // runtime may still be reading the caller's arrays when hipMemcpyAsync returns, so the call waits for the copies.
     {
-        hipPointerAttribute_t at;
-        c->upload_pinned = hipPointerGetAttributes(&at, d->adc) == hipSuccess && at.type == hipMemoryTypeHost;
+        // EVERY array of the caller must be page-locked for the call to return before the copies are done (round-2 advisor: deciding
+        // from adc alone let the runtime read freed pageable arrays); the offset tables were copied into the context above
+        const void *arrs[] = { d->adc, d->cal_offset, d->cal_scale, d->basecall, d->refseq, d->ref2query, d->query2ref, d->ref2del, d->ref_start,
+                               d->ref_end, d->is_reverse };
+        bool pinned = true;
+        for (const void *a : arrs) {
+            hipPointerAttribute_t at;
+            if (!(hipPointerGetAttributes(&at, a) == hipSuccess && at.type == hipMemoryTypeHost)) { pinned = false; break; }
+        }
         (void)hipGetLastError();
+        c->upload_pinned = pinned;
         if (!c->upload_pinned) HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     c->h_res.assign(n, ReadRes{});
@@ -931,6 +983,10 @@ int dn_host_unregister(void *p) { return (p && hipHostUnregister(p) == hipSucces
 #define CHECK_READ(stage_, name_)                                     \
     int rc = need(c, stage_, name_); if (rc) return rc;              \
     if (read >= (uint32_t)c->B.n_reads) return DN_ERR_ARG;
+// every tap states how many records the caller's arrays hold; the true count is the library's
+#define CHECK_CAP(name_, need_, cap_)                                 \
+    if ((uint64_t)(need_) > (uint64_t)(cap_))                         \
+        return fail(c, DN_ERR_ARG, "%s: read %u has %llu records, the caller's arrays hold %llu", name_, read, (unsigned long long)(need_), (unsigned long long)(cap_));
 
 int dn_debug_keep_k1(dn_ctx *c, int on) {
     if (!c) return DN_ERR_ARG;
@@ -938,8 +994,9 @@ int dn_debug_keep_k1(dn_ctx *c, int on) {
     return DN_OK;
 }
 
-int dn_get_prefix_sums(dn_ctx *c, uint32_t read, double *sum, double *sumsq) {
+int dn_get_prefix_sums(dn_ctx *c, uint32_t read, uint64_t cap, double *sum, double *sumsq) {
     CHECK_READ(2, "dn_get_prefix_sums");
+    CHECK_CAP("dn_get_prefix_sums", c->h_samp_off[read + 1] - c->h_samp_off[read], cap);
     if (!c->B.psum) return fail(c, DN_ERR_STATE, "dn_debug_keep_k1(ctx, 1) must precede dn_batch_upload: prefix sums do not leave the kernels otherwise");
     const uint64_t s0 = c->h_samp_off[read]; const size_t n = (size_t)(c->h_samp_off[read + 1] - s0);
     std::vector<double2> tmp(n);
@@ -949,19 +1006,21 @@ int dn_get_prefix_sums(dn_ctx *c, uint32_t read, double *sum, double *sumsq) {
     return DN_OK;
 }
 
-int dn_get_tstats(dn_ctx *c, uint32_t read, float *a, float *b) {
+int dn_get_tstats(dn_ctx *c, uint32_t read, uint64_t cap, float *a, float *b) {
     CHECK_READ(2, "dn_get_tstats");
+    CHECK_CAP("dn_get_tstats", c->h_samp_off[read + 1] - c->h_samp_off[read], cap);
     if (!c->B.t1) return fail(c, DN_ERR_STATE, "dn_debug_keep_k1(ctx, 1) must precede dn_batch_upload: t-statistics do not leave the kernels otherwise");
     const uint64_t s0 = c->h_samp_off[read]; const size_t n = (size_t)(c->h_samp_off[read + 1] - s0);
     if ((rc = d2h(c, a, c->B.t1 + s0, n))) return rc;
     return d2h(c, b, c->B.t2 + s0, n);
 }
 
-int dn_get_scrappie_events(dn_ctx *c, uint32_t read, uint32_t *start, float *length, float *mean) {
+int dn_get_scrappie_events(dn_ctx *c, uint32_t read, uint64_t cap, uint32_t *start, float *length, float *mean) {
     CHECK_READ(2, "dn_get_scrappie_events");
     if (!c->B.et_start) return fail(c, DN_ERR_STATE, "dn_debug_keep_k1(ctx, 1) must precede dn_batch_upload: the scrappie event table does not leave the kernels otherwise");
     if ((rc = fetch_res(c))) return rc;
     const size_t n = c->h_res[read].n_scrappie; const uint64_t e0 = c->h_ev_off[read];
+    CHECK_CAP("dn_get_scrappie_events", n, cap);
     std::vector<uint32_t> st(n);
     if ((rc = d2h(c, st.data(), c->B.et_start + e0, n))) return rc;
     if (start) memcpy(start, st.data(), n * sizeof(uint32_t));
@@ -975,45 +1034,51 @@ int dn_get_scrappie_events(dn_ctx *c, uint32_t read, uint32_t *start, float *len
     return d2h(c, mean, c->B.et_mean + e0, n);
 }
 
-int dn_get_events(dn_ctx *c, uint32_t read, double *mean, uint32_t *raw_start, uint32_t *raw_len) {
+int dn_get_events(dn_ctx *c, uint32_t read, uint64_t cap, double *mean, uint32_t *raw_start, uint32_t *raw_len) {
     CHECK_READ(2, "dn_get_events");
     if ((rc = fetch_res(c))) return rc;
     const size_t n = c->h_res[read].n_events; const uint64_t e0 = c->h_ev_off[read];
+    CHECK_CAP("dn_get_events", n, cap);
     if ((rc = d2h(c, mean, c->B.ev_mean + e0, n))) return rc;
     if ((rc = d2h(c, raw_start, c->B.ev_start + e0, n))) return rc;
     return d2h(c, raw_len, c->B.ev_len + e0, n);
 }
 
-int dn_get_kmer_ranks(dn_ctx *c, uint32_t read, uint32_t *rq, uint32_t *rr) {
+int dn_get_kmer_ranks(dn_ctx *c, uint32_t read, uint64_t cap_q, uint64_t cap_r, uint32_t *rq, uint32_t *rr) {
     CHECK_READ(2, "dn_get_kmer_ranks");
     const uint64_t b0 = c->h_base_off[read], f0 = c->h_ref_off[read];
     const size_t nq = (size_t)(c->h_base_off[read + 1] - b0) - DN_K + 1, nr = (size_t)(c->h_ref_off[read + 1] - f0) - DN_K + 1;
+    if (rq) { CHECK_CAP("dn_get_kmer_ranks (query)", nq, cap_q); }
+    if (rr) { CHECK_CAP("dn_get_kmer_ranks (reference)", nr, cap_r); }
     if ((rc = d2h(c, rq, c->B.rank_q + b0, nq))) return rc;
     return d2h(c, rr, c->B.rank_r + f0, nr);
 }
 
-int dn_get_alignment(dn_ctx *c, uint32_t read, uint32_t *ev, uint32_t *km) {
+int dn_get_alignment(dn_ctx *c, uint32_t read, uint64_t cap, uint32_t *ev, uint32_t *km) {
     CHECK_READ(4, "dn_get_alignment");
     if ((rc = fetch_res(c))) return rc;
     const ReadRes &R = c->h_res[read];
+    CHECK_CAP("dn_get_alignment", R.n_aligned, cap);
     const uint64_t a0 = c->h_aln_off[read] + R.aln_begin;
     if ((rc = d2h(c, ev, c->B.aln_event + a0, R.n_aligned))) return rc;
     return d2h(c, km, c->B.aln_kmer + a0, R.n_aligned);
 }
 
-int dn_get_cleaned(dn_ctx *c, uint32_t read, double *sig, uint32_t *rank) {
+int dn_get_cleaned(dn_ctx *c, uint32_t read, uint64_t cap, double *sig, uint32_t *rank) {
     CHECK_READ(4, "dn_get_cleaned");
     if ((rc = fetch_res(c))) return rc;
     const ReadRes &R = c->h_res[read];
+    CHECK_CAP("dn_get_cleaned", R.n_cleaned, cap);
     const uint64_t a0 = c->h_aln_off[read];
     if ((rc = d2h(c, sig, c->B.cl_sig + a0, R.n_cleaned))) return rc;
     return d2h(c, rank, c->B.cl_rank + a0, R.n_cleaned);
 }
 
-int dn_get_trace(dn_ctx *c, uint32_t read, uint8_t *trace, int32_t *band_event, int32_t *band_kmer) {
+int dn_get_trace(dn_ctx *c, uint32_t read, uint64_t cap, uint8_t *trace, int32_t *band_event, int32_t *band_kmer) {
     CHECK_READ(4, "dn_get_trace");
     if ((rc = fetch_res(c))) return rc;
     const size_t nb = c->h_res[read].n_bands;
+    CHECK_CAP("dn_get_trace", nb, cap);
     std::vector<uint64_t> rows(nb * (DN_TROW / 8));
     if ((rc = d2h(c, (uint8_t *)rows.data(), c->B.trace + c->h_trace_off[read] * DN_TROW, nb * DN_TROW))) return rc;
     // rows are planar 2-bit codes by slot (k2_banded.hip put_row): {A0, A1, B0, B1}; slot s = event & 127, register s & 1, lane s >> 1
@@ -1035,11 +1100,12 @@ int dn_get_trace(dn_ctx *c, uint32_t read, uint8_t *trace, int32_t *band_event, 
     return DN_OK;
 }
 
-int dn_get_positions(dn_ctx *c, uint32_t read, uint32_t *coord, uint32_t *query_idx, uint32_t *ref_idx, int32_t *indel_score, char *kmer9,
+int dn_get_positions(dn_ctx *c, uint32_t read, uint64_t cap, uint32_t *coord, uint32_t *query_idx, uint32_t *ref_idx, int32_t *indel_score, char *kmer9,
                      uint32_t *n_signal, float *signal20, float *core, float *residual) {
     CHECK_READ(6, "dn_get_positions");
     if ((rc = fetch_res(c))) return rc;
     const size_t np = c->h_res[read].n_positions; const uint64_t f0 = c->h_ref_off[read];
+    CHECK_CAP("dn_get_positions", np, cap);
     if ((rc = d2h(c, coord, c->ea.coord + f0, np)) || (rc = d2h(c, query_idx, c->ea.qidx + f0, np)) ||
         (rc = d2h(c, indel_score, c->ea.indel + f0, np)) || (rc = d2h(c, n_signal, c->ea.nsig + f0, np)) ||
         (rc = d2h(c, signal20, c->ea.sig + f0 * DN_RAWDEPTH, np * DN_RAWDEPTH)) || (rc = d2h(c, core, c->ea.core + f0, np)) ||
@@ -1056,10 +1122,11 @@ int dn_get_positions(dn_ctx *c, uint32_t read, uint32_t *coord, uint32_t *query_
     return DN_OK;
 }
 
-int dn_get_windows(dn_ctx *c, uint32_t read, uint32_t *ref_index, uint32_t *window_len, uint32_t *n_obs, double *score) {
+int dn_get_windows(dn_ctx *c, uint32_t read, uint64_t cap, uint32_t *ref_index, uint32_t *window_len, uint32_t *n_obs, double *score) {
     CHECK_READ(6, "dn_get_windows");
     if ((rc = fetch_res(c))) return rc;
     const size_t nw = c->h_res[read].n_windows; const uint64_t f0 = c->h_ref_off[read];
+    CHECK_CAP("dn_get_windows", nw, cap);
     if ((rc = d2h(c, ref_index, c->ea.win_ref + f0, nw)) || (rc = d2h(c, window_len, c->ea.win_len + f0, nw)) ||
         (rc = d2h(c, n_obs, c->ea.win_T + f0, nw))) return rc;
     return d2h(c, score, c->ea.win_score + f0, nw);
@@ -1068,6 +1135,8 @@ int dn_get_windows(dn_ctx *c, uint32_t read, uint32_t *ref_index, uint32_t *wind
 int dn_load_cnn(dn_ctx *c, const dn_cnn_op *ops, uint32_t n_ops, const float *weights, uint64_t n_weights, uint32_t n_buffers) {
     if (!c || !ops || !weights || n_ops == 0 || n_buffers == 0 || n_buffers > 8) return DN_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    // the encoder is what marks a pass's live rows (validity bytes): every later epilogue masks by them
+    if (ops[0].op != DN_CNN_ENCODE_GRU) return fail(c, DN_ERR_ARG, "cnn op 0 must be ENCODE_GRU (it writes the row validity mask every later op reads)");
     for (uint32_t i = 0; i < n_ops; i++) {
         const dn_cnn_op &o = ops[i];
         if (o.op < DN_CNN_ENCODE_GRU || o.op > DN_CNN_CONV_ADD) return fail(c, DN_ERR_ARG, "cnn op %u: unknown type %d", i, o.op);
@@ -1364,10 +1433,11 @@ int dn_cnn_infer(dn_ctx *c, uint32_t n_seq, const uint32_t *len, const float *co
     return d2h(c, probs, (const float *)c->cnn_out.p, L * 3);
 }
 
-int dn_get_probabilities(dn_ctx *c, uint32_t read, float *probs) {
+int dn_get_probabilities(dn_ctx *c, uint32_t read, uint64_t cap, float *probs) {
     CHECK_READ(7, "dn_get_probabilities");
     if ((rc = cnn_settle(c))) return rc;
     if ((rc = fetch_res(c))) return rc;
+    CHECK_CAP("dn_get_probabilities", c->h_res[read].n_positions, cap);
     return d2h(c, probs, c->d_probs + c->h_ref_off[read] * 3, (size_t)c->h_res[read].n_positions * 3);
 }
 
@@ -1443,10 +1513,11 @@ int dn_run_hmm(dn_ctx *c) {
     return DN_OK;
 }
 
-int dn_get_hmm_calls(dn_ctx *c, uint32_t read, uint32_t *pos_on_ref, uint32_t *pos_on_query, int32_t *global_pos, uint32_t *n_events,
+int dn_get_hmm_calls(dn_ctx *c, uint32_t read, uint64_t cap, uint32_t *pos_on_ref, uint32_t *pos_on_query, int32_t *global_pos, uint32_t *n_events,
                      double *log_analogue, double *log_thymidine, double *llr) {
     CHECK_READ(5, "dn_get_hmm_calls");
     if (!c->hmm_done) return fail(c, DN_ERR_STATE, "dn_get_hmm_calls before dn_run_hmm");
+    CHECK_CAP("dn_get_hmm_calls", read < c->h_nhmm.size() ? c->h_nhmm[read] : 0u, cap);
     const uint64_t f0 = c->h_ref_off[read];
     const unsigned np = c->h_npoi[read];
     if (np == 0) return DN_OK;

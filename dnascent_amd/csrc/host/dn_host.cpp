@@ -483,7 +483,7 @@ int llAcrossRead(dn_ctx *ctx, ReadBatch &batch, std::vector<ReadCalls> &calls) {
         if (s.status != DN_READ_OK) continue;                            // detect.cpp:879-883
         const size_t k = s.n_hmm_calls;
         pr.resize(k); pq.resize(k); gp.resize(k); llr.resize(k);
-        if ((rc = dn_get_hmm_calls(ctx, (uint32_t)r, pr.data(), pq.data(), gp.data(), nullptr, nullptr, nullptr, llr.data()))) return rc;
+        if ((rc = dn_get_hmm_calls(ctx, (uint32_t)r, k, pr.data(), pq.data(), gp.data(), nullptr, nullptr, nullptr, llr.data()))) return rc;
         const std::string bc(batch.basecall.data() + batch.basecall_off[r], batch.basecall.data() + batch.basecall_off[r + 1]);
         const std::string rf(batch.refseq.data() + batch.refseq_off[r], batch.refseq.data() + batch.refseq_off[r + 1]);
         calls[r].humanReadable_detectOut = formatHmmRecord(batch.readID[r], batch.contig[r], batch.ref_start[r], batch.ref_end[r],

@@ -618,8 +618,10 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
 // ---------------------------------------------------------------------------------------------------------
 #define SEP_XP 40                                           // floats per raw-tile row
 #define SEP_XPW 36                                          // ... of the wave-specialised kernel's raw slices (see its depthwise)
+// (the bf16x6 form of the 128-column tile holds 83 KB of LDS and ~300 registers: ONE workgroup per CU, and it says so -- round 2 asked for
+// two and the compiler reported "desired occupancy 2, final 1"; the persistent grid below follows the same number)
 template <int BN, int KW, bool ADD, int NP>
-__global__ __launch_bounds__(256, 2) void k3_sep_split(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wd,
+__global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_split(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wd,
                                                     const uint16_t *__restrict__ Wb, const float *__restrict__ scale,
                                                     const float *__restrict__ shift, const float *__restrict__ Add,
                                                     const uint8_t *__restrict__ valid, int rows, const int *__restrict__ live, int cin, int cout, int relu, float post,
@@ -1171,18 +1173,22 @@ struct CnnRun {
     unsigned *row_off_w; int *live;   // device: this pass's row offsets (written by k3_layout) and its live row count
 };
 
-static unsigned k3_cu_count() {                            // persistent kernels: one workgroup per CU of the current device (DN_CNN_WS_WGS overrides)
-    static const unsigned n = [] {
-        if (getenv("DN_CNN_WS_WGS") && atoi(getenv("DN_CNN_WS_WGS")) > 0) return (unsigned)atoi(getenv("DN_CNN_WS_WGS"));
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return (unsigned)v;
-    }();
-    return n;
+static unsigned k3_cu_count() {                            // persistent kernels: one workgroup per CU of the CURRENT device (DN_CNN_WS_WGS overrides)
+    static const unsigned env = (getenv("DN_CNN_WS_WGS") && atoi(getenv("DN_CNN_WS_WGS")) > 0) ? (unsigned)atoi(getenv("DN_CNN_WS_WGS")) : 0u;
+    if (env) return env;
+    static unsigned per_dev[64] = { 0 };                   // cached per device: one process may drive devices with different CU counts
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!per_dev[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        per_dev[dev] = (unsigned)v;
+    }
+    return per_dev[dev];
 }
-static unsigned k3_sep_wgs(int bn) {                       // persistent k3_sep_split: workgroups per launch = what a CU holds (two of the 128-column
+static unsigned k3_sep_wgs(int bn, int np = 2) {                       // persistent k3_sep_split: workgroups per launch = what a CU holds (two of the 128-column
     static const unsigned env = (getenv("DN_CNN_SEP_WGS") && atoi(getenv("DN_CNN_SEP_WGS")) > 0) ? (unsigned)atoi(getenv("DN_CNN_SEP_WGS")) : 0u;   // form, three of the 64-column one)
-    return env ? env : (bn == 64 ? 3u : 2u) * k3_cu_count();
+    return env ? env : (bn == 64 ? 3u : (np == 3 ? 1u : 2u)) * k3_cu_count();
 }
 static bool k3_sep_ws_enabled() { static const bool on = !(getenv("DN_CNN_SEP_WS") && atoi(getenv("DN_CNN_SEP_WS")) == 0); return on; }
 static bool k3_bm256_enabled() { static const bool on = !(getenv("DN_CNN_BM256") && atoi(getenv("DN_CNN_BM256")) == 0); return on; }
@@ -1214,7 +1220,7 @@ static int k3_launch_sep(const CnnRun &c, int i, const float *in, float *out, co
     const unsigned rows = c.rows.rows;
 #define SEP_ARGS in, out, c.wts + d.w, c.wts_split + c.wb_off[i + 1], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, c.live, \
         o.cin, o.cout, o.relu, c.post[i + 1], c.range_flag
-#define SEP_GO(KW_) hipLaunchKernelGGL((k3_sep_split<BN, KW_, ADD, NP>), dim3(o.cout == BN ? min(conv_grid(rows, o.cout, BN), k3_sep_wgs(BN)) : conv_grid(rows, o.cout, BN)), dim3(256), 0, st, SEP_ARGS)
+#define SEP_GO(KW_) hipLaunchKernelGGL((k3_sep_split<BN, KW_, ADD, NP>), dim3(o.cout == BN ? min(conv_grid(rows, o.cout, BN), k3_sep_wgs(BN, NP)) : conv_grid(rows, o.cout, BN)), dim3(256), 0, st, SEP_ARGS)
     if (NP == 2 && d.k == 17 && o.cout == 256 && o.cin % 64 == 0 && k3_sep_ws_enabled()) {      // BN == cout: one column tile
         if (c.mark) c.mark(c.mark_who, 1, 0, st);
         hipLaunchKernelGGL((k3_sep_ws<256, 17, ADD, 2>), dim3(min(conv_grid(rows, o.cout, 256), k3_cu_count())), dim3(512), 0, st, SEP_ARGS);
@@ -1238,6 +1244,8 @@ int k3_run(const CnnRun &c, hipStream_t st) {
     // depthwise op would have written, and the two logical buffers swap their pointers.
     float *pb[8];
     for (int b = 0; b < 8; b++) pb[b] = c.buf[b];
+    // row offsets and the live row count of THIS pass: every kernel below reads them, whatever the description's first op is
+    hipLaunchKernelGGL(k3_layout, dim3(1), dim3(64), 0, st, c.row_off_w, c.rows.n_pos, c.rows.r0, c.rows.r1, c.live);
     for (int i = 0; i < c.n_ops; i++) {
         const dn_cnn_op &o = c.ops[i];
         if (k3_can_fuse(c, i)) {
@@ -1260,7 +1268,6 @@ int k3_run(const CnnRun &c, hipStream_t st) {
         }
         switch (o.op) {
             case DN_CNN_ENCODE_GRU:
-                hipLaunchKernelGGL(k3_layout, dim3(1), dim3(64), 0, st, c.row_off_w, c.rows.n_pos, c.rows.r0, c.rows.r1, c.live);
                 hipMemsetAsync(pb[o.dst], 0, (size_t)rows * 64 * sizeof(float), st);
                 hipMemsetAsync(c.enc_hist, 0, 2 * ENC_BINS * sizeof(unsigned), st);
                 hipLaunchKernelGGL(k3_encode_len, dim3((c.max_pos + 255) / 256, c.rows.r1 - c.rows.r0), dim3(256), 0, st, c.sig, c.rows, c.enc_len, c.enc_hist);

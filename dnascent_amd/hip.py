@@ -22,7 +22,7 @@ SYMBOLS = ["dn_abi_version", "dn_device_count", "dn_ctx_create", "dn_ctx_destroy
            "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_set_align_table", "dn_get_align_rows", "dn_get_align_table", "dn_load_cnn", "dn_cnn_set_math", "dn_cnn_range_escalations", "dn_run_cnn", "dn_get_probabilities", "dn_cnn_infer", "dn_load_fit_models", "dn_run_hmm", "dn_get_hmm_calls", "dn_get_summaries", "dn_get_prefix_sums",
            "dn_get_tstats", "dn_get_scrappie_events", "dn_get_events", "dn_get_kmer_ranks", "dn_get_alignment",
            "dn_get_cleaned", "dn_get_trace", "dn_get_positions", "dn_get_windows", "dn_profile_enable", "dn_profile_get",
-           "dn_profile_reset", "dn_kernel_name", "dn_device_bytes"]
+           "dn_profile_reset", "dn_kernel_name", "dn_device_bytes", "dn_shutdown"]
 
 
 class BatchDesc(C.Structure):
@@ -106,9 +106,9 @@ def lib():
         L.dn_cnn_range_escalations.argtypes = [C.c_void_p]; L.dn_cnn_range_escalations.restype = C.c_uint64
         L.dn_load_fit_models.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.dn_run_hmm.argtypes = [C.c_void_p]
-        L.dn_get_hmm_calls.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 7
+        L.dn_get_hmm_calls.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 7
         L.dn_cnn_infer.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.dn_get_probabilities.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.dn_get_probabilities.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
         L.dn_get_summaries.argtypes = [C.c_void_p, C.c_void_p]
         L.dn_collect.argtypes = [C.c_void_p, C.POINTER(ResultBatch)]
         L.dn_debug_emission.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -117,16 +117,16 @@ def lib():
         L.dn_host_free.argtypes = [C.c_void_p]
         L.dn_host_register.argtypes = [C.c_void_p, C.c_size_t]
         L.dn_host_unregister.argtypes = [C.c_void_p]
-        L.dn_get_prefix_sums.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
-        L.dn_get_tstats.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
-        L.dn_get_scrappie_events.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.dn_get_events.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.dn_get_kmer_ranks.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
-        L.dn_get_alignment.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
-        L.dn_get_cleaned.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
-        L.dn_get_trace.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.dn_get_positions.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 9
-        L.dn_get_windows.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 4
+        L.dn_get_prefix_sums.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.dn_get_tstats.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.dn_get_scrappie_events.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dn_get_events.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dn_get_kmer_ranks.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.dn_get_alignment.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.dn_get_cleaned.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.dn_get_trace.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dn_get_positions.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 9
+        L.dn_get_windows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 4
         L.dn_set_align_table.argtypes = [C.c_void_p, C.c_int]
         L.dn_get_align_rows.argtypes = [C.c_void_p, C.c_void_p]
         L.dn_get_align_table.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4
@@ -136,6 +136,7 @@ def lib():
         L.dn_kernel_name.argtypes = [C.c_int]
         L.dn_device_bytes.restype = C.c_size_t
         L.dn_device_bytes.argtypes = [C.c_void_p]
+        L.dn_shutdown.restype = C.c_int
         _lib = L
     return _lib
 
@@ -196,7 +197,7 @@ class Context:
     def hmm_calls(self, r, n):
         d = dict(pos_on_ref=np.zeros(n, np.uint32), pos_on_query=np.zeros(n, np.uint32), global_pos=np.zeros(n, np.int32),
                  n_events=np.zeros(n, np.uint32), log_analogue=np.zeros(n), log_thymidine=np.zeros(n), llr=np.zeros(n))
-        self._chk(lib().dn_get_hmm_calls(self.h, r, *[d[k].ctypes.data for k in ("pos_on_ref", "pos_on_query", "global_pos", "n_events",
+        self._chk(lib().dn_get_hmm_calls(self.h, r, n, *[d[k].ctypes.data for k in ("pos_on_ref", "pos_on_query", "global_pos", "n_events",
                                                                                 "log_analogue", "log_thymidine", "llr")]), "dn_get_hmm_calls")
         return d
 
@@ -213,7 +214,7 @@ class Context:
 
     def probabilities(self, r, n):
         p = np.zeros((n, 3), np.float32)
-        self._chk(lib().dn_get_probabilities(self.h, r, p.ctypes.data), "dn_get_probabilities")
+        self._chk(lib().dn_get_probabilities(self.h, r, n, p.ctypes.data), "dn_get_probabilities")
         return p
 
     def upload(self, desc, n_reads, keep=None):
@@ -260,42 +261,42 @@ class Context:
     # ---- taps -------------------------------------------------------------------------------
     def prefix_sums(self, r, n):
         a = np.zeros(n + 1); b = np.zeros(n + 1)
-        self._chk(lib().dn_get_prefix_sums(self.h, r, a.ctypes.data, b.ctypes.data), "dn_get_prefix_sums")
+        self._chk(lib().dn_get_prefix_sums(self.h, r, n, a.ctypes.data, b.ctypes.data), "dn_get_prefix_sums")
         return a, b
 
     def tstats(self, r, n):
         a = np.zeros(n, np.float32); b = np.zeros(n, np.float32)
-        self._chk(lib().dn_get_tstats(self.h, r, a.ctypes.data, b.ctypes.data), "dn_get_tstats")
+        self._chk(lib().dn_get_tstats(self.h, r, n, a.ctypes.data, b.ctypes.data), "dn_get_tstats")
         return a, b
 
     def scrappie_events(self, r, n):
         st = np.zeros(n, np.uint32); ln = np.zeros(n, np.float32); mn = np.zeros(n, np.float32)
-        self._chk(lib().dn_get_scrappie_events(self.h, r, st.ctypes.data, ln.ctypes.data, mn.ctypes.data), "dn_get_scrappie_events")
+        self._chk(lib().dn_get_scrappie_events(self.h, r, n, st.ctypes.data, ln.ctypes.data, mn.ctypes.data), "dn_get_scrappie_events")
         return st, ln, mn
 
     def events(self, r, n):
         mean = np.zeros(n); st = np.zeros(n, np.uint32); ln = np.zeros(n, np.uint32)
-        self._chk(lib().dn_get_events(self.h, r, mean.ctypes.data, st.ctypes.data, ln.ctypes.data), "dn_get_events")
+        self._chk(lib().dn_get_events(self.h, r, n, mean.ctypes.data, st.ctypes.data, ln.ctypes.data), "dn_get_events")
         return mean, st, ln
 
     def kmer_ranks(self, r, nq, nr):
         q = np.zeros(nq, np.uint32); f = np.zeros(nr, np.uint32)
-        self._chk(lib().dn_get_kmer_ranks(self.h, r, q.ctypes.data, f.ctypes.data), "dn_get_kmer_ranks")
+        self._chk(lib().dn_get_kmer_ranks(self.h, r, nq, nr, q.ctypes.data, f.ctypes.data), "dn_get_kmer_ranks")
         return q, f
 
     def alignment(self, r, n):
         e = np.zeros(n, np.uint32); k = np.zeros(n, np.uint32)
-        self._chk(lib().dn_get_alignment(self.h, r, e.ctypes.data, k.ctypes.data), "dn_get_alignment")
+        self._chk(lib().dn_get_alignment(self.h, r, n, e.ctypes.data, k.ctypes.data), "dn_get_alignment")
         return e, k
 
     def cleaned(self, r, n):
         s = np.zeros(n); k = np.zeros(n, np.uint32)
-        self._chk(lib().dn_get_cleaned(self.h, r, s.ctypes.data, k.ctypes.data), "dn_get_cleaned")
+        self._chk(lib().dn_get_cleaned(self.h, r, n, s.ctypes.data, k.ctypes.data), "dn_get_cleaned")
         return s, k
 
     def trace(self, r, n_bands):
         t = np.zeros(n_bands * 100, np.uint8); e = np.zeros(n_bands, np.int32); k = np.zeros(n_bands, np.int32)
-        self._chk(lib().dn_get_trace(self.h, r, t.ctypes.data, e.ctypes.data, k.ctypes.data), "dn_get_trace")
+        self._chk(lib().dn_get_trace(self.h, r, n_bands, t.ctypes.data, e.ctypes.data, k.ctypes.data), "dn_get_trace")
         return t.reshape(n_bands, 100), e, k
 
     def positions(self, r, n):
@@ -303,7 +304,7 @@ class Context:
                  indel=np.zeros(n, np.int32), n_signal=np.zeros(n, np.uint32), signal=np.zeros((n, 20), np.float32),
                  core=np.zeros(n, np.float32), residual=np.zeros(n, np.float32))
         km = np.zeros(n * 9, np.uint8)
-        self._chk(lib().dn_get_positions(self.h, r, d["coord"].ctypes.data, d["query_idx"].ctypes.data, d["ref_idx"].ctypes.data,
+        self._chk(lib().dn_get_positions(self.h, r, n, d["coord"].ctypes.data, d["query_idx"].ctypes.data, d["ref_idx"].ctypes.data,
                                          d["indel"].ctypes.data, km.ctypes.data, d["n_signal"].ctypes.data, d["signal"].ctypes.data,
                                          d["core"].ctypes.data, d["residual"].ctypes.data), "dn_get_positions")
         d["kmer"] = np.frombuffer(km.tobytes(), dtype="S9").copy() if n else np.zeros(0, "S9")
@@ -326,7 +327,7 @@ class Context:
 
     def windows(self, r, n):
         a = np.zeros(n, np.uint32); b = np.zeros(n, np.uint32); t = np.zeros(n, np.uint32); s = np.zeros(n)
-        self._chk(lib().dn_get_windows(self.h, r, a.ctypes.data, b.ctypes.data, t.ctypes.data, s.ctypes.data), "dn_get_windows")
+        self._chk(lib().dn_get_windows(self.h, r, n, a.ctypes.data, b.ctypes.data, t.ctypes.data, s.ctypes.data), "dn_get_windows")
         return a, b, t, s
 
     # ---- measurement ------------------------------------------------------------------------

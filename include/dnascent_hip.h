@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 2
+#define DN_ABI_VERSION 3
 #define DN_KMER 9            /* config.h:45 */
 #define DN_NKMER 262144      /* 4^9, data_IO.cpp:177 */
 #define DN_BANDWIDTH 100     /* config.h:41 AdaptiveBanded_Params.bandwidth */
@@ -130,7 +130,7 @@ enum { DN_CNN_MATH_FP32 = 0, DN_CNN_MATH_BF16X6 = 1, DN_CNN_MATH_F16X3 = 2 };
 int dn_cnn_set_math(dn_ctx *ctx, int mode);
 uint64_t dn_cnn_range_escalations(dn_ctx *ctx);
 int dn_run_cnn(dn_ctx *ctx);            /* runCNN for every read that passed eventalign */
-int dn_get_probabilities(dn_ctx *ctx, uint32_t read, float *probs /* [n_positions * 3] */);
+int dn_get_probabilities(dn_ctx *ctx, uint32_t read, uint64_t cap /* positions `probs` holds */, float *probs /* [n_positions * 3] */);
 /* the TF_SessionRun seam itself (detect.cpp:653): n_seq sequences given as the three host tensors runCNN builds --
  * core [sum len], residual [sum len], signal [sum len][20] -- -> probs [sum len][3].  Needs only dn_load_cnn; it lets a
  * maintainer keep the reference's CPU eventalign and replace just the TensorFlow call. */
@@ -153,8 +153,9 @@ int dn_get_align_table(dn_ctx *ctx, uint32_t read, uint32_t n_rows, uint32_t *co
 int dn_load_fit_models(dn_ctx *ctx, const double *unlabelled_mean, const double *unlabelled_std, const double *analogue_mean,
                        const double *analogue_std /* each [DN_NKMER] */);
 int dn_run_hmm(dn_ctx *ctx);
-int dn_get_hmm_calls(dn_ctx *ctx, uint32_t read, uint32_t *pos_on_ref, uint32_t *pos_on_query, int32_t *global_pos /* :531-541 */,
-                     uint32_t *n_events, double *log_analogue, double *log_thymidine, double *llr /* each [n_hmm_calls] */);
+int dn_get_hmm_calls(dn_ctx *ctx, uint32_t read, uint64_t cap /* calls every array holds */, uint32_t *pos_on_ref, uint32_t *pos_on_query,
+                     int32_t *global_pos /* :531-541 */, uint32_t *n_events, double *log_analogue, double *log_thymidine,
+                     double *llr /* each [n_hmm_calls] */);
 
 /* ---- per-read results ---- */
 typedef struct {
@@ -197,23 +198,28 @@ typedef struct {
 } dn_result_batch;
 int dn_collect(dn_ctx *ctx, dn_result_batch *out);
 
-/* ---- intermediate taps (parity tests; sizes from dn_read_summary; NULL pointers are skipped) ---- */
+/* ---- intermediate taps (parity tests; NULL pointers are skipped) ----
+ * Every tap takes `cap`: how many records (samples / events / k-mers / pairs / bands / positions / windows) EACH of the caller's arrays
+ * holds.  The library knows the true count (dn_read_summary reports it); a tap whose count exceeds `cap` writes nothing and returns
+ * DN_ERR_ARG with the two numbers in dn_last_error -- a stale summary can therefore never make a tap write past a buffer. */
 /* prefix sums and t-statistics live only in registers / LDS of the segmentation kernels; dn_debug_keep_k1(ctx, 1) BEFORE
  * dn_batch_upload makes the next batches also write them to HBM (24 bytes per sample) so that the two taps below work */
 int dn_debug_keep_k1(dn_ctx *ctx, int on);
-int dn_get_prefix_sums(dn_ctx *ctx, uint32_t read, double *sum /* [n+1] */, double *sumsq /* [n+1] */);
-int dn_get_tstats(dn_ctx *ctx, uint32_t read, float *t_short, float *t_long /* [n_samples] */);
-int dn_get_scrappie_events(dn_ctx *ctx, uint32_t read, uint32_t *start, float *length, float *mean /* [n_scrappie] */);
-int dn_get_events(dn_ctx *ctx, uint32_t read, double *mean, uint32_t *raw_start, uint32_t *raw_len /* [n_events] */);
-int dn_get_kmer_ranks(dn_ctx *ctx, uint32_t read, uint32_t *rank_query, uint32_t *rank_ref);
-int dn_get_alignment(dn_ctx *ctx, uint32_t read, uint32_t *event_idx, uint32_t *kmer_idx /* [n_aligned] */);
-int dn_get_cleaned(dn_ctx *ctx, uint32_t read, double *signal, uint32_t *rank /* [n_cleaned], backtrack order */);
-int dn_get_trace(dn_ctx *ctx, uint32_t read, uint8_t *trace /* [n_bands*100] */, int32_t *band_event /* [n_bands] ll.event_idx */,
-                 int32_t *band_kmer /* [n_bands] */);
+int dn_get_prefix_sums(dn_ctx *ctx, uint32_t read, uint64_t cap /* samples */, double *sum /* [cap+1] */, double *sumsq /* [cap+1] */);
+int dn_get_tstats(dn_ctx *ctx, uint32_t read, uint64_t cap /* samples */, float *t_short, float *t_long /* [n_samples] */);
+int dn_get_scrappie_events(dn_ctx *ctx, uint32_t read, uint64_t cap, uint32_t *start, float *length, float *mean /* [n_scrappie] */);
+int dn_get_events(dn_ctx *ctx, uint32_t read, uint64_t cap, double *mean, uint32_t *raw_start, uint32_t *raw_len /* [n_events] */);
+int dn_get_kmer_ranks(dn_ctx *ctx, uint32_t read, uint64_t cap_query, uint64_t cap_ref, uint32_t *rank_query /* [n_kmers_query] */,
+                      uint32_t *rank_ref /* [n_kmers_ref] */);
+int dn_get_alignment(dn_ctx *ctx, uint32_t read, uint64_t cap, uint32_t *event_idx, uint32_t *kmer_idx /* [n_aligned] */);
+int dn_get_cleaned(dn_ctx *ctx, uint32_t read, uint64_t cap, double *signal, uint32_t *rank /* [n_cleaned], backtrack order */);
+int dn_get_trace(dn_ctx *ctx, uint32_t read, uint64_t cap /* bands */, uint8_t *trace /* [n_bands*100] */,
+                 int32_t *band_event /* [n_bands] ll.event_idx */, int32_t *band_kmer /* [n_bands] */);
 /* eventalign outputs, creation order == sequencing direction (reads.h:305-372) */
-int dn_get_positions(dn_ctx *ctx, uint32_t read, uint32_t *coord, uint32_t *query_idx, uint32_t *ref_idx, int32_t *indel_score,
-                     char *kmer9, uint32_t *n_signal, float *signal20, float *core, float *residual);
-int dn_get_windows(dn_ctx *ctx, uint32_t read, uint32_t *ref_index, uint32_t *window_len, uint32_t *n_obs, double *score);
+int dn_get_positions(dn_ctx *ctx, uint32_t read, uint64_t cap /* positions */, uint32_t *coord, uint32_t *query_idx, uint32_t *ref_idx,
+                     int32_t *indel_score, char *kmer9, uint32_t *n_signal, float *signal20, float *core, float *residual);
+int dn_get_windows(dn_ctx *ctx, uint32_t read, uint64_t cap /* windows */, uint32_t *ref_index, uint32_t *window_len, uint32_t *n_obs,
+                   double *score);
 
 /* the emission term of builtinViterbi as the device lattice evaluates it -- eln(normalPDF(mu, sigma, x)), alignment.cpp:273,347 with
  * probability.cpp:35-47,145-148; sigma of dn_load_pore_model -- for n (observation, level) pairs; log 0 comes back as NaN.
@@ -229,7 +235,11 @@ int dn_profile_enable(dn_ctx *ctx, int on);     /* HIP events around every kerne
 int dn_profile_get(dn_ctx *ctx, int kernel, double *total_ms, uint32_t *launches);
 int dn_profile_reset(dn_ctx *ctx);
 const char *dn_kernel_name(int kernel);
-size_t dn_device_bytes(const dn_ctx *ctx);      /* HBM currently held by the context */
+size_t dn_device_bytes(const dn_ctx *ctx);      /* HBM currently held by the context + the CNN lanes of its device (shared by its contexts) */
+/* Frees the process-wide CNN lanes (streams + activation buffers) of every device.  dn_ctx_destroy of the LAST context of a device does
+ * it for that device by itself; dn_shutdown is for hosts that keep contexts alive but want the lanes' HBM back between runs.  The
+ * lanes come back on the next dn_run_cnn. */
+int dn_shutdown(void);
 
 #ifdef __cplusplus
 }
