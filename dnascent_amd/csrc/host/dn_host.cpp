@@ -70,7 +70,32 @@ int parseCigar(const std::vector<uint32_t> &ops, const std::vector<uint32_t> &le
     return (int)refLen;
 }
 
-void ReadBatch::clear() { *this = ReadBatch(); }
+void ReadBatch::clear() {                                   // keeps the vectors' capacity: a streamed host reuses its batch objects
+    unpin();
+    readID.clear(); contig.clear(); adc.clear(); adc_off.assign(1, 0); cal_offset.clear(); cal_scale.clear();
+    basecall.clear(); basecall_off.assign(1, 0); refseq.clear(); refseq_off.assign(1, 0);
+    ref2query.clear(); query2ref.clear(); ref2del.clear(); ref_start.clear(); ref_end.clear(); is_reverse.clear(); summary.clear();
+}
+
+int ReadBatch::pin() {
+    unpin();
+    auto reg = [&](const void *p, size_t bytes) {
+        if (!bytes) return true;
+        if (dn_host_register(const_cast<void *>(p), bytes) != DN_OK) return false;
+        pinned.push_back(const_cast<void *>(p));
+        return true;
+    };
+    const bool ok = reg(adc.data(), adc.size() * 2) && reg(cal_offset.data(), cal_offset.size() * 4) && reg(cal_scale.data(), cal_scale.size() * 4) &&
+                    reg(basecall.data(), basecall.size()) && reg(refseq.data(), refseq.size()) && reg(ref2query.data(), ref2query.size() * 4) &&
+                    reg(query2ref.data(), query2ref.size() * 4) && reg(ref2del.data(), ref2del.size()) && reg(ref_start.data(), ref_start.size() * 4) &&
+                    reg(ref_end.data(), ref_end.size() * 4) && reg(is_reverse.data(), is_reverse.size());
+    if (!ok) { unpin(); return DN_ERR_HIP; }
+    return DN_OK;
+}
+void ReadBatch::unpin() {
+    for (void *p : pinned) dn_host_unregister(p);
+    pinned.clear();
+}
 
 int ReadBatch::add(const ReadInput &in) {
     // ---- signal slice (pod5.cpp:75-93) ----
@@ -201,6 +226,12 @@ bool ReadContainerReader::next(OwnedRead &o) {
     in.signalLength = sl; in.signalTrim = st; in.signalStartCoord = sc; in.isSplit = split != 0; in.isReverse = rev != 0; in.refStart = rs;
     in.adc = o.adc.data(); in.n_adc = o.adc.size();
     seen++;
+    return true;
+}
+uint64_t ReadContainerReader::tell() const { return f ? (uint64_t)ftello((FILE *)f) : 0; }
+bool ReadContainerReader::seek(uint64_t offset) {
+    if (!f || fseeko((FILE *)f, (off_t)offset, SEEK_SET) != 0) { bad = true; return false; }
+    seen = 0;                                                // the caller addresses records by offset from here on
     return true;
 }
 void ReadContainerReader::close() { if (f) fclose((FILE *)f); f = nullptr; }
@@ -338,57 +369,88 @@ int runCNN(dn_ctx *ctx, ReadBatch &batch, bool humanReadable, std::vector<ReadCa
 // ---- the buffer-of-reads loop of detect.cpp:821-907 with several batches in flight on one GPU, driven by ONE host thread ----
 // Batch i runs on context i % n_ctx.  Nothing in the loop waits except dn_collect of the OLDEST batch in flight, and while the
 // host formats and writes its records the GPU works on the n_ctx - 1 younger batches.  Records are written in input order.
+static double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+DetectStream::DetectStream(dn_ctx **ctxs, int n_ctx, bool emit_) : ctx(ctxs, ctxs + n_ctx), slot_batch((size_t)n_ctx, nullptr), slot_tag((size_t)n_ctx, 0),
+                                                                 emit(emit_), t_open(now_s()) {}
+
+int DetectStream::submit(ReadBatch *batch, uint64_t tag) {
+    if (full() || !batch) return DN_ERR_STATE;
+    const int slot = (head + inflight) % (int)ctx.size();
+    const double a = now_s();
+    const dn_batch_desc d = batch->desc();
+    int rc = dn_batch_upload(ctx[(size_t)slot], &d);
+    if (rc) return rc;
+    S.seconds_upload += now_s() - a;
+    if ((rc = dn_run_detect(ctx[(size_t)slot]))) return rc;
+    slot_batch[(size_t)slot] = batch; slot_tag[(size_t)slot] = tag;
+    inflight++;
+    return DN_OK;
+}
+
+int DetectStream::collect(Result &out) {
+    if (inflight == 0) return DN_ERR_STATE;
+    dn_ctx *c = ctx[(size_t)head];
+    ReadBatch &B = *slot_batch[(size_t)head];
+    out.tag = slot_tag[(size_t)head]; out.batch = &B;
+    out.record_bytes.clear(); out.text.clear();
+    const double a = now_s();
+    int rc = dn_collect(c, &out.res);
+    if (rc) return rc;
+    const double b = now_s();
+    const dn_result_batch &res = out.res;
+    S.seconds_collect += b - a;
+    S.reads += res.n_reads; S.calls += res.n_calls; S.samples += B.totalSamples();
+    B.summary.assign(res.summary, res.summary + res.n_reads);
+    for (uint32_t r = 0; r < res.n_reads; r++) if (res.summary[r].status == DN_READ_OK) { S.reads_ok++; S.positions += res.summary[r].n_positions; }
+    out.record_bytes.assign(res.n_reads, 0);
+    if (emit) {
+        formatCalls(B, res, true, calls);
+        size_t total = 0;
+        for (size_t r = 0; r < calls.size(); r++) if (res.summary[r].status == DN_READ_OK) total += calls[r].humanReadable_detectOut.size();
+        out.text.reserve(total);
+        for (size_t r = 0; r < calls.size(); r++) {
+            if (res.summary[r].status != DN_READ_OK) continue;
+            out.record_bytes[r] = calls[r].humanReadable_detectOut.size();
+            out.text += calls[r].humanReadable_detectOut;
+        }
+        S.bytes_out += total;
+        S.seconds_emit += now_s() - b;
+    }
+    head = (head + 1) % (int)ctx.size(); inflight--;
+    S.seconds_total = now_s() - t_open;
+    return DN_OK;
+}
+
 int streamDetect(dn_ctx **ctxs, int n_ctx, ReadBatch **batches, int n_batches, bool emit, const char *outPath, const char *header,
                  StreamStats *st, StreamKeep *keep) {
-    StreamStats S{};
     FILE *f = nullptr;
     if (emit && outPath) { f = fopen(outPath, "wb"); if (!f) return DN_ERR_ARG; if (header) fwrite(header, 1, strlen(header), f); }
-    std::vector<ReadCalls> calls;
-    const auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; };
-    const double t0 = now();
+    const double t0 = now_s();
+    DetectStream ds(ctxs, n_ctx, emit);
+    DetectStream::Result R;
     int rc = DN_OK;
-    for (int i = 0; i < n_batches + n_ctx && rc == DN_OK; i++) {
-        dn_ctx *ctx = ctxs[i % n_ctx];
-        const int j = i - n_ctx;                             // the batch this context has been working on
-        if (j >= 0 && j < n_batches) {
-            ReadBatch &B = *batches[j];
-            dn_result_batch res;
-            const double a = now();
-            if ((rc = dn_collect(ctx, &res))) break;
-            const double b = now();
-            S.seconds_collect += b - a;
-            S.reads += res.n_reads; S.calls += res.n_calls; S.samples += B.totalSamples();
-            B.summary.assign(res.summary, res.summary + res.n_reads);
-            for (uint32_t r = 0; r < res.n_reads; r++) if (res.summary[r].status == DN_READ_OK) { S.reads_ok++; S.positions += res.summary[r].n_positions; }
-            if (keep) {
-                for (uint32_t r = 0; r < res.n_reads; r++) keep->read_calls.push_back(res.call_off[r + 1] - res.call_off[r]);
-                keep->record_bytes.resize(keep->read_calls.size(), 0);     // filled below when records are formatted
-                keep->coord.insert(keep->coord.end(), res.ref_coord, res.ref_coord + res.n_calls);
-                keep->p_edu.insert(keep->p_edu.end(), res.p_edu, res.p_edu + res.n_calls);
-                keep->p_brdu.insert(keep->p_brdu.end(), res.p_brdu, res.p_brdu + res.n_calls);
-            }
-            if (emit) {
-                formatCalls(B, res, true, calls);
-                for (size_t r = 0; r < calls.size(); r++) {
-                    if (res.summary[r].status != DN_READ_OK) continue;
-                    if (keep) keep->record_bytes[keep->record_bytes.size() - calls.size() + r] = calls[r].humanReadable_detectOut.size();
-                    S.bytes_out += calls[r].humanReadable_detectOut.size();
-                    if (f) fwrite(calls[r].humanReadable_detectOut.data(), 1, calls[r].humanReadable_detectOut.size(), f);
-                }
-                S.seconds_emit += now() - b;
-            }
+    auto drain_one = [&]() -> int {
+        int e = ds.collect(R);
+        if (e) return e;
+        const dn_result_batch &res = R.res;
+        if (keep) {
+            for (uint32_t r = 0; r < res.n_reads; r++) keep->read_calls.push_back(res.call_off[r + 1] - res.call_off[r]);
+            keep->record_bytes.insert(keep->record_bytes.end(), R.record_bytes.begin(), R.record_bytes.end());
+            keep->coord.insert(keep->coord.end(), res.ref_coord, res.ref_coord + res.n_calls);
+            keep->p_edu.insert(keep->p_edu.end(), res.p_edu, res.p_edu + res.n_calls);
+            keep->p_brdu.insert(keep->p_brdu.end(), res.p_brdu, res.p_brdu + res.n_calls);
         }
-        if (i < n_batches) {
-            const double a = now();
-            const dn_batch_desc d = batches[i]->desc();
-            if ((rc = dn_batch_upload(ctx, &d))) break;
-            S.seconds_upload += now() - a;
-            if ((rc = dn_run_detect(ctx))) break;
-        }
+        if (f && !R.text.empty()) fwrite(R.text.data(), 1, R.text.size(), f);
+        return DN_OK;
+    };
+    for (int i = 0; i < n_batches && rc == DN_OK; i++) {
+        if (ds.full()) rc = drain_one();
+        if (rc == DN_OK) rc = ds.submit(batches[i], (uint64_t)i);
     }
+    while (rc == DN_OK && ds.inFlight()) rc = drain_one();
     if (f) fclose(f);
-    S.seconds_total = now() - t0;
-    if (st) *st = S;
+    if (st) { *st = ds.stats(); st->seconds_total = now_s() - t0; }
     return rc;
 }
 
@@ -615,6 +677,82 @@ int64_t dnh_container_load_list(void *b, const char *path, const uint64_t *ordin
     }
     return accepted;
 }
+
+// index of a container: sample count and file offset of every record (one pass of seeks); returns the read count or -1
+int64_t dnh_container_index(const char *path, uint64_t *sizes, uint64_t *offsets, uint64_t cap) {
+    DNAscent::ReadContainerReader r;
+    if (!r.open(path)) return -1;
+    uint64_t i = 0, ns = 0;
+    for (;;) {
+        const uint64_t at = r.tell();
+        if (!r.skip(&ns)) break;
+        if (i < cap) { if (sizes) sizes[i] = ns; if (offsets) offsets[i] = at; }
+        i++;
+    }
+    return r.failed() ? -1 : (int64_t)i;
+}
+// adds the records at the given file offsets (dnh_container_index) to the batch, in the given order: the records are read by all
+// host cores (one FILE per thread), then packed in order.  accepted[j] = 1 if the batch took record j, 0 if it was REJECTED by the
+// reference's own filters (ReadBatch::add: empty / too short signal, CIGAR that does not span the reference slice: detect.cpp:839,
+// pod5.cpp:64) -- such a read counts as failed, it is not an error.  Returns the number accepted, or -1 on an I/O error / a
+// truncated record (nothing usable: the batch is left as it was).
+int64_t dnh_container_load_at(void *b, const char *path, const uint64_t *offsets, uint64_t n, uint8_t *accepted) {
+    ReadBatch *B = (ReadBatch *)b;
+    int64_t got = 0;
+    bool io_bad = false;
+    const uint64_t chunk = 256;
+    const size_t first = B->size();
+    for (uint64_t c0 = 0; c0 < n && !io_bad; c0 += chunk) {
+        const uint64_t m = std::min(chunk, n - c0);
+        std::vector<DNAscent::OwnedRead> rd((size_t)m);
+        std::vector<uint8_t> ok((size_t)m, 0);
+#pragma omp parallel
+        {
+            DNAscent::ReadContainerReader r;
+            const bool open_ok = r.open(path);
+#pragma omp for schedule(dynamic, 4)
+            for (long j = 0; j < (long)m; j++) ok[(size_t)j] = open_ok && r.seek(offsets[c0 + (uint64_t)j]) && r.next(rd[(size_t)j]);
+        }
+        for (uint64_t j = 0; j < m; j++) {
+            if (!ok[(size_t)j]) { io_bad = true; break; }
+            const bool took = B->add(rd[(size_t)j].in) >= 0;
+            if (accepted) accepted[c0 + j] = took ? 1 : 0;
+            got += took;
+        }
+    }
+    if (io_bad) {                                            // all or nothing: a half-loaded batch would shift every later ordinal
+        if (first == 0) B->clear();
+        return -1;
+    }
+    return got;
+}
+
+// ---- DNAscent::DetectStream behind C signatures ----
+void *dnh_stream_open(void **ctxs, int n_ctx, int emit) { return new DNAscent::DetectStream((dn_ctx **)ctxs, n_ctx, emit != 0); }
+void dnh_stream_close(void *s) { delete (DNAscent::DetectStream *)s; }
+int dnh_stream_full(void *s) { return ((DNAscent::DetectStream *)s)->full() ? 1 : 0; }
+int dnh_stream_inflight(void *s) { return ((DNAscent::DetectStream *)s)->inFlight(); }
+int dnh_stream_submit(void *s, void *batch, uint64_t tag) { return ((DNAscent::DetectStream *)s)->submit((ReadBatch *)batch, tag); }
+void *dnh_result_new(void) { return new DNAscent::DetectStream::Result(); }
+void dnh_result_free(void *r) { delete (DNAscent::DetectStream::Result *)r; }
+// waits for the oldest batch in flight; *tag its tag, *n_reads its reads; record_bytes [n_reads] / text: owned by the result object,
+// valid until its next use; status [n_reads] (DN_READ_*), calls: dn_result_batch arrays (valid until the context's next upload)
+int dnh_stream_collect(void *s, void *result, uint64_t *tag, uint32_t *n_reads, const uint64_t **record_bytes, const char **text, uint64_t *text_bytes,
+                       dn_result_batch *res) {
+    DNAscent::DetectStream::Result &R = *(DNAscent::DetectStream::Result *)result;
+    const int rc = ((DNAscent::DetectStream *)s)->collect(R);
+    if (rc) return rc;
+    if (tag) *tag = R.tag;
+    if (n_reads) *n_reads = R.res.n_reads;
+    if (record_bytes) *record_bytes = R.record_bytes.data();
+    if (text) *text = R.text.data();
+    if (text_bytes) *text_bytes = R.text.size();
+    if (res) *res = R.res;
+    return DN_OK;
+}
+void dnh_stream_stats(void *s, DNAscent::StreamStats *st) { *st = ((DNAscent::DetectStream *)s)->stats(); }
+int dnh_batch_pin(void *b) { return ((ReadBatch *)b)->pin(); }
+void dnh_batch_unpin(void *b) { ((ReadBatch *)b)->unpin(); }
 
 void dnh_batch_desc(void *b, dn_batch_desc *out) { *out = ((ReadBatch *)b)->desc(); }
 

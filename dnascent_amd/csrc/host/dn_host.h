@@ -51,6 +51,14 @@ public:
     size_t size() const { return readID.size(); }
     dn_batch_desc desc() const;
     uint64_t totalSamples() const { return adc_off.empty() ? 0 : adc_off.back(); }
+    // Page-lock the arrays dn_batch_upload reads (dn_host_register): the upload then returns before its copies are done and the batch
+    // must stay untouched until the context's next dn_collect / dn_sync.  unpin() before the batch is modified again (add / clear).
+    int pin();
+    void unpin();
+    ~ReadBatch() { unpin(); }
+    ReadBatch() = default;
+    ReadBatch(const ReadBatch &) = delete;
+    ReadBatch &operator=(const ReadBatch &) = delete;
 
     std::vector<std::string> readID, contig;
     std::vector<int16_t> adc; std::vector<uint64_t> adc_off{0};
@@ -60,6 +68,8 @@ public:
     std::vector<uint32_t> ref2query; std::vector<int32_t> query2ref; std::vector<uint8_t> ref2del;
     std::vector<int32_t> ref_start, ref_end; std::vector<uint8_t> is_reverse;
     std::vector<dn_read_summary> summary;               // filled by normaliseEvents / eventalign
+private:
+    std::vector<void *> pinned;
 };
 
 // ---- binary read container ----------------------------------------------------------------------------
@@ -86,6 +96,8 @@ public:
     uint64_t count() const { return n; }
     bool next(OwnedRead &out);                                             // false at the end or on a truncated record
     bool skip(uint64_t *nSamples);                                         // seek over the next record, reporting its sample count
+    uint64_t tell() const;                                                 // file offset of the next record (for an index)
+    bool seek(uint64_t offset);                                            // ... and back to it: next() then reads THAT record
     bool failed() const { return bad; }
     void close();
     ~ReadContainerReader() { close(); }
@@ -137,6 +149,29 @@ struct StreamStats {
 };
 int streamDetect(dn_ctx **ctxs, int n_ctx, ReadBatch **batches, int n_batches, bool emit, const char *outPath, const char *header,
                  StreamStats *st, StreamKeep *keep = nullptr);
+
+// The same loop OPEN-ENDED, for hosts that do not have their batches up front (detect.cpp:821-907 reads its buffer of reads from the
+// BAM as it goes, and writes records as reads complete): submit() uploads a batch to the free context and enqueues its whole per-read
+// body, collect() waits for the OLDEST batch in flight and hands back its records.  At most n_ctx batches are in flight; a batch
+// must stay alive and untouched between its submit() and its collect().  streamDetect() above is this class driven over a list.
+class DetectStream {
+public:
+    struct Result {
+        uint64_t tag = 0; ReadBatch *batch = nullptr;
+        dn_result_batch res{};                              // valid until the context's next upload (= the submit() after next on a full stream)
+        std::vector<uint64_t> record_bytes;                 // per read: length of its .detect record (0: failed read / emit off)
+        std::string text;                                   // the records of the passing reads, batch order (emit only)
+    };
+    DetectStream(dn_ctx **ctxs, int n_ctx, bool emit);
+    bool full() const { return inflight == (int)ctx.size(); }
+    int inFlight() const { return inflight; }
+    int submit(ReadBatch *batch, uint64_t tag);             // DN_ERR_STATE when full(): collect() first
+    int collect(Result &out);                               // DN_ERR_STATE when nothing is in flight
+    const StreamStats &stats() const { return S; }
+private:
+    std::vector<dn_ctx *> ctx; std::vector<ReadBatch *> slot_batch; std::vector<uint64_t> slot_tag;
+    int head = 0, inflight = 0; bool emit; StreamStats S{}; std::vector<ReadCalls> calls; double t_open;
+};
 
 // `detect --HMM` (detect.cpp:885): llAcrossRead for every read that passed normaliseEvents; fills
 // calls[i].humanReadable_detectOut with ">readID contig start end strand" + "pos\tlogLR\tkmerRef\tkmerQuery" lines (:414, :571)

@@ -76,6 +76,23 @@ def lib():
         L.dnh_keep_free.argtypes = [C.c_void_p]
         L.dnh_keep_get.restype = C.c_uint64
         L.dnh_keep_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.dnh_container_index.restype = C.c_int64
+        L.dnh_container_index.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.dnh_container_load_at.restype = C.c_int64
+        L.dnh_container_load_at.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.dnh_stream_open.restype = C.c_void_p
+        L.dnh_stream_open.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.dnh_stream_close.argtypes = [C.c_void_p]
+        L.dnh_stream_full.argtypes = [C.c_void_p]
+        L.dnh_stream_inflight.argtypes = [C.c_void_p]
+        L.dnh_stream_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.dnh_result_new.restype = C.c_void_p
+        L.dnh_result_free.argtypes = [C.c_void_p]
+        L.dnh_stream_collect.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_uint64), C.POINTER(_hip.ResultBatch)]
+        L.dnh_stream_stats.argtypes = [C.c_void_p, C.POINTER(StreamStats)]
+        L.dnh_batch_pin.argtypes = [C.c_void_p]
+        L.dnh_batch_unpin.argtypes = [C.c_void_p]
         L.dnh_revcomp.restype = C.c_int
         L.dnh_revcomp.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         _lib = L
@@ -169,6 +186,19 @@ def container_sizes(path):
     return out[:n]
 
 
+def container_index(path):
+    """(sample counts, file offsets) of every record of a container, uint64 arrays: ONE pass of seeks; the offsets let any subset of
+    the records be read directly afterwards (ReadBatch.add_container_at)"""
+    n = container_count(path)
+    if n < 0:
+        raise IOError(path)
+    sizes = np.zeros(max(n, 1), np.uint64); offs = np.zeros(max(n, 1), np.uint64)
+    got = int(lib().dnh_container_index(path.encode(), sizes.ctypes.data, offs.ctypes.data, n))
+    if got != n:
+        raise IOError("%s: malformed container" % path)
+    return sizes[:n], offs[:n]
+
+
 class ReadBatch:
     """DNAscent::ReadBatch: reads packed as SoA, ready for dn_batch_upload."""
 
@@ -212,6 +242,30 @@ class ReadBatch:
         """the reads with the given ascending ordinals of a container; returns how many were accepted (-1: malformed / bad list)"""
         o = np.ascontiguousarray(ordinals, np.uint64)
         return int(lib().dnh_container_load_list(self.h, path.encode(), o.ctypes.data, o.shape[0]))
+
+    def add_container_at(self, path, offsets):
+        """the records at the given file offsets (container_index), in that order, read by all host cores.  Returns a uint8 array:
+        1 where the batch accepted the record, 0 where the reference's own filters reject it (a failed read, not an error).
+        Raises IOError on a truncated / unreadable record."""
+        o = np.ascontiguousarray(offsets, np.uint64)
+        acc = np.zeros(o.shape[0], np.uint8)
+        got = int(lib().dnh_container_load_at(self.h, path.encode(), o.ctypes.data, o.shape[0], acc.ctypes.data))
+        if got < 0:
+            raise IOError("%s: truncated or unreadable record" % path)
+        return acc
+
+    def clear(self):
+        """empty the batch, keeping its buffers (a streaming host reuses its batch objects)"""
+        lib().dnh_batch_clear(self.h)
+        self.reads = []
+
+    def pin(self):
+        """page-lock the arrays dn_batch_upload reads: the upload then returns before its copies are done"""
+        if lib().dnh_batch_pin(self.h) != 0:
+            raise _hip.DnError("dnh_batch_pin failed")
+
+    def unpin(self):
+        lib().dnh_batch_unpin(self.h)
 
     def size(self):
         return int(lib().dnh_batch_size(self.h))
@@ -285,3 +339,72 @@ def stream_detect(ctxs, batches, emit=True, out_path=None, header=None, keep=Fal
     finally:
         if kh:
             lib().dnh_keep_free(kh)
+
+
+class DetectStream:
+    """DNAscent::DetectStream: the buffer-of-reads loop of detect.cpp:821-907 OPEN-ENDED.  submit() uploads a batch to the free
+    context and enqueues its whole per-read body; collect() waits for the OLDEST batch in flight and returns its records.  At most
+    len(ctxs) batches are in flight; a batch stays alive and untouched between its submit() and its collect()."""
+
+    def __init__(self, ctxs, emit=True):
+        self.ctxs = list(ctxs)
+        hc = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        self.h = C.c_void_p(lib().dnh_stream_open(hc, len(ctxs), int(emit)))
+        self.res = C.c_void_p(lib().dnh_result_new())
+        self._batches = {}
+
+    def close(self):
+        if self.h:
+            lib().dnh_stream_close(self.h); lib().dnh_result_free(self.res)
+            self.h = C.c_void_p(); self.res = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def full(self):
+        return bool(lib().dnh_stream_full(self.h))
+
+    def in_flight(self):
+        return int(lib().dnh_stream_inflight(self.h))
+
+    def _fail(self, what, rc):
+        msgs = [_hip.lib().dn_last_error(c.h).decode() for c in self.ctxs]
+        raise _hip.DnError("%s failed (%d): %s" % (what, rc, "; ".join(m for m in msgs if m)))
+
+    def submit(self, batch, tag):
+        rc = lib().dnh_stream_submit(self.h, batch.h, int(tag))
+        if rc != 0:
+            self._fail("DetectStream.submit", rc)
+        self._batches[int(tag)] = batch
+
+    def collect(self, calls=False):
+        """-> dict(tag, batch, status [n_reads], record_bytes [n_reads], text (bytes: the records of the passing reads, batch order));
+        calls=True adds read_calls / coord / p_edu / p_brdu (copies of the dn_result_batch arrays)"""
+        tag = C.c_uint64(); n = C.c_uint32(); rb = C.c_void_p(); tx = C.c_void_p(); tb = C.c_uint64(); res = _hip.ResultBatch()
+        rc = lib().dnh_stream_collect(self.h, self.res, C.byref(tag), C.byref(n), C.byref(rb), C.byref(tx), C.byref(tb), C.byref(res))
+        if rc != 0:
+            self._fail("DetectStream.collect", rc)
+        nr = int(n.value)
+
+        def arr(ptr, dtype, cnt):
+            if cnt == 0 or not ptr:
+                return np.zeros(0, dtype)
+            return np.frombuffer((C.c_char * (cnt * np.dtype(dtype).itemsize)).from_address(ptr), dtype=dtype).copy()
+        summ = arr(res.summary, _hip.SUMMARY_DTYPE, nr)
+        out = dict(tag=int(tag.value), batch=self._batches.pop(int(tag.value)), status=summ["status"].copy() if nr else np.zeros(0, np.int32),
+                   n_positions=summ["n_positions"].copy() if nr else np.zeros(0, np.uint32),
+                   record_bytes=arr(rb.value, np.uint64, nr), text=C.string_at(tx.value, tb.value) if tb.value else b"")
+        if calls:
+            k = int(res.n_calls)
+            off = arr(res.call_off, np.uint64, nr + 1 if nr else 0)
+            out.update(read_calls=np.diff(off) if nr else np.zeros(0, np.uint64), coord=arr(res.ref_coord, np.uint32, k), p_edu=arr(res.p_edu, np.float32, k),
+                       p_brdu=arr(res.p_brdu, np.float32, k))
+        return out
+
+    def stats(self):
+        st = StreamStats()
+        lib().dnh_stream_stats(self.h, C.byref(st))
+        return st

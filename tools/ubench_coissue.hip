@@ -21,24 +21,26 @@ template <int KIND> __device__ __forceinline__ void vec24(f32x2 (&o)[8], float (
             if (KIND == 5) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(o[i]) : "v"(w));
         }
 }
-template <int KIND>
-__global__ __launch_bounds__(512) void k(float *out, unsigned long long *ticks, int iters, int mode) {
+template <int KIND, int NV>
+__global__ __launch_bounds__(256 + 256 * NV) void k(float *out, unsigned long long *ticks, int iters, int mode) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool mf = wave < 4;
     if ((mode == 0 && !mf) || (mode == 1 && mf)) return;
     __syncthreads();   // (only the waves that stay take part: the others have exited)
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     if (mf) {
-        f32x16 acc[8];
-        for (int i = 0; i < 8; i++) for (int q = 0; q < 16; q++) acc[i][q] = 0.f;
+        f32x16 acc[4];                                   // 64 registers: fits beside three vector wavefronts per SIMD without spilling
+        for (int i = 0; i < 4; i++) for (int q = 0; q < 16; q++) acc[i][q] = 0.f;
         f16x8 a, b;
         for (int q = 0; q < 8; q++) { a[q] = (_Float16)(lane * 0.01f + q); b[q] = (_Float16)(q - lane * 0.02f); }
         for (int it = 0; it < iters; it++) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
         }
         float sum = 0.f;
-        for (int i = 0; i < 8; i++) for (int q = 0; q < 16; q++) sum += acc[i][q];
+        for (int i = 0; i < 4; i++) for (int q = 0; q < 16; q++) sum += acc[i][q];
         if (sum == 1234.5f) out[0] = sum;
     } else {
         f32x2 o[8], x = {lane * 0.5f, 1.f}, w = {1.0001f, 0.9999f};
@@ -54,21 +56,25 @@ __global__ __launch_bounds__(512) void k(float *out, unsigned long long *ticks, 
 }
 template <int KIND> void run(const char *name, float *out, unsigned long long *tk) {
     const int iters = 2000;
-    unsigned long long h[8];
-    double r[3][2];
-    for (int mode = 0; mode < 3; mode++) {
-        (void)hipMemset(tk, 0, 64);
-        hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(512), 0, 0, out, tk, iters, mode);
-        (void)hipDeviceSynchronize();
-        (void)hipMemcpy(h, tk, 64, hipMemcpyDeviceToHost);
-        r[mode][0] = h[0] / (8.0 * iters); r[mode][1] = h[4] / (24.0 * iters);
+    unsigned long long h[16];
+    for (int nv = 1; nv <= 3; nv++) {                      // vector wavefronts per SIMD beside ONE matrix wavefront per SIMD
+        double r[3][2];
+        for (int mode = 0; mode < 3; mode++) {
+            (void)hipMemset(tk, 0, 128);
+            if (nv == 1) hipLaunchKernelGGL((k<KIND, 1>), dim3(256), dim3(512), 0, 0, out, tk, iters, mode);
+            if (nv == 2) hipLaunchKernelGGL((k<KIND, 2>), dim3(256), dim3(768), 0, 0, out, tk, iters, mode);
+            if (nv == 3) hipLaunchKernelGGL((k<KIND, 3>), dim3(256), dim3(1024), 0, 0, out, tk, iters, mode);
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(h, tk, 128, hipMemcpyDeviceToHost);
+            r[mode][0] = h[0] / (8.0 * iters); r[mode][1] = h[4] / (24.0 * iters);
+        }
+        printf("%-14s %d vector wave(s)/SIMD: alone %6.2f ticks/instr/wave (aggregate %5.2f) | beside MFMA %6.2f (aggregate %5.2f) | MFMA alone %.1f, beside %.1f ticks\n", name, nv,
+               r[1][1], r[1][1] / nv, r[2][1], r[2][1] / nv, r[0][0], r[2][0]);
     }
-    printf("%-14s alone %6.2f ticks/instr | beside MFMA %6.2f ticks/instr | MFMA alone %.1f, beside %s %.1f ticks\n", name, r[1][1], r[2][1], r[0][0], name, r[2][0]);
 }
 int main() {
     float *out; unsigned long long *tk;
-    (void)hipMalloc(&out, 64); (void)hipMalloc(&tk, 64);
-    run<0>("v_pk_fma_f32", out, tk); run<1>("v_fma_f32", out, tk); run<4>("v_fmac_f32", out, tk); run<2>("v_pk_mul_f32", out, tk);
-    run<5>("v_pk_add_f32", out, tk); run<3>("v_cvt_f16_f32", out, tk);
+    (void)hipMalloc(&out, 64); (void)hipMalloc(&tk, 128);
+    run<0>("v_pk_fma_f32", out, tk); run<1>("v_fma_f32", out, tk); run<3>("v_cvt_f16_f32", out, tk);
     return 0;
 }
