@@ -50,7 +50,7 @@ def build_hip(force=False):
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
            "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
            "-fhip-fp32-correctly-rounded-divide-sqrt",
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", HIP_SO] + srcs
+           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", HIP_SO] + os.environ.get("DN_HIPCC_FLAGS", "").split() + srcs   # DN_HIPCC_FLAGS: experiment builds (-DDN_WS_TRACE=<workgroup>)
     _run(cmd)
     return HIP_SO
 

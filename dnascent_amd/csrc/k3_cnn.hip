@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
 }
 
 #ifdef DN_WS_TRACE       /* experiment build only (tools/ws_trace.py): shader-clock stamps of one workgroup's phases */
-__device__ unsigned long long ws_trace[8][64];
+__device__ unsigned long long ws_trace[16][64];
 #define WS_T(i) do { if (blockIdx.x == DN_WS_TRACE && lane == 0) ws_trace[wave][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define WS_TRACE_TILE 2                                   /* the workgroup's third tile: steady state */
 extern "C" int dn_debug_ws_trace(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ws_trace), sizeof(ws_trace)); }
@@ -1068,6 +1068,12 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     }
 }
 
+// (Round 3: k3_sep_ws16 -- SIXTEEN wavefronts, two producers (row slice x channel half) and two consumers (64 x 64 outputs) per SIMD,
+// every wavefront under 128 registers -- is in tools/k3_sep_ws16_experiment.hip with its phase traces: bit-identical, and SLOWER in both
+// of its forms: roles overlapping 4 065 us for the five 256 -> 256 layers, roles alternating (a second barrier per step) 4 302 us, this
+// kernel 3 802 us in the same session.  What the traces say: alone (alternating form) a producer's 68-FMA filter takes 1.5 k ticks and
+// the consumers' 2 x 12 MFMAs 2.5 k -- three times what the matrix pipe needs; overlapping, the producers crawl at ~22 ticks per
+// instruction.  More wavefronts per SIMD do not buy issue slots here)
 // depthwise part of SeparableConv1D: each thread owns 4 channels of DW_ROWS consecutive rows and slides a register window
 // over them, so every input row is read once per thread instead of k times
 #define DW_ROWS 16

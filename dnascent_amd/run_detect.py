@@ -6,25 +6,33 @@
         -m dnascent_amd.run_detect --container reads.dnrc --out out.detect
 
 The product path of SURVEY.md s8e end to end, one process per GPU (`torch.distributed` is plumbing: backend nccl == RCCL over xGMI;
---backend gloo with ranks sharing a device exists for the tests):
+--backend gloo with ranks sharing a device exists for the tests).  It is a STREAM, like the reference's loop over a bounded buffer of
+reads (detect.cpp:821-907), never "load everything, run, gather everything":
 
-  1. every rank scans the container's record sizes (seeks, no payload) and takes ITS reads: shard.assign_reads, longest-processing-
-     time-first by sample count, deterministic -- no data-path collective (detect.cpp:852: reads are independent);
-  2. its reads are cut into length-bucketed batches (shard.make_batches) and streamed through --inflight contexts by one host thread
-     (DNAscent::streamDetect: upload, normaliseEvents, eventalign, CNN, dn_collect, records formatted in parallel);
-  3. the per-read records go to the writer rank in ONE grouped send / recv (shard.gather_records) and are written in INPUT order,
-     so the file is byte-identical whatever the number of ranks (the reference writes in completion order, detect.cpp:902-906;
-     input order is what it produces with one thread);
-  4. one all-reduce of the counters (reads ok / failed, samples).
+  1. every rank indexes the container (record sizes + offsets: seeks, no payload) and derives the same PLAN from it: windows of
+     consecutive reads (--window-batches x world x --batch-samples samples), each cut into length-bucketed batches (shard.plan_windows);
+  2. the ranks PULL batch ids from one shared counter (shard.WorkCounter: a TCPStore add, no collective) -- the reference's
+     `schedule(dynamic)` (detect.cpp:852): a rank whose reads fail QC early, or are short, takes more batches;
+  3. a rank holds at most --inflight + 2 batches on the host: the next one is loaded (all cores, direct seeks) while --inflight of
+     them are on the GPU (DNAscent::DetectStream: upload, normaliseEvents, eventalign, CNN, dn_collect, records formatted);
+  4. when a rank has collected its last batch of a window, the window's records go to the writer rank point to point, in pieces of
+     --gather-chunk-mb, and are written in INPUT order while the GPUs work on the next window -- the file is byte-identical
+     whatever the number of ranks (the reference writes in completion order, detect.cpp:902-906; input order is what it produces
+     with one thread).  No rank ever holds more text than one window's;
+  5. one all-reduce of the counters (reads ok / failed, samples) at the end.
+
+A read the reference's own filters reject (empty / too short signal, detect.cpp:839, pod5.cpp:64) counts as FAILED, as there.  A
+truncated container is fatal: the rank raises the shared abort flag, every rank stops pulling, walks the remaining (empty) window
+gathers -- so nothing hangs -- and the run exits non-zero without a half-written claim of success.
 
 The CNN is loaded from --model PREFIX (tools/convert_savedmodel.py output) or, without it, is the seeded-random default model --
 whose probabilities are synthetic (a warning says so).  Pore model: --pore-model FILE (text: kmer<TAB>mean, data_IO.cpp:160-175) or
 the synthetic table of the tests.
 """
 import argparse
+import json
 import os
 import sys
-import tempfile
 import time
 
 import numpy as np
@@ -61,8 +69,12 @@ def main(argv=None):
     ap.add_argument("--inflight", type=int, default=4)
     ap.add_argument("--batch-samples", type=float, default=300e6, help="sample budget of one batch")
     ap.add_argument("--batch-reads", type=int, default=2000)
+    ap.add_argument("--window-batches", type=float, default=4.0,
+                    help="a window (the unit of the ordered gather + write) holds about this many batches PER RANK")
+    ap.add_argument("--gather-chunk-mb", type=int, default=64)
     ap.add_argument("--backend", default=os.environ.get("DN_BACKEND", "nccl"))
     ap.add_argument("--header", default=None, help="text written before the records (e.g. DNAscent::writeDetectHeader)")
+    ap.add_argument("--stats", default=None, help="rank 0 writes a JSON with per-rank busy / gather seconds, batches, peak buffered bytes")
     a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -78,9 +90,8 @@ def main(argv=None):
         dist.init_process_group(a.backend, rank=rank, world_size=world)
     from dnascent_amd import cnn_model, hip, host, shard, synth
     t0 = time.time()
-    sizes = host.container_sizes(a.container)
-    mine = shard.assign_reads(sizes, world)[rank]                        # ascending input ordinals of this rank
-    local_batches = shard.make_batches(sizes[mine], a.batch_samples, a.batch_reads)
+    sizes, offsets = host.container_index(a.container)
+    batches, window_of = shard.plan_windows(sizes, a.window_batches * world * a.batch_samples, a.batch_samples, a.batch_reads)
     pore = load_pore_model(a.pore_model) if a.pore_model else synth.pore_model()
     if a.model:
         desc, blob = cnn_model.load(a.model)
@@ -89,49 +100,58 @@ def main(argv=None):
         if rank == 0:
             print("run_detect: NO --model given: the CNN runs seeded RANDOM weights; the probabilities are synthetic", file=sys.stderr)
     ndev = max(1, hip.lib().dn_device_count())
-    ctxs = [hip.Context(local % ndev) for _ in range(max(1, min(a.inflight, max(1, len(local_batches)))))]
+    ctxs = [hip.Context(local % ndev) for _ in range(max(1, min(a.inflight, max(1, len(batches)))))]
     for c in ctxs:
         c.load_pore_model(pore, 0.14)
         c.load_cnn(desc, blob)
-    batches, ordinals = [], []
-    for idx in local_batches:
-        b = host.ReadBatch()
-        ords = mine[idx]                                                  # ascending within a batch
-        got = b.add_container_list(a.container, ords)
-        if got != len(ords):
-            raise SystemExit("run_detect: container read failed / a read was rejected (%d of %d)" % (got, len(ords)))
-        batches.append(b); ordinals += [int(o) for o in ords]
-    records, n_ok, n_fail, samples = [], 0, 0, 0
-    if batches:
-        with tempfile.NamedTemporaryFile(prefix="dn_rank%d_" % rank, suffix=".detect", delete=False) as tf:
-            tmp = tf.name
-        try:
-            st, kept = host.stream_detect(ctxs, batches, emit=True, out_path=tmp, keep=True)
-            blob_txt = open(tmp, "rb").read()
-        finally:
-            os.unlink(tmp)
-        o = 0
-        for ln in kept["record_bytes"]:
-            records.append(blob_txt[o:o + int(ln)]); o += int(ln)
-        assert o == len(blob_txt) and len(records) == len(ordinals)
-        n_ok, n_fail, samples = int(st.reads_ok), int(st.reads - st.reads_ok), int(st.samples)
-    merged = shard.gather_records(dist, ordinals, records, dst=0, device=dev_t)
-    tot = shard.reduce_counters(dist, [n_ok, n_fail, samples], device=dev_t)
+    engine = host.DetectStream(ctxs, emit=True)
+    free = []
+
+    def load(ords):
+        b = free.pop() if free else host.ReadBatch()
+        b.clear()
+        return b, b.add_container_at(a.container, offsets[ords])
+
+    out_f = None
     if rank == 0:
-        with open(a.out, "wb") as f:
-            if a.header:
-                f.write(a.header.encode())
-            for _, rec in merged:
-                f.write(rec)
+        out_f = open(a.out, "wb")
+        if a.header:
+            out_f.write(a.header.encode())
+
+    def write(merged):
+        for _, rec in merged:
+            out_f.write(rec)
+
+    drv = shard.StreamDriver(dist, batches, window_of, engine, load, write, release=free.append, dst=0, device=dev_t,
+                             chunk_bytes=a.gather_chunk_mb << 20)
+    ok = drv.run()
+    st = engine.stats()
+    tot = shard.reduce_counters(dist, [drv.n_ok, drv.n_fail, int(st.samples), 0 if ok else 1], device=dev_t)
+    per_rank = shard.gather_stats(dist, dict(rank=rank, batches=drv.batches_done, busy_s=round(drv.busy_s, 3), gather_s=round(drv.gather_s, 3),
+                                             peak_buffered_bytes=int(drv.peak_pending_bytes), max_gather_bytes=int(drv.max_gather_bytes),
+                                             reads_ok=drv.n_ok, reads_failed=drv.n_fail), device=dev_t)
+    failed = tot[3] > 0
+    if rank == 0:
+        out_f.close()
         dt = time.time() - t0
-        print("run_detect: %d reads ok, %d failed, %.1f M samples, %d rank(s), %.2f s (%.1f Msamples/s incl. ingestion)" %
-              (tot[0], tot[1], tot[2] / 1e6, world, dt, tot[2] / 1e6 / dt))
+        if failed:
+            os.unlink(a.out)                                   # a partial file must not pass for a result
+            print("run_detect: ABORTED: a rank could not read its share of %s" % a.container, file=sys.stderr)
+        else:
+            busy = [p["busy_s"] for p in per_rank]
+            print("run_detect: %d reads ok, %d failed, %.1f M samples, %d rank(s), %d batches in %d window(s), %.2f s (%.1f Msamples/s incl. "
+                  "ingestion); per-rank busy %.2f .. %.2f s, gather %.2f s max, at most %.1f MB of records buffered on a rank" %
+                  (tot[0], tot[1], tot[2] / 1e6, world, len(batches), drv.n_windows, dt, tot[2] / 1e6 / dt, min(busy), max(busy),
+                   max(p["gather_s"] for p in per_rank), max(p["peak_buffered_bytes"] for p in per_rank) / 1e6))
+        if a.stats:
+            json.dump(dict(world=world, batches=len(batches), windows=drv.n_windows, seconds=dt, ranks=per_rank, failed=failed), open(a.stats, "w"))
+    engine.close()
     for c in ctxs:
         c.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return 1 if failed else 0
 
 
 if __name__ == "__main__":

@@ -74,6 +74,25 @@ def reduce_max(dist, value, device="cpu"):
     return float(t.item())
 
 
+def gather_stats(dist, obj, device="cpu"):
+    """a small JSON-able dict of every rank to every rank (run statistics: a few hundred bytes through gather_bytes' all_gather path)"""
+    import json
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [obj]
+    import torch
+    raw = json.dumps(obj).encode()
+    world = dist.get_world_size()
+    ln = torch.tensor([len(raw)], dtype=torch.int64, device=device)
+    lens = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(lens, ln)
+    m = max(int(x.item()) for x in lens)
+    buf = torch.zeros(m, dtype=torch.uint8, device=device)
+    buf[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    outs = [torch.zeros(m, dtype=torch.uint8, device=device) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    return [json.loads(bytes(o.cpu().numpy()[:int(l.item())]).decode()) for o, l in zip(outs, lens)]
+
+
 def gather_bytes(dist, blob, dst=0, device="cpu"):
     """Variable-size byte blocks of every rank to the writer rank `dst`: a tiny all_gather of the lengths, then ONE grouped
     send / recv (batch_isend_irecv) -- every rank sends its block straight to the writer, the writer posts one receive per peer, so
@@ -315,39 +334,60 @@ class StreamDriver:
                 self.max_gather_bytes = max(self.max_gather_bytes, nbytes)
             self.flushed += 1
 
-    def run(self):
+    def run(self, prefetch=True):
+        """prefetch: the NEXT batch is pulled and loaded by a helper thread while this one drives the engine (the loader reads the
+        container with all host cores; without it the GPU idles while a 600 MB batch comes off the disk)"""
         import time
+        from concurrent.futures import ThreadPoolExecutor
         self._tag_ords = {}
         t_busy0 = time.perf_counter()
-        while True:
+        pool = ThreadPoolExecutor(1) if prefetch else None
+
+        def pull():
+            """next batch id of this rank -> (id, future / result of its load), or None when the counter is exhausted / the run aborted"""
             if self.error or self.counter.aborted():
                 self.error = True
-                break
+                return None
             b = self.counter.next()
             if b >= len(self.batches):
-                break
+                return None
+            self.frontier = max(self.frontier, int(self.window_of[b]))      # every batch of an earlier window has been handed out
+            return b, (pool.submit(self.load, self.batches[b]) if pool else None)
+
+        nxt = pull()
+        while nxt is not None:
+            b, fut = nxt
             w = int(self.window_of[b])
-            self.frontier = max(self.frontier, w)              # every batch of an earlier window has been handed out
-            while self.engine.full():
-                self._collect_one()
-                self._flush_ready()
             ords = self.batches[b]
             try:
-                obj, accepted = self.load(ords)
+                obj, accepted = fut.result() if fut is not None else self.load(ords)
             except IOError:
                 self.error = True
                 self.counter.abort()
                 break
+            nxt = pull()                                       # ... and its load runs while this batch is submitted / older ones collected
             keep = [int(o) for o, a in zip(ords, accepted) if a]
             self.n_fail += len(ords) - len(keep)               # rejected by the reference's own filters: failed reads, not errors
             if not keep:
                 if self.release:
                     self.release(obj)
                 continue
+            while self.engine.full():
+                self._collect_one()
+                self._flush_ready()
             self._tag_ords[b] = keep
             self.open[w] = self.open.get(w, 0) + 1
             self.engine.submit(obj, b)
             self._flush_ready()
+        if nxt is not None and nxt[1] is not None:             # aborted with a load in flight: let it finish, drop it
+            try:
+                obj, _ = nxt[1].result()
+                if self.release:
+                    self.release(obj)
+            except IOError:
+                pass
+        if pool:
+            pool.shutdown(wait=True)
         self.frontier = self.n_windows
         while self.engine.in_flight():
             self._collect_one()

@@ -71,3 +71,55 @@ def test_container_rejects_malformed_files(model, tmp_path):
     assert host.container_count(bad) == -1 and host.ReadBatch().add_container(bad) == -1
     open(bad, "wb").write(raw[: len(raw) // 2])             # truncated inside a record
     assert host.container_count(bad) == len(reads) and host.ReadBatch().add_container(bad) == -1
+
+
+def test_container_index_and_direct_loads(model, tmp_path):
+    """container_index (sizes + offsets from one pass of seeks) and add_container_at (records by offset, any order, read by all host
+    cores): the streamed product driver's loader.  Same SoA as the sequential loader; a record the reference's own filters reject
+    (here: a signal trimmed to nothing, pod5.cpp:64) is reported as rejected, not as an error; a truncated record IS an error; and a
+    cleared batch object can be reused."""
+    reads = [synth.make_read(seed, n, model=model, **kw) for seed, n, kw in SPECS]
+    path = str(tmp_path / "reads.dnr")
+    host.write_container(path, reads)
+    sizes, offs = host.container_index(path)
+    assert sizes.tolist() == [r.n_samples() for r in reads] == host.container_sizes(path).tolist()
+    assert np.all(np.diff(offs.astype(np.int64)) > 0) and offs[0] == 16                  # "DNRC" + version + count
+    seq = host.ReadBatch(); assert seq.add_container(path) == len(reads)
+    a = _soa(seq)
+    order = [2, 0, 3]
+    b = host.ReadBatch()
+    acc = b.add_container_at(path, offs[order])
+    assert acc.tolist() == [1, 1, 1] and b.size() == 3
+    p = _soa(b)
+    for j, i in enumerate(order):
+        assert np.array_equal(p["adc"][int(p["adc_off"][j]):int(p["adc_off"][j + 1])], a["adc"][int(a["adc_off"][i]):int(a["adc_off"][i + 1])])
+        assert np.array_equal(p["refseq"][int(p["refseq_off"][j]):int(p["refseq_off"][j + 1])], a["refseq"][int(a["refseq_off"][i]):int(a["refseq_off"][i + 1])])
+    b.clear()
+    assert b.size() == 0 and b.samples() == 0
+    assert b.add_container_at(path, offs).tolist() == [1] * len(reads)
+    q = _soa(b)
+    for k in a:
+        if k != "n":
+            assert np.array_equal(a[k], q[k]), k
+    # a rejected read among accepted ones: trimmed to 10 samples (< 16)
+    tpath = str(tmp_path / "trim.dnr")
+    w = host.lib().dnh_container_create(tpath.encode())
+    for i, sr in enumerate(reads[:3]):
+        qq = np.ascontiguousarray(host.revcomp(sr.basecall) if sr.is_reverse else sr.basecall); f = np.ascontiguousarray(host.revcomp(sr.refseq) if sr.is_reverse else sr.refseq)
+        adc = np.ascontiguousarray(sr.adc)
+        assert host.lib().dnh_container_add(w, sr.read_id.encode(), sr.contig.encode(), adc.ctypes.data, adc.shape[0], sr.cal_offset, sr.cal_scale,
+                                            10 if i == 1 else -1, 0, 0, 0, qq.ctypes.data, qq.shape[0], f.ctypes.data, f.shape[0], sr.cigar_op.ctypes.data,
+                                            sr.cigar_len.ctypes.data, sr.cigar_op.shape[0], sr.ref_start, int(sr.is_reverse)) == 0
+    assert host.lib().dnh_container_close(w) == 0
+    _, toffs = host.container_index(tpath)
+    t = host.ReadBatch()
+    assert t.add_container_at(tpath, toffs).tolist() == [1, 0, 1] and t.size() == 2
+    # truncated inside the last record: fatal, and the batch is left empty
+    raw = open(path, "rb").read()
+    bad = str(tmp_path / "bad.dnr"); open(bad, "wb").write(raw[: int(offs[-1]) + 40])
+    e = host.ReadBatch()
+    with pytest.raises(IOError):
+        e.add_container_at(bad, offs)
+    assert e.size() == 0
+    with pytest.raises(IOError):
+        host.container_index(str(tmp_path / "missing.dnr"))

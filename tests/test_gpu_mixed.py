@@ -1,0 +1,164 @@
+"""GPU: BASELINE configs[3] and configs[4] at their SHAPE, scaled down (round-2 verdict: both were untested).
+
+configs[4] -- "mixed-length PromethION-like batch, 1-200 kb log-normal, dynamic load-balancing": 420 reads drawn from the config's
+length law clip(exp(N(ln 20 000, 0.9^2)), 1 000, 200 000) go through the PRODUCT driver (python -m dnascent_amd.run_detect: container ->
+plan of windows and length-bucketed batches -> ranks pull batches from the shared counter -> DetectStream -> per-window gather ->
+ordered write) with one rank and with two gloo ranks sharing the GPU: the files must be byte-identical; then 21 of the reads -- the
+shortest, the longest, the QC failures and a spread of the rest -- are checked against the ORACLE: status, scalings, event-alignment
+tensors bit for bit, and their records in the file equal the oracle's formatting of the device's probabilities.
+
+configs[3] -- "100 000 x 50 kb sharded across 8 GPUs" is 12 500 reads per GPU streamed through the contexts in flight: 2 000 x 50 kb
+reads as 4 batches through 3 contexts (DNAscent::DetectStream) must give, read by read, the digests of the same reads run one batch
+at a time on one context."""
+import hashlib
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+from dnascent_amd import cnn_model, hip, host, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_MIXED = 420
+NOISY = (37, 205, 333)                                      # reads whose noise makes the banded QC fail (detect.cpp:879: counted, not written)
+
+
+def _mixed_reads(model):
+    rng = np.random.default_rng(20260)
+    lens = np.clip(np.exp(rng.normal(np.log(20000), 0.9, N_MIXED)), 1000, 200000).astype(int)
+    lens[11] = 1000; lens[17] = 200000                      # both ends of the clip are present whatever the draw
+    return [synth.make_read(7100000 + i, int(l), model=model, is_reverse=bool(i & 1), sub_rate=0.002, ins_rate=0.001, del_rate=0.001,
+                            noise_pa=6.5 if i in NOISY else 1.6) for i, l in enumerate(lens)], lens
+
+
+def _records(blob):
+    """{read id: record bytes} of a .detect file (records start with '>')"""
+    out = {}
+    for part in blob.split(b">")[1:]:
+        rec = b">" + part
+        out[rec[1:rec.index(b" ")].decode()] = rec
+    return out
+
+
+def test_mixed_lengths_one_and_two_ranks_and_oracle(model, tmp_path):
+    reads, lens = _mixed_reads(model)
+    assert lens.min() == 1000 and lens.max() == 200000 and 15000 < np.median(lens) < 27000
+    cont = str(tmp_path / "mixed.dnrc")
+    host.write_container(cont, reads)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    one, two = str(tmp_path / "one.detect"), str(tmp_path / "two.detect")
+    s1, s2 = str(tmp_path / "one.json"), str(tmp_path / "two.json")
+    # ~150 M samples: batches of 12 M samples (~12 batches), windows of 2 batches per rank, 3 batches in flight per rank
+    common = ["--container", cont, "--batch-samples", "12e6", "--batch-reads", "256", "--inflight", "3", "--window-batches", "2", "--header", "#mixed\n",
+              "--gather-chunk-mb", "1"]
+    r = subprocess.run([sys.executable, "-m", "dnascent_amd.run_detect", "--out", one, "--stats", s1] + common, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "dnascent_amd.run_detect", "--out", two, "--stats", s2, "--backend", "gloo"] + common,
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    a, b = open(one, "rb").read(), open(two, "rb").read()
+    assert a == b and a.startswith(b"#mixed\n")
+    recs = _records(a)
+    assert N_MIXED - 12 <= len(recs) <= N_MIXED - len(NOISY)                             # the noisy reads fail; a handful of the 1-2 kb ones may too
+    assert [rid for rid in (r.read_id for r in reads) if rid in recs] == [x[1:x.index(b" ")].decode() for x in (b">" + p for p in a.split(b">")[1:])]   # INPUT order
+    st1, st2 = json.load(open(s1)), json.load(open(s2))
+    assert st1["windows"] >= 3 and st2["windows"] >= 2 and st2["world"] == 2
+    assert sum(p["batches"] for p in st2["ranks"]) == st2["batches"] and all(p["batches"] > 0 for p in st2["ranks"])    # both ranks pulled work
+    assert sum(p["reads_ok"] for p in st2["ranks"]) == len(recs) and sum(p["reads_failed"] for p in st2["ranks"]) == N_MIXED - len(recs)
+    text = len(a)
+    assert max(p["peak_buffered_bytes"] for p in st2["ranks"]) < 0.7 * text              # a rank buffers windows, not the run
+    # ---- 21 reads against the oracle ----
+    order = np.argsort(lens)
+    pick = sorted(set([int(order[0]), int(order[-1])] + list(NOISY) + [int(order[i]) for i in np.linspace(5, N_MIXED - 6, 16).astype(int)]))
+    assert len(pick) >= 20
+    ctx = hip.Context(0); ctx.load_pore_model(model, 0.14)
+    desc, blob, _ = cnn_model.default_model(); ctx.load_cnn(desc, blob)
+    bt = host.ReadBatch()
+    for i in pick:
+        assert bt.add_synth(reads[i]) >= 0
+    bt.upload(ctx); ctx.run("detect"); ctx.sync()
+    s = ctx.summaries()
+    n_fail = 0
+    for j, i in enumerate(pick):
+        o = po.OracleRead(reads[i], model)
+        o.normalise()
+        n = o.norm
+        assert s["status"][j] == n.status, (i, s["status"][j], n.status)
+        assert s["n_events"][j] == n.n_events
+        if n.status != 0:
+            assert reads[i].read_id not in recs
+            n_fail += 1
+            o.free()
+            continue
+        assert np.float64(s["shift"][j]).tobytes() == np.float64(n.shift).tobytes() and np.float64(s["scale"][j]).tobytes() == np.float64(n.scale).tobytes()
+        assert o.eventalign() == 0
+        got, want = ctx.positions(j, int(s["n_positions"][j])), o.positions()
+        for k in ("coord", "query_idx", "ref_idx", "core", "residual", "kmer"):
+            assert np.array_equal(got[k], want[k]), (i, k)
+        assert got["signal"].tobytes() == want["signal"].tobytes()
+        rec = o.format_detect(ctx.probabilities(j, int(s["n_positions"][j])))
+        assert recs[reads[i].read_id] == rec, i                                           # the product driver's file holds exactly this record
+        o.free()
+    assert n_fail >= len(NOISY)
+    ctx.close()
+
+
+def _digest(res, r, lo, hi):
+    h = hashlib.sha256()
+    h.update(np.int32(res["status"][r]).tobytes()); h.update(np.uint64(res["record_bytes"][r]).tobytes())
+    for k in ("coord", "p_edu", "p_brdu"):
+        h.update(np.ascontiguousarray(res[k][lo:hi]).tobytes())
+    return h.hexdigest()
+
+
+def _stream(ctxs, batches):
+    ds = host.DetectStream(ctxs, emit=True)
+    out = {}
+
+    def take():
+        res = ds.collect(calls=True)
+        off = np.concatenate([[0], np.cumsum(res["read_calls"])]).astype(np.int64)
+        pos = 0
+        dg = []
+        for r in range(len(res["status"])):
+            h = _digest(res, r, off[r], off[r + 1])
+            n = int(res["record_bytes"][r])
+            dg.append(h + hashlib.sha256(res["text"][pos:pos + n]).hexdigest()[:16]); pos += n
+        out[res["tag"]] = dg
+    for i, b in enumerate(batches):
+        if ds.full():
+            take()
+        ds.submit(b, i)
+    while ds.in_flight():
+        take()
+    st = ds.stats()
+    ds.close()
+    return [out[i] for i in range(len(batches))], st
+
+
+def test_two_thousand_50kb_reads_streamed_equal_one_batch_at_a_time(model):
+    nb, per = 4, 500
+    batches = []
+    for j in range(nb):
+        b = host.ReadBatch()
+        assert b.fill_synth(model, 3300000 + j * per, per, 50000) == per
+        batches.append(b)
+    desc, blob, _ = cnn_model.default_model()
+    ctxs = [hip.Context(0) for _ in range(3)]
+    for c in ctxs:
+        c.load_pore_model(model, 0.14); c.load_cnn(desc, blob)
+    streamed, st = _stream(ctxs, batches)                                 # 3 in flight, one host thread
+    assert st.reads == nb * per and st.reads_ok >= 0.97 * nb * per and st.samples > 2.2e9 and st.calls > 20e6
+    one, _ = _stream(ctxs[:1], batches)                                   # the same reads, one batch at a time on one context
+    assert streamed == one
+    assert all(c.cnn_range_escalations() == 0 for c in ctxs)
+    for c in ctxs:
+        c.close()

@@ -23,7 +23,7 @@ def test_two_ranks_write_the_same_file_as_one(model, tmp_path):
     assert host.container_sizes(cont).tolist() == [r.n_samples() for r in reads]
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     one = str(tmp_path / "one.detect"); two = str(tmp_path / "two.detect")
-    common = ["--container", cont, "--batch-samples", "60000", "--inflight", "2", "--header", "#hdr\n"]
+    common = ["--container", cont, "--batch-samples", "60000", "--inflight", "2", "--window-batches", "2", "--header", "#hdr\n"]
     r = subprocess.run([sys.executable, "-m", "dnascent_amd.run_detect", "--out", one] + common, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()

@@ -81,3 +81,141 @@ def test_two_rank_gloo():
     merged = res[0][3]
     assert [o for o, _ in merged] == list(range(40))                          # input order restored on the writer rank
     assert all(b == (">read%d\n" % o).encode() + b"x" * (o % 7) for o, b in merged)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# dynamic balancing + streamed windowed gather (shard.plan_windows / WorkCounter / gather_window / StreamDriver), world_size 2, gloo.
+# The engine is a stand-in with the DetectStream interface (the real one needs a GPU: tests/test_gpu_run_detect.py): a read's record is
+# a pure function of its ordinal, "failed" reads have none, rejected reads never reach the engine.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _record(o):
+    return (">read%d\n" % o).encode() + b"y" * (o % 11)
+
+
+class _FakeEngine:
+    """DetectStream's interface over a FIFO; every batch costs `delay(rank)` seconds so that ranks run at different speeds"""
+
+    def __init__(self, depth, delay):
+        self.depth, self.delay, self.q = depth, delay, []
+
+    def full(self):
+        return len(self.q) >= self.depth
+
+    def in_flight(self):
+        return len(self.q)
+
+    def submit(self, batch, tag):
+        self.q.append((batch, tag))
+
+    def collect(self):
+        import time
+        time.sleep(self.delay)
+        batch, tag = self.q.pop(0)
+        status = np.array([1 if o % 13 == 5 else 0 for o in batch], np.int32)          # every 13th read fails QC
+        recs = [_record(o) if s == 0 else b"" for o, s in zip(batch, status)]
+        return dict(tag=tag, batch=batch, status=status, record_bytes=np.array([len(r) for r in recs], np.uint64), text=b"".join(recs))
+
+
+def _sizes(n):
+    rng = np.random.default_rng(11)
+    return np.clip(np.exp(rng.normal(np.log(20000), 0.9, n)), 1000, 200000).astype(np.int64) * 12     # config 5 length law
+
+
+def test_plan_windows_properties():
+    n = _sizes(2000)
+    batches, window_of = shard.plan_windows(n, window_samples=8 * 30e6, batch_samples=30e6, batch_reads=500)
+    assert sorted(np.concatenate(batches).tolist()) == list(range(2000))                # every read exactly once
+    assert np.all(np.diff(window_of) >= 0)                                               # batch ids ascend with the window
+    lo = 0
+    for w in range(int(window_of[-1]) + 1):                                              # a window is a range of CONSECUTIVE reads
+        idx = np.sort(np.concatenate([b for b, ww in zip(batches, window_of) if ww == w]))
+        assert idx[0] == lo and np.all(np.diff(idx) == 1)
+        assert n[idx].sum() <= 8 * 30e6 or len(idx) == 1
+        lo = idx[-1] + 1
+    assert lo == 2000
+    eb, ew = shard.plan_windows([], 10, 10)
+    assert len(eb) == 0 and len(ew) == 0                                                 # empty input: no batches, no windows
+
+
+def _stream_worker(rank, world, port, q, bad_at):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = _sizes(600)
+        batches, window_of = shard.plan_windows(n, window_samples=2 * world * 8e6, batch_samples=8e6, batch_reads=64)
+        written = []
+        live = [0, 0]                                            # batches alive on the host now / at most
+
+        def load(ords):
+            if bad_at is not None and bad_at in ords.tolist():
+                raise IOError("truncated record")
+            live[0] += 1; live[1] = max(live[1], live[0])
+            acc = np.array([0 if o % 17 == 3 else 1 for o in ords], np.uint8)            # rejected by the reader's filters
+            return [int(o) for o, a in zip(ords, acc) if a], acc
+
+        def release(_):
+            live[0] -= 1
+
+        eng = _FakeEngine(depth=3, delay=0.004 if rank == 0 else 0.001)                  # rank 1 is 4x faster: it must take more batches
+        drv = shard.StreamDriver(dist, batches, window_of, eng, load, lambda m: written.extend(m), release=release, dst=0, chunk_bytes=700)
+        ok = drv.run()
+        tot = shard.reduce_counters(dist, [drv.n_ok, drv.n_fail, drv.batches_done])
+        q.put((rank, ok, tot, written, drv.batches_done, drv.peak_pending_bytes, drv.max_gather_bytes, live[1], len(batches), drv.n_windows))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_stream(world, bad_at=None):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_stream_worker, args=(r, world, port, q, bad_at)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in ps:
+        r = q.get(timeout=180)
+        res[r[0]] = r
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_streamed_dynamic_two_ranks():
+    res = _run_stream(2)
+    expect_fail = sum(1 for o in range(600) if o % 17 == 3 or o % 13 == 5)
+    expect = [(o, _record(o)) for o in range(600) if not (o % 17 == 3 or o % 13 == 5)]
+    assert res[0][1] and res[1][1]
+    assert res[0][2] == res[1][2] and res[0][2][0] == len(expect) and res[0][2][1] == expect_fail     # counters: ok / failed (rejected + QC)
+    assert res[1][3] == [] and res[0][3] == expect                          # the writer got every record, in INPUT order, nobody else anything
+    n_batches, n_windows = res[0][8], res[0][9]
+    assert n_windows >= 4 and res[0][2][2] == n_batches                     # every batch processed exactly once across the ranks
+    assert res[1][4] > res[0][4]                                            # the faster rank pulled more batches (dynamic balance)
+    total_text = sum(len(r) for _, r in expect)
+    for r in (0, 1):
+        assert res[r][7] <= 3 + 2                                           # at most depth + 2 batches alive on a host
+        assert res[r][5] < 0.6 * total_text and res[r][6] < 0.6 * total_text   # buffered / gathered bytes are bounded by the window, not the run
+
+
+def test_streamed_one_rank_matches():
+    """world 1 (no process group): same records, same order, windows flushed as they complete"""
+    n = _sizes(600)
+    batches, window_of = shard.plan_windows(n, window_samples=2 * 20e6, batch_samples=20e6, batch_reads=64)
+    written = []
+    eng = _FakeEngine(depth=2, delay=0.0)
+    drv = shard.StreamDriver(None, batches, window_of, eng, lambda ords: ([int(o) for o in ords if o % 17 != 3], np.array([o % 17 != 3 for o in ords], np.uint8)),
+                             lambda m: written.extend(m))
+    assert drv.run(prefetch=False)
+    assert written == [(o, _record(o)) for o in range(600) if not (o % 17 == 3 or o % 13 == 5)]
+
+
+def test_streamed_abort_does_not_hang():
+    """a rank that cannot read a record raises the shared abort flag: every rank stops pulling, walks the remaining gathers (so the
+    point-to-point transfers pair up) and reports failure; the writer writes nothing after the error"""
+    res = _run_stream(2, bad_at=301)
+    assert not res[0][1] and not res[1][1]
+    assert len(res[0][3]) < 560                                             # not a complete file

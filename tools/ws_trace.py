@@ -15,7 +15,7 @@ for i in range(64):
     b.add_synth(synth.make_read(9000 + i, 20000, model=model, sub_rate=0.002))
 b.upload(ctx)
 ctx.run("normalise"); ctx.run("eventalign"); ctx.run("cnn"); ctx.sync(); ctx.run("cnn"); ctx.sync()
-t = np.zeros((8, 64), np.uint64)
+t = np.zeros((16, 64), np.uint64)
 rc = hip.lib().dn_debug_ws_trace(C.c_void_p(t.ctypes.data))
 assert rc == 0, rc
 t0 = int(t[t > 0].min())
@@ -25,8 +25,10 @@ for cb in range(0, 8, 2):
 names_c = {3: "[tile start]", 40: "epilogue"}
 for cb in range(8):
     names_c.update({4 + 3 * cb: "mma0(%d)" % cb, 5 + 3 * cb: "mma1", 6 + 3 * cb: "barrier"})
-for w in range(8):
-    names = names_c if w < 4 else names_p
+ws16 = os.environ.get("DN_CNN_WS16", "1") != "0"
+ncons = 8 if ws16 else 4
+for w in range(16 if ws16 else 8):
+    names = names_c if w < ncons else names_p
     idx = [i for i in sorted(names) if t[w, i] > 0]
     line = []
     prev = None
@@ -34,4 +36,4 @@ for w in range(8):
         v = int(t[w, i]) - t0
         line.append("%s %d" % (names[i], v if prev is None else v - prev))
         prev = v
-    print("wave %d (%s) total %d: " % (w, "consumer" if w < 4 else "producer", prev - (int(t[w, idx[0]]) - t0)) + " | ".join(line))
+    print("wave %d (%s) total %d: " % (w, "consumer" if w < ncons else "producer", prev - (int(t[w, idx[0]]) - t0)) + " | ".join(line))
