@@ -37,6 +37,7 @@ struct CnnRun { const dn_cnn_op *ops; int n_ops; const float *wts; float *buf[8]
                  void (*mark)(void *who, int begin, int kind, hipStream_t st); void *mark_who;
                  unsigned *row_off_w; int *live; };
 int k3_run(const CnnRun &, hipStream_t);
+int k3_describe(const CnnRun &, int, char *, size_t);
 struct HmmConstsH { double D2D, D2M, I2M, M2D, M2I, I2I, ln025, ln05; };
 struct HmmReadH { double iM2M, eM2M, endM; };
 struct HmmDevH { const double4 *unl, *ana; unsigned *poi, *n_poi, *n_ev; unsigned char *ok; double *la, *lt; };
@@ -67,7 +68,7 @@ struct DevBuf {
     void *p = nullptr; size_t cap = 0;
 };
 
-struct ProfRec { int k; hipEvent_t a, b; };
+struct ProfRec { int k; hipEvent_t a, b; int layer; };      // k == -1: op `layer` of the CNN description
 
 }  // namespace
 
@@ -174,6 +175,7 @@ struct dn_ctx {
     std::vector<ProfRec> pending;
     double prof_ms[DN_K_COUNT] = {0};
     uint32_t prof_n[DN_K_COUNT] = {0};
+    std::vector<double> layer_ms; std::vector<uint32_t> layer_n;     // per op of the CNN description (dn_profile_get_layer)
 };
 
 // Contexts are meant to be used several at a time (one per in-flight batch); their streams only run concurrently when the
@@ -259,7 +261,7 @@ static int dgrow(dn_ctx *c, DevBuf &b, size_t bytes) {
 }
 
 static const char *KNAMES[DN_K_COUNT] = { "k1_scan", "k1_tstat", "k1_detect", "k1_events", "k_ranks", "k_quantile", "k_prep",
-                                          "k2_fill", "k2_chase+k2_post", "k_theilsen", "k2b_viterbi", "k3_cnn", "k_hmm", "k3_sep_ws", "k3_sep9" };
+                                          "k2_fill", "k2_chase+k2_post", "k_theilsen", "k2b_viterbi", "k3_cnn", "k_hmm" };
 
 struct Timed {
     dn_ctx *c; int k; hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
@@ -267,7 +269,7 @@ struct Timed {
         if (c->prof) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); }
     }
     ~Timed() {
-        if (c->prof) { hipEventRecord(b, st); c->pending.push_back({k, a, b}); }
+        if (c->prof) { hipEventRecord(b, st); c->pending.push_back({k, a, b, -1}); }
     }
 };
 
@@ -317,11 +319,10 @@ static CnnLane *lane_get(dn_ctx *c) {
     return g_lane[c->device][c->lane_id];
 }
 
-// HIP event pairs around every launch of the network's two largest kernels (kind 0: k3_sep_ws, the 17-tap separable layers; kind 1:
-// k3_sep_split<128, 9>, the 9-tap 128 -> 128 ones), profiling only
-static void cnn_mark(void *who, int begin, int kind, hipStream_t st) {
+// HIP event pairs around every op of the network (layer = index into the description's op list), profiling only
+static void cnn_mark(void *who, int begin, int layer, hipStream_t st) {
     dn_ctx *c = (dn_ctx *)who;
-    if (begin) { hipEvent_t a; hipEventCreate(&a); hipEventRecord(a, st); c->pending.push_back({kind ? DN_K_CNN_SEP9 : DN_K_CNN_SEPWS, a, nullptr}); }
+    if (begin) { hipEvent_t a; hipEventCreate(&a); hipEventRecord(a, st); c->pending.push_back({-1, a, nullptr, layer}); }
     else if (!c->pending.empty() && !c->pending.back().b) { hipEvent_t b; hipEventCreate(&b); hipEventRecord(b, st); c->pending.back().b = b; }
 }
 
@@ -330,7 +331,10 @@ static void prof_collect(dn_ctx *c) {
     hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->prof_ms[p.k] += ms; c->prof_n[p.k]++; }
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            if (p.k >= 0) { c->prof_ms[p.k] += ms; c->prof_n[p.k]++; }
+            else if (p.layer >= 0 && (size_t)p.layer < c->layer_ms.size()) { c->layer_ms[(size_t)p.layer] += ms; c->layer_n[(size_t)p.layer]++; }
+        }
         hipEventDestroy(p.a); hipEventDestroy(p.b);
     }
     c->pending.clear();
@@ -1250,6 +1254,7 @@ int dn_load_cnn(dn_ctx *c, const dn_cnn_op *ops, uint32_t n_ops, const float *we
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cnn_ops.assign(ops, ops + n_ops);
     c->cnn_nbuf = (int)n_buffers;
+    c->layer_ms.assign(n_ops, 0.0); c->layer_n.assign(n_ops, 0u);
     return DN_OK;
 }
 
@@ -1552,6 +1557,7 @@ int dn_profile_reset(dn_ctx *c) {
     if (!c) return DN_ERR_ARG;
     prof_collect(c);
     for (int i = 0; i < DN_K_COUNT; i++) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+    std::fill(c->layer_ms.begin(), c->layer_ms.end(), 0.0); std::fill(c->layer_n.begin(), c->layer_n.end(), 0u);
     return DN_OK;
 }
 int dn_profile_get(dn_ctx *c, int k, double *ms, uint32_t *launches) {
@@ -1559,6 +1565,23 @@ int dn_profile_get(dn_ctx *c, int k, double *ms, uint32_t *launches) {
     prof_collect(c);
     if (ms) *ms = c->prof_ms[k];
     if (launches) *launches = c->prof_n[k];
+    return DN_OK;
+}
+
+int dn_profile_get_layer(dn_ctx *c, uint32_t op, double *ms, uint32_t *launches, char *kernel, size_t kernel_cap) {
+    if (!c || op >= c->cnn_ops.size()) return DN_ERR_ARG;
+    prof_collect(c);
+    if (ms) *ms = c->layer_ms[op];
+    if (launches) *launches = c->layer_n[op];
+    if (kernel && kernel_cap) {
+        CnnRun run{};
+        run.ops = c->cnn_ops.data(); run.n_ops = (int)c->cnn_ops.size();
+        const int math = (c->cnn_math == DN_CNN_MATH_F16X3 && c->cnn_f16_off) ? DN_CNN_MATH_BF16X6 : c->cnn_math;
+        run.wts_split = math == DN_CNN_MATH_FP32 ? nullptr : (const uint16_t *)(uintptr_t)1;       // only its nullness is looked at
+        run.pieces = math == DN_CNN_MATH_F16X3 ? 2 : 3;
+        run.rows.rows = 256;                                   // pass row counts are multiples of 256 (cnn_execute)
+        if (k3_describe(run, (int)op, kernel, kernel_cap) < 0) return DN_ERR_ARG;
+    }
     return DN_OK;
 }
 

@@ -1220,6 +1220,9 @@ static bool k3_can_fuse(const CnnRun &c, int i) {
 // Which fused kernel: the wave-specialised one pays off where the depthwise filter is long and the layer wide (17 taps, 256
 // output channels: one workgroup covers ALL 256 columns, so the filter is applied once per row tile); the short filters of the
 // narrow layers are memory-side and run better as k3_sep_split with 2-3 workgroups per CU.
+static bool k3_takes_ws(int np, const dn_cnn_op &d, const dn_cnn_op &o) { return np == 2 && d.k == 17 && o.cout == 256 && o.cin % 64 == 0 && k3_sep_ws_enabled(); }
+static bool k3_takes_bm256(int pieces, const dn_cnn_op &o, unsigned rows) { return pieces == 2 && o.cout % 128 == 0 && o.k >= 9 && o.cin >= 128 && rows % 256 == 0 && k3_bm256_enabled(); }
+
 template <int BN, bool ADD, int NP>
 static int k3_launch_sep(const CnnRun &c, int i, const float *in, float *out, const float *add, hipStream_t st) {
     const dn_cnn_op &d = c.ops[i], &o = c.ops[i + 1];
@@ -1227,16 +1230,11 @@ static int k3_launch_sep(const CnnRun &c, int i, const float *in, float *out, co
 #define SEP_ARGS in, out, c.wts + d.w, c.wts_split + c.wb_off[i + 1], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, c.live, \
         o.cin, o.cout, o.relu, c.post[i + 1], c.range_flag
 #define SEP_GO(KW_) hipLaunchKernelGGL((k3_sep_split<BN, KW_, ADD, NP>), dim3(o.cout == BN ? min(conv_grid(rows, o.cout, BN), k3_sep_wgs(BN, NP)) : conv_grid(rows, o.cout, BN)), dim3(256), 0, st, SEP_ARGS)
-    if (NP == 2 && d.k == 17 && o.cout == 256 && o.cin % 64 == 0 && k3_sep_ws_enabled()) {      // BN == cout: one column tile
-        if (c.mark) c.mark(c.mark_who, 1, 0, st);
+    if (k3_takes_ws(NP, d, o)) {                            // BN == cout: one column tile
         hipLaunchKernelGGL((k3_sep_ws<256, 17, ADD, 2>), dim3(min(conv_grid(rows, o.cout, 256), k3_cu_count())), dim3(512), 0, st, SEP_ARGS);
-        if (c.mark) c.mark(c.mark_who, 0, 0, st);
         return 0;
     }
-    const bool mark9 = c.mark && NP == 2 && BN == 128 && d.k == 9 && o.cin == 128;
-    if (mark9) c.mark(c.mark_who, 1, 1, st);
     switch (d.k) { case 3: SEP_GO(3); break; case 5: SEP_GO(5); break; case 9: SEP_GO(9); break; case 17: SEP_GO(17); break; default: return -1; }
-    if (mark9) c.mark(c.mark_who, 0, 1, st);
 #undef SEP_GO
 #undef SEP_ARGS
     return 0;
@@ -1254,6 +1252,10 @@ int k3_run(const CnnRun &c, hipStream_t st) {
     hipLaunchKernelGGL(k3_layout, dim3(1), dim3(64), 0, st, c.row_off_w, c.rows.n_pos, c.rows.r0, c.rows.r1, c.live);
     for (int i = 0; i < c.n_ops; i++) {
         const dn_cnn_op &o = c.ops[i];
+        // profiling: one HIP event pair around EVERY op of the description (a fused separable layer counts under its depthwise op), so
+        // that the run itself says which kernel family dominates (bench.py); k3_describe names the kernel an op takes
+        struct Mark { const CnnRun &c; int i; hipStream_t st; Mark(const CnnRun &c_, int i_, hipStream_t s_) : c(c_), i(i_), st(s_) { if (c.mark) c.mark(c.mark_who, 1, i, st); }
+                      ~Mark() { if (c.mark) c.mark(c.mark_who, 0, i, st); } } mark_op(c, i, st);
         if (k3_can_fuse(c, i)) {
             const dn_cnn_op &pw = c.ops[i + 1];
             const float *add = pw.op == DN_CNN_CONV_ADD ? pb[pw.a] : nullptr;
@@ -1296,7 +1298,7 @@ int k3_run(const CnnRun &c, hipStream_t st) {
 #define CONV_GO_BM(BN_, ADD_) hipLaunchKernelGGL((k3_conv_split<BN_, ADD_, 2, 256>), dim3(conv_grid(rows, o.cout, BN_, 256)), dim3(512), 0, st, \
         pb[o.src], pb[o.dst], c.wts_split + c.wb_off[i], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, c.live, o.k, o.cin, o.cout, o.relu, \
         c.post[i], c.range_flag)
-#define CONV_GO_BF(BN_, ADD_) do { if (c.pieces == 3) CONV_GO_SP(BN_, ADD_, 3); else if (BN_ == 128 && o.k >= 9 && o.cin >= 128 && rows % 256 == 0 && k3_bm256_enabled()) CONV_GO_BM(128, ADD_); \
+#define CONV_GO_BF(BN_, ADD_) do { if (c.pieces == 3) CONV_GO_SP(BN_, ADD_, 3); else if (BN_ == 128 && k3_takes_bm256(c.pieces, o, rows)) CONV_GO_BM(128, ADD_); \
         else CONV_GO_SP(BN_, ADD_, 2); } while (0)
                 if (c.wts_split) {
                     // (256-column workgroups -- each wavefront 64 rows x 128 columns, 12 LDS fragment reads per 24 MFMAs instead of 8 per 12 --
@@ -1333,4 +1335,36 @@ int k3_run(const CnnRun &c, hipStream_t st) {
         }
     }
     return 0;
+}
+
+// The kernel op i of the description takes, named as rocprofv3 prints it (template arguments included) -- the same predicates k3_run
+// dispatches on.  Returns 0 for an op that is covered by the previous one (the pointwise half of a fused separable layer).
+int k3_describe(const CnnRun &c, int i, char *buf, size_t cap) {
+    if (i < 0 || i >= c.n_ops || !buf || !cap) return -1;
+    buf[0] = 0;
+    const dn_cnn_op &o = c.ops[i];
+    const int np = c.pieces;
+    if (i > 0 && k3_can_fuse(c, i - 1)) return 0;
+    if (k3_can_fuse(c, i)) {
+        const dn_cnn_op &pw = c.ops[i + 1];
+        const char *add = pw.op == DN_CNN_CONV_ADD ? "true" : "false";
+        if (k3_takes_ws(np, o, pw)) snprintf(buf, cap, "k3_sep_ws<256, 17, %s, 2>", add);
+        else snprintf(buf, cap, "k3_sep_split<%d, %d, %s, %d>", pw.cout % 128 == 0 ? 128 : 64, o.k, add, np);
+        return 1;
+    }
+    switch (o.op) {
+        case DN_CNN_ENCODE_GRU: snprintf(buf, cap, "k3_encode"); return 1;
+        case DN_CNN_CONV: case DN_CNN_CONV_ADD: {
+            const char *add = o.op == DN_CNN_CONV_ADD ? "true" : "false";
+            const int bn = o.cout % 128 == 0 ? 128 : 64;
+            if (!c.wts_split) snprintf(buf, cap, "k3_conv<%d, %d, %s>", bn, bn == 128 ? 2 : 1, add);
+            else if (bn == 128 && k3_takes_bm256(np, o, c.rows.rows)) snprintf(buf, cap, "k3_conv_split<128, %s, 2, 256>", add);
+            else snprintf(buf, cap, "k3_conv_split<%d, %s, %d, 128>", bn, add, np);
+            return 1;
+        }
+        case DN_CNN_DWCONV: snprintf(buf, cap, "k3_dwconv<%d>", o.k); return 1;
+        case DN_CNN_ADD_RELU: snprintf(buf, cap, "k3_add_relu"); return 1;
+        case DN_CNN_DENSE_SOFTMAX: snprintf(buf, cap, "k3_dense_softmax"); return 1;
+    }
+    return -1;
 }

@@ -11,7 +11,7 @@ from . import build as _build
 
 DN_OK = 0
 K_NAMES = ["DN_K_SCAN", "DN_K_TSTAT", "DN_K_DETECT", "DN_K_EVENTS", "DN_K_RANKS", "DN_K_QUANTILE", "DN_K_PREP",
-           "DN_K_BAND_FILL", "DN_K_BAND_TRACE", "DN_K_THEILSEN", "DN_K_VITERBI", "DN_K_CNN", "DN_K_HMM", "DN_K_CNN_SEPWS", "DN_K_CNN_SEP9"]
+           "DN_K_BAND_FILL", "DN_K_BAND_TRACE", "DN_K_THEILSEN", "DN_K_VITERBI", "DN_K_CNN", "DN_K_HMM"]
 DN_K_COUNT = len(K_NAMES)
 for _i, _n in enumerate(K_NAMES):
     globals()[_n] = _i
@@ -22,7 +22,7 @@ SYMBOLS = ["dn_abi_version", "dn_device_count", "dn_ctx_create", "dn_ctx_destroy
            "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_set_align_table", "dn_get_align_rows", "dn_get_align_table", "dn_load_cnn", "dn_cnn_set_math", "dn_cnn_range_escalations", "dn_run_cnn", "dn_get_probabilities", "dn_cnn_infer", "dn_load_fit_models", "dn_run_hmm", "dn_get_hmm_calls", "dn_get_summaries", "dn_get_prefix_sums",
            "dn_get_tstats", "dn_get_scrappie_events", "dn_get_events", "dn_get_kmer_ranks", "dn_get_alignment",
            "dn_get_cleaned", "dn_get_trace", "dn_get_positions", "dn_get_windows", "dn_profile_enable", "dn_profile_get",
-           "dn_profile_reset", "dn_kernel_name", "dn_device_bytes", "dn_shutdown"]
+           "dn_profile_reset", "dn_profile_get_layer", "dn_kernel_name", "dn_device_bytes", "dn_shutdown"]
 
 
 class BatchDesc(C.Structure):
@@ -132,6 +132,7 @@ def lib():
         L.dn_get_align_table.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4
         L.dn_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.dn_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        L.dn_profile_get_layer.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t]
         L.dn_kernel_name.restype = C.c_char_p
         L.dn_kernel_name.argtypes = [C.c_int]
         L.dn_device_bytes.restype = C.c_size_t
@@ -343,6 +344,15 @@ class Context:
             ms = C.c_double(0); n = C.c_uint32(0)
             lib().dn_profile_get(self.h, k, C.byref(ms), C.byref(n))
             out[lib().dn_kernel_name(k).decode()] = (ms.value, n.value)
+        return out
+
+    def profile_layers(self, n_ops):
+        """[(ms, launches, kernel name)] per op of the loaded CNN description (dn_profile_get_layer)"""
+        out = []
+        for i in range(n_ops):
+            ms = C.c_double(0); n = C.c_uint32(0); buf = C.create_string_buffer(96)
+            self._chk(lib().dn_profile_get_layer(self.h, i, C.byref(ms), C.byref(n), buf, len(buf)), "dn_profile_get_layer")
+            out.append((ms.value, n.value, buf.value.decode()))
         return out
 
     def device_bytes(self):

@@ -228,12 +228,13 @@ int dn_debug_emission(dn_ctx *ctx, uint32_t n, const double *x, const double *mu
 
 /* ---- measurement ---- */
 enum { DN_K_SCAN = 0, DN_K_TSTAT, DN_K_DETECT, DN_K_EVENTS, DN_K_RANKS, DN_K_QUANTILE, DN_K_PREP, DN_K_BAND_FILL,
-       DN_K_BAND_TRACE, DN_K_THEILSEN, DN_K_VITERBI, DN_K_CNN /* the whole network of a batch */, DN_K_HMM,
-       DN_K_CNN_SEPWS /* every single launch of the 17-tap separable layers (k3_sep_ws) */,
-       DN_K_CNN_SEP9 /* ... and of the 9-tap 128 -> 128 separable layers (k3_sep_split<128, 9>): the two largest kernels of the run */, DN_K_COUNT };
+       DN_K_BAND_TRACE, DN_K_THEILSEN, DN_K_VITERBI, DN_K_CNN /* the whole network of a batch */, DN_K_HMM, DN_K_COUNT };
 int dn_profile_enable(dn_ctx *ctx, int on);     /* HIP events around every kernel launch on the context's stream */
 int dn_profile_get(dn_ctx *ctx, int kernel, double *total_ms, uint32_t *launches);
 int dn_profile_reset(dn_ctx *ctx);
+/* the network layer by layer: summed time and launches of op `op` of the loaded description (a fused separable layer is reported under
+ * its depthwise op, its pointwise op reads 0), and the name of the kernel the op takes as rocprofv3 prints it ("" for a covered op) */
+int dn_profile_get_layer(dn_ctx *ctx, uint32_t op, double *total_ms, uint32_t *launches, char *kernel, size_t kernel_cap);
 const char *dn_kernel_name(int kernel);
 size_t dn_device_bytes(const dn_ctx *ctx);      /* HBM currently held by the context + the CNN lanes of its device (shared by its contexts) */
 /* Frees the process-wide CNN lanes (streams + activation buffers) of every device.  dn_ctx_destroy of the LAST context of a device does
