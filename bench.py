@@ -15,11 +15,15 @@ gathered to rank 0 inside the timed region; value = samples of all ranks / max-o
 `--scope banded` is BASELINE.json configs[1] (1 000 x 20 kb, normaliseEvents only, batch resident in HBM, CNN stubbed): the
 scope the adaptive-banded kernel's HBM roofline is quoted on.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel of the run: the CNN (all layers of one batch = one
-"launch" of dn_run_cnn) against the dense fp16 MFMA peak in the full scope, k2_fill against the HBM peak in the banded
-scope; achieved = ALGORITHMIC flops / bytes per launch / mean launch duration from HIP events on the
-library's streams inside the timed region.  `cpu_baseline` times the oracle (CPU restatement, kind "port") with OpenMP
-schedule(dynamic) on all host cores over a bounded sample of the same reads.
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel FAMILY of the run, found from the run itself: HIP events
+bracket every launch of every layer of the network (dn_profile_get_layer) and every per-read stage on the streams they run on; the
+family with the largest summed time inside the timed region is `roofline`, all of them are listed in `roofline_families`.  achieved =
+ALGORITHMIC flops / bytes (per-position figures x the positions the launches processed) / summed launch time; `bound`
+follows from the family's arithmetic intensity against the ridge of the arithmetic in use.  `traffic` (HBM bytes per launch, PMC) and
+`roofline_chip` (whole-chip HBM / MFMA fractions of a step) come from the committed counter passes of tools/r03_profile.sh when they
+were taken at this workload's shape -- counters cannot be collected inside a timed run.  k2_fill against the HBM peak is
+`roofline_banded` (and `roofline` in the banded scope).  `cpu_baseline` times the oracle (CPU restatement, kind "port") with OpenMP
+schedule(dynamic) on all host cores over a bounded sample of the same reads, several reads per thread.
 """
 import argparse
 import json
@@ -53,11 +57,17 @@ def cpu_baseline(model, n_bases, seed0, full, budget_reads):
     import pyoracle as po
     from dnascent_amd import synth
     cores = os.cpu_count() or 1
-    n = max(1, min(budget_reads, cores))
+    # the reference's loop hands reads to threads one at a time (schedule(dynamic), detect.cpp:852): with one read per thread nothing is
+    # ever scheduled (round-2 verdict), so the sample holds reads_per_thread reads for every thread -- on FEWER threads when the budget of
+    # reads would not cover all cores (the per-thread rate is what scales to the box; the value reported is rate x cores)
+    reads_per_thread = 4
+    threads = max(1, min(cores, budget_reads // reads_per_thread))
+    n = threads * reads_per_thread
     reads = [synth.make_read(seed0 + i, n_bases, model=model, is_reverse=bool(i & 1), sub_rate=0.002, ins_rate=0.001, del_rate=0.001)
              for i in range(n)]
-    secs, samples, positions, ok = po.bench_reads(reads, model, full, cores)
-    what = "oracle normaliseEvents%s, OpenMP schedule(dynamic), %d threads: %.1f s" % (" + eventalign" if full else "", cores, secs)
+    secs, samples, positions, ok = po.bench_reads(reads, model, full, threads)
+    what = "oracle normaliseEvents%s, OpenMP schedule(dynamic), %d reads on %d threads (%d per thread): %.1f s" % (
+        " + eventalign" if full else "", n, threads, reads_per_thread, secs)
     cnn_s = 0.0
     if full and positions:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -80,11 +90,30 @@ def cpu_baseline(model, n_bases, seed0, full, budget_reads):
             cnn_torch_ref.run(ref, pos["core"][:k], pos["residual"][:k], pos["signal"][:k])
             reps += 1
         pos_per_s = reps * k / (time.time() - t0)
-        cnn_s = positions / (pos_per_s * cores)
-        what += "; CNN: PyTorch CPU fp32 rendering, %.0f positions/s on one thread, credited x %d cores: %d positions of the sample -> %.1f s" % (
-            pos_per_s, cores, positions, cnn_s)
-    return {"value": samples / (secs + cnn_s) / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%d of the %d-base reads of the workload (%d pass QC); %s" % (n, n_bases, ok, what)}
+        cnn_s = positions / (pos_per_s * threads)
+        what += "; CNN: PyTorch CPU fp32 rendering, %.0f positions/s on one thread, credited x %d threads: %d positions of the sample -> %.1f s" % (
+            pos_per_s, threads, positions, cnn_s)
+    per_thread = samples / (secs + cnn_s) / 1e6 / threads
+    return {"value": per_thread * cores, "unit": "Msamples/s", "cores": cores, "kind": "port", "threads_timed": threads,
+            "Msamples_per_s_per_thread": per_thread, "per_thread_without_cnn": samples / secs / 1e6 / threads,
+            "reference_probe_per_thread": "0.15-0.20 Msamples/s (SURVEY.md s6: the real reference, one thread, normaliseEvents + eventalign)",
+            "sample": "%d of the %d-base reads of the workload (%d pass QC); %s; value = per-thread rate x %d cores" % (n, n_bases, ok, what, cores)}
+
+
+def load_pmc(reads_per_step, bases, what):
+    """The committed counter passes (tools/r03_profile.sh -> tools/r03_collect.py -> profiles/r03_pmc_*.json): HBM bytes per launch and per
+    step, vector instructions of k2_fill, MFMA busy cycles.  Only used when they were taken at THIS workload's shape."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % ("banded" if what == "banded" else "bench"))
+    if not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+    except ValueError:
+        return None
+    w = d.get("workload", {})
+    if w.get("reads_per_step") != reads_per_step or w.get("bases") != bases or (what != "banded" and w.get("cnn_math") != what):
+        return None
+    return d
 
 
 def _hbm_info():
@@ -116,6 +145,8 @@ def main():
     ap.add_argument("--out", default=None, help="full scope: .detect output path (default: formatted and counted, not written)")
     ap.add_argument("--cnn-math", choices=["f16x3", "bf16x6", "fp32"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp32-steps", type=int, default=4, help="full scope, 1 GPU: after the run, this many steps again with the CNN in exact fp32 MFMA "
+                                                              "arithmetic (value_fp32: the headline metric without the 16-bit split); 0 = off")
     args = ap.parse_args()
     full = args.scope == "full"
     rps = args.reads_per_step or (500 if full else 1000)
@@ -243,14 +274,18 @@ def main():
                 raise SystemExit("bench: in-flight slot %d disagrees with slot 0 on the per-read results" % j)
 
     prof = {}
+    ctxs_layers = []
     for c in ctxs:
         for k, v in c.profile_get().items():
             a = prof.get(k, (0.0, 0))
             prof[k] = (a[0] + v[0], a[1] + v[1])
+        if full:
+            ctxs_layers.append(c.profile_layers(len(cnn_desc["ops"])))
         c.profile(False)
 
     # the same kernels with the GPU to itself (outside the timed region): one batch, nothing else in flight
     solo = {}
+    solo_layers, solo_positions = None, 0.0
     if rank == 0:
         c = ctxs[0]
         c.profile(True); c.profile_reset()
@@ -263,11 +298,34 @@ def main():
         for k, v in c.profile_get().items():
             if v[1]:
                 solo[k] = v[0] / v[1]
+        if full:
+            solo_layers = c.profile_layers(len(cnn_desc["ops"]))
         c.profile(False)
         summ = c.summaries()
+        solo_positions = float(np.sum(summ["n_positions"][summ["status"] == 0]))
+
+    # the same pipeline with the network's products in exact fp32 (v_mfma_f32_32x32x2_f32): a few steps, timed the same way, after the run
+    fp32_leg = None
+    if full and world == 1 and args.fp32_steps > 0 and cnn_math != "fp32":
+        for c in ctxs:
+            c.cnn_set_math("fp32")
+        leg = batches[-min(args.fp32_steps, len(batches)):]
+        host.stream_detect(ctxs, leg[:1], emit=bool(args.emit), out_path=None)          # first fp32 pass: its kernels' code objects load here
+        for c in ctxs:
+            c.sync()
+        t1 = time.perf_counter()
+        st32 = host.stream_detect(ctxs, leg, emit=bool(args.emit), out_path=None)
+        dt32 = time.perf_counter() - t1
+        fp32_leg = {"value_fp32": float(st32.samples) / dt32 / 1e6, "steps": len(leg), "ms_per_step": dt32 / len(leg) * 1e3,
+                    "note": "the same full pipeline with --cnn-math fp32 (exact fp32 MFMA products), %d steps of %d reads after the main run" % (len(leg), rps)}
+        for c in ctxs:
+            c.cnn_set_math(cnn_math)
 
     # the only collectives of the path: MAX of the elapsed time, SUM of the counters (dnascent_amd/shard.py)
+    rank_stats = None
     if dist is not None:
+        busy_local = float(st.seconds_total) if st is not None else dt
+        rank_stats = shard.gather_stats(dist, dict(rank=rank, busy_s=busy_local, gather_s=gather_s, elapsed_s=dt), device=red_dev)
         dt = shard.reduce_max(dist, dt, device=red_dev)
         samples_total = shard.reduce_counters(dist, [samples_total], device=red_dev)[0]
 
@@ -284,11 +342,15 @@ def main():
         if "k2_fill" in solo:
             roof_banded["solo_launch_ms"] = solo["k2_fill"]
             roof_banded["solo_frac"] = alg_bytes / (solo["k2_fill"] / 1e3) / 1e9 / HBM_PEAK_GBS
-        pm_path = os.path.join(ROOT, "profiles", "r02_pmc_k2_fill.json")
-        if os.path.exists(pm_path):          # HBM bytes per launch from the committed PMC passes (cannot be collected inside a timed run)
-            pm = json.load(open(pm_path))
-            if pm.get("workload") == {"reads": rps, "bases": bases}:
-                roof_banded["traffic"] = pm["write_bytes"] + pm["fetch_bytes_corrected"]
+        if not full:
+            pmb = load_pmc(rps, bases, "banded")
+            if pmb and pmb.get("k2_fill"):
+                kf = pmb["k2_fill"]
+                roof_banded["traffic"] = kf["write_bytes_per_launch"] + kf["fetch_bytes_per_launch_corrected"]
+                if kf.get("valu_insts_per_launch") and fill_s > 0:
+                    t_issue = kf["valu_insts_per_launch"] * 4.0 / (1024.0 * 2.4e9)
+                    roof_banded["issue_bound_frac"] = alg_bytes / t_issue / 1e9 / HBM_PEAK_GBS
+                    roof_banded["valu_insts_per_launch"] = kf["valu_insts_per_launch"]
         out = {
             "metric": "raw-signal Msamples/sec (whole node) on `detect`" + ("" if full else " -- banded-HMM scope only (configs[1])"),
             "value": samples_total / dt / 1e6,
@@ -320,42 +382,93 @@ def main():
                 "reads_per_step": rps, "bases_per_read": bases, "reads_per_gpu": args.steps * rps, "samples_per_gpu": int(st.samples),
                 "reads_passing_qc_per_gpu": int(st.reads_ok), "calls_per_gpu": int(st.calls),
                 "parallelism": "reads sharded, %d rank(s), %d batches in flight per GPU, one host thread per rank" % (world, nctx)}
-            # ---- the two largest kernels of the run (profiles/r02_kernel_stats.csv): k3_sep_split<128, 9> (the eleven 9-tap separable
-            #      layers 128 -> 128) and k3_sep_ws<256, 17> (the six 17-tap ones -> 256 channels).  HIP events bracket EVERY launch of
-            #      both on the CNN lane's stream; the one with the larger summed time is `roofline`, the other `roofline_second`.
-            #      A fused separable layer does 2 (k cin + cin cout) flops per position for 4 (cin + cout) bytes of activation I/O:
-            #      34 flop/B (9 x 128 -> 128) and 68 flop/B (17 x 256 -> 256) against a ridge of 104 at the f16x3 rate (833 TFLOP/s
-            #      over 8 TB/s) -- both sit on the HBM side of the roofline, so `bound` is "hbm" and `achieved` the layer I/O per
-            #      second (PMC: HBM traffic = 1.03-1.05 x that, profiles/r02_pmc_k3_traffic.csv); the matrix-core view is kept beside it.
+            # ---- the network, layer by layer, from THIS run: HIP events bracket every launch of every op on the CNN lane's stream
+            #      (dn_profile_get_layer); ops are grouped by the kernel they take (named as rocprofv3 prints it) and kernels by family
+            #      (the template name).  A fused separable layer is one op (its pointwise half reports nothing).
             ops = cnn_desc["ops"]
-            def sep_roofline(name, label, pairs):
-                ms, n = prof.get(name, (0.0, 0))
-                if not n or cnn_math != "f16x3":
-                    return None, 0.0
-                fl = 2.0 * sum(d["k"] * d["c"] + p["cin"] * p["cout"] for d, p in pairs) * float(st.positions)
-                by = 4.0 * sum(p["cin"] + p["cout"] + (p["cout"] if p.get("add", -1) >= 0 else 0) for d, p in pairs) * float(st.positions)   # + the residual read
-                gbs = by / (ms / 1e3) / 1e9
-                tf = fl / (ms / 1e3) / 1e12
-                r = {"bound": "hbm", "kernel": label, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "traffic": None, "launches": n, "mean_launch_ms": ms / n, "algorithmic_bytes_per_launch": by / n,
-                        "algorithmic_flops_per_launch": fl / n, "mfma_TFLOPs": tf, "mfma_frac": tf / MFMA_F16_PEAK, "mfma_issued_frac": 3.0 * tf / MFMA_F16_PEAK,
-                        "note": "achieved = activation I/O of the layer (4 B x (cin + cout [+ cout residual]) x positions) / launch time, HIP events around every launch "
-                                "in the timed region; a launch shares the chip with the other CNN lanes and the per-read stages of the batches in "
-                                "flight; mfma_*: the same launches as algorithmic fp32 flops against the dense fp16 MFMA peak (x 3 issued); "
-                                "solo_*: the same kernel in one batch that has the chip to itself (untimed pass after the run)"}
-                if name in solo and solo[name] > 0:
-                    r["solo_launch_ms"] = solo[name]
-                    r["solo_frac"] = (by / n) / (solo[name] / 1e3) / 1e9 / HBM_PEAK_GBS
-                return r, ms
-            ws_pairs = [(o, ops[i + 1]) for i, o in enumerate(ops) if o["op"] == "dwconv" and o["k"] == 17 and ops[i + 1]["cout"] == 256]
-            s9_pairs = [(o, ops[i + 1]) for i, o in enumerate(ops) if o["op"] == "dwconv" and o["k"] == 9 and o["c"] == 128 and ops[i + 1]["cout"] == 128]
-            r_ws, t_ws = sep_roofline("k3_sep_ws", "k3_sep_ws<256, 17> (SeparableConv1D 17 taps -> 256 channels, depthwise fused into the pointwise GEMM, persistent)", ws_pairs)
-            r_s9, t_s9 = sep_roofline("k3_sep9", "k3_sep_split<128, 9> (SeparableConv1D 9 taps 128 -> 128 channels, depthwise fused into the pointwise GEMM)", s9_pairs)
-            first, second = (r_s9, r_ws) if t_s9 >= t_ws else (r_ws, r_s9)
-            if first:
-                out["roofline"] = first
-            if second:
-                out["roofline_second"] = second
+            lay = {}
+            for c in ctxs_layers:
+                for i, (ms, n, name) in enumerate(c):
+                    if n:
+                        a_ = lay.setdefault(i, [0.0, 0, name]); a_[0] += ms; a_[1] += n
+            positions = float(st.positions)
+            issued = {"f16x3": 3.0, "bf16x6": 6.0, "fp32": 1.0}[cnn_math]
+            peak = MFMA_F32_PEAK if cnn_math == "fp32" else MFMA_F16_PEAK
+            ridge = (peak / issued) * 1e12 / (HBM_PEAK_GBS * 1e9)          # flop per byte at which the two roofs meet for the arithmetic in use
+
+            def op_cost(i):
+                """algorithmic (flops, HBM bytes) per position of op i (fp32 activations in and out, + the residual read)"""
+                o = ops[i]
+                if o["op"] == "dwconv" and i + 1 < len(ops) and lay.get(i, [0, 0, ""])[2].startswith("k3_sep"):
+                    p = ops[i + 1]
+                    return 2.0 * (o["k"] * o["c"] + p["cin"] * p["cout"]), 4.0 * (p["cin"] + p["cout"] + (p["cout"] if p.get("add", -1) >= 0 else 0))
+                if o["op"] == "conv":
+                    return 2.0 * o["k"] * o["cin"] * o["cout"], 4.0 * (o["cin"] + o["cout"] + (o["cout"] if o.get("add", -1) >= 0 else 0))
+                if o["op"] == "dwconv":
+                    return 2.0 * o["k"] * o["c"], 8.0 * o["c"]
+                if o["op"] == "encode_gru":
+                    return 2.0 * 47040, 4.0 * (20 + 2 + 64)
+                if o["op"] == "dense_softmax":
+                    return 2.0 * o["cin"] * o["cout"], 4.0 * (o["cin"] + o["cout"])
+                if o["op"] == "add_relu":
+                    return float(o["c"]), 12.0 * o["c"]
+                return 0.0, 0.0
+            kern = {}
+            for i, (ms, n, name) in lay.items():
+                fl, by = op_cost(i)
+                k_ = kern.setdefault(name, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0, layers=0))
+                k_["ms"] += ms; k_["launches"] += n; k_["flops"] += fl * positions; k_["bytes"] += by * positions; k_["layers"] += 1
+            fam = {}
+            for name, k_ in kern.items():
+                f_ = fam.setdefault(name.split("<")[0], dict(ms=0.0, launches=0, flops=0.0, bytes=0.0, kernels={}))
+                for q in ("ms", "launches", "flops", "bytes"):
+                    f_[q] += k_[q]
+                f_["kernels"][name] = k_
+            k3_ms = sum(f_["ms"] for f_ in fam.values()) or 1.0
+            pmc = load_pmc(rps, bases, cnn_math)
+
+            def roof(label, d, solo_key=None):
+                secs = d["ms"] / 1e3
+                inten = d["flops"] / d["bytes"] if d["bytes"] else 0.0
+                tf, gbs = d["flops"] / secs / 1e12, d["bytes"] / secs / 1e9
+                r = {"kernel": label, "launches": d["launches"], "mean_launch_ms": d["ms"] / d["launches"], "share_of_network_time": d["ms"] / k3_ms,
+                     "algorithmic_flops_per_launch": d["flops"] / d["launches"], "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                     "flop_per_byte": inten, "ridge_flop_per_byte": ridge, "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "mfma_TFLOPs": tf,
+                     "mfma_frac": tf / peak, "mfma_issued_frac": issued * tf / peak, "traffic": None}
+                if inten >= ridge:
+                    r.update(bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak)
+                else:
+                    r.update(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
+                return r
+            fams = []
+            for fname, f_ in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+                r = roof(fname + " (%d kernel instance(s), %d layers of the network)" % (len(f_["kernels"]), sum(k_["layers"] for k_ in f_["kernels"].values())), f_)
+                r["instances"] = {}
+                tr_w = tr_f = 0.0; tr_n = 0
+                for name, k_ in sorted(f_["kernels"].items(), key=lambda kv: -kv[1]["ms"]):
+                    ri = roof(name, k_)
+                    if pmc and name in pmc.get("kernels", {}):
+                        pk = pmc["kernels"][name]
+                        ri["traffic"] = pk["write_bytes_per_launch"] + pk["fetch_bytes_per_launch_corrected"]
+                        ri["traffic_over_algorithmic"] = ri["traffic"] / ri["algorithmic_bytes_per_launch"] * (pk.get("positions_per_launch_ratio", 1.0))
+                        tr_w += pk["write_bytes_per_launch"] * pk["launches"]; tr_f += pk["fetch_bytes_per_launch_corrected"] * pk["launches"]; tr_n += pk["launches"]
+                    r["instances"][name] = {q: ri[q] for q in ("launches", "mean_launch_ms", "bound", "frac", "hbm_frac", "mfma_frac", "mfma_issued_frac", "traffic",
+                                                               "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch")}
+                if tr_n:
+                    r["traffic"] = (tr_w + tr_f) / tr_n                      # HBM bytes per launch of the family, PMC (launch-weighted over its instances)
+                fams.append(r)
+            note = ("achieved = algorithmic work of the launches (per-position figures x positions processed) / summed launch time, HIP events around every launch "
+                    "in the timed region on the stream it runs on; a launch shares the chip with the other CNN lanes and the per-read stages of the batches in flight. "
+                    "bound: flop/byte of the family against the ridge (%.0f flop/B for %s at %g issued products per fp32 product). traffic: HBM bytes per launch from the "
+                    "committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r03_pmc_bench.json) when they match this workload, else null" % (ridge, cnn_math, issued))
+            if fams:
+                out["roofline"] = dict(fams[0], note=note)
+                out["roofline_families"] = [{q: f_[q] for q in ("kernel", "share_of_network_time", "launches", "mean_launch_ms", "bound", "achieved", "peak", "unit", "frac",
+                                                               "hbm_frac", "mfma_frac", "mfma_issued_frac", "traffic")} for f_ in fams]
+            mac = cnn_macs(cnn_desc)
+            cnn_ms, cnn_n = prof.get("k3_cnn", (0.0, 0))
+            flops = 2.0 * mac * positions / max(cnn_n, 1)
+            ach = flops / ((cnn_ms / max(cnn_n, 1)) / 1e3) / 1e12 if cnn_ms > 0 else 0.0
             roof_net = {"bound": "mfma", "kernel": "k3_cnn (all layers of one batch = one dn_run_cnn)", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                         "frac": ach / peak, "traffic": None, "algorithmic_flops_per_launch": flops, "mean_launch_ms": cnn_ms / max(cnn_n, 1),
                         "issued_frac": ach * issued / peak,
@@ -364,10 +477,49 @@ def main():
             if "k3_cnn" in solo:
                 roof_net["solo_launch_ms"] = solo["k3_cnn"]
                 roof_net["solo_frac"] = flops / (solo["k3_cnn"] / 1e3) / 1e12 / peak
+            if solo_layers:                                                    # the same families with the chip to themselves (one untimed batch after the run)
+                sfam = {}
+                for i, (ms, n, name) in enumerate(solo_layers):
+                    if n:
+                        fl, by = op_cost(i)
+                        f_ = sfam.setdefault(name.split("<")[0], dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+                        f_["ms"] += ms; f_["launches"] += n; f_["flops"] += fl * solo_positions; f_["bytes"] += by * solo_positions
+                for r in [out.get("roofline")] + out.get("roofline_families", []):
+                    f_ = sfam.get(r["kernel"].split(" ")[0]) if r else None
+                    if f_ and f_["ms"] > 0:
+                        r["solo_mean_launch_ms"] = f_["ms"] / f_["launches"]
+                        r["solo_frac"] = (f_["flops"] / (f_["ms"] / 1e3) / 1e12 / peak) if r["bound"] == "mfma" else (f_["bytes"] / (f_["ms"] / 1e3) / 1e9 / HBM_PEAK_GBS)
             out["roofline_network"] = roof_net
             if "roofline" not in out:
                 out["roofline"] = roof_net
+            if pmc and pmc.get("step"):
+                stp = pmc["step"]
+                hbm = (stp["write_bytes"] + stp["fetch_bytes_corrected"]) / (dt / args.steps) / 1e9
+                mf = issued * 2.0 * mac * positions / args.steps / (dt / args.steps) / 1e12
+                out["roofline_chip"] = {"hbm_bytes_per_step": stp["write_bytes"] + stp["fetch_bytes_corrected"], "hbm_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS,
+                                        "mfma_issued_TFLOPs": mf, "mfma_issued_frac": mf / peak, "mfma_util_counter": stp.get("mfma_util"),
+                                        "note": "whole chip over one step of THIS run: HBM bytes of all kernels of a step (PMC passes at this workload's shape: "
+                                                "FETCH_SIZE x 2 + WRITE_SIZE) / ms_per_step / 8 TB/s; issued 16-bit MFMA flops of the network per step / ms_per_step / "
+                                                "the dense peak; mfma_util_counter = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of the counter pass"}
+            if pmc and pmc.get("k2_fill"):
+                kf = pmc["k2_fill"]
+                roof_banded["traffic"] = kf["write_bytes_per_launch"] + kf["fetch_bytes_per_launch_corrected"]
+                if kf.get("valu_insts_per_launch") and fill_s > 0:
+                    # the fill is a serial chain per read: its ceiling is vector ISSUE, not bytes.  SQ_INSTS_VALU of the launch at one instruction per
+                    # 4 cycles on every SIMD of the chip gives the shortest time this instruction stream can take; the algorithmic bytes over THAT
+                    # time is the fraction of the HBM roof the formulation can reach at all
+                    t_issue = kf["valu_insts_per_launch"] * 4.0 / (1024.0 * 2.4e9)
+                    roof_banded["issue_bound_frac"] = alg_bytes / t_issue / 1e9 / HBM_PEAK_GBS
+                    roof_banded["valu_insts_per_launch"] = kf["valu_insts_per_launch"]
             out["roofline_banded"] = roof_banded
+            if fp32_leg:
+                out["value_fp32"] = fp32_leg["value_fp32"]
+                out["fp32_leg"] = fp32_leg
+            if rank_stats:
+                out["ranks"] = {"busy_s_min": min(r["busy_s"] for r in rank_stats), "busy_s_max": max(r["busy_s"] for r in rank_stats),
+                                "gather_s_max": max(r["gather_s"] for r in rank_stats), "per_rank": rank_stats,
+                                "note": "busy_s: a rank's own stream (first upload to its last records on the host); gather_s: its part of the RCCL gather of the "
+                                        "per-call results to rank 0, inside the timed region"}
             out["hbm"] = _hbm_info()
             out["host"] = {"datagen_s": t_gen, "upload_s": st.seconds_upload, "collect_wait_s": st.seconds_collect, "emit_s": st.seconds_emit,
                            "gather_s": gather_s, "emission": {"records_per_s": st.calls / st.seconds_emit if st.seconds_emit > 0 else None,
@@ -381,7 +533,7 @@ def main():
                              "parallelism": "reads sharded, %d rank(s), %d batches in flight per GPU, one host thread per rank" % (world, nctx)}
             out["roofline"] = roof_banded
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, bases, seed_base, full, budget_reads=256)
+            out["cpu_baseline"] = cpu_baseline(model, bases, seed_base, full, budget_reads=128)
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()
