@@ -50,7 +50,7 @@ struct VitReadH { double iM2M, eM2M, eM2MorD, eOrI; int fail, pad; };   // fail:
 struct EaDevH { unsigned *coord, *qidx, *ridx; int *indel; unsigned *nsig; float *sig, *core, *resid;
                 unsigned *win_ref, *win_len, *win_T; double *win_score;
                 unsigned *al_coord, *al_rpos; double *al_val; unsigned char *al_kind; const unsigned long long *al_off; unsigned *al_n;
-                unsigned char *redo; };
+                unsigned char *redo; unsigned *resume; };
 void k2b_rowcap_launch(const BatchDev &, unsigned long long *, hipStream_t);
 void k2b_emission_tap_launch(const double *, const double *, double *, unsigned, const void *, hipStream_t);
 // k_collect.hip: per-read call counts (centre base T), their exclusive scan, ordered compaction of the per-call outputs
@@ -643,7 +643,8 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
         (rc = dalloc(c, &c->ea.indel, (size_t)NR)) || (rc = dalloc(c, &c->ea.nsig, (size_t)NR)) || (rc = dalloc(c, &c->ea.sig, (size_t)NR * DN_RAWDEPTH)) ||
         (rc = dalloc(c, &c->ea.core, (size_t)NR)) || (rc = dalloc(c, &c->ea.resid, (size_t)NR)) || (rc = dalloc(c, &c->ea.win_ref, (size_t)NR)) ||
         (rc = dalloc(c, &c->ea.win_len, (size_t)NR)) || (rc = dalloc(c, &c->ea.win_T, (size_t)NR)) || (rc = dalloc(c, &c->ea.win_score, (size_t)NR)) ||
-        (rc = dalloc(c, &c->d_vitread, (size_t)n)) || (rc = dalloc(c, &c->d_probs, (size_t)NR * 3)) || (rc = dalloc(c, &c->ea.redo, (size_t)n))) return rc;
+        (rc = dalloc(c, &c->d_vitread, (size_t)n)) || (rc = dalloc(c, &c->d_probs, (size_t)NR * 3)) || (rc = dalloc(c, &c->ea.redo, (size_t)n)) ||
+        (rc = dalloc(c, &c->ea.resume, (size_t)n * 8))) return rc;
         return DN_OK;
     };
     c->measuring = true; c->measured = 0;

@@ -37,7 +37,9 @@ struct EaDev {               // outputs, all at ref_off[r] (capacity = reference
     // `DNAscent align` table (alignment.cpp:697-733), optional (al_val == nullptr: not requested): one row per raw sample of
     // every event labelled M and of every event labelled I before the window's last match; rows of read r start at al_off[r]
     unsigned *al_coord, *al_rpos; double *al_val; unsigned char *al_kind; const unsigned long long *al_off; unsigned *al_n;
-    unsigned char *redo;     // [n_reads] set by the VT_TFAST pass for reads that need the VT_TMAX pass
+    unsigned char *redo;     // [n_reads] where a read stands between the passes of k2b_launch: 0 finished, 1 stopped at a window the 224 lattice cannot
+                             // hold, 2 that window done by the 512 lattice, 3 stopped a second time
+    unsigned *resume;        // [n_reads][8] the walk's state at the window it stopped at: ri, readHead, npos, nwin, al_rows
 };
 
 // log(0) is NaN in the reference (probability.cpp) and every use of it is one of: NaN + x = NaN, and lnGreaterThan
@@ -105,8 +107,13 @@ template <class C> __device__ __forceinline__ double emission(double x, double m
     return e;
 }
 
+// The windows of a read are walked by up to four launches (k2b_launch).  mode 0: every read from its first window in the 224-observation
+// lattice; a window that does not fit stops the walk THERE (state to O.resume, redo = 1).  mode 1 (512 lattice): the reads with redo == 1
+// do that ONE window and hand back (redo = 2).  mode 2 (224): they continue; a second oversized window stops them again (redo = 3).
+// mode 3 (512): those go on to their end.  Round 2 redid such a read FROM ITS FIRST WINDOW in the 512 variant: a handful of wavefronts
+// held the batch for up to 105 ms (rocprof max of k2b_eventalign<512>), longer than the whole first pass.
 template <int TMAX>
-__global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const VitRead *vrs, VitConsts vc) {
+__global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const VitRead *vrs, VitConsts vc, int mode) {
     __shared__ double xs[TMAX];                           // scaled observations of the window
     __shared__ unsigned tk_start[TMAX], tk_len[TMAX];     // raw span of each taken event (event.raw, reads.h:68-72)
     __shared__ unsigned ev_slot[TMAX], ev_cnt0[TMAX];     // label pass: position slot of an M-labelled event / samples before it
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
     __shared__ unsigned ev_aoff[TMAX];                    // align table: first row of each printed event (0xffffffff: not printed)
     const int r = blockIdx.x;
     const int lane = threadIdx.x;
-    if (TMAX == VT_TMAX && !O.redo[r]) return;            // second pass: only the reads the first one handed over
+    if (mode != 0 && O.redo[r] != mode) return;           // later passes: only the reads the pass before handed over
     ReadRes &R = B.res[r];
     const VitRead vr = vrs[r];
     if (R.status == 0 && vr.fail) {                       // eln() of a negative number: the reference throws NegativeLog (probability.cpp:45)
@@ -148,6 +155,11 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
     unsigned npos = 0, nwin = 0;
     unsigned al_rows = 0;                                 // rows of the align table written so far
     int fail = 0;
+    unsigned *const saved = O.resume + 8 * (size_t)r;
+    if (mode != 0) { ri = (int)saved[0]; readHead = saved[1]; npos = saved[2]; nwin = saved[3]; al_rows = saved[4]; }   // wave-uniform loads
+    auto park = [&](unsigned char next) {                 // stop here; the pass `next` picks the walk up at this window
+        if (lane == 0) { saved[0] = (unsigned)ri; saved[1] = readHead; saved[2] = npos; saved[3] = nwin; saved[4] = al_rows; O.redo[r] = next; }
+    };
 
     while (ri < n_ref - (DN_K - 1)) {                     // alignment.cpp:556
         const int toEnd = n_ref - ri;
@@ -195,8 +207,8 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
         const int indel = (int)(qhi - qlo) - (int)(W - DN_K + 1);       // :635-638
         if (nt < 2) { ri += W; continue; }                // :641
         if (nt > (unsigned)TMAX) {
-            if (TMAX < VT_TMAX) { if (lane == 0) O.redo[r] = 1; return; }     // wave-uniform: the whole read again in the large variant
-            fail = 6; break;
+            if (TMAX < VT_TMAX) { park(mode == 0 ? 1 : 3); return; }          // wave-uniform: THIS window goes to the large lattice (readHead already
+            fail = 6; break;                                                  // points at its first event: gathering it again gives the same events)
         }
         const int T = (int)nt;
         __syncthreads();
@@ -415,12 +427,14 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
         readHead += (unsigned)lastM_ev + 1u;                // :739-740
         ri += lastM_ref + 1;
         __syncthreads();
+        if (mode == 1) { park(2); return; }                 // the one oversized window is done: back to the small lattice
     }
     if (lane == 0) {
         if (O.al_n) O.al_n[r] = fail ? 0u : al_rows;
         R.n_positions = fail ? 0u : npos;
         R.n_windows = nwin;
         if (fail) R.status = fail;
+        O.redo[r] = 0;
     }
 }
 
@@ -475,7 +489,9 @@ void k2b_launch(const BatchDev &B, const void *ea, const void *vr, const void *v
     const EaDev O = *reinterpret_cast<const EaDev *>(ea);
     const VitConsts V = *reinterpret_cast<const VitConsts *>(vc);
     hipMemsetAsync(O.redo, 0, (size_t)B.n_reads, st);
-    hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, dim3(B.n_reads), dim3(64), 0, st, B, O, (const VitRead *)vr, V);
-    hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), 0, st, B, O, (const VitRead *)vr, V);
+    hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, dim3(B.n_reads), dim3(64), 0, st, B, O, (const VitRead *)vr, V, 0);
+    hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), 0, st, B, O, (const VitRead *)vr, V, 1);
+    hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, dim3(B.n_reads), dim3(64), 0, st, B, O, (const VitRead *)vr, V, 2);
+    hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), 0, st, B, O, (const VitRead *)vr, V, 3);
     hipLaunchKernelGGL(k2b_features, dim3((max_ref + 255) / 256, B.n_reads), dim3(256), 0, st, B, O);
 }

@@ -9,6 +9,7 @@ inputs (seeded synthetic int16 signals + calibration) and the reference's result
 Files:
   ref_segmentation.npz   for each case: adc (int16), cal_offset, cal_scale -> reference detect_events (start, length,
                          mean, stdv) with the reference's default detector parameters (event_detection.h:19-25)
+  ref_segmentation_50kb.npz  the same for ONE 50 kb read (the headline read length): the reference's event table only, the signal by seed + SHA-256
   ref_common.npz         IUPAC sequences -> reference reverseComplement; fp64 vectors -> reference vectorMean (common.h)
   ref_logspace.npz       argument grids -> reference eexp / eln / lnSum / lnProd / lnGreaterThan / normalPDF (bit patterns)
   ref_emission.npz       (level, observation) pairs -> reference eln(normalPDF(level, 0.14, observation)): builtinViterbi's emission
@@ -24,6 +25,9 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import pyoracle as po  # noqa: E402
 from dnascent_amd import synth  # noqa: E402
+
+
+SEG50 = (950, 50000, dict(sub_rate=0.002, ins_rate=0.001, del_rate=0.001))      # the 50 kb segmentation golden (tests/test_golden.py uses the same tuple)
 
 
 def main():
@@ -46,6 +50,15 @@ def main():
         out["mean_%d" % i] = mn
         out["stdv_%d" % i] = sd
     np.savez_compressed(os.path.join(HERE, "ref_segmentation.npz"), **out)
+    # one read of the HEADLINE length (50 kb, ~575 k samples, ~110 k events): the reference-pinned GPU test then covers the length the
+    # bench is quoted on (round-2 verdict).  The signal is regenerated from its seed (its SHA-256 is stored), only the reference's event
+    # table is kept: start (uint32), length, mean (fp32 bit patterns)
+    import hashlib
+    r = synth.make_read(*SEG50[:2], model=model, **SEG50[2])
+    raw = ((r.adc.astype(np.float32) + np.float32(r.cal_offset)) * np.float32(r.cal_scale)).astype(np.float64)
+    st, ln, mn, sd = po.ref_detect_events(raw)
+    np.savez_compressed(os.path.join(HERE, "ref_segmentation_50kb.npz"), adc_sha256=np.frombuffer(hashlib.sha256(r.adc.tobytes()).digest(), np.uint8),
+                        n_samples=np.int64(r.adc.shape[0]), cal=np.array([r.cal_offset, r.cal_scale], np.float32), start=st.astype(np.uint32), length=ln, mean=mn)
 
     rng = np.random.default_rng(20251002)
     xs = np.concatenate([[0.0, -0.0, 1.0, 1e-320, 5e-324, 1e308, np.inf, -np.inf, np.nan, 0.14, 745.2, -745.2, -708.5, 709.9],
@@ -87,7 +100,7 @@ def main():
                         **{"seq_%d" % i: np.frombuffer(q, np.uint8) for i, q in enumerate(seqs)},
                         **{"rc_%d" % i: np.frombuffer(q, np.uint8) for i, q in enumerate(rc)},
                         **{"vm_in_%d" % i: v for i, v in enumerate(vm_in)})
-    for f in ("ref_segmentation.npz", "ref_logspace.npz", "ref_emission.npz", "ref_common.npz"):
+    for f in ("ref_segmentation.npz", "ref_segmentation_50kb.npz", "ref_logspace.npz", "ref_emission.npz", "ref_common.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

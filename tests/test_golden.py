@@ -30,6 +30,28 @@ def test_oracle_segmentation_matches_reference_goldens():
             assert np.array_equal(_bits(ev[f]), _bits(g["%s_%d" % (f, i)])), (i, f)
 
 
+SEG50 = (950, 50000, dict(sub_rate=0.002, ins_rate=0.001, del_rate=0.001))      # tests/golden/make_golden.py SEG50
+
+
+def _seg50_read(model):
+    import hashlib
+    from dnascent_amd import synth
+    g = np.load(os.path.join(G, "ref_segmentation_50kb.npz"))
+    r = synth.make_read(*SEG50[:2], model=model, **SEG50[2])
+    assert r.adc.shape[0] == int(g["n_samples"]) and hashlib.sha256(r.adc.tobytes()).digest() == g["adc_sha256"].tobytes()    # the signal the reference saw
+    assert np.array_equal(np.array([r.cal_offset, r.cal_scale], np.float32), g["cal"])
+    return r, g
+
+
+def test_oracle_segmentation_matches_reference_golden_at_50kb(model):
+    """the headline read length: one 50 kb read (575 k samples), 110 746 events of the reference's own detect_events"""
+    r, g = _seg50_read(model)
+    ev = po.detect_events(po.adc_to_pa(r.adc, r.cal_offset, r.cal_scale))
+    assert ev["start"].shape[0] == g["start"].shape[0] > 100000
+    assert np.array_equal(ev["start"], g["start"].astype(np.uint64))
+    assert np.array_equal(_bits(ev["length"]), _bits(g["length"])) and np.array_equal(_bits(ev["mean"]), _bits(g["mean"]))
+
+
 def test_oracle_logspace_matches_reference_goldens():
     g = np.load(os.path.join(G, "ref_logspace.npz"))
     o = po.oracle()
@@ -124,6 +146,41 @@ def test_hip_segmentation_matches_reference_goldens(model):
             assert s["n_events"][i] == kept.shape[0]
             em, es, el = ctx.events(i, int(s["n_events"][i]))
             assert np.array_equal(_bits(em), _bits(want_mean)) and np.array_equal(es, want_start) and np.array_equal(el, want_len)
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_segmentation_matches_reference_golden_at_50kb(model):
+    """The device segmentation of a 50 kb read -- the bench's read length -- against the REFERENCE's event table (not the oracle's): the
+    scrappie table through the tap, and the DNAscent events the product path keeps (event_handling.cpp:549-575), bit for bit; the read
+    sits between two others so that its chunks are not the first of the batch."""
+    from dnascent_amd import hip, host, synth
+    r, g = _seg50_read(model)
+    others = [synth.make_read(951, 3000, model=model), synth.make_read(952, 7000, model=model, is_reverse=True)]
+    b = host.ReadBatch()
+    for x in (others[0], r, others[1]):
+        assert b.add_synth(x) >= 0
+    gs, gm = g["start"], g["mean"]
+    for taps in (True, False):
+        ctx = hip.Context(0)
+        ctx.load_pore_model(model)
+        ctx.keep_k1(taps)
+        b.upload(ctx)
+        ctx.run("segment")
+        s = ctx.summaries()
+        assert s["n_scrappie"][1] == gs.shape[0] and s["detector_rechecks"][1] == 0
+        if taps:
+            st, ln, mn = ctx.scrappie_events(1, int(s["n_scrappie"][1]))
+            assert np.array_equal(st, gs) and np.array_equal(_bits(ln), _bits(g["length"])) and np.array_equal(_bits(mn), _bits(gm))
+        kept = np.flatnonzero((np.arange(gs.shape[0]) > 0) & (gm.astype(np.float64) > 0))
+        prev = np.concatenate([[-1], kept[:-1]])
+        want_mean = np.where(prev >= 0, gm[np.maximum(prev, 0)].astype(np.float64), 0.0)
+        want_start = np.where(prev >= 0, gs[np.maximum(prev, 0)], 0).astype(np.uint32)
+        last = np.minimum(gs[kept].astype(np.int64) - 1, int(s["n_samples"][1]) - 1)
+        want_len = np.maximum(last - want_start.astype(np.int64) + 1, 0).astype(np.uint32)
+        assert s["n_events"][1] == kept.shape[0]
+        em, es, el = ctx.events(1, int(s["n_events"][1]))
+        assert np.array_equal(_bits(em), _bits(want_mean)) and np.array_equal(es, want_start) and np.array_equal(el, want_len)
         ctx.close()
 
 

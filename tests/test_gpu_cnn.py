@@ -160,3 +160,61 @@ def test_in_place_convolution_is_rejected():
     with pytest.raises(Exception, match="in place"):
         ctx.load_cnn(d, blob)
     ctx.load_cnn(desc, blob)                                # the context is still usable
+
+
+def _blown_up_model():
+    desc, blob, _ = cnn_model.default_model()
+    blob = blob.copy()
+    first = next(o for o in desc["ops"] if o["op"] == "conv")
+    blob[first["scale"]:first["scale"] + first["cout"]] *= 2.0 ** 20
+    return desc, blob
+
+
+def test_deferred_escalation_through_run_detect_and_collect(model):
+    """The ASYNCHRONOUS path of the same safeguard (round-2 advisor: untested): dn_run_detect only enqueues, so the fp16 range flag of
+    a batch is looked at by whoever synchronises next -- dn_collect -- which then repeats the batch's network with bf16 pieces.  The
+    collected calls must equal a context that was told to use bf16x6 from the start, bit for bit, the repeat is counted once, and the
+    context stays on bf16 pieces (a second batch is not repeated).  A batch that raised the flag and was never collected must not leave
+    it to the next batch of the context."""
+    desc, blob = _blown_up_model()
+    specs = [(7601, 2500, dict()), (7602, 3000, dict(is_reverse=True, **GOOD)), (7603, 2000, dict(noise_pa=6.5))]
+    reads = [synth.make_read(seed, n, model=model, **kw) for seed, n, kw in specs]
+    b = host.ReadBatch()
+    for r in reads:
+        assert b.add_synth(r) >= 0
+
+    def fresh(math):
+        c = hip.Context(0)
+        c.load_pore_model(model, 0.14); c.load_cnn(desc, blob); c.cnn_set_math(math)
+        return c
+    ref = fresh("bf16x6")
+    b.upload(ref); ref.run("detect"); want = ref.collect()
+    assert ref.cnn_range_escalations() == 0 and int(want["call_off"][-1]) > 500
+    ctx = fresh("f16x3")
+    b.upload(ctx); ctx.run("detect")
+    got = ctx.collect()                                     # the flag is seen here: the network of the batch runs again in bf16x6
+    assert ctx.cnn_range_escalations() == 1
+    for k in ("call_off", "ref_coord", "p_edu", "p_brdu", "kmer"):
+        assert got[k].tobytes() == want[k].tobytes(), k
+    b.upload(ctx); ctx.run("detect"); again = ctx.collect()  # stays on bf16 pieces: no second repeat, same answer
+    assert ctx.cnn_range_escalations() == 1 and again["p_edu"].tobytes() == want["p_edu"].tobytes()
+    # dropped batch: flag raised, never collected; the next upload must start clean (and remember that the model does not fit fp16)
+    drop = fresh("f16x3")
+    b.upload(drop); drop.run("detect"); drop.sync()
+    b.upload(drop); drop.run("detect"); after = drop.collect()
+    assert after["p_edu"].tobytes() == want["p_edu"].tobytes() and drop.cnn_range_escalations() == 1
+    for c in (ref, ctx, drop):
+        c.close()
+
+
+def test_cnn_description_must_start_with_the_encoder():
+    """the encoder writes the row validity mask every later epilogue reads: a description without it first is rejected, not run on
+    stale lane state (round-2 advisor)"""
+    import copy
+    desc, blob, _ = cnn_model.default_model()
+    d = copy.deepcopy(desc)
+    d["ops"] = d["ops"][1:]
+    ctx = hip.Context(0)
+    with pytest.raises(Exception, match="ENCODE_GRU"):
+        ctx.load_cnn(d, blob)
+    ctx.close()

@@ -136,3 +136,31 @@ def test_dalloc_exact_size_retry(model, monkeypatch):
     c = _ctx(model); b.upload(c); c.run("detect"); rc = c.collect()
     _same(ra, rc)
     a.close(); c.close()
+
+
+def test_page_locked_batch_uploads_asynchronously_with_the_same_result(model):
+    """dn_batch_upload returns before its copies are done only when EVERY array it reads is page-locked (round-2 advisor: the decision
+    used to look at adc alone, and nothing exercised the asynchronous branch).  ReadBatch.pin() registers all of them (dn_host_register);
+    a pinned batch streamed through two contexts gives the bits of the pageable one, and a batch with only adc registered takes the
+    synchronous path (its other arrays may be reused the moment the call returns)."""
+    import ctypes as C
+    b, reads = _batch(model, SPECS)
+    a = _ctx(model); b.upload(a); a.run("detect"); ra = a.collect()
+    b.pin()
+    c = _ctx(model); d = _ctx(model)
+    b.upload(c); c.run("detect")                             # both uploads in flight from the same page-locked arrays
+    b.upload(d); d.run("detect")
+    rc = c.collect(); rd = d.collect()
+    _same(ra, rc); _same(ra, rd)
+    b.unpin()
+    # only adc page-locked: must not be treated as an asynchronous upload
+    desc = b.desc()
+    n_adc = int(C.cast(desc.adc_off, C.POINTER(C.c_uint64))[b.size()]) * 2
+    assert hip.lib().dn_host_register(desc.adc, n_adc) == 0
+    try:
+        b.upload(c); c.run("detect"); re_ = c.collect()
+        _same(ra, re_)
+    finally:
+        assert hip.lib().dn_host_unregister(desc.adc) == 0
+    for x in (a, c, d):
+        x.close()

@@ -134,3 +134,59 @@ def test_align_table_and_record_text(run, model, tmp_path):
     ctx.run("eventalign"); ctx.sync()
     with pytest.raises(Exception):
         ctx.align_rows(len(reads))
+
+
+def test_oversized_windows_resume_where_they_stopped(model):
+    """Windows holding more observations than the fast lattice (224) are handed to the 512-observation lattice ONE AT A TIME and the
+    walk continues where it stopped (k2b_launch: four passes; round 2 redid such a read from its first window).  Slow translocation
+    (long dwells) makes events per base rise: a read with exactly one oversized window (passes 0, 1, 2), one with two (all four
+    passes), one with many, ordinary neighbours in the same batch -- window walk, positions, features and the `align` table bit for
+    bit against the oracle, which has no such limit; a read with windows beyond 512 observations is reported DN_READ_FAIL_WINDOW_EVENTS
+    (the documented divergence) without disturbing the others."""
+    specs = [(4243, 6000, dict(mean_dwell=16.0, sub_rate=0.002, is_reverse=True)),      # 1 window > 224
+             (201, 3000, dict()),
+             (4242, 6000, dict(mean_dwell=16.0, sub_rate=0.002)),                       # 2
+             (4242, 6000, dict(mean_dwell=20.0, sub_rate=0.002)),                       # 16 of 114
+             (4242, 6000, dict(mean_dwell=50.0, sub_rate=0.002)),                       # some beyond 512
+             (202, 5000, dict(is_reverse=True))]
+    reads = [synth.make_read(seed, n, model=model, **kw) for seed, n, kw in specs]
+    ctx = hip.Context(0)
+    ctx.load_pore_model(model, 0.14)
+    b = host.ReadBatch()
+    for r in reads:
+        assert b.add_synth(r) >= 0
+    b.upload(ctx)
+    ctx.set_align_table(True)
+    ctx.run("normalise"); ctx.run("eventalign"); ctx.sync()
+    s = ctx.summaries()
+    rows = ctx.align_rows(len(reads))
+    big = []
+    for i, r in enumerate(reads):
+        o = po.OracleRead(r, model)
+        assert o.normalise() == 0 and o.eventalign() == 0
+        wr, wl, wt, ws = o.windows()
+        big.append(int((wt > 224).sum()))
+        if (wt > 512).any():
+            assert s["status"][i] == 6 and s["n_positions"][i] == 0                      # DN_READ_FAIL_WINDOW_EVENTS
+            o.free()
+            continue
+        assert s["status"][i] == 0 and s["n_windows"][i] == wr.shape[0]
+        gr, gl, gt, gs = ctx.windows(i, wr.shape[0])
+        assert np.array_equal(gr, wr) and np.array_equal(gl, wl) and np.array_equal(gt, wt)
+        assert np.allclose(gs, ws, rtol=1e-9, atol=0.0, equal_nan=True)
+        p = o.positions()
+        n = p["coord"].shape[0]
+        assert s["n_positions"][i] == n
+        g = ctx.positions(i, n)
+        for f in ("coord", "query_idx", "ref_idx", "indel", "n_signal"):
+            assert np.array_equal(g[f], p[f]), (i, f)
+        assert g["signal"].tobytes() == p["signal"].tobytes() and g["core"].tobytes() == p["core"].tobytes()
+        t = o.align_table()
+        assert rows[i] == t["coord"].shape[0]
+        gtab = ctx.align_table(i, int(rows[i]))
+        for f in ("coord", "ref_pos", "kind"):
+            assert np.array_equal(gtab[f], t[f]), (i, f)
+        assert gtab["value"].tobytes() == t["value"].tobytes()
+        o.free()
+    assert big[0] == 1 and big[1] == 0 and big[2] == 2 and big[3] >= 10 and big[5] == 0
+    ctx.close()
