@@ -176,6 +176,141 @@ __global__ __launch_bounds__(64) void k3_encode(const float *core, const float *
     valid_out[row] = 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k3_encode_mfma (round 3): the same encoder with the GRU's matrix-vector products on the MATRIX cores.  k3_encode spends ~2 200 vector
+// instructions per time step on three 16 x 48 products per position (wave-uniform weights as SGPR operands of v_pk_fma_f32); batched
+// over the 32 positions of a wavefront they are 32 x 16 x 48 GEMMs -- v_mfma_f32_32x32x16_f16 with K = the 16 units exactly:
+//     D'[output (32 rows)][position (32 columns)] += W^T[output][unit] * h^T[unit][position]
+//   A operand = W^T: lane (i = lane & 31, hh = lane >> 5) holds the 8 inputs k' = 8 hh .. 8 hh + 7 of output row i
+//   B operand = h^T: lane (p = lane & 31, hh) holds 8 units of position p
+//   D'              : lane (p, hh), register q: row (q & 3) + 8 (q >> 2) + 4 hh
+// With rows 0-15 = one 16-unit block and rows 16-31 = another, lane (p, hh) ends up with exactly the units (e & 3) + 8 (e >> 2) + 4 hh,
+// e = 0 .. 7, of both blocks (registers e and 8 + e) -- and if k' = 8 hh + e is DEFINED to be that same unit (the contraction index may be
+// permuted freely as long as A and B agree), the lane's results are the lane's next B operand: no shuffle between time steps at all.
+// Tiles: layer 1 [z; r] and [g_rec; 0] from R1; layer 2 [z; r] from K2 (input n1) + R2 (input h2), [xh; hh_rec] from [K2g; 0] and [0; R2g].
+// fp32 accuracy as in the convolutions: every operand split into two fp16 pieces, three products (dropped < 2^-22); the states are in
+// [-1, 1] and the weights O(1), so fp16's range is not an issue here.  18 MFMAs + ~400 vector instructions per step and 32 positions
+// (k3_encode: ~1 100 per 32).  Biases and the 1-wide input kernel of layer 1 sit in LDS as per-lane tiles (two variants, by hh).
+// Not bit-identical to k3_encode (other summation order): checked against the PyTorch fp32 rendering at 1e-4 like everything in K3;
+// the exact-fp32 mode (DN_CNN_MATH_FP32) keeps k3_encode.
+// ---------------------------------------------------------------------------------------------------------
+typedef _Float16 gh16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void enc_split8(const float (&v)[8], gh16x8 &h, gh16x8 &l) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) { const _Float16 hh = (_Float16)v[e]; h[e] = hh; l[e] = (_Float16)(v[e] - (float)hh); }
+}
+__device__ __forceinline__ f32x16 enc_mma3(const gh16x8 ah, const gh16x8 al, const gh16x8 bh, const gh16x8 bl, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);      // smallest terms first, as in the convolutions
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+}
+__global__ __launch_bounds__(64, 16) void k3_encode_mfma(const float *core, const float *resid, const float *sig, const uint64_t *perm_src,
+                                                     const unsigned *perm_row, const unsigned *hist, uint8_t *valid_out, float *out,
+                                                     const float *wts, dn_cnn_op op) {
+    // constant tiles (float, [tile][16 registers][lane half]: a lane's values depend on its half only, so the reads are broadcasts):
+    // accumulator initial values of the four tiles, layer 1's input kernel (z, r, g) and its candidate gate's input bias
+    __shared__ float ctile[6][16][2];
+    unsigned n_total = 0;
+    for (int b = 0; b < DN_RAWDEPTH_DEV + 1; b++) n_total += hist[b];
+    const int lane = threadIdx.x, p = lane & 31, hh = lane >> 5;
+    if (blockIdx.x * 32 >= n_total) return;
+    const unsigned i = blockIdx.x * 32 + p;
+    const bool live = i < n_total;
+    const float *K1 = wts + op.aux[0], *R1 = wts + op.aux[1], *b1 = wts + op.aux[2];
+    const float *K2 = wts + op.aux[3], *R2 = wts + op.aux[4], *b2 = wts + op.aux[5];
+    auto unit = [&](int e, int half) { return (e & 3) + 8 * (e >> 2) + 4 * half; };
+    // ---- A fragments: lane = output row i_ = lane & 31 of the tile, k' = 8 hh + kk <-> input unit(kk, hh) ----
+    auto afrag = [&](const float *Wlo, int col_lo, const float *Whi, int col_hi, gh16x8 &ah, gh16x8 &al) {
+        // rows 0-15 of the tile: column col_lo + row of matrix Wlo ([16][48]); rows 16-31: column col_hi + (row - 16) of Whi; nullptr = zero rows
+        float v[8];
+        const int r_ = p;
+        const float *W = r_ < 16 ? Wlo : Whi;
+        const int col = r_ < 16 ? col_lo + r_ : col_hi + r_ - 16;
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) v[kk] = W ? W[unit(kk, hh) * 48 + col] : 0.0f;
+        enc_split8(v, ah, al);
+    };
+    gh16x8 aR1a_h, aR1a_l, aR1b_h, aR1b_l, aK2a_h, aK2a_l, aK2b_h, aK2b_l, aR2a_h, aR2a_l, aR2b_h, aR2b_l;
+    afrag(R1, 0, R1, 16, aR1a_h, aR1a_l);                 // layer 1 [z; r]
+    afrag(R1, 32, nullptr, 0, aR1b_h, aR1b_l);            // layer 1 [g_rec; 0]
+    afrag(K2, 0, K2, 16, aK2a_h, aK2a_l);                 // layer 2 [z; r], input part
+    afrag(R2, 0, R2, 16, aR2a_h, aR2a_l);                 // ... recurrent part
+    afrag(K2, 32, nullptr, 0, aK2b_h, aK2b_l);            // layer 2 [xh; 0] from n1
+    afrag(nullptr, 0, R2, 32, aR2b_h, aR2b_l);            // layer 2 [0; hh_rec] from h2
+    // ---- constant tiles: register q of lane (p, hh) belongs to block q >> 3, unit(q & 7, hh) ----
+    if (lane < 32) {                                       // 32 (register, half) slots, one lane each
+        const int q = lane >> 1, hf = lane & 1;
+        const int u = unit(q & 7, hf), blk = q >> 3;
+        ctile[0][q][hf] = blk == 0 ? b1[u] + b1[48 + u] : b1[16 + u] + b1[64 + u];       // layer 1 [z; r]: input bias + recurrent bias
+        ctile[1][q][hf] = blk == 0 ? b1[80 + u] : 0.0f;                                    // layer 1 [g_rec; -]
+        ctile[2][q][hf] = blk == 0 ? b2[u] + b2[48 + u] : b2[16 + u] + b2[64 + u];       // layer 2 [z; r]
+        ctile[3][q][hf] = blk == 0 ? b2[32 + u] : b2[80 + u];                              // layer 2 [xh; hh_rec]
+        ctile[4][q][hf] = blk == 0 ? K1[u] : K1[16 + u];                                   // layer 1 input kernel: z | r
+        ctile[5][q][hf] = blk == 0 ? K1[32 + u] : b1[32 + u];                              // ... g | the candidate gate's input bias
+    }
+    __syncthreads();
+    auto tile = [&](int t) { f32x16 c;
+#pragma unroll
+        for (int q = 0; q < 16; q++) c[q] = ctile[t][q][hh];
+        return c; };
+    const uint64_t src = perm_src[live ? i : 0];
+    float h1[8], h2[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { h1[e] = 0.f; h2[e] = 0.f; }
+    gh16x8 h1h, h1l, h2h, h2l;
+    enc_split8(h1, h1h, h1l); enc_split8(h2, h2h, h2l);
+    for (int t = 0; t < DN_RAWDEPTH_DEV; t++) {
+        const float x = live ? sig[src * DN_RAWDEPTH_DEV + t] : 0.0f;
+        const bool on = x != 0.0f;                        // masked time step: both layers keep their state (reads.h:161)
+        if (__ballot(on) == 0) continue;
+        // ---- layer 1 ----
+        f32x16 zr = enc_mma3(aR1a_h, aR1a_l, h1h, h1l, tile(0));
+        f32x16 gr = enc_mma3(aR1b_h, aR1b_l, h1h, h1l, tile(1));
+        const f32x16 k1a = tile(4), k1b = tile(5);
+        float n1[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float zz = sigmoidf_(__builtin_fmaf(x, k1a[e], zr[e]));
+            const float rg = sigmoidf_(__builtin_fmaf(x, k1a[8 + e], zr[8 + e]));
+            const float c = tanhf_(__builtin_fmaf(x, k1b[e], k1b[8 + e]) + rg * gr[e]);
+            n1[e] = zz * h1[e] + (1.0f - zz) * c;
+        }
+        gh16x8 n1h, n1l;
+        enc_split8(n1, n1h, n1l);
+        // ---- layer 2 ----
+        zr = enc_mma3(aK2a_h, aK2a_l, n1h, n1l, tile(2));
+        zr = enc_mma3(aR2a_h, aR2a_l, h2h, h2l, zr);
+        gr = enc_mma3(aK2b_h, aK2b_l, n1h, n1l, tile(3));
+        gr = enc_mma3(aR2b_h, aR2b_l, h2h, h2l, gr);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float zz = sigmoidf_(zr[e]);
+            const float rg = sigmoidf_(zr[8 + e]);
+            const float c = tanhf_(gr[e] + rg * gr[8 + e]);
+            const float n2 = zz * h2[e] + (1.0f - zz) * c;
+            h1[e] = on ? n1[e] : h1[e];
+            h2[e] = on ? n2 : h2[e];
+        }
+        enc_split8(h1, h1h, h1l); enc_split8(h2, h2h, h2l);
+    }
+    if (!live) return;
+    const unsigned row = perm_row[i];
+    float4 *o = reinterpret_cast<float4 *>(out + (size_t)row * 64);
+    o[hh] = make_float4(h2[0], h2[1], h2[2], h2[3]);              // units 4 hh .. 4 hh + 3
+    o[2 + hh] = make_float4(h2[4], h2[5], h2[6], h2[7]);          // units 8 + 4 hh ..
+    const unsigned ci = (unsigned)core[src] - 1u, ri = (unsigned)resid[src] - 1u;     // reads.h:112-138 indices are 1-based
+    if (hh == 0) {
+#pragma unroll
+        for (int j = 0; j < 5; j++) { const unsigned d = (ci >> (2 * (4 - j))) & 3u; o[4 + j] = make_float4(d == 0, d == 1, d == 2, d == 3); }
+        valid_out[row] = 1;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const unsigned d = (ri >> (2 * (3 - j))) & 3u; o[9 + j] = make_float4(d == 0, d == 1, d == 2, d == 3); }
+#pragma unroll
+        for (int q = 13; q < 16; q++) o[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 // signal length of a position = index of its last non-zero sample + 1 (reads.h:147 pads with zeros; a masked step is x == 0)
 #define ENC_BINS (DN_RAWDEPTH_DEV + 1)
 __global__ __launch_bounds__(256) void k3_encode_len(const float *sig, CnnRows R, uint8_t *len_by_row, unsigned *hist) {
@@ -1196,6 +1331,8 @@ static unsigned k3_sep_wgs(int bn, int np = 2) {                       // persis
     static const unsigned env = (getenv("DN_CNN_SEP_WGS") && atoi(getenv("DN_CNN_SEP_WGS")) > 0) ? (unsigned)atoi(getenv("DN_CNN_SEP_WGS")) : 0u;   // form, three of the 64-column one)
     return env ? env : (bn == 64 ? 3u : (np == 3 ? 1u : 2u)) * k3_cu_count();
 }
+// the GRU products on the matrix cores whenever the convolutions are (split modes); DN_CNN_ENC_MFMA=0: the vector-unit encoder everywhere
+static bool k3_encode_mfma_enabled(const CnnRun &c) { static const bool on = !(getenv("DN_CNN_ENC_MFMA") && atoi(getenv("DN_CNN_ENC_MFMA")) == 0); return on && c.wts_split != nullptr; }
 static bool k3_sep_ws_enabled() { static const bool on = !(getenv("DN_CNN_SEP_WS") && atoi(getenv("DN_CNN_SEP_WS")) == 0); return on; }
 static bool k3_bm256_enabled() { static const bool on = !(getenv("DN_CNN_BM256") && atoi(getenv("DN_CNN_BM256")) == 0); return on; }
 static bool k3_fuse_enabled() { static const bool on = !(getenv("DN_CNN_FUSE") && atoi(getenv("DN_CNN_FUSE")) == 0); return on; }
@@ -1281,7 +1418,10 @@ int k3_run(const CnnRun &c, hipStream_t st) {
                 hipLaunchKernelGGL(k3_encode_len, dim3((c.max_pos + 255) / 256, c.rows.r1 - c.rows.r0), dim3(256), 0, st, c.sig, c.rows, c.enc_len, c.enc_hist);
                 hipLaunchKernelGGL(k3_encode_perm, dim3((c.max_pos + 255) / 256, c.rows.r1 - c.rows.r0), dim3(256), 0, st, c.rows, c.enc_len, c.enc_hist,
                                    c.enc_hist + ENC_BINS, c.perm_src, c.perm_row);
-                if (c.n_pass_pos)
+                if (c.n_pass_pos && k3_encode_mfma_enabled(c))
+                    hipLaunchKernelGGL(k3_encode_mfma, dim3((c.n_pass_pos + 31) / 32), dim3(64), 0, st, c.core, c.resid, c.sig, c.perm_src, c.perm_row, c.enc_hist,
+                                       c.valid, pb[o.dst], c.wts, o);
+                else if (c.n_pass_pos)
                     hipLaunchKernelGGL(k3_encode, dim3((c.n_pass_pos + 63) / 64), dim3(64), 0, st, c.core, c.resid, c.sig, c.perm_src, c.perm_row, c.enc_hist,
                                        c.valid, pb[o.dst], c.wts, o);
                 break;
@@ -1353,7 +1493,7 @@ int k3_describe(const CnnRun &c, int i, char *buf, size_t cap) {
         return 1;
     }
     switch (o.op) {
-        case DN_CNN_ENCODE_GRU: snprintf(buf, cap, "k3_encode"); return 1;
+        case DN_CNN_ENCODE_GRU: snprintf(buf, cap, k3_encode_mfma_enabled(c) ? "k3_encode_mfma" : "k3_encode"); return 1;
         case DN_CNN_CONV: case DN_CNN_CONV_ADD: {
             const char *add = o.op == DN_CNN_CONV_ADD ? "true" : "false";
             const int bn = o.cout % 128 == 0 ? 128 : 64;
