@@ -728,6 +728,13 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
     conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, m0, n0, wm, wn, lane, cout, relu, post);
 }
 
+// (Round 3: k3_conv_dma -- the weight tile by LDS-DMA (global_load_lds_dwordx4, swizzled through the source address) into two buffers,
+// three taps = 72 MFMAs per wavefront and ONE barrier per step, fragments one group ahead, 256 x 128 tiles, one workgroup per CU -- is in
+// tools/k3_conv_dma_experiment.hip: bit-identical, and slower on every layer (17 x 128 -> 256: 3.59-3.66 ms against 3.09-3.19; 9 x 128 -> 128:
+// 1.13-1.17 against 0.98-1.00; 3 x 256 -> 256: 1.51-1.53 against 1.47-1.49).  The reason is in tools/ubench_tick.hip: under a chip-wide
+// MFMA load the clock settles at 1.5-1.8 GHz and the matrix pipe then delivers 1.5-1.9 PFLOP/s of dense fp16, not 2.5; the 17-tap layer's
+// 1.30 PFLOP/s of issued products is already 70-85 % of that.  Removing barriers and staging instructions does not buy what a second
+// workgroup per CU does)
 // ---------------------------------------------------------------------------------------------------------
 // k3_sep_split: SeparableConv1D in ONE kernel -- the depthwise filter is applied while the A tile of the pointwise GEMM is
 // staged, so its output never goes to HBM (as two kernels the pair moves 4 x rows x C x 4 bytes, fused 2 x; the 29 separable
