@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--reads-per-step", type=int, default=None, help="reads per batch (default 500 full / 1000 banded)")
     ap.add_argument("--bases", type=int, default=None, help="bases per read (default 50000 full / 20000 banded)")
     ap.add_argument("--inflight", type=int, default=None,
-                    help="batches in flight per GPU, each on its own context / stream / workspace (default 6 full / 8 banded)")
+                    help="batches in flight per GPU, each on its own context / stream / workspace (default 8)")
     ap.add_argument("--emit", type=int, default=1, help="full scope: format + write the .detect records inside the timed region")
     ap.add_argument("--out", default=None, help="full scope: .detect output path (default: formatted and counted, not written)")
     ap.add_argument("--cnn-math", choices=["f16x3", "bf16x6", "fp32"], default=None)
@@ -151,7 +151,7 @@ def main():
     full = args.scope == "full"
     rps = args.reads_per_step or (500 if full else 1000)
     bases = args.bases or (50000 if full else 20000)
-    inflight = args.inflight or (6 if full else 8)         # full: 3 -> 548, 4 -> 587, 6 -> 617 Msamples/s in one session; 8 does not fit beside the CNN lanes
+    inflight = args.inflight or 8                          # full, one session (round 3, gpurun_out/r3i): 6 -> 665, 8 -> 675, 10 -> 659 Msamples/s; 8 x 21 GB of workspaces + 4 CNN lanes = 238 of 309 GB
     os.environ.setdefault("DN_CNN_ROWS", str(4 << 20))      # activation rows resident per CNN pass and lane: 4 Mi rows = 16 GiB (2 Mi: -6 %, 8 Mi: -3 %)
 
     rank = int(os.environ.get("RANK", "0"))
