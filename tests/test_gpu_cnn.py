@@ -218,3 +218,39 @@ def test_cnn_description_must_start_with_the_encoder():
     with pytest.raises(Exception, match="ENCODE_GRU"):
         ctx.load_cnn(d, blob)
     ctx.close()
+
+
+def _hbm_used():
+    import ctypes
+    rt = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert rt.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return total.value - free.value
+
+
+def test_cnn_lanes_are_released_with_the_last_context_and_by_dn_shutdown(monkeypatch):
+    """The CNN lanes (stream + activation buffers, shared by the contexts of a device) used to outlive every context (round-2 advisor: ~64 GB
+    per device in a long-lived host).  They are counted in dn_device_bytes, go with the LAST context of their device, and dn_shutdown
+    frees them under live contexts (they come back on the next pass)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cnn_default_model.npz"))
+    desc, blob, _ = cnn_model.default_model()
+    monkeypatch.setenv("DN_CNN_ROWS", str(1 << 20))
+    lens = np.tile(g["lens"], 40); core = np.tile(g["core"], 40); resid = np.tile(g["resid"], 40); sig = np.tile(g["signal"], (40, 1))
+    base = _hbm_used()
+    a = hip.Context(0); b = hip.Context(0)
+    a.load_cnn(desc, blob); b.load_cnn(desc, blob)
+    before = a.device_bytes()
+    want = a.cnn_infer(lens, core, resid, sig)
+    lane_bytes = a.device_bytes() - before
+    assert lane_bytes > 16 * int(lens.sum()) * 256                       # 4 activation buffers x 256 floats per row are now counted
+    held = _hbm_used()
+    assert held - base > lane_bytes
+    assert hip.lib().dn_shutdown() == 0                                  # lanes freed under live contexts ...
+    assert _hbm_used() < held - 0.9 * lane_bytes and a.device_bytes() < before + (8 << 20)
+    again = b.cnn_infer(lens, core, resid, sig)                          # ... and come back
+    assert np.array_equal(again, want)
+    a.close()
+    mid = _hbm_used()
+    b.close()                                                            # the last context of the device takes the lanes with it
+    assert _hbm_used() < mid - 0.9 * lane_bytes and _hbm_used() - base < (256 << 20)
