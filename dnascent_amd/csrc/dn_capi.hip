@@ -1318,7 +1318,7 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned
         if ((rc = lane_grow(c, L, L->buf[b], (size_t)max_rows * 256 * sizeof(float)))) return rc;
     if ((rc = lane_grow(c, L, L->enclen, (size_t)max_rows)) || (rc = lane_grow(c, L, L->enchist, 64 * sizeof(unsigned))) ||
         (rc = lane_grow(c, L, L->permsrc, (size_t)max_rows * sizeof(uint64_t))) || (rc = lane_grow(c, L, L->permrow, (size_t)max_rows * sizeof(unsigned))) ||
-        (rc = lane_grow(c, L, L->valid, (size_t)max_rows)) || (rc = lane_grow(c, L, L->live, 256))) return rc;
+        (rc = lane_grow(c, L, L->valid, (size_t)max_rows + 256)) || (rc = lane_grow(c, L, L->live, 256))) return rc;    // + 256: k3_sep_pair's 120-row tiles look up to 127 rows past the pass
     if ((rc = dgrow(c, c->cnn_rowoff, n * sizeof(unsigned))) || (rc = dgrow(c, c->cnn_iooff, n * sizeof(uint64_t)))) return rc;
     if (!c->p_cnn_flag) HIPCHK(c, hipHostMalloc((void **)&c->p_cnn_flag, sizeof(unsigned), hipHostMallocDefault));
     // hand the batch over to the lane: everything the context's stream has enqueued so far (eventalign, the position counts)

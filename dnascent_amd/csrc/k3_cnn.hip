@@ -379,7 +379,7 @@ template <int BN, bool ADD>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][BN / 64], float *__restrict__ Y, const float *__restrict__ scale,
                                               const float *__restrict__ shift, const float *__restrict__ Add,
                                               const uint8_t *__restrict__ valid, int m0, int n0, int wm, int wn, int lane, int cout, int relu,
-                                              float post = 1.0f) {
+                                              float post = 1.0f, int wave_rows = 64) {
     // y = max(acc * scale + shift (+ residual), floor), zero on padding rows.  An accumulator register q of row block i holds row
     // 32 i + 8 (q >> 2) + (q & 3) + 4 (lane >> 5): the row is wave-uniform up to the lane half, so per (i, q) the row's base
     // address and its padding mask are SCALAR (one SGPR pair each: the select is a v_cndmask on that pair, the address an SGPR
@@ -401,7 +401,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][BN / 64], float *
         return (void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
     };
     const size_t wbase = (size_t)(m0 + wm * 64) * cout;
-    const int wbytes = 64 * cout * 4;
+    const int wbytes = max(min(wave_rows, 64), 0) * cout * 4;     // wave_rows < 64: the wavefront's last rows are not stored (they fall outside the descriptor)
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(Y + wbase), 0, wbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float *>(ADD ? Add + wbase : Y + wbase)), 0, wbytes, 0x00020000);
     const int voff = (4 * (lane >> 5) * cout + colb) * 4;
@@ -939,6 +939,9 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
     if (NP == 2 && __any(amax > 65504.0f) && lane == 0) atomicOr(range_flag, 1u);
 }
 
+// (Round 3: k3_sep_pair -- two consecutive 9-tap 128 -> 128 separable layers in one launch, the intermediate activations in LDS, 120-row
+// tiles, HBM bytes per pair 0.52 x -- is in tools/k3_sep_pair_experiment.hip: bit-identical, and slower (746 us per pair against 2 x 262):
+// one phase-locked 512-thread workgroup per CU loses to two independent k3_sep_split workgroups that overlap each other's phases.)
 #ifdef DN_WS_TRACE       /* experiment build only (tools/ws_trace.py): shader-clock stamps of one workgroup's phases */
 __device__ unsigned long long ws_trace[16][64];
 #define WS_T(i) do { if (blockIdx.x == DN_WS_TRACE && lane == 0) ws_trace[wave][i] = __builtin_amdgcn_s_memtime(); } while (0)
