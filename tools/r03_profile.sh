@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 evidence, everything into gpurun_out/r03/ (tools/r03_collect.py turns it into profiles/r03_*):
 #   (1) the default bench exactly as the driver runs it (BASELINE configs[2]: 10 000 x 50 kb, full pipeline, CPU baseline + fp32 leg)
-#   (2) the same workload under rocprofv3 --kernel-trace --stats (fewer steps: the trace of 25 batches is large)
+#   (2) the same command line under rocprofv3 --kernel-trace --stats (the per-kernel averages must agree with the bench line's own HIP-event means)
 #   (3) counter passes AT THE BENCH'S LAUNCH SHAPE (500 x 50 kb per step, 4 Mi-row CNN passes), one batch in flight, each its own run:
 #       WRITE_SIZE | FETCH_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 #   (4) configs[1] (banded scope) bench, and the same three counter passes for it
@@ -10,7 +10,7 @@
 OUT=gpurun_out/r03; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.log 2>&1; tail -1 $OUT/bench_default.log > $OUT/bench_default.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --no-cpu-baseline --fp32-steps 0 --steps 8 --warmup 6 > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --no-cpu-baseline --fp32-steps 0 --steps 20 --warmup 5 > $OUT/bench_under_rocprof.log 2>&1
 grep '^{"metric' $OUT/bench_under_rocprof.log | tail -1 > $OUT/bench_under_rocprof.json
 rm -f $OUT/stats/*kernel_trace.csv $OUT/stats/*/*kernel_trace.csv
 PMC_MFMA="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
