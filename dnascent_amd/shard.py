@@ -225,11 +225,13 @@ class WorkCounter:
         return self.store is not None and int(self.store.add(self.name + "_abort", 0)) > 0
 
 
-def gather_window(dist, ordinals, records, dst=0, device="cpu", chunk_bytes=64 << 20, error=False):
+def gather_window(dist, ordinals, records, dst=0, device="cpu", chunk_bytes=64 << 20, error=False, pending=None):
     """The records of ONE window to the writer rank: per peer a 24-byte header {n records, payload bytes, error flag} and the payload
     [(ordinal, length) * n, text] in pieces of at most `chunk_bytes` (the staging tensor on the device is bounded by the chunk, not by
     the window: round-2 advisor).  Point-to-point only: peers send, the writer receives peer by peer; no rank other than the writer
-    ever holds another rank's text.  Returns (merged [(ordinal, bytes)] sorted by ordinal, any_error) on `dst`, (None, None) elsewhere."""
+    ever holds another rank's text.  Returns (merged [(ordinal, bytes)] sorted by ordinal, any_error) on `dst`, (None, None) elsewhere.
+    pending (a list): the peers' sends are posted with isend and their (work, tensor) pairs appended to it instead of being waited for
+    -- a rank that is ahead of the writer then goes on pulling batches; the caller bounds how many windows it lets pile up."""
     import torch
     head = np.zeros(2 * len(records), dtype=np.int64)
     for j, (o, rec) in enumerate(zip(ordinals, records)):
@@ -240,9 +242,12 @@ def gather_window(dist, ordinals, records, dst=0, device="cpu", chunk_bytes=64 <
     if rank != dst:
         payload = np.frombuffer(head.tobytes() + b"".join(records), dtype=np.uint8)
         hd = torch.tensor([len(records), payload.shape[0], int(bool(error))], dtype=torch.int64, device=device)
-        dist.send(hd, dst)
-        for a in range(0, payload.shape[0], chunk_bytes):
-            dist.send(torch.from_numpy(payload[a:a + chunk_bytes].copy()).to(device), dst)
+        parts = [hd] + [torch.from_numpy(payload[a:a + chunk_bytes].copy()).to(device) for a in range(0, payload.shape[0], chunk_bytes)]
+        for t in parts:
+            if pending is None:
+                dist.send(t, dst)
+            else:
+                pending.append((dist.isend(t, dst), t))       # the tensor stays referenced until its send has completed
         return None, None
     merged = list(zip((int(o) for o in ordinals), records))
     any_err = bool(error)
@@ -282,7 +287,8 @@ class StreamDriver:
     write(merged records of one window) is called on the writer rank only, windows ascending.
     """
 
-    def __init__(self, dist, batches, window_of, engine, load, write, release=None, dst=0, device="cpu", chunk_bytes=64 << 20, counter=None):
+    def __init__(self, dist, batches, window_of, engine, load, write, release=None, dst=0, device="cpu", chunk_bytes=64 << 20, counter=None,
+                 max_pending_windows=2):
         self.dist, self.batches, self.window_of = dist, batches, window_of
         self.engine, self.load, self.write, self.release = engine, load, write, release
         self.dst, self.device, self.chunk = dst, device, chunk_bytes
@@ -297,6 +303,10 @@ class StreamDriver:
         self.batches_done = 0; self.busy_s = 0.0; self.gather_s = 0.0
         self.error = False
         self.rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
+        # a peer posts its window with isend and goes on (dynamic balance would otherwise stop at every window: the writer only receives
+        # window k when its own batches of k are done); at most max_pending_windows windows of text wait in a rank's send queue
+        self.max_pending_windows = max_pending_windows
+        self._sends = []             # per posted window: [(work, tensor), ...]
 
     def _collect_one(self):
         r = self.engine.collect()
@@ -322,8 +332,14 @@ class StreamDriver:
             recs = self.pending.pop(w, [])
             t0 = time.perf_counter()
             nbytes = sum(len(x[1]) for x in recs)
+            while len(self._sends) >= self.max_pending_windows:          # bound the text parked in this rank's send queue
+                for wk, _ in self._sends.pop(0):
+                    wk.wait()
+            posted = []
             merged, err = gather_window(self.dist, [x[0] for x in recs], [x[1] for x in recs], dst=self.dst, device=self.device,
-                                        chunk_bytes=self.chunk, error=self.error)
+                                        chunk_bytes=self.chunk, error=self.error, pending=posted if self.rank != self.dst else None)
+            if posted:
+                self._sends.append(posted)
             self.gather_s += time.perf_counter() - t0
             if merged is not None:
                 self.max_gather_bytes = max(self.max_gather_bytes, sum(len(x[1]) for x in merged))
@@ -394,4 +410,8 @@ class StreamDriver:
             self._flush_ready()
         self.busy_s = time.perf_counter() - t_busy0 - self.gather_s
         self._flush_ready(final=True)                          # every rank walks ALL windows: the gathers always pair up
+        for posted in self._sends:
+            for wk, _ in posted:
+                wk.wait()
+        self._sends = []
         return not self.error

@@ -158,8 +158,9 @@ def _stream_worker(rank, world, port, q, bad_at):
         def release(_):
             live[0] -= 1
 
-        eng = _FakeEngine(depth=3, delay=0.004 if rank == 0 else 0.001)                  # rank 1 is 4x faster: it must take more batches
+        eng = _FakeEngine(depth=3, delay=0.03 if rank == 0 else 0.003)                   # rank 1 is 10x faster: it must take more batches
         drv = shard.StreamDriver(dist, batches, window_of, eng, load, lambda m: written.extend(m), release=release, dst=0, chunk_bytes=700)
+        dist.barrier()                                           # both ranks start pulling together (process start-up skew is not what is tested)
         ok = drv.run()
         tot = shard.reduce_counters(dist, [drv.n_ok, drv.n_fail, drv.batches_done])
         q.put((rank, ok, tot, written, drv.batches_done, drv.peak_pending_bytes, drv.max_gather_bytes, live[1], len(batches), drv.n_windows))
