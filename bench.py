@@ -36,6 +36,8 @@ sys.path.insert(0, ROOT)
 # Every in-flight batch has its own HIP stream; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and
 # streams that share a queue serialise.  Must be set before the HIP runtime initialises (torch or libdnascent_hip).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the host library's OpenMP teams must SLEEP between their loops: spinning threads starve the HIP runtime's callback thread (dn_host.cpp hostThreads)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 import numpy as np  # noqa: E402
 

@@ -8,8 +8,24 @@
 #include <time.h>
 
 #include <algorithm>
+#include <omp.h>
+#include <stdlib.h>
 
 namespace DNAscent {
+
+// Threads of the host-side parallel loops (record formatting, container reads).  NOT every hardware thread: on the 256-thread hosts of the
+// pool a 256-wide team that spin-waits after its loop (libgomp's default wait policy) starves the HIP runtime's callback thread -- the one
+// that computes the per-read libm constants between two stream operations -- and formats SLOWER: 1.63 s against 0.30 s of emission per
+// 8 000 reads, 657-667 against 704 Msamples/s end to end (round 3, gpurun_out/r3t).  DN_HOST_THREADS overrides; the Python drivers also
+// export OMP_WAIT_POLICY=passive before the library loads.
+int hostThreads() {
+    static const int n = [] {
+        const char *e = getenv("DN_HOST_THREADS");
+        const int want = e ? atoi(e) : 64;
+        return std::max(1, std::min(want > 0 ? want : 64, omp_get_max_threads()));
+    }();
+    return n;
+}
 
 std::string reverseComplement(const std::string &s) {
     // common.h:91-150: reverse, then complement (IUPAC codes the reference maps are kept; anything else is dropped there,
@@ -341,7 +357,7 @@ void modBamFields(size_t n, const uint32_t *queryIdx, const uint32_t *refIdx, co
 void formatCalls(const ReadBatch &batch, const dn_result_batch &res, bool humanReadable, std::vector<ReadCalls> &calls) {
     const long n = (long)batch.size();
     calls.assign((size_t)n, ReadCalls());
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(hostThreads())
     for (long r = 0; r < n; r++) {
         if (res.summary[r].status != DN_READ_OK) continue;                 // detect.cpp:879-894: failed reads are counted, not written
         const uint64_t o = res.call_off[r], k = res.call_off[r + 1] - o;
@@ -706,7 +722,7 @@ int64_t dnh_container_load_at(void *b, const char *path, const uint64_t *offsets
         const uint64_t m = std::min(chunk, n - c0);
         std::vector<DNAscent::OwnedRead> rd((size_t)m);
         std::vector<uint8_t> ok((size_t)m, 0);
-#pragma omp parallel
+#pragma omp parallel num_threads(DNAscent::hostThreads())
         {
             DNAscent::ReadContainerReader r;
             const bool open_ok = r.open(path);

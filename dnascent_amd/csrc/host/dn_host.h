@@ -41,6 +41,7 @@ int parseCigar(const std::vector<uint32_t> &ops, const std::vector<uint32_t> &le
                std::vector<uint32_t> &ref2query, std::vector<int32_t> &query2ref, std::vector<uint8_t> &ref2del);
 
 std::string reverseComplement(const std::string &s);    // common.h:91
+int hostThreads();                                       // threads of the host-side parallel loops (DN_HOST_THREADS, default min(64, cores))
 
 class ReadBatch {
 public:

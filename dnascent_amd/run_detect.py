@@ -38,6 +38,8 @@ import time
 import numpy as np
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the host library's OpenMP teams must SLEEP between their loops: spinning threads starve the HIP runtime's callback thread (dn_host.cpp hostThreads)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 
 def load_pore_model(path):
