@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--emit", type=int, default=1, help="full scope: format + write the .detect records inside the timed region")
     ap.add_argument("--out", default=None, help="full scope: .detect output path (default: formatted and counted, not written)")
     ap.add_argument("--cnn-math", choices=["f16x3", "bf16x6", "fp32"], default=None)
+    ap.add_argument("--pin", type=int, default=0, help="page-lock the input batches (dn_host_register, before the timed region): uploads become asynchronous")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32-steps", type=int, default=4, help="full scope, 1 GPU: after the run, this many steps again with the CNN in exact fp32 MFMA "
                                                               "arithmetic (value_fp32: the headline metric without the 16-bit split); 0 = off")
@@ -202,6 +203,9 @@ def main():
         assert got == rps, (got, rps)
         batches.append(B)
     t_gen = time.perf_counter() - t_gen
+    if args.pin and full:
+        for B in batches:
+            B.pin()
 
     def barrier():
         for c in ctxs:
