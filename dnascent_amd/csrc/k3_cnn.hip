@@ -204,21 +204,68 @@ __device__ __forceinline__ f32x16 enc_mma3(const gh16x8 ah, const gh16x8 al, con
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
 }
-__global__ __launch_bounds__(64, 16) void k3_encode_mfma(const float *core, const float *resid, const float *sig, const uint64_t *perm_src,
-                                                     const unsigned *perm_row, const unsigned *hist, uint8_t *valid_out, float *out,
-                                                     const float *wts, dn_cnn_op op) {
+// The order by signal length is LOCAL here: a workgroup takes 256 consecutive positions of one sequence, counting-sorts them by descending
+// length in LDS and hands 32 of them to each of its 8 wavefronts -- within 256 positions the lengths (3 .. 20, mean ~10) already fill
+// every wavefront with one or two adjacent values, and the two global sort kernels of k3_encode (histogram + atomically placed
+// permutation: 0.27 ms per 1.2 M positions beside 0.58 for this kernel behind them; 0.65 ms like this) are not launched.
+#ifndef ENC_WG
+#define ENC_WG 512                                         // threads of a k3_encode_mfma workgroup: 8 wavefronts of 32 positions (two lanes each)
+#endif
+__global__ __launch_bounds__(ENC_WG, 2) void k3_encode_mfma(const float *core, const float *resid, const float *sig, CnnRows R, uint8_t *valid_out, float *out,
+                                                         const float *wts, dn_cnn_op op) {
     // constant tiles (float, [tile][16 registers][lane half]: a lane's values depend on its half only, so the reads are broadcasts):
     // accumulator initial values of the four tiles, layer 1's input kernel (z, r, g) and its candidate gate's input bias
     __shared__ float ctile[6][16][2];
-    unsigned n_total = 0;
-    for (int b = 0; b < DN_RAWDEPTH_DEV + 1; b++) n_total += hist[b];
-    const int lane = threadIdx.x, p = lane & 31, hh = lane >> 5;
-    if (blockIdx.x * 32 >= n_total) return;
-    const unsigned i = blockIdx.x * 32 + p;
-    const bool live = i < n_total;
+    __shared__ unsigned lh[DN_RAWDEPTH_DEV + 1], lbase[DN_RAWDEPTH_DEV + 1];
+    __shared__ unsigned short order[ENC_WG / 2];
+    const int r = R.r0 + blockIdx.y;
+    const unsigned npos = R.n_pos[r], p0 = blockIdx.x * (ENC_WG / 2);
+    if (p0 >= npos) return;                                // workgroup-uniform: the grid covers the bound of the positions
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, hh = lane >> 5;
+    const uint64_t seq0 = R.io_off[r];
+    {   // ---- thread tid < ENC_WG / 2 looks at position p0 + tid: its signal length (index of the last non-zero sample + 1; 0 beyond the sequence) ----
+        if (tid < DN_RAWDEPTH_DEV + 1) lh[tid] = 0;
+        __syncthreads();
+        unsigned len = 0, rank = 0;
+        if (tid < ENC_WG / 2) {
+            if (p0 + tid < npos) {
+                const float4 *x = reinterpret_cast<const float4 *>(sig + (seq0 + p0 + tid) * DN_RAWDEPTH_DEV);   // 80-byte rows: 16-byte aligned
+#pragma unroll
+                for (int q = 0; q < DN_RAWDEPTH_DEV / 4; q++) {
+                    const float4 v = x[q];
+                    if (v.x != 0.0f) len = 4 * q + 1;
+                    if (v.y != 0.0f) len = 4 * q + 2;
+                    if (v.z != 0.0f) len = 4 * q + 3;
+                    if (v.w != 0.0f) len = 4 * q + 4;
+                }
+            }
+            rank = atomicAdd(&lh[len], 1u);
+        }
+        __syncthreads();
+        if (tid < DN_RAWDEPTH_DEV + 1) { unsigned longer = 0; for (int b = tid + 1; b < DN_RAWDEPTH_DEV + 1; b++) longer += lh[b]; lbase[tid] = longer; }
+        __syncthreads();
+        if (tid < ENC_WG / 2) order[lbase[len] + rank] = (unsigned short)tid;   // longest first; positions beyond the sequence (length 0, with the masked ones) last
+        __syncthreads();
+    }
+    const unsigned pp = p0 + order[32 * wave + p];        // the position this lane pair works on
+    const bool live = pp < npos;
+    const bool idle = __ballot(live) == 0;                 // a wavefront with nothing but positions beyond the sequence: it only joins the barrier below
     const float *K1 = wts + op.aux[0], *R1 = wts + op.aux[1], *b1 = wts + op.aux[2];
     const float *K2 = wts + op.aux[3], *R2 = wts + op.aux[4], *b2 = wts + op.aux[5];
     auto unit = [&](int e, int half) { return (e & 3) + 8 * (e >> 2) + 4 * half; };
+    // ---- constant tiles: register q of lane (p, hh) belongs to block q >> 3, unit(q & 7, hh) ----
+    if (tid < 32) {                                        // 32 (register, half) slots, one thread each (wavefront 0, idle or not)
+        const int q = tid >> 1, hf = tid & 1;
+        const int u = unit(q & 7, hf), blk = q >> 3;
+        ctile[0][q][hf] = blk == 0 ? b1[u] + b1[48 + u] : b1[16 + u] + b1[64 + u];       // layer 1 [z; r]: input bias + recurrent bias
+        ctile[1][q][hf] = blk == 0 ? b1[80 + u] : 0.0f;                                    // layer 1 [g_rec; -]
+        ctile[2][q][hf] = blk == 0 ? b2[u] + b2[48 + u] : b2[16 + u] + b2[64 + u];       // layer 2 [z; r]
+        ctile[3][q][hf] = blk == 0 ? b2[32 + u] : b2[80 + u];                              // layer 2 [xh; hh_rec]
+        ctile[4][q][hf] = blk == 0 ? K1[u] : K1[16 + u];                                   // layer 1 input kernel: z | r
+        ctile[5][q][hf] = blk == 0 ? K1[32 + u] : b1[32 + u];                              // ... g | the candidate gate's input bias
+    }
+    __syncthreads();
+    if (idle) return;
     // ---- A fragments: lane = output row i_ = lane & 31 of the tile, k' = 8 hh + kk <-> input unit(kk, hh) ----
     auto afrag = [&](const float *Wlo, int col_lo, const float *Whi, int col_hi, gh16x8 &ah, gh16x8 &al) {
         // rows 0-15 of the tile: column col_lo + row of matrix Wlo ([16][48]); rows 16-31: column col_hi + (row - 16) of Whi; nullptr = zero rows
@@ -237,23 +284,11 @@ __global__ __launch_bounds__(64, 16) void k3_encode_mfma(const float *core, cons
     afrag(R2, 0, R2, 16, aR2a_h, aR2a_l);                 // ... recurrent part
     afrag(K2, 32, nullptr, 0, aK2b_h, aK2b_l);            // layer 2 [xh; 0] from n1
     afrag(nullptr, 0, R2, 32, aR2b_h, aR2b_l);            // layer 2 [0; hh_rec] from h2
-    // ---- constant tiles: register q of lane (p, hh) belongs to block q >> 3, unit(q & 7, hh) ----
-    if (lane < 32) {                                       // 32 (register, half) slots, one lane each
-        const int q = lane >> 1, hf = lane & 1;
-        const int u = unit(q & 7, hf), blk = q >> 3;
-        ctile[0][q][hf] = blk == 0 ? b1[u] + b1[48 + u] : b1[16 + u] + b1[64 + u];       // layer 1 [z; r]: input bias + recurrent bias
-        ctile[1][q][hf] = blk == 0 ? b1[80 + u] : 0.0f;                                    // layer 1 [g_rec; -]
-        ctile[2][q][hf] = blk == 0 ? b2[u] + b2[48 + u] : b2[16 + u] + b2[64 + u];       // layer 2 [z; r]
-        ctile[3][q][hf] = blk == 0 ? b2[32 + u] : b2[80 + u];                              // layer 2 [xh; hh_rec]
-        ctile[4][q][hf] = blk == 0 ? K1[u] : K1[16 + u];                                   // layer 1 input kernel: z | r
-        ctile[5][q][hf] = blk == 0 ? K1[32 + u] : b1[32 + u];                              // ... g | the candidate gate's input bias
-    }
-    __syncthreads();
     auto tile = [&](int t) { f32x16 c;
 #pragma unroll
         for (int q = 0; q < 16; q++) c[q] = ctile[t][q][hh];
         return c; };
-    const uint64_t src = perm_src[live ? i : 0];
+    const uint64_t src = seq0 + (live ? pp : p0);
     float h1[8], h2[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) { h1[e] = 0.f; h2[e] = 0.f; }
@@ -294,7 +329,7 @@ __global__ __launch_bounds__(64, 16) void k3_encode_mfma(const float *core, cons
         enc_split8(h1, h1h, h1l); enc_split8(h2, h2h, h2l);
     }
     if (!live) return;
-    const unsigned row = perm_row[i];
+    const unsigned row = R.row_off[r] + pp;
     float4 *o = reinterpret_cast<float4 *>(out + (size_t)row * 64);
     o[hh] = make_float4(h2[0], h2[1], h2[2], h2[3]);              // units 4 hh .. 4 hh + 3
     o[2 + hh] = make_float4(h2[4], h2[5], h2[6], h2[7]);          // units 8 + 4 hh ..
@@ -1424,14 +1459,16 @@ int k3_run(const CnnRun &c, hipStream_t st) {
         switch (o.op) {
             case DN_CNN_ENCODE_GRU:
                 hipMemsetAsync(pb[o.dst], 0, (size_t)rows * 64 * sizeof(float), st);
+                if (c.n_pass_pos && k3_encode_mfma_enabled(c)) {       // sorts by signal length inside its workgroups
+                    hipLaunchKernelGGL(k3_encode_mfma, dim3((c.max_pos + ENC_WG / 2 - 1) / (ENC_WG / 2), c.rows.r1 - c.rows.r0), dim3(ENC_WG), 0, st, c.core, c.resid, c.sig,
+                                       c.rows, c.valid, pb[o.dst], c.wts, o);
+                    break;
+                }
                 hipMemsetAsync(c.enc_hist, 0, 2 * ENC_BINS * sizeof(unsigned), st);
                 hipLaunchKernelGGL(k3_encode_len, dim3((c.max_pos + 255) / 256, c.rows.r1 - c.rows.r0), dim3(256), 0, st, c.sig, c.rows, c.enc_len, c.enc_hist);
                 hipLaunchKernelGGL(k3_encode_perm, dim3((c.max_pos + 255) / 256, c.rows.r1 - c.rows.r0), dim3(256), 0, st, c.rows, c.enc_len, c.enc_hist,
                                    c.enc_hist + ENC_BINS, c.perm_src, c.perm_row);
-                if (c.n_pass_pos && k3_encode_mfma_enabled(c))
-                    hipLaunchKernelGGL(k3_encode_mfma, dim3((c.n_pass_pos + 31) / 32), dim3(64), 0, st, c.core, c.resid, c.sig, c.perm_src, c.perm_row, c.enc_hist,
-                                       c.valid, pb[o.dst], c.wts, o);
-                else if (c.n_pass_pos)
+                if (c.n_pass_pos)
                     hipLaunchKernelGGL(k3_encode, dim3((c.n_pass_pos + 63) / 64), dim3(64), 0, st, c.core, c.resid, c.sig, c.perm_src, c.perm_row, c.enc_hist,
                                        c.valid, pb[o.dst], c.wts, o);
                 break;
