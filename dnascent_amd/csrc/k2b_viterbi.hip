@@ -68,23 +68,39 @@ __device__ __forceinline__ double in_vgpr(double x) { asm volatile("" : "+v"(x))
 // one lattice cell (alignment.cpp:278-285/:351-356 insertion, :305-310/:372-381 match, :326-328/:408-413 deletion).
 // Position 0 has no left neighbour and may come from START instead; it is expressed through the INPUTS so the cell has
 // no per-lane special case: for lane 0 the shifted-in left values are log(0), `s0` carries start_prev (0 at t == 0, log(0)
-// after; log(0) for every other lane) and tr3 is eOrI instead of D2M.  The codes a position-0 cell records are
-// re-read accordingly in the traceback (M: 3 means START, else M_0;  D: always START).
+// after; log(0) for every other lane) and tr3 is eOrI instead of D2M.
 // ("+ insProb" with insProb == 0.0 is dropped: it can only change the sign of an exact zero.)
+// What a cell records for the traceback is the DECODED move of each of its three states, so that the serial walk is a shift and a
+// mask per step (round 3; it used to record the arg-max index and the walk re-derived the move, position 0's special cases included):
+//   bits 0-2  from M: next state (0 D, 1 M, 2 I, 3 = START: the walk ends) | 4 if the move steps one position left
+//   bits 3-4  from I: next state (1, 2 or 3)                 (an insertion stays at its position)
+//   bits 5-6  from D: next state (0, 1 or 3)                 (a deletion always steps left, along the column)
+// The values are the arg-max chain's own selects with other constants (VitCodes: per lane, position 0 differs), at no extra cost.
+struct VitCodes { unsigned m0, m1, m2, m3, d0, d1; };
+__device__ __forceinline__ VitCodes vit_codes(bool pos0) {
+    VitCodes k;
+    k.m0 = pos0 ? 1u : (2u | 4u);        // arg-max 0: from I at the left position            position 0: {M_0, START}: anything but 3 is M_0 one
+    k.m1 = pos0 ? 1u : (1u | 4u);        //         1: from M at the left position                        column earlier, same position
+    k.m2 = 1u;                           //         2: from M at the same position
+    k.m3 = pos0 ? 3u : (0u | 4u);        //         3: from D at the left position            position 0: START
+    k.d0 = pos0 ? (3u << 5) : (1u << 5); // deletion from M at the left position              position 0: D_0 always comes from START
+    k.d1 = pos0 ? (3u << 5) : (0u << 5); //          from D at the left position
+    return k;
+}
 __device__ __forceinline__ void vit_cell(const double s0, const double l3, const double tr3, const double Ip, const double Mp,
                                          const double lI2, const double lM2, const double lM1, const double lD1, const double e,
-                                         const VitHot &vc, const VitHot &vr, double &In, double &Mn, double &Dn, unsigned &code) {
-    double bi = Ip + vc.I2I; unsigned ci = 0;
-    { const double v = Mp + vc.M2I; if (ln_gt(v, bi)) { bi = v; ci = 1; } }
-    { const double v = s0 + vc.M2I; if (ln_gt(v, bi)) { bi = v; ci = 2; } }
-    double bm = lI2 + vc.I2M + e; unsigned cm = 0;
-    { const double v = lM2 + vr.eM2M + e; if (ln_gt(v, bm)) { bm = v; cm = 1; } }
-    { const double v = Mp + vr.iM2M + e;  if (ln_gt(v, bm)) { bm = v; cm = 2; } }
-    { const double v = l3 + tr3 + e;      if (ln_gt(v, bm)) { bm = v; cm = 3; } }
-    double bd = lM1 + vc.M2D; unsigned cd = 0;
-    { const double v = lD1 + vc.D2D; if (ln_gt(v, bd)) { bd = v; cd = 1; } }
+                                         const VitHot &vc, const VitHot &vr, const VitCodes &k, double &In, double &Mn, double &Dn, unsigned &code) {
+    double bi = Ip + vc.I2I; unsigned ci = 2u << 3;                                        // from I: stays I
+    { const double v = Mp + vc.M2I; if (ln_gt(v, bi)) { bi = v; ci = 1u << 3; } }         // from M
+    { const double v = s0 + vc.M2I; if (ln_gt(v, bi)) { bi = v; ci = 3u << 3; } }         // from START
+    double bm = lI2 + vc.I2M + e; unsigned cm = k.m0;
+    { const double v = lM2 + vr.eM2M + e; if (ln_gt(v, bm)) { bm = v; cm = k.m1; } }
+    { const double v = Mp + vr.iM2M + e;  if (ln_gt(v, bm)) { bm = v; cm = k.m2; } }
+    { const double v = l3 + tr3 + e;      if (ln_gt(v, bm)) { bm = v; cm = k.m3; } }
+    double bd = lM1 + vc.M2D; unsigned cd = k.d0;
+    { const double v = lD1 + vc.D2D; if (ln_gt(v, bd)) { bd = v; cd = k.d1; } }
     In = bi; Mn = bm; Dn = bd;
-    code = ci | (cm << 2) | (cd << 5);
+    code = ci | cm | cd;
 }
 
 template <class C> __device__ __forceinline__ double emission(double x, double mu, const C &vc) {
@@ -112,6 +128,16 @@ template <class C> __device__ __forceinline__ double emission(double x, double m
 // do that ONE window and hand back (redo = 2).  mode 2 (224): they continue; a second oversized window stops them again (redo = 3).
 // mode 3 (512): those go on to their end.  Round 2 redid such a read FROM ITS FIRST WINDOW in the 512 variant: a handful of wavefronts
 // held the batch for up to 105 ms (rocprof max of k2b_eventalign<512>), longer than the whole first pass.
+#ifdef DN_K2B_TRACE       /* experiment build only (tools/k2b_trace.py): shader-clock ticks per phase of the window walk, summed over all reads */
+__device__ unsigned long long k2b_trace[8];
+extern "C" int dn_debug_k2b_trace(unsigned long long *out, int reset) {
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(k2b_trace), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(k2b_trace), sizeof(k2b_trace));
+}
+#define K2B_T(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[k] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define K2B_T(k) do { } while (0)
+#endif
 template <int TMAX>
 __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const VitRead *vrs, VitConsts vc, int mode) {
     __shared__ double xs[TMAX];                           // scaled observations of the window
@@ -161,7 +187,16 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
         if (lane == 0) { saved[0] = (unsigned)ri; saved[1] = readHead; saved[2] = npos; saved[3] = nwin; saved[4] = al_rows; O.redo[r] = next; }
     };
 
+#ifdef DN_K2B_TRACE
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
     while (ri < n_ref - (DN_K - 1)) {                     // alignment.cpp:556
+        K2B_T(6);
+        // the walk's state is wave-uniform by construction; say so, or one value the compiler cannot prove uniform turns the whole window loop
+        // (its branches, the traceback) into divergent code with execution masks
+        ri = __builtin_amdgcn_readfirstlane(ri); readHead = (unsigned)__builtin_amdgcn_readfirstlane((int)readHead);
+        npos = (unsigned)__builtin_amdgcn_readfirstlane((int)npos); nwin = (unsigned)__builtin_amdgcn_readfirstlane((int)nwin);
+        al_rows = (unsigned)__builtin_amdgcn_readfirstlane((int)al_rows);
         const int toEnd = n_ref - ri;
         int W = toEnd < 50 ? toEnd : 50;
         if ((double)toEnd > 75.0) {                       // :564 break-point search in a 75-base look-ahead
@@ -183,6 +218,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             if (__any(bad)) { ri += W; continue; }        // :599-604
         }
         const int N = W - (DN_K - 1);
+        K2B_T(0);
         const unsigned qlo = r2q[ri], qhi = r2q[ri + W - DN_K + 1];
         // ---- events rough-aligned to the window (:611-632), order-preserving compaction ----
         unsigned nt = 0; bool first = true;
@@ -210,14 +246,16 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             if (TMAX < VT_TMAX) { park(mode == 0 ? 1 : 3); return; }          // wave-uniform: THIS window goes to the large lattice (readHead already
             fail = 6; break;                                                  // points at its first event: gathering it again gives the same events)
         }
-        const int T = (int)nt;
+        const int T = __builtin_amdgcn_readfirstlane((int)nt);
         __syncthreads();
+        K2B_T(1);
         const int coord0 = is_rev ? (ref_end - ri - DN_K / 2) : (ref_start + ri + DN_K / 2);
 
         // ---- Viterbi, anti-diagonal sweep: lane i = position i, time t = d - i ----
         const bool is0 = lane == 0;
         const double mu = (lane < N) ? model[rank_r[ri + lane]] : 0.0;
         const double tr3 = is0 ? vr.eOrI : vc.D2M;
+        const VitCodes kc = vit_codes(is0);
         double I1 = NaN, M1 = NaN, D1 = (lane < VT_NS) ? vc.initD[lane] : NaN;       // own last results (init column, :234-251)
         double oI2 = I1, oM2 = M1, oD2 = D1;                                       // own results one step earlier (tail cell only)
         double sI1 = NaN, sM1 = NaN, sD1 = shl_prev_d(D1, NaN, lane);              // lane i-1's results of the last step
@@ -227,14 +265,18 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
         const double mu64 = tail ? model[rank_r[ri + 64]] : 0.0;
         double tI = NaN, tM = NaN, tD = vc.initD[64];
         const int nsteps = T + N - 1;                      // N == 65: T + 64 steps also cover the tail cell's last step
+        // the observation of lane i at step d is xs[d - i]: what lane i - 1 held one step earlier.  It travels through the lanes like the
+        // states do (DPP shift); only lane 0 reads LDS, one step ahead -- the read used to sit on every step's critical path.
+        double xq = xs[0];
 #pragma unroll 2
         for (int d = 0; d < nsteps; d++) {
+            const double x0n = xs[min(d + 1, T - 1)];      // lane 0's next observation (wave-uniform address)
             if (tail) {
                 const int t64 = d - 64;
                 if (t64 >= 0 && t64 < T) {                 // uses lane 63's results of steps d-1 (time t64) and d-2 (time t64-1)
                     const double e = emission(xs[t64], mu64, hot);
                     double In, Mn, Dn; unsigned code;
-                    vit_cell(NaN, oD2, hot.D2M, tI, tM, oI2, oM2, M1, D1, e, hot, hot, In, Mn, Dn, code);
+                    vit_cell(NaN, oD2, hot.D2M, tI, tM, oI2, oM2, M1, D1, e, hot, hot, kc, In, Mn, Dn, code);   // (lane 63 stores it: not position 0's codes)
                     tI = In; tM = Mn; tD = Dn;
                     if (lane == 63) bt[(t64 + 1) * VT_NS + 64] = (unsigned char)code;
                 }
@@ -242,16 +284,18 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             }
             const int t = d - lane;
             const bool act = (t >= 0) && (t < T) && (lane < N);
-            const double e = emission(xs[act ? t : 0], mu, hot);
+            const double e = emission(xq, mu, hot);
             const double s0 = (is0 && t == 0) ? 0.0 : NaN;                          // start_prev (:235, :432), position 0 only
             const double l3 = is0 ? s0 : sD2;
             double a, b, c2; unsigned code;
-            vit_cell(s0, l3, tr3, I1, M1, sI2, sM2, sM1, sD1, e, hot, hot, a, b, c2, code);
+            vit_cell(s0, l3, tr3, I1, M1, sI2, sM2, sM1, sD1, e, hot, hot, kc, a, b, c2, code);
             if (act) { bt[(t + 1) * VT_NS + lane] = (unsigned char)code; I1 = a; M1 = b; D1 = c2; }
             sI2 = sI1; sM2 = sM1; sD2 = sD1;
             sI1 = shl_prev_d(I1, NaN, lane); sM1 = shl_prev_d(M1, NaN, lane); sD1 = shl_prev_d(D1, NaN, lane);
+            xq = shl_prev_d(xq, x0n, lane);
         }
         __syncthreads();
+        K2B_T(2);
         // ---- termination (:446-476) ----
         double fD, fM, fI;
         if (tail) { fD = bcast_d(tD, 63); fM = bcast_d(tM, 63); fI = bcast_d(tI, 63); }
@@ -260,49 +304,70 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
         { const double v = fM + vr.eM2MorD; if (ln_gt(v, score)) { score = v; st = 1; } }
         { const double v = fI + vc.I2M; if (ln_gt(v, score)) { score = v; st = 2; } }
         // ---- traceback (:460-509), wave-uniform.  Every emitting state (M or I) visited at column col emitted observation
-        // col-1, so the walk writes one label per observation; silent D states only move along the column. ----
+        // col-1, so the walk writes one label per observation; silent D states only move along the column.
+        // The walk is a serial chain of look-ups, one per observation.  Round 3 (tools/k2b_trace.py, ticks per window of the 500 x 50 kb
+        // batch): its state lives in SCALAR registers (the window loop's state is provably wave-uniform now, see the top of the loop), the
+        // bytes of a column sit in a vector register (lane = position; position 64 in the second byte), fetched a block of 8 columns ahead,
+        // and a step is v_readlane + a shift and two masks on the decoded move: 77 k -> 34 k.  Before, the compiler had the whole window
+        // loop as DIVERGENT code -- every `if` an execution-mask dance, ~600 ticks per step of this walk -- because one loop-carried value
+        // (lastM_ref) came out of a shuffle; with only that repaired the walk took 57 k, and the branchy scalar form of it 58 k. ----
         {
             int i = N - 1, col = T;
-            bool done = false;
-            int guard = 3 * N * (T + 1) + 8;
-            // (Round 2 phase trace, 500 x 50 kb, cycles per window: event gather 9 k, lattice 103 k, termination + this walk 72 k, feature fill
-            // 15 k.  The walk is a serial chain of LDS look-ups, ~360 cycles per step; a version with the lattice row in a register, the next
-            // row prefetched and the walk on the scalar unit (v_readlane with the scalar position) was bit-identical and no faster alone
-            // (81.3 against 82.4 ms) or in the pipeline: the chain is LDS latency, which other wavefronts of the SIMD fill.  Not kept.)
+            st = __builtin_amdgcn_readfirstlane(st);
             // labels are parked in registers (lane = observation & 63) and leave through ONE 64-lane LDS store per 64
             // observations: a single-lane LDS store per step costs ~50 cycles in this wave-uniform walk
             unsigned lab = 0u; int last_ob = -1;
-            while (!done && guard-- > 0) {
-                const unsigned code = (col > 0) ? bt[col * VT_NS + i] : 0u;
-                if (st == 0) {
-                    const unsigned cdx = (i == 0) ? 2u : ((col == 0) ? 1u : ((code >> 5) & 3u));    // D_0 always comes from START
-                    if (cdx == 2) done = true; else { st = (cdx == 0) ? 1 : 0; i -= 1; }
-                } else if (col <= 0) {
-                    done = true;                             // only reachable in an all-log(0) lattice
-                } else {
-                    {
-                        const int ob = col - 1;
-                        lab = (lane == (ob & 63)) ? (unsigned)((st << 8) | i) : lab;
-                        if ((ob & 63) == 0) evlab[ob + lane] = (unsigned short)lab;       // observations ob .. ob + 63 are complete
-                        last_ob = ob;
-                    }
-                    if (st == 1) {
-                        unsigned cmx = (code >> 2) & 7u;
-                        if (i == 0) cmx = (cmx == 3u) ? 4u : 2u;                 // position 0: {M_0, START}
-                        if (cmx == 4) done = true;
-                        else { st = (cmx == 0) ? 2 : ((cmx == 3) ? 0 : 1); i -= (cmx != 2) ? 1 : 0; }
-                    } else {
-                        const unsigned cix = code & 3u;
-                        if (cix == 2) done = true; else st = (cix == 0) ? 2 : 1;
-                    }
-                    col -= 1;
+            int done = 0;
+            // codes of 8 columns per block: low byte = the lane's position, second byte = position 64 (wave-uniform); the next block's
+            // bytes are requested while this one is walked, so no LDS latency sits between two steps
+            unsigned nlo[8], nhi[8];
+            auto fetch = [&](int c0) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int c = c0 - k, cc = c < 1 ? 1 : c;                      // columns that do not exist are never looked at
+                    nlo[k] = bt[cc * VT_NS + lane]; nhi[k] = bt[cc * VT_NS + 64];
                 }
-                if (col < 0 || i < 0) done = true;          // cannot happen for a finite score; guards all-log(0) lattices
+            };
+            fetch(T);
+            for (int cb = T; !done; cb -= 8) {
+                unsigned rows[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) rows[k] = nlo[k] | (nhi[k] << 8);
+                fetch(cb - 8);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {                // col == cb - k here unless the walk is done
+                    auto code_at = [&]() -> unsigned {
+                        const unsigned both = (unsigned)__builtin_amdgcn_readlane((int)rows[k], i & 63);
+                        return ((i >> 6) ? (both >> 8) : both) & 0xffu;
+                    };
+                    while (st == 0 && !done) {               // silent deletions: along the column
+                        const unsigned nx = (col > 0) ? ((code_at() >> 5) & 3u) : ((i == 0) ? 3u : 0u);   // column 0 (alignment.cpp:241-251): D all the way to D_0 <- START
+                        if (nx == 3u) done = 1; else { st = (int)nx; i -= 1; }
+                    }
+                    if (!done) {
+                        if (col <= 0) done = 1;              // only reachable in an all-log(0) lattice
+                        else {
+                            const unsigned code = code_at();
+                            const int ob = col - 1;
+                            lab = (lane == (ob & 63)) ? (unsigned)((st << 8) | i) : lab;
+                            if ((ob & 63) == 0) evlab[ob + lane] = (unsigned short)lab;       // observations ob .. ob + 63 are complete
+                            last_ob = ob;
+                            const unsigned isM = (st == 1) ? 1u : 0u;
+                            const unsigned f = code >> (isM ? 0u : 3u);                       // the state's field at bit 0
+                            const unsigned nx = f & 3u;
+                            i -= (int)((f >> 2) & isM);                                       // only a match can step left
+                            done = (nx == 3u) ? 1 : 0;
+                            st = done ? st : (int)nx;
+                            col -= 1;
+                        }
+                    }
+                }
             }
             // a walk that stopped inside a group of 64 (only in an all-log(0) lattice) still leaves what it labelled
             if (last_ob > 0 && (last_ob & 63) != 0 && lane >= (last_ob & 63)) evlab[(last_ob & ~63) + lane] = (unsigned short)lab;
         }
         __syncthreads();
+        K2B_T(3);
         // ---- window log ----
         if (lane == 0) {
             O.win_ref[f0 + nwin] = (unsigned)ri; O.win_len[f0 + nwin] = (unsigned)W; O.win_T[f0 + nwin] = (unsigned)T;
@@ -361,8 +426,8 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
                 // carries
                 if (mm) {
                     const int ll = 63 - __clzll((long long)mm);
-                    carry_pos = (int)(__shfl((int)L, ll) & 0xff);
-                    carry_cnt = __shfl(before + len, ll);
+                    carry_pos = __builtin_amdgcn_readlane((int)L, ll) & 0xff;        // readlane, not a shuffle: the walk's state (ri, readHead through
+                    carry_cnt = (unsigned)__builtin_amdgcn_readlane((int)(before + len), ll);   // lastM_*) must stay PROVABLY wave-uniform, or the whole window loop is compiled as divergent code
                     lastM_ev = base + ll; lastM_ref = carry_pos;
                 }
                 carry_slots += (unsigned)__popcll(hm);
@@ -389,6 +454,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
                 O.indel[f0 + slot] = indel; O.nsig[f0 + slot] = ps_cnt[q];
             }
         }
+        K2B_T(4);
         // ---- `align` table rows of this window (:697-733): events in order, each with all of its raw samples ----
         if (O.al_val) {
             unsigned carry = 0;
@@ -403,7 +469,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
 #pragma unroll
                 for (int dlt = 1; dlt < 64; dlt <<= 1) { const unsigned up = __shfl_up(run, dlt); if (lane >= dlt) run += up; }
                 if (in) ev_aoff[e] = emit ? (al_rows + carry + run - len) : 0xffffffffu;
-                carry += __shfl(run, 63);
+                carry += (unsigned)__builtin_amdgcn_readlane((int)run, 63);
             }
             __syncthreads();
             const unsigned long long A0 = O.al_off[r];
@@ -424,11 +490,18 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             }
             al_rows += carry;
         }
+        K2B_T(5);
+#ifdef DN_K2B_TRACE
+        tacc[7] += 1;
+#endif
         readHead += (unsigned)lastM_ev + 1u;                // :739-740
         ri += lastM_ref + 1;
         __syncthreads();
         if (mode == 1) { park(2); return; }                 // the one oversized window is done: back to the small lattice
     }
+#ifdef DN_K2B_TRACE
+    if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&k2b_trace[k], tacc[k]);
+#endif
     if (lane == 0) {
         if (O.al_n) O.al_n[r] = fail ? 0u : al_rows;
         R.n_positions = fail ? 0u : npos;
