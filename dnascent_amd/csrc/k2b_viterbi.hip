@@ -58,6 +58,16 @@ __device__ __forceinline__ double shl_prev_d(double v, double fill, int lane) { 
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
+// lane l <- lane l-1, lane 0 <- 0.0.  The lattice never USES what lane 0 receives: its copies of the transition constants that are
+// added to a left neighbour's value are log(0) (VitHot of the lane, below), and 0.0 + log(0) is log(0) -- the value the reference has
+// there.  With an explicit fill the compiler re-materialised the fill register before every DPP move: 6 of a step's ~65 instructions.
+__device__ __forceinline__ double shl_prev_z(double v) {
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x138, 0xf, 0xf, true);
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x138, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
 // The constants of the inner loop, held in VECTOR registers (every lane the same value).  As kernel-argument scalars they lost the
 // fight for the ~100 SGPRs against the ~60 pointers of BatchDev / EaDev that stay live across the lattice loop: the compiler kept them
 // spilled in VGPR lanes and fetched each one back with v_readlane before every use -- 65 v_readlane per lattice step beside its ~60
@@ -129,9 +139,9 @@ template <class C> __device__ __forceinline__ double emission(double x, double m
 // mode 3 (512): those go on to their end.  Round 2 redid such a read FROM ITS FIRST WINDOW in the 512 variant: a handful of wavefronts
 // held the batch for up to 105 ms (rocprof max of k2b_eventalign<512>), longer than the whole first pass.
 #ifdef DN_K2B_TRACE       /* experiment build only (tools/k2b_trace.py): shader-clock ticks per phase of the window walk, summed over all reads */
-__device__ unsigned long long k2b_trace[8];
+__device__ unsigned long long k2b_trace[12];
 extern "C" int dn_debug_k2b_trace(unsigned long long *out, int reset) {
-    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(k2b_trace), z, sizeof(z)); }
+    if (reset) { unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(k2b_trace), z, sizeof(z)); }
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(k2b_trace), sizeof(k2b_trace));
 }
 #define K2B_T(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[k] += now_ - tlast; tlast = now_; } while (0)
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
     };
 
 #ifdef DN_K2B_TRACE
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
     while (ri < n_ref - (DN_K - 1)) {                     // alignment.cpp:556
         K2B_T(6);
@@ -231,12 +241,14 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             const bool inw = in && lane < limit && qlo <= q && q < qhi;
             const unsigned long long wm = __ballot(inw);
             if (first && wm) { readHead = j + (unsigned)(__ffsll((long long)wm) - 1); first = false; }
-            unsigned e_idx = 0; double mean = 0.;
-            if (inw) { e_idx = ae[jj]; mean = ev_mean[e_idx]; }
+            // two dependent rounds of loads, not four: the event index travels with the k-mer index, the event's span with its mean
+            const unsigned e_idx = in ? ae[jj] : 0u;
+            double mean = 0.; unsigned e_st = 0, e_ln = 0;
+            if (inw) { mean = ev_mean[e_idx]; e_st = ev_start[e_idx]; e_ln = ev_len[e_idx]; }
             const bool take = inw && (0. < mean) && (mean < 250.);      // :624
             const unsigned long long tm = __ballot(take);
             const unsigned p = nt + (unsigned)__popcll(tm & ((1ull << lane) - 1ull));
-            if (take && p < (unsigned)TMAX) { tk_start[p] = ev_start[e_idx]; tk_len[p] = ev_len[e_idx]; xs[p] = (mean - shift) / scale; }
+            if (take && p < (unsigned)TMAX) { tk_start[p] = e_st; tk_len[p] = e_ln; xs[p] = (mean - shift) / scale; }
             nt += (unsigned)__popcll(tm);
             if (stopm) break;
         }
@@ -256,15 +268,21 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
         const double mu = (lane < N) ? model[rank_r[ri + lane]] : 0.0;
         const double tr3 = is0 ? vr.eOrI : vc.D2M;
         const VitCodes kc = vit_codes(is0);
+        VitHot hotl = hot;                                  // the lane's constants: position 0 has no left neighbour
+        if (is0) { hotl.I2M = NaN; hotl.eM2M = NaN; hotl.M2D = NaN; hotl.D2D = NaN; }
         double I1 = NaN, M1 = NaN, D1 = (lane < VT_NS) ? vc.initD[lane] : NaN;       // own last results (init column, :234-251)
         double oI2 = I1, oM2 = M1, oD2 = D1;                                       // own results one step earlier (tail cell only)
-        double sI1 = NaN, sM1 = NaN, sD1 = shl_prev_d(D1, NaN, lane);              // lane i-1's results of the last step
+        double sI1 = NaN, sM1 = NaN, sD1 = shl_prev_z(D1);                         // lane i-1's results of the last step (lane 0: never used, see shl_prev_z)
         double sI2 = sI1, sM2 = sM1, sD2 = sD1;                                    // ... and of the step before
         // tail cell: position 64 (only when N == 65), kept in lane 63
         const bool tail = N == 65;
         const double mu64 = tail ? model[rank_r[ri + 64]] : 0.0;
         double tI = NaN, tM = NaN, tD = vc.initD[64];
         const int nsteps = T + N - 1;                      // N == 65: T + 64 steps also cover the tail cell's last step
+        // (Round 3, tools/k2b_trace.py: 95 k of a window's 158 k ticks are this loop, ~530 per step for ~60 vector instructions on a lone
+        // wavefront.  Fewer instructions do not shorten it -- 6 fewer moves per step: nothing; v_max_f64 instead of compare + select:
+        // slower; without the vote on the exp() underflow below: -9 % (the compare -> branch turn-around) -- the step is the issue
+        // latency of a single wavefront on its SIMD, which other wavefronts fill in the pipeline.)
         // the observation of lane i at step d is xs[d - i]: what lane i - 1 held one step earlier.  It travels through the lanes like the
         // states do (DPP shift); only lane 0 reads LDS, one step ahead -- the read used to sit on every step's critical path.
         double xq = xs[0];
@@ -288,10 +306,10 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             const double s0 = (is0 && t == 0) ? 0.0 : NaN;                          // start_prev (:235, :432), position 0 only
             const double l3 = is0 ? s0 : sD2;
             double a, b, c2; unsigned code;
-            vit_cell(s0, l3, tr3, I1, M1, sI2, sM2, sM1, sD1, e, hot, hot, kc, a, b, c2, code);
+            vit_cell(s0, l3, tr3, I1, M1, sI2, sM2, sM1, sD1, e, hotl, hotl, kc, a, b, c2, code);
             if (act) { bt[(t + 1) * VT_NS + lane] = (unsigned char)code; I1 = a; M1 = b; D1 = c2; }
             sI2 = sI1; sM2 = sM1; sD2 = sD1;
-            sI1 = shl_prev_d(I1, NaN, lane); sM1 = shl_prev_d(M1, NaN, lane); sD1 = shl_prev_d(D1, NaN, lane);
+            sI1 = shl_prev_z(I1); sM1 = shl_prev_z(M1); sD1 = shl_prev_z(D1);
             xq = shl_prev_d(xq, x0n, lane);
         }
         __syncthreads();
@@ -435,7 +453,12 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             npos += carry_slots;
             const int n_new = (int)carry_slots;
             __syncthreads();
-            for (int e = lane; e < T; e += 64) {            // samples: one lane per event
+            K2B_T(8);
+            // samples: one lane per event.  14 k of a window's 162 k ticks, and it is the HBM latency of the raw samples (untouched since
+            // K1): round 3 tried all of an event's samples requested first (20 loads in flight: 18.5 k, the fp64 division then runs for the
+            // longest event of every 64) and one lane per sample through an LDS slot map (14.4 k, with or without interleaved divisions):
+            // a lone wavefront pays two or three misses per window either way, and beside other wavefronts they are hidden.  Not kept.
+            for (int e = lane; e < T; e += 64) {
                 const unsigned slot = ev_slot[e];
                 if (slot == 0xffffffffu) continue;
                 const unsigned c0 = ev_cnt0[e], rs = tk_start[e], rl = tk_len[e];
@@ -445,6 +468,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
                     O.sig[(f0 + slot) * DN_RAWDEPTH_DEV + c0 + j] = (float)scaled;       // reads.h:156
                 }
             }
+            K2B_T(9);
             for (int q = lane; q < n_new; q += 64) {        // position records: one lane per new position
                 const unsigned p = ps_p[q];
                 const unsigned idxRef = (unsigned)(ri + (int)p + DN_K / 2);
@@ -500,7 +524,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
         if (mode == 1) { park(2); return; }                 // the one oversized window is done: back to the small lattice
     }
 #ifdef DN_K2B_TRACE
-    if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&k2b_trace[k], tacc[k]);
+    if (lane == 0) for (int k = 0; k < 12; k++) atomicAdd(&k2b_trace[k], tacc[k]);
 #endif
     if (lane == 0) {
         if (O.al_n) O.al_n[r] = fail ? 0u : al_rows;

@@ -19,16 +19,18 @@ if traced:
     hip.lib().dn_debug_k2b_trace(None, 1)
 ctx.profile_reset()
 for _ in range(3):
-    ctx.run("eventalign")
+    ctx.run("normalise"); ctx.run("eventalign")
 ctx.sync()
 for k, v in ctx.profile_get().items():
     if v[1]: print("%-20s %9.3f ms per launch (%d launches)" % (k, v[0] / v[1], v[1]))
 if traced:
-    t = np.zeros(8, np.uint64)
+    t = np.zeros(12, np.uint64)
     assert hip.lib().dn_debug_k2b_trace(C.c_void_p(t.ctypes.data), 0) == 0
     nw = float(t[7])
-    names = ["window setup", "event gather", "lattice", "termination + traceback", "feature fill", "align table", "between windows"]
-    tot = float(t[:7].sum())
+    names = ["window setup", "event gather", "lattice", "termination + traceback", "fill: position records", "align table", "between windows"]
+    names += [None, "fill: label pass", "fill: samples"]
+    tot = float(t[:7].sum() + t[8:].sum())
     for i, n in enumerate(names):
+        if n is None: continue
         print("%-24s %9.0f ticks per window  %5.1f %%" % (n, float(t[i]) / nw, 100.0 * float(t[i]) / tot))
     print("%-24s %9.0f ticks per window, %d windows" % ("total", tot / nw, int(nw) // 3))
