@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
         const int nsteps = T + N - 1;                      // N == 65: T + 64 steps also cover the tail cell's last step
         // (Round 3, tools/k2b_trace.py: 95 k of a window's 158 k ticks are this loop, ~530 per step for ~60 vector instructions on a lone
         // wavefront.  Fewer instructions do not shorten it -- 6 fewer moves per step: nothing; v_max_f64 instead of compare + select:
-        // slower; without the vote on the exp() underflow below: -9 % (the compare -> branch turn-around) -- the step is the issue
+        // slower; without the vote on the exp() underflow below: -9 %, but taking that vote one step ahead of its branch: -1 % -- the step is the issue
         // latency of a single wavefront on its SIMD, which other wavefronts fill in the pipeline.)
         // the observation of lane i at step d is xs[d - i]: what lane i - 1 held one step earlier.  It travels through the lanes like the
         // states do (DPP shift); only lane 0 reads LDS, one step ahead -- the read used to sit on every step's critical path.
