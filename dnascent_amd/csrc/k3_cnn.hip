@@ -1248,6 +1248,11 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     }
 }
 
+// (Round 3: k3_sep_ring -- the A planes in a ring of 2-4 stages with LDS counters (written / consumed, polled) instead of the workgroup
+// barrier, so that the producers run ahead through the consumers' epilogue -- is in tools/k3_sep_ring_experiment.hip: bit-identical, and
+// SLOWER at every depth (five 256 -> 256 layers: 4 197-4 397 us against 3 822 in the same session).  A polled hand-over costs more than
+// s_barrier's, and the consumers' own chain -- 8 x 3.35 k ticks of MFMA phases + 8.5 k of epilogue -- is nearly the tile's 41 k already:
+// the run-ahead only moves producer instructions into the issue-bound epilogue.)
 // (Round 3: k3_sep_ws16 -- SIXTEEN wavefronts, two producers (row slice x channel half) and two consumers (64 x 64 outputs) per SIMD,
 // every wavefront under 128 registers -- is in tools/k3_sep_ws16_experiment.hip with its phase traces: bit-identical, and SLOWER in both
 // of its forms: roles overlapping 4 065 us for the five 256 -> 256 layers, roles alternating (a second barrier per step) 4 302 us, this
