@@ -407,6 +407,11 @@ __global__ __launch_bounds__(256) void k3_encode_perm(CnnRows R, const uint8_t *
 #define CNN_PITCH 36
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// (Round 3: the TRANSPOSED epilogue -- weights as the A operand of every MFMA, so that a lane holds one row and 4 x 4 consecutive channels and
+// the residual loads and stores are 16-byte accesses, a quarter of the instructions of this issue-bound epilogue -- was built for all conv
+// kernels and is bit-identical, but the network took 19.2 ms against 17.0 per 1.2 M positions in one session (gpurun_out/r3t2; 5-tap
+// separable layers +30 %, 17-tap +17 %, 3-tap convolutions +6-23 %): an instruction then writes 32 bytes to each of 32 rows, and four of them
+// complete a 128-byte line, where the layout below writes whole 128-byte row segments.  The memory side does care.  Not kept.)
 // epilogue shared by the conv kernels: C/D layout of 32x32 tiles: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) +
 // 4 * (lane >> 5).  Row validity of the wavefront's 64 rows is one ballot; the residual values are fetched 16 at a time
 // (no load -> wait -> load chains).
