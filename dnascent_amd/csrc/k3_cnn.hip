@@ -1253,6 +1253,12 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     }
 }
 
+// (Round 3: k3_sep_ts -- the same layer TIME-SLICED instead of wave-specialised: all eight wavefronts filter 128 input channels (rows straight
+// from global memory into registers, taps in LDS, no MFMA in flight so the vector pipe runs at its full rate), then all eight multiply, four
+// barriers per tile -- is in tools/k3_sep_ts_experiment.hip with its phase traces: bit-identical, 4 018 us against 3 810 for the five
+// 256 -> 256 layers alone and 717-721 against 733-736 Msamples/s in the pipeline.  The filter phases do run at the predicted 2.7-4.3 k ticks
+// (3.4 k per 32 channels beside the MFMAs here), but the multiply phases take 12-18 k where the MFMAs need 6 k: every latency this kernel
+// overlaps across its two roles is exposed there.)
 // (Round 3: k3_sep_ring -- the A planes in a ring of 2-4 stages with LDS counters (written / consumed, polled) instead of the workgroup
 // barrier, so that the producers run ahead through the consumers' epilogue -- is in tools/k3_sep_ring_experiment.hip: bit-identical, and
 // SLOWER at every depth (five 256 -> 256 layers: 4 197-4 397 us against 3 822 in the same session).  A polled hand-over costs more than
