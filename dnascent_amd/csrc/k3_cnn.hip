@@ -998,7 +998,8 @@ extern "C" int dn_debug_ws_trace(unsigned long long *out) { return (int)hipMemcp
 // wavefronts with fixed roles, two per SIMD:
 //     producers (4)  raw rows global -> registers -> their own slice of LDS (32 + KW - 1 rows each: no cross-wave dependency),
 //                    depthwise filter out of that slice, 16-bit pieces into the A planes of the NEXT channel block
-//     consumers (4)  the MFMAs of the CURRENT channel block on its A planes and B tile; B tile of the next block to LDS
+//     consumers (4)  the MFMAs of the CURRENT channel block on its A planes; each owns ALL 128 rows x 64 columns (round 3: as 2 x 2 wavefronts
+//                    of 64 x 128 every weight fragment was fetched from L2 by two of them), B fragments straight from L2
 // A planes, B tile and tap table are double-buffered: ONE barrier per channel block, and the vector work of block cb + 1 runs
 // beside the matrix work of block cb on every SIMD (the matrix pipe and the vector pipe issue from different wavefronts).
 // ---------------------------------------------------------------------------------------------------------
@@ -1031,7 +1032,7 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     const int nb = my_tiles * cblocks;                     // steps of this workgroup (even: cblocks is)
     auto tile_m0 = [&](int it) { return ((int)blockIdx.x + it * (int)gridDim.x) * CNN_BM; };
     // ---- consumer state ----
-    const int cw = wave & 3, wm = cw >> 1, wn = cw & 1;
+    const int cw = wave & 3;
     const int ct = tid & 255;
     // ---- producer state ----
     const int pw = wave & 3;                               // slice: output rows 32 pw .. 32 pw + 31 of the tile
@@ -1185,33 +1186,34 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
         if (NP == 2 && __any(amax > 65504.0f) && lane == 0) atomicOr(range_flag, 1u);
         return;
     }
-    f32x16 acc[2][NJ];
+    constexpr int CJ = BN / 128;                           // consumer = ALL 128 rows x BN / 4 columns (CJ column blocks of 32): a weight fragment is
+    f32x16 acc[4][CJ];                                     // fetched by ONE wavefront of the CU (as 2 x 2 wavefronts of 64 x BN / 2 each was fetched by two)
     // B fragments come STRAIGHT from L2 into registers (pre-split weights [channel block][piece][cout][32]: a fragment is one
     // 16-byte load, 64-byte rows of consecutive lanes coalesce): no B tile in LDS -- that tile was 82 of the kernel's 155 KB, which
     // kept this workgroup off every CU where a per-read stage of another batch held some LDS, and half of its LDS traffic.
     // Double-buffered per k16 step: the loads of step s + 1 are in flight during the MFMAs of step s.
     const int fm = lane & 31, fk = (lane >> 5) * 8;
-    const uint16_t *wlane = Wb + ((size_t)(n0 + wn * (BN / 2) + fm)) * 32 + fk;
-    auto loadB = [&](u32x4 (&b)[NJ][NP], int step) {            // step = 2 * cb + k16
+    const uint16_t *wlane = Wb + ((size_t)(n0 + cw * (BN / 4) + fm)) * 32 + fk;
+    auto loadB = [&](u32x4 (&b)[CJ][NP], int step) {            // step = 2 * cb + k16
         const int cb = (step >> 1) % cblocks, k16 = step & 1;          // the weights of a step depend on its channel block only
 #pragma unroll
         for (int pc = 0; pc < NP; pc++)
 #pragma unroll
-            for (int j = 0; j < NJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(wlane + ((size_t)(cb * NP + pc) * cout + j * 32) * 32 + k16 * 16);
+            for (int j = 0; j < CJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(wlane + ((size_t)(cb * NP + pc) * cout + j * 32) * 32 + k16 * 16);
     };
-    u32x4 b0[NJ][NP], b1[NJ][NP];
+    u32x4 b0[CJ][NP], b1[CJ][NP];
     loadB(b0, 0);
     __syncthreads();
     __syncthreads();
-    auto mma = [&](int cur, int k16, u32x4 (&b)[NJ][NP]) {
+    auto mma = [&](int cur, int k16, u32x4 (&b)[CJ][NP]) {
 #ifdef DN_WS_NOMMA
         return;
 #endif
-        u32x4 a[2][NP];
+        u32x4 a[4][NP];
 #pragma unroll
         for (int pc = 0; pc < NP; pc++)
 #pragma unroll
-            for (int i = 0; i < 2; i++) a[i][pc] = *reinterpret_cast<const u32x4 *>(&As[cur][pc][(wm * 64 + i * 32 + fm) * CNN_BP + k16 * 16 + fk]);
+            for (int i = 0; i < 4; i++) a[i][pc] = *reinterpret_cast<const u32x4 *>(&As[cur][pc][(i * 32 + fm) * CNN_BP + k16 * 16 + fk]);
         constexpr int NT = NP == 3 ? 6 : 3;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
@@ -1219,18 +1221,18 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
             constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
             const int pa = NP == 3 ? PA3[t] : PA2[t % 3], pb = NP == 3 ? PB3[t] : PB2[t % 3];
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j < NJ; j++)
+                for (int j = 0; j < CJ; j++)
                     acc[i][j] = mfma16<NP>(a[i][pa], b[j][pb], acc[i][j]);
         }
     };
     for (int it = 0; it < my_tiles; it++) {
         const bool tr = it == WS_TRACE_TILE; (void)tr;
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int j = 0; j < NJ; j++)
+            for (int j = 0; j < CJ; j++)
 #pragma unroll
                 for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
         if (tr) WS_T(3);
@@ -1248,7 +1250,9 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
             __syncthreads();
             if (tr) WS_T(6 + 3 * cb);
         }
-        conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, tile_m0(it), n0, wm, wn, lane, cout, relu, post);
+        // two row halves, each the epilogue of a 64 x (BN / 4)-column wavefront tile of a BN / 2-wide workgroup tile
+        conv_epilogue<BN / 2, ADD>(*reinterpret_cast<f32x16 (*)[2][CJ]>(&acc[0]), Y, scale, shift, Add, valid, tile_m0(it), n0 + (cw >> 1) * (BN / 2), 0, cw & 1, lane, cout, relu, post);
+        conv_epilogue<BN / 2, ADD>(*reinterpret_cast<f32x16 (*)[2][CJ]>(&acc[2]), Y, scale, shift, Add, valid, tile_m0(it), n0 + (cw >> 1) * (BN / 2), 1, cw & 1, lane, cout, relu, post);
         if (tr) WS_T(40);
     }
 }
