@@ -276,31 +276,130 @@ static inline char *put_u32(char *o, uint32_t v) {
 
 char *formatProbForTest(char *o, float p) { return put_prob(o, p); }
 
+// one line of a record: "coord\tEdU\tBrdU\tkmer\n" (detect.cpp:716-721); km = the strand 9-mer, printed reverse-complemented for reverse reads (:699)
+static inline char *put_call(char *o, uint32_t coord, float pEdU, float pBrdU, const char *km, bool isReverse) {
+    o = put_u32(o, coord); *o++ = '\t';
+    o = put_prob(o, pEdU); *o++ = '\t';
+    o = put_prob(o, pBrdU); *o++ = '\t';
+    if (isReverse) {                                         // reverseComplement of the 9-mer (:699): A/C/G/T only reach here (T-centred, ACGT windows)
+        for (int z = 0; z < 9; z++) {
+            const char c = km[8 - z];
+            o[z] = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'G' ? 'C' : c == 'C' ? 'G' : c;
+        }
+    } else memcpy(o, km, 9);
+    o[9] = '\n';
+    return o + 10;
+}
+static std::string detectHeaderLine(const std::string &readID, const std::string &contig, int refStart, int refEnd, bool isReverse) {
+    return ">" + readID + " " + contig + " " + std::to_string(refStart) + " " + std::to_string(refEnd) + " " + (isReverse ? "rev" : "fwd") + "\n";
+}
+
 // the record of one read from its CALLS (positions whose strand 9-mer has 'T' in the middle, detect.cpp:690), creation order
 static std::string formatDetectCalls(const std::string &readID, const std::string &contig, int refStart, int refEnd, bool isReverse,
                                      size_t n, const uint32_t *coord, const char *kmer9, const float *pEdU, const float *pBrdU) {
-    std::string out = ">" + readID + " " + contig + " " + std::to_string(refStart) + " " + std::to_string(refEnd) + " " +
-                      (isReverse ? "rev" : "fwd") + "\n";
+    std::string out = detectHeaderLine(readID, contig, refStart, refEnd, isReverse);
     const size_t head = out.size();
     out.resize(head + n * 128);                              // a line is at most 10 + 1 + 47 + 1 + 47 + 1 + 9 + 1 bytes
     char *o = &out[head];
     for (size_t q = 0; q < n; q++) {
         const size_t i = isReverse ? n - 1 - q : q;          // std::reverse of the line vector (:722)
-        o = put_u32(o, coord[i]); *o++ = '\t';
-        o = put_prob(o, pEdU[i]); *o++ = '\t';
-        o = put_prob(o, pBrdU[i]); *o++ = '\t';
-        const char *km = kmer9 + i * 9;
-        if (isReverse) {                                     // reverseComplement of the 9-mer (:699): A/C/G/T only reach here (T-centred, ACGT windows)
-            for (int z = 0; z < 9; z++) {
-                const char c = km[8 - z];
-                o[z] = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'G' ? 'C' : c == 'C' ? 'G' : c;
-            }
-        } else memcpy(o, km, 9);
-        o[9] = '\n';
-        o += 10;
+        o = put_call(o, coord[i], pEdU[i], pBrdU[i], kmer9 + i * 9, isReverse);
     }
     out.resize((size_t)(o - out.data()));
     return out;
+}
+
+// ---- packed per-call results: what a rank sends to the writer rank instead of text (16 bytes per call against ~40 of text) ----
+// per call {u32 coord, f32 P(EdU), f32 P(BrdU), u32 9-mer at 3 bits per base (A C G T N = 0 .. 4, first base in the low bits)}; per read a
+// meta row {count, header bytes, flags} and in the payload its header line followed by the calls.  A read whose 9-mers hold anything
+// else (IUPAC codes in a reference) travels as its formatted TEXT instead (flag DN_PACK_TEXT): the writer passes it through, so the file
+// is the same bytes whatever the alphabet.
+static inline int packBase(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : c == 'N' ? 4 : -1; }
+void packCalls(const ReadBatch &batch, const dn_result_batch &res, std::vector<uint64_t> &meta, std::vector<uint8_t> &payload) {
+    const long n = (long)batch.size();
+    std::vector<std::string> hdr((size_t)n);
+    std::vector<uint8_t> as_text((size_t)n, 0), ok((size_t)n, 0);
+    std::vector<uint64_t> bytes((size_t)n, 0);
+#pragma omp parallel for schedule(dynamic, 4) num_threads(hostThreads())
+    for (long r = 0; r < n; r++) {
+        if (res.summary[r].status != DN_READ_OK) continue;
+        ok[(size_t)r] = 1;
+        const uint64_t o = res.call_off[r], k = res.call_off[r + 1] - o;
+        bool plain = true;
+        for (uint64_t i = 0; i < 9 * k && plain; i++) plain = packBase(res.kmer9[9 * o + i]) >= 0;
+        if (plain) {
+            hdr[(size_t)r] = detectHeaderLine(batch.readID[r], batch.contig[r], batch.ref_start[r], batch.ref_end[r], batch.is_reverse[r] != 0);
+            bytes[(size_t)r] = hdr[(size_t)r].size() + 16 * k;
+        } else {
+            as_text[(size_t)r] = 1;
+            hdr[(size_t)r] = formatDetectCalls(batch.readID[r], batch.contig[r], batch.ref_start[r], batch.ref_end[r], batch.is_reverse[r] != 0, k,
+                                               res.ref_coord + o, res.kmer9 + 9 * o, res.p_edu + o, res.p_brdu + o);
+            bytes[(size_t)r] = hdr[(size_t)r].size();
+        }
+    }
+    std::vector<uint64_t> off((size_t)n + 1, 0);
+    size_t n_ok = 0;
+    for (long r = 0; r < n; r++) { off[(size_t)r + 1] = off[(size_t)r] + bytes[(size_t)r]; n_ok += ok[(size_t)r]; }
+    meta.assign(4 * n_ok, 0);
+    payload.resize(off[(size_t)n]);
+    size_t j = 0;
+    for (long r = 0; r < n; r++) {
+        if (!ok[(size_t)r]) continue;
+        const uint64_t k = res.call_off[r + 1] - res.call_off[r];
+        meta[4 * j] = (uint64_t)r;
+        meta[4 * j + 1] = as_text[(size_t)r] ? hdr[(size_t)r].size() : k;
+        meta[4 * j + 2] = as_text[(size_t)r] ? 0 : hdr[(size_t)r].size();
+        meta[4 * j + 3] = (batch.is_reverse[r] ? DN_PACK_REVERSE : 0u) | (as_text[(size_t)r] ? DN_PACK_TEXT : 0u);
+        j++;
+    }
+#pragma omp parallel for schedule(dynamic, 4) num_threads(hostThreads())
+    for (long r = 0; r < n; r++) {
+        if (!ok[(size_t)r]) continue;
+        uint8_t *p = payload.data() + off[(size_t)r];
+        memcpy(p, hdr[(size_t)r].data(), hdr[(size_t)r].size());
+        if (as_text[(size_t)r]) continue;
+        p += hdr[(size_t)r].size();
+        const uint64_t o = res.call_off[r], k = res.call_off[r + 1] - o;
+        for (uint64_t i = 0; i < k; i++) {
+            uint32_t km = 0;
+            for (int z = 0; z < 9; z++) km |= (uint32_t)packBase(res.kmer9[9 * (o + i) + z]) << (3 * z);
+            uint32_t w[4];
+            w[0] = res.ref_coord[o + i]; memcpy(&w[1], &res.p_edu[o + i], 4); memcpy(&w[2], &res.p_brdu[o + i], 4); w[3] = km;
+            memcpy(p + 16 * i, w, 16);
+        }
+    }
+}
+
+// the writer rank's half: reads in the order given (pointers into the gathered payloads), formatted in parallel, laid end to end
+void formatPacked(size_t n, const uint64_t *meta3 /* [n][3]: count, header bytes, flags */, const uint8_t *const *read_ptr, std::string &text,
+                  uint64_t *record_bytes /* [n] */) {
+    std::vector<std::string> rec(n);
+#pragma omp parallel for schedule(dynamic, 4) num_threads(hostThreads())
+    for (long r = 0; r < (long)n; r++) {
+        const uint64_t cnt = meta3[3 * r], hb = meta3[3 * r + 1], fl = meta3[3 * r + 2];
+        const uint8_t *p = read_ptr[r];
+        std::string &out = rec[(size_t)r];
+        if (fl & DN_PACK_TEXT) { out.assign((const char *)p, (size_t)cnt); continue; }
+        const bool rev = (fl & DN_PACK_REVERSE) != 0;
+        out.assign((const char *)p, (size_t)hb);
+        out.resize((size_t)hb + (size_t)cnt * 128);
+        char *o = &out[(size_t)hb];
+        p += hb;
+        for (uint64_t q = 0; q < cnt; q++) {
+            const uint64_t i = rev ? cnt - 1 - q : q;
+            uint32_t w[4]; float e, b;
+            memcpy(w, p + 16 * i, 16); memcpy(&e, &w[1], 4); memcpy(&b, &w[2], 4);
+            char km[9];
+            for (int z = 0; z < 9; z++) km[z] = "ACGTN???"[(w[3] >> (3 * z)) & 7u];
+            o = put_call(o, w[0], e, b, km, rev);
+        }
+        out.resize((size_t)(o - out.data()));
+    }
+    std::vector<uint64_t> off(n + 1, 0);
+    for (size_t r = 0; r < n; r++) { off[r + 1] = off[r] + rec[r].size(); if (record_bytes) record_bytes[r] = rec[r].size(); }
+    text.resize(off[n]);
+#pragma omp parallel for schedule(static) num_threads(hostThreads())
+    for (long r = 0; r < (long)n; r++) memcpy(&text[off[(size_t)r]], rec[(size_t)r].data(), rec[(size_t)r].size());
 }
 
 std::string formatDetectRecord(const std::string &readID, const std::string &contig, int refStart, int refEnd, bool isReverse,
@@ -387,7 +486,7 @@ int runCNN(dn_ctx *ctx, ReadBatch &batch, bool humanReadable, std::vector<ReadCa
 // host formats and writes its records the GPU works on the n_ctx - 1 younger batches.  Records are written in input order.
 static double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
-DetectStream::DetectStream(dn_ctx **ctxs, int n_ctx, bool emit_) : ctx(ctxs, ctxs + n_ctx), slot_batch((size_t)n_ctx, nullptr), slot_tag((size_t)n_ctx, 0),
+DetectStream::DetectStream(dn_ctx **ctxs, int n_ctx, int emit_) : ctx(ctxs, ctxs + n_ctx), slot_batch((size_t)n_ctx, nullptr), slot_tag((size_t)n_ctx, 0),
                                                                  emit(emit_), t_open(now_s()) {}
 
 int DetectStream::submit(ReadBatch *batch, uint64_t tag) {
@@ -420,7 +519,12 @@ int DetectStream::collect(Result &out) {
     B.summary.assign(res.summary, res.summary + res.n_reads);
     for (uint32_t r = 0; r < res.n_reads; r++) if (res.summary[r].status == DN_READ_OK) { S.reads_ok++; S.positions += res.summary[r].n_positions; }
     out.record_bytes.assign(res.n_reads, 0);
-    if (emit) {
+    out.packed_meta.clear(); out.packed.clear();
+    if (emit == EMIT_PACKED) {
+        packCalls(B, res, out.packed_meta, out.packed);
+        S.bytes_out += out.packed.size();
+        S.seconds_emit += now_s() - b;
+    } else if (emit == EMIT_TEXT) {
         formatCalls(B, res, true, calls);
         size_t total = 0;
         for (size_t r = 0; r < calls.size(); r++) if (res.summary[r].status == DN_READ_OK) total += calls[r].humanReadable_detectOut.size();
@@ -443,7 +547,7 @@ int streamDetect(dn_ctx **ctxs, int n_ctx, ReadBatch **batches, int n_batches, b
     FILE *f = nullptr;
     if (emit && outPath) { f = fopen(outPath, "wb"); if (!f) return DN_ERR_ARG; if (header) fwrite(header, 1, strlen(header), f); }
     const double t0 = now_s();
-    DetectStream ds(ctxs, n_ctx, emit);
+    DetectStream ds(ctxs, n_ctx, emit ? DetectStream::EMIT_TEXT : DetectStream::EMIT_NONE);
     DetectStream::Result R;
     int rc = DN_OK;
     auto drain_one = [&]() -> int {
@@ -744,7 +848,7 @@ int64_t dnh_container_load_at(void *b, const char *path, const uint64_t *offsets
 }
 
 // ---- DNAscent::DetectStream behind C signatures ----
-void *dnh_stream_open(void **ctxs, int n_ctx, int emit) { return new DNAscent::DetectStream((dn_ctx **)ctxs, n_ctx, emit != 0); }
+void *dnh_stream_open(void **ctxs, int n_ctx, int emit /* 0 none, 1 text records, 2 packed calls */) { return new DNAscent::DetectStream((dn_ctx **)ctxs, n_ctx, emit); }
 void dnh_stream_close(void *s) { delete (DNAscent::DetectStream *)s; }
 int dnh_stream_full(void *s) { return ((DNAscent::DetectStream *)s)->full() ? 1 : 0; }
 int dnh_stream_inflight(void *s) { return ((DNAscent::DetectStream *)s)->inFlight(); }
@@ -766,6 +870,30 @@ int dnh_stream_collect(void *s, void *result, uint64_t *tag, uint32_t *n_reads, 
     if (res) *res = R.res;
     return DN_OK;
 }
+// the packed form of the last collected batch (stream opened with emit == 2): meta [n_packed][4], payload bytes; owned by the result object
+uint64_t dnh_result_packed(void *result, const uint64_t **meta, const uint8_t **payload, uint64_t *payload_bytes) {
+    DNAscent::DetectStream::Result &R = *(DNAscent::DetectStream::Result *)result;
+    if (meta) *meta = R.packed_meta.data();
+    if (payload) *payload = R.packed.data();
+    if (payload_bytes) *payload_bytes = R.packed.size();
+    return R.packed_meta.size() / 4;
+}
+// packCalls for a batch and a result the caller supplies (CPU tests: no stream, no device); read back with dnh_result_packed
+uint64_t dnh_pack_calls(void *batch, const dn_result_batch *res, void *result) {
+    DNAscent::DetectStream::Result &R = *(DNAscent::DetectStream::Result *)result;
+    DNAscent::packCalls(*(ReadBatch *)batch, *res, R.packed_meta, R.packed);
+    return R.packed_meta.size() / 4;
+}
+// the writer rank's formatter: n reads in output order, read_ptr[i] = address of read i's payload; returns a text handle
+void *dnh_format_packed(uint64_t n, const uint64_t *meta3, const uint64_t *read_ptr, uint64_t *record_bytes) {
+    std::string *t = new std::string();
+    static_assert(sizeof(uint64_t) == sizeof(const uint8_t *), "64-bit host");
+    DNAscent::formatPacked((size_t)n, meta3, (const uint8_t *const *)read_ptr, *t, record_bytes);
+    return t;
+}
+const char *dnh_text_data(void *t) { return ((std::string *)t)->data(); }
+uint64_t dnh_text_size(void *t) { return ((std::string *)t)->size(); }
+void dnh_text_free(void *t) { delete (std::string *)t; }
 void dnh_stream_stats(void *s, DNAscent::StreamStats *st) { *st = ((DNAscent::DetectStream *)s)->stats(); }
 int dnh_batch_pin(void *b) { return ((ReadBatch *)b)->pin(); }
 void dnh_batch_unpin(void *b) { ((ReadBatch *)b)->unpin(); }

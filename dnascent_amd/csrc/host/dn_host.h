@@ -135,6 +135,16 @@ char *formatProbForTest(char *o, float p);               // the "%f" fast path o
 // the output half alone, for a batch whose result has been collected
 void formatCalls(const ReadBatch &batch, const dn_result_batch &res, bool humanReadable, std::vector<ReadCalls> &calls);
 
+// ---- packed per-call results for the gather to the writer rank (detect.cpp:902-906 is where the reference writes) ----
+// What a rank of a multi-GPU run sends instead of text: per passing read a meta row {index in the batch, count, header bytes, flags} and, in
+// the payload, the read's header line (">readID contig start end strand\n") followed by 16 bytes per call {u32 coord, f32 P(EdU),
+// f32 P(BrdU), u32 strand 9-mer at 3 bits per base}.  A read whose 9-mers hold anything but A C G T N travels as its formatted text
+// (DN_PACK_TEXT: count = text bytes, header bytes = 0).  formatPacked is the writer's half: same bytes as formatCalls' records.
+enum { DN_PACK_REVERSE = 1, DN_PACK_TEXT = 2 };
+void packCalls(const ReadBatch &batch, const dn_result_batch &res, std::vector<uint64_t> &meta /* [passing reads][4] */, std::vector<uint8_t> &payload);
+void formatPacked(size_t n, const uint64_t *meta3 /* [n][3]: count, header bytes, flags */, const uint8_t *const *read_ptr /* [n] */, std::string &text,
+                  uint64_t *record_bytes /* [n] or null */);
+
 // The buffer-of-reads loop of detect.cpp:821-907 as a stream: batch i is uploaded to context i % n_ctx and its whole per-read
 // body (normaliseEvents -> eventalign -> runCNN) enqueued; ONE host thread keeps n_ctx batches in flight and only ever waits for
 // the oldest one (dn_collect).  emit: format the .detect records of every collected batch (in parallel) and write them, in input
@@ -161,9 +171,12 @@ public:
         uint64_t tag = 0; ReadBatch *batch = nullptr;
         dn_result_batch res{};                              // valid until the context's next upload (= the submit() after next on a full stream)
         std::vector<uint64_t> record_bytes;                 // per read: length of its .detect record (0: failed read / emit off)
-        std::string text;                                   // the records of the passing reads, batch order (emit only)
+        std::string text;                                   // the records of the passing reads, batch order (emit == EMIT_TEXT)
+        std::vector<uint64_t> packed_meta;                  // emit == EMIT_PACKED: packCalls' meta rows ...
+        std::vector<uint8_t> packed;                        // ... and payload (the multi-rank driver gathers these; the writer rank formats)
     };
-    DetectStream(dn_ctx **ctxs, int n_ctx, bool emit);
+    enum { EMIT_NONE = 0, EMIT_TEXT = 1, EMIT_PACKED = 2 };
+    DetectStream(dn_ctx **ctxs, int n_ctx, int emit);
     bool full() const { return inflight == (int)ctx.size(); }
     int inFlight() const { return inflight; }
     int submit(ReadBatch *batch, uint64_t tag);             // DN_ERR_STATE when full(): collect() first
@@ -171,7 +184,7 @@ public:
     const StreamStats &stats() const { return S; }
 private:
     std::vector<dn_ctx *> ctx; std::vector<ReadBatch *> slot_batch; std::vector<uint64_t> slot_tag;
-    int head = 0, inflight = 0; bool emit; StreamStats S{}; std::vector<ReadCalls> calls; double t_open;
+    int head = 0, inflight = 0; int emit; StreamStats S{}; std::vector<ReadCalls> calls; double t_open;
 };
 
 // `detect --HMM` (detect.cpp:885): llAcrossRead for every read that passed normaliseEvents; fills

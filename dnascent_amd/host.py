@@ -91,6 +91,17 @@ def lib():
         L.dnh_stream_collect.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_uint64), C.POINTER(_hip.ResultBatch)]
         L.dnh_stream_stats.argtypes = [C.c_void_p, C.POINTER(StreamStats)]
+        L.dnh_result_packed.restype = C.c_uint64
+        L.dnh_result_packed.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.dnh_pack_calls.restype = C.c_uint64
+        L.dnh_pack_calls.argtypes = [C.c_void_p, C.POINTER(_hip.ResultBatch), C.c_void_p]
+        L.dnh_format_packed.restype = C.c_void_p
+        L.dnh_format_packed.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dnh_text_data.restype = C.c_void_p
+        L.dnh_text_data.argtypes = [C.c_void_p]
+        L.dnh_text_size.restype = C.c_uint64
+        L.dnh_text_size.argtypes = [C.c_void_p]
+        L.dnh_text_free.argtypes = [C.c_void_p]
         L.dnh_batch_pin.argtypes = [C.c_void_p]
         L.dnh_batch_unpin.argtypes = [C.c_void_p]
         L.dnh_revcomp.restype = C.c_int
@@ -341,15 +352,37 @@ def stream_detect(ctxs, batches, emit=True, out_path=None, header=None, keep=Fal
             lib().dnh_keep_free(kh)
 
 
+PACK_REVERSE, PACK_TEXT = 1, 2          # DNAscent::DN_PACK_* (flags of a packed read's meta row)
+
+
+def format_packed(meta3, read_ptr):
+    """DNAscent::formatPacked: the writer rank's formatter.  meta3 uint64 [n][3] (count, header bytes, flags), read_ptr uint64 [n] (address
+    of every read's payload, output order) -> (text bytes of the n records laid end to end, record_bytes uint64 [n])."""
+    m = np.ascontiguousarray(meta3, np.uint64); p = np.ascontiguousarray(read_ptr, np.uint64)
+    n = p.shape[0]
+    rb = np.zeros(max(n, 1), np.uint64)
+    if n == 0:
+        return b"", rb[:0]
+    t = C.c_void_p(lib().dnh_format_packed(n, m.ctypes.data, p.ctypes.data, rb.ctypes.data))
+    try:
+        text = C.string_at(lib().dnh_text_data(t), lib().dnh_text_size(t))
+    finally:
+        lib().dnh_text_free(t)
+    return text, rb[:n]
+
+
 class DetectStream:
     """DNAscent::DetectStream: the buffer-of-reads loop of detect.cpp:821-907 OPEN-ENDED.  submit() uploads a batch to the free
     context and enqueues its whole per-read body; collect() waits for the OLDEST batch in flight and returns its records.  At most
-    len(ctxs) batches are in flight; a batch stays alive and untouched between its submit() and its collect()."""
+    len(ctxs) batches are in flight; a batch stays alive and untouched between its submit() and its collect().
+    emit: False / 0 nothing, True / 1 the text records, "packed" / 2 the packed per-call results (16 bytes per call: what a rank of a
+    multi-GPU run hands to the writer rank, which formats them -- shard.StreamDriver)."""
 
     def __init__(self, ctxs, emit=True):
         self.ctxs = list(ctxs)
         hc = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
-        self.h = C.c_void_p(lib().dnh_stream_open(hc, len(ctxs), int(emit)))
+        self.emit = 2 if emit in ("packed", 2) else int(bool(emit))
+        self.h = C.c_void_p(lib().dnh_stream_open(hc, len(ctxs), self.emit))
         self.res = C.c_void_p(lib().dnh_result_new())
         self._batches = {}
 
@@ -397,6 +430,11 @@ class DetectStream:
         out = dict(tag=int(tag.value), batch=self._batches.pop(int(tag.value)), status=summ["status"].copy() if nr else np.zeros(0, np.int32),
                    n_positions=summ["n_positions"].copy() if nr else np.zeros(0, np.uint32),
                    record_bytes=arr(rb.value, np.uint64, nr), text=C.string_at(tx.value, tb.value) if tb.value else b"")
+        if self.emit == 2:
+            mp = C.c_void_p(); pp = C.c_void_p(); pb = C.c_uint64()
+            k = int(lib().dnh_result_packed(self.res, C.byref(mp), C.byref(pp), C.byref(pb)))
+            out["packed_meta"] = arr(mp.value, np.uint64, 4 * k).reshape(k, 4)        # rows: index in the batch, count, header bytes, flags
+            out["packed"] = arr(pp.value, np.uint8, int(pb.value))
         if calls:
             k = int(res.n_calls)
             off = arr(res.call_off, np.uint64, nr + 1 if nr else 0)

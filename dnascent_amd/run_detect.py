@@ -15,10 +15,13 @@ reads (detect.cpp:821-907), never "load everything, run, gather everything":
      `schedule(dynamic)` (detect.cpp:852): a rank whose reads fail QC early, or are short, takes more batches;
   3. a rank holds at most --inflight + 2 batches on the host: the next one is loaded (all cores, direct seeks) while --inflight of
      them are on the GPU (DNAscent::DetectStream: upload, normaliseEvents, eventalign, CNN, dn_collect, records formatted);
-  4. when a rank has collected its last batch of a window, the window's records go to the writer rank point to point, in pieces of
-     --gather-chunk-mb, and are written in INPUT order while the GPUs work on the next window -- the file is byte-identical
-     whatever the number of ranks (the reference writes in completion order, detect.cpp:902-906; input order is what it produces
-     with one thread).  No rank ever holds more text than one window's;
+  4. when a rank has collected its last batch of a window, the window's PACKED per-call results (16 bytes per call: coordinate, P(EdU),
+     P(BrdU), 9-mer; ~40 % of the text's bytes) go to the writer rank: sizes through the process group's store, bytes in ONE grouped
+     receive from all peers per window (pieces of --gather-chunk-mb), on a gather thread of every rank, so neither the sends nor the
+     receives hold up the thread that drives the GPU.  The writer formats them (the C++ formatter on its host threads) and writes them
+     in INPUT order while the GPUs work on the next window -- the file is byte-identical whatever the number of ranks (the reference
+     writes in completion order, detect.cpp:902-906; input order is what it produces with one thread).  No rank ever holds more than
+     a few windows' results;
   5. one all-reduce of the counters (reads ok / failed, samples) at the end.
 
 A read the reference's own filters reject (empty / too short signal, detect.cpp:839, pod5.cpp:64) counts as FAILED, as there.  A
@@ -40,6 +43,9 @@ import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # the host library's OpenMP teams must SLEEP between their loops: spinning threads starve the HIP runtime's callback thread (dn_host.cpp hostThreads)
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "DN_HOST_THREADS" not in os.environ:
+    # N ranks share the host's cores: each rank's loader / packer / formatter loops take their share (dn_host.cpp hostThreads)
+    os.environ["DN_HOST_THREADS"] = str(max(4, min(64, (os.cpu_count() or 64) // int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"])))))
 
 
 def load_pore_model(path):
@@ -73,7 +79,7 @@ def main(argv=None):
     ap.add_argument("--batch-reads", type=int, default=2000)
     ap.add_argument("--window-batches", type=float, default=4.0,
                     help="a window (the unit of the ordered gather + write) holds about this many batches PER RANK")
-    ap.add_argument("--gather-chunk-mb", type=int, default=64)
+    ap.add_argument("--gather-chunk-mb", type=int, default=256)
     ap.add_argument("--backend", default=os.environ.get("DN_BACKEND", "nccl"))
     ap.add_argument("--header", default=None, help="text written before the records (e.g. DNAscent::writeDetectHeader)")
     ap.add_argument("--stats", default=None, help="rank 0 writes a JSON with per-rank busy / gather seconds, batches, peak buffered bytes")
@@ -88,11 +94,12 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
             torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-            dev_t = "cuda"
+            dev_t = "cuda:%d" % (local % max(1, torch.cuda.device_count()))
         dist.init_process_group(a.backend, rank=rank, world_size=world)
     from dnascent_amd import cnn_model, hip, host, shard, synth
     t0 = time.time()
     sizes, offsets = host.container_index(a.container)
+    t_index = time.time() - t0
     batches, window_of = shard.plan_windows(sizes, a.window_batches * world * a.batch_samples, a.batch_samples, a.batch_reads)
     pore = load_pore_model(a.pore_model) if a.pore_model else synth.pore_model()
     if a.model:
@@ -106,7 +113,7 @@ def main(argv=None):
     for c in ctxs:
         c.load_pore_model(pore, 0.14)
         c.load_cnn(desc, blob)
-    engine = host.DetectStream(ctxs, emit=True)
+    engine = host.DetectStream(ctxs, emit="packed")
     free = []
 
     def load(ords):
@@ -120,33 +127,39 @@ def main(argv=None):
         if a.header:
             out_f.write(a.header.encode())
 
-    def write(merged):
-        for _, rec in merged:
-            out_f.write(rec)
+    def write(text, ordinals, record_bytes):
+        out_f.write(text)
 
     drv = shard.StreamDriver(dist, batches, window_of, engine, load, write, release=free.append, dst=0, device=dev_t,
                              chunk_bytes=a.gather_chunk_mb << 20)
     ok = drv.run()
     st = engine.stats()
     tot = shard.reduce_counters(dist, [drv.n_ok, drv.n_fail, int(st.samples), 0 if ok else 1], device=dev_t)
+    if drv.failure is not None:
+        print("run_detect: rank %d aborted: %r" % (rank, drv.failure), file=sys.stderr)
     per_rank = shard.gather_stats(dist, dict(rank=rank, batches=drv.batches_done, busy_s=round(drv.busy_s, 3), gather_s=round(drv.gather_s, 3),
-                                             peak_buffered_bytes=int(drv.peak_pending_bytes), max_gather_bytes=int(drv.max_gather_bytes),
-                                             reads_ok=drv.n_ok, reads_failed=drv.n_fail), device=dev_t)
+                                             format_s=round(drv.format_s, 3), peak_buffered_bytes=int(drv.peak_pending_bytes),
+                                             max_gather_bytes=int(drv.max_gather_bytes), reads_ok=drv.n_ok, reads_failed=drv.n_fail,
+                                             upload_s=round(st.seconds_upload, 3), collect_wait_s=round(st.seconds_collect, 3),
+                                             pack_s=round(st.seconds_emit, 3)), device=dev_t)
     failed = tot[3] > 0
     if rank == 0:
         out_f.close()
         dt = time.time() - t0
         if failed:
             os.unlink(a.out)                                   # a partial file must not pass for a result
-            print("run_detect: ABORTED: a rank could not read its share of %s" % a.container, file=sys.stderr)
+            print("run_detect: ABORTED: a rank failed on its share of %s (loader or engine error; see its message above)" % a.container, file=sys.stderr)
         else:
             busy = [p["busy_s"] for p in per_rank]
             print("run_detect: %d reads ok, %d failed, %.1f M samples, %d rank(s), %d batches in %d window(s), %.2f s (%.1f Msamples/s incl. "
-                  "ingestion); per-rank busy %.2f .. %.2f s, gather %.2f s max, at most %.1f MB of records buffered on a rank" %
+                  "ingestion); per-rank busy %.2f .. %.2f s, gather %.2f s max, writer formatting %.2f s, at most %.1f MB of packed results "
+                  "buffered on a rank" %
                   (tot[0], tot[1], tot[2] / 1e6, world, len(batches), drv.n_windows, dt, tot[2] / 1e6 / dt, min(busy), max(busy),
-                   max(p["gather_s"] for p in per_rank), max(p["peak_buffered_bytes"] for p in per_rank) / 1e6))
+                   max(p["gather_s"] for p in per_rank), drv.format_s, max(p["peak_buffered_bytes"] for p in per_rank) / 1e6))
         if a.stats:
-            json.dump(dict(world=world, batches=len(batches), windows=drv.n_windows, seconds=dt, ranks=per_rank, failed=failed), open(a.stats, "w"))
+            json.dump(dict(world=world, batches=len(batches), windows=drv.n_windows, seconds=dt, samples=tot[2], Msamples_per_s=tot[2] / 1e6 / dt,
+                           reads_ok=tot[0], reads_failed=tot[1], text_bytes=int(drv.text_bytes), index_s=round(t_index, 3), inflight=len(ctxs),
+                           recv_groups=drv.stats.get("recv_groups", []), ranks=per_rank, failed=failed), open(a.stats, "w"))
     engine.close()
     for c in ctxs:
         c.close()

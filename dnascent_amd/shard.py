@@ -198,12 +198,15 @@ def plan_windows(sample_counts, window_samples, batch_samples, batch_reads=4096)
 class WorkCounter:
     """One shared counter the ranks pull batch ids from: `next()` returns 0, 1, 2, ... exactly once each across all ranks.
     Backed by the process group's TCPStore (`add` is atomic on the store's server: no collective, nobody waits for anybody);
-    a plain local counter for one rank.  `abort()` / `aborted()`: a rank that hit a fatal error tells the others to stop pulling."""
+    a plain local counter for one rank.  `abort()` / `aborted()`: a rank that hit a fatal error tells the others to stop pulling.
+    `name` must be unique per run on a process group (StreamDriver derives it from a per-process run sequence number that every rank
+    advances alike): the store's keys outlive a run, and a second run on stale keys would see an exhausted counter (round-3 advisor)."""
 
     def __init__(self, dist=None, name="dn_work"):
         self.local = 0
         self.store = None
         self.name = name
+        self.local_abort = False
         if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
             from torch.distributed.distributed_c10d import _get_default_store
             self.store = _get_default_store()
@@ -215,203 +218,415 @@ class WorkCounter:
         return int(self.store.add(self.name, 1)) - 1
 
     def abort(self):
+        self.local_abort = True
         if self.store is not None:
             self.store.add(self.name + "_abort", 1)
-        self.local_abort = True
 
     def aborted(self):
-        if getattr(self, "local_abort", False):
+        if self.local_abort:
             return True
         return self.store is not None and int(self.store.add(self.name + "_abort", 0)) > 0
 
 
-def gather_window(dist, ordinals, records, dst=0, device="cpu", chunk_bytes=64 << 20, error=False, pending=None):
-    """The records of ONE window to the writer rank: per peer a 24-byte header {n records, payload bytes, error flag} and the payload
-    [(ordinal, length) * n, text] in pieces of at most `chunk_bytes` (the staging tensor on the device is bounded by the chunk, not by
-    the window: round-2 advisor).  Point-to-point only: peers send, the writer receives peer by peer; no rank other than the writer
-    ever holds another rank's text.  Returns (merged [(ordinal, bytes)] sorted by ordinal, any_error) on `dst`, (None, None) elsewhere.
-    pending (a list): the peers' sends are posted with isend and their (work, tensor) pairs appended to it instead of being waited for
-    -- a rank that is ahead of the writer then goes on pulling batches; the caller bounds how many windows it lets pile up."""
+# ---- the window gather: packed per-call results, ONE grouped receive per window on the writer -----------------------------------
+# A rank's share of a window travels as one blob  [ordinal int64 x n | meta uint64 x 3 n | payload]  (host.PACK_*: per read a meta row
+# {count, header bytes, flags} and in the payload its header line + 16 bytes per call -- or, flag PACK_TEXT, its finished text).  The
+# SIZES travel through the process group's TCPStore (host side, no GPU work), the BYTES through torch.distributed point to point:
+#   peer    store.set(<key>/r<rank>, "n nbytes err")  ->  waits for <key>/go  ->  isend(blob), in pieces of `chunk_bytes`
+#   writer  waits for every peer's announcement  ->  store.set(<key>/go)  ->  ONE batch_isend_irecv with a receive from EVERY peer
+#           (per piece round): over RCCL all its xGMI links carry the window at once, and because a peer only posts its send after
+#           `go`, no send kernel sits spinning on a peer's GPU while the writer is still busy with its own batches (round-3 verdict).
+# The exchange runs on every rank's GATHER THREAD (StreamDriver), so neither side's wait holds up the thread that drives the GPU.
+PACK_REVERSE, PACK_TEXT = 1, 2
+
+
+def pack_text_records(ordinals, records):
+    """reads that exist only as finished text (the CPU tests' stand-in engine, DetectStream(emit=True)) in the packed wire form"""
+    o = np.asarray([int(x) for x in ordinals], np.int64)
+    meta = np.zeros((o.shape[0], 3), np.uint64)
+    meta[:, 0] = [len(r) for r in records]
+    meta[:, 2] = PACK_TEXT
+    return o, meta, np.frombuffer(b"".join(records), np.uint8)
+
+
+def payload_sizes(meta):
+    """bytes of every read's payload from its meta row: the text, or the header line + 16 bytes per call"""
+    m = np.asarray(meta, np.uint64).reshape(-1, 3)
+    text = (m[:, 2] & np.uint64(PACK_TEXT)) != 0
+    return np.where(text, m[:, 0], m[:, 1] + np.uint64(16) * m[:, 0]).astype(np.int64)
+
+
+def build_blob(chunks):
+    """[(ordinals, meta [n][3], payload uint8)] of one window on one rank -> (n, blob uint8)"""
+    if not chunks:
+        return 0, np.zeros(0, np.uint8)
+    o = np.concatenate([np.asarray(c[0], np.int64) for c in chunks])
+    m = np.concatenate([np.asarray(c[1], np.uint64).reshape(-1, 3) for c in chunks])
+    parts = [o.view(np.uint8), m.reshape(-1).view(np.uint8)] + [np.asarray(c[2], np.uint8) for c in chunks]
+    return int(o.shape[0]), np.concatenate(parts)
+
+
+def split_blob(n, blob):
+    """(n, blob) -> (ordinals int64 [n], meta uint64 [n][3], payload uint8) -- views into the blob"""
+    o = blob[:8 * n].view(np.int64)
+    m = blob[8 * n:32 * n].view(np.uint64).reshape(n, 3)
+    return o, m, blob[32 * n:]
+
+
+class StoreKeys:
+    """the few store operations the exchange needs, with a polling wait: TCPStore.wait() holds the client's lock for its whole
+    duration, which would stall the OTHER thread of this process that pulls batch ids from the same client"""
+
+    def __init__(self, store, dead_key, poll_s=0.002, timeout_s=1800.0):
+        self.store, self.dead_key, self.poll_s, self.timeout_s = store, dead_key, poll_s, timeout_s
+
+    def set(self, key, value):
+        self.store.set(key, value)
+
+    def wait(self, key):
+        import time
+        t0, k = time.perf_counter(), 0
+        while not self.store.check([key]):
+            k += 1
+            if k % 64 == 0:
+                if self.store.check([self.dead_key]):
+                    raise RuntimeError("a rank's gather thread died: window exchange abandoned")
+                if time.perf_counter() - t0 > self.timeout_s:
+                    raise RuntimeError("timed out waiting for %s" % key)
+            time.sleep(self.poll_s)
+        return self.store.get(key).decode()
+
+    def delete(self, key):
+        try:
+            self.store.delete_key(key)
+        except Exception:
+            pass
+
+
+def exchange_window(dist, keys, key, n, blob, error, dst=0, device="cpu", chunk_bytes=256 << 20, stats=None):
+    """One window's blobs to the writer (protocol above).  Returns ([(n_r, blob_r)] by rank, any_error) on `dst`, (None, None) elsewhere.
+    stats (a dict): "recv_groups" collects the number of receives of every grouped call the writer made."""
     import torch
-    head = np.zeros(2 * len(records), dtype=np.int64)
-    for j, (o, rec) in enumerate(zip(ordinals, records)):
-        head[2 * j] = int(o); head[2 * j + 1] = len(rec)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return sorted(zip((int(o) for o in ordinals), records), key=lambda t: t[0]), bool(error)
+        return [(n, blob)], bool(error)
     world, rank = dist.get_world_size(), dist.get_rank()
+    if error:
+        n, blob = 0, np.zeros(0, np.uint8)                      # an aborted run ships nothing; the flag is what travels
+    nbytes = int(blob.shape[0])
     if rank != dst:
-        payload = np.frombuffer(head.tobytes() + b"".join(records), dtype=np.uint8)
-        hd = torch.tensor([len(records), payload.shape[0], int(bool(error))], dtype=torch.int64, device=device)
-        parts = [hd] + [torch.from_numpy(payload[a:a + chunk_bytes].copy()).to(device) for a in range(0, payload.shape[0], chunk_bytes)]
-        for t in parts:
-            if pending is None:
-                dist.send(t, dst)
-            else:
-                pending.append((dist.isend(t, dst), t))       # the tensor stays referenced until its send has completed
+        keys.set("%s/r%d" % (key, rank), "%d %d %d" % (n, nbytes, int(bool(error))))
+        if nbytes:
+            keys.wait(key + "/go")
+            for a in range(0, nbytes, chunk_bytes):
+                t = torch.from_numpy(blob[a:a + chunk_bytes])
+                if device != "cpu":
+                    t = t.to(device)                             # staging on the device is bounded by the piece, not the window
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, dst)]):
+                    w.wait()
         return None, None
-    merged = list(zip((int(o) for o in ordinals), records))
+    peers = {}
     any_err = bool(error)
     for r in range(world):
         if r == dst:
             continue
-        hd = torch.zeros(3, dtype=torch.int64, device=device)
-        dist.recv(hd, r)
-        n, nbytes, err = (int(x) for x in hd.tolist())
-        any_err = any_err or bool(err)
-        parts = []
-        for a in range(0, nbytes, chunk_bytes):
-            t = torch.empty(min(chunk_bytes, nbytes - a), dtype=torch.uint8, device=device)
-            dist.recv(t, r)
-            parts.append(t.cpu().numpy().tobytes())
-        bl = b"".join(parts)
-        hdr = np.frombuffer(bl[:16 * n], dtype=np.int64).reshape(n, 2)
-        pos = 16 * n
-        for o, ln in hdr:
-            merged.append((int(o), bl[pos:pos + int(ln)])); pos += int(ln)
-    merged.sort(key=lambda t: t[0])
-    return merged, any_err
+        nr, nb, er = (int(x) for x in keys.wait("%s/r%d" % (key, r)).split())
+        peers[r] = (nr, nb); any_err = any_err or bool(er)
+    bufs = {r: np.empty(nb, np.uint8) for r, (_, nb) in peers.items()}
+    if any(nb for _, nb in peers.values()):
+        keys.set(key + "/go", "1")
+    rounds = max([(nb + chunk_bytes - 1) // chunk_bytes for _, nb in peers.values()] + [0])
+    for j in range(rounds):
+        ops, stage = [], {}
+        for r, (_, nb) in peers.items():
+            a = j * chunk_bytes
+            if nb > a:
+                ln = min(chunk_bytes, nb - a)
+                t = torch.from_numpy(bufs[r][a:a + ln]) if device == "cpu" else torch.empty(ln, dtype=torch.uint8, device=device)
+                stage[r] = (t, a, ln)
+                ops.append(dist.P2POp(dist.irecv, t, r))
+        if stats is not None:
+            stats.setdefault("recv_groups", []).append(len(ops))
+        for w in dist.batch_isend_irecv(ops):                    # ONE grouped call: a receive from every peer that has this piece
+            w.wait()
+        if device != "cpu":
+            for r, (t, a, ln) in stage.items():
+                bufs[r][a:a + ln] = t.cpu().numpy()
+    for r in peers:
+        keys.delete("%s/r%d" % (key, r))
+    keys.delete(key + "/go")
+    return [(n, blob) if r == dst else (peers[r][0], bufs[r]) for r in range(world)], any_err
+
+
+def format_window(blobs, formatter, write, group_bytes=256 << 20):
+    """the writer's half: the reads of every rank's blob merged by input ordinal, formatted in groups of bounded text size (the C++
+    formatter on the host's threads), handed to write(text, ordinals, record_bytes) in INPUT order.  Returns (reads, text bytes)."""
+    os_, ms_, ps_ = [], [], []
+    for n, blob in blobs:
+        if n == 0:
+            continue
+        o, m, pay = split_blob(n, blob)
+        sz = payload_sizes(m)
+        off = np.concatenate([[0], np.cumsum(sz)[:-1]]).astype(np.uint64)
+        os_.append(o); ms_.append(m); ps_.append(np.uint64(pay.ctypes.data) + off)
+    if not os_:
+        return 0, 0
+    o = np.concatenate(os_); m = np.concatenate(ms_); p = np.concatenate(ps_)
+    order = np.argsort(o, kind="stable")
+    o, m, p = o[order], np.ascontiguousarray(m[order]), np.ascontiguousarray(p[order])
+    est = np.where((m[:, 2] & np.uint64(PACK_TEXT)) != 0, m[:, 0], m[:, 1] + np.uint64(40) * m[:, 0]).astype(np.int64)
+    total, lo = 0, 0
+    while lo < o.shape[0]:
+        hi, acc = lo, 0
+        while hi < o.shape[0] and (hi == lo or acc + int(est[hi]) <= group_bytes):
+            acc += int(est[hi]); hi += 1
+        text, rb = formatter(m[lo:hi], p[lo:hi])
+        write(text, o[lo:hi], rb)
+        total += len(text); lo = hi
+    return int(o.shape[0]), total
+
+
+_RUN_SEQ = [0]
 
 
 class StreamDriver:
     """One rank's loop of the streamed, dynamically balanced run (the product driver, dnascent_amd/run_detect.py, and the CPU tests
     with a stand-in engine):
 
-        pull a batch id from the shared counter -> load ITS reads (bounded: at most depth + 1 batches exist on the host) ->
-        submit to the engine -> collect the oldest batch when the engine is full -> file its records under its window ->
-        a window whose batches this rank has all collected, and past which the counter has moved, is GATHERED to the writer and
-        written in input order -- windows in ascending order on every rank, so the point-to-point gathers pair up without a
-        collective -- while the engine keeps working on the next window's batches.
+        pull a batch id from the shared counter -> load ITS reads (bounded: at most depth + 2 batches exist on the host) ->
+        submit to the engine -> collect the oldest batch when the engine is full -> file its packed results under its window ->
+        a window whose batches this rank has all collected, and past which the counter has moved, is handed to the GATHER THREAD,
+        which exchanges it with the writer rank (exchange_window: sizes through the store, bytes in one grouped receive) -- windows in
+        ascending order on every rank, so the exchanges pair up without a collective -- and, on the writer, formats and writes it in
+        input order while the engine keeps working on the next window's batches.
 
-    engine:  .full() .in_flight() .submit(batch_obj, tag) .collect() -> dict(tag, batch, status, record_bytes, text)
+    engine:  .full() .in_flight() .submit(batch_obj, tag) .collect() -> dict(tag, batch, status, and either packed_meta [k][4] +
+             packed (host.DetectStream(emit="packed")) or record_bytes + text)
     load(ordinals) -> (batch_obj, accepted mask) or raises IOError (fatal: the run is aborted on every rank, nothing hangs)
-    write(merged records of one window) is called on the writer rank only, windows ascending.
+    write(text, ordinals, record_bytes) is called on the writer rank only, in input order.
+    formatter(meta3, read_ptr) -> (text, record_bytes): host.format_packed.
+    Any exception of the engine or the loader aborts the run COOPERATIVELY: the shared abort flag goes up, every rank stops pulling and
+    walks the remaining windows with the error flag (so every exchange still pairs up), run() returns False (round-3 advisor).
     """
 
-    def __init__(self, dist, batches, window_of, engine, load, write, release=None, dst=0, device="cpu", chunk_bytes=64 << 20, counter=None,
-                 max_pending_windows=2):
+    def __init__(self, dist, batches, window_of, engine, load, write, release=None, dst=0, device="cpu", chunk_bytes=256 << 20, counter=None,
+                 max_pending_windows=2, formatter=None, group_bytes=256 << 20):
         self.dist, self.batches, self.window_of = dist, batches, window_of
         self.engine, self.load, self.write, self.release = engine, load, write, release
         self.dst, self.device, self.chunk = dst, device, chunk_bytes
-        self.counter = counter or WorkCounter(dist)
+        _RUN_SEQ[0] += 1                                        # every rank constructs its drivers in the same order: same id everywhere
+        self.run_key = "dn_run%d" % _RUN_SEQ[0]
+        self.counter = counter or WorkCounter(dist, name=self.run_key + "_work")
         self.n_windows = int(window_of[-1]) + 1 if len(window_of) else 0
-        self.pending = {}            # window -> [(ordinal, record bytes)] of this rank
-        self.open = {}               # window -> batches of it this rank still has in flight
-        self.flushed = 0             # windows [0, flushed) are gathered
+        self.pending = {}            # window -> [(ordinals, meta, payload)] of this rank
+        self.open = {}               # window -> batches of it this rank holds (pulled, not yet collected)
+        self.flushed = 0             # windows [0, flushed) are handed to the gather thread
         self.frontier = 0            # the counter has moved past every batch of windows < frontier (as seen by this rank)
         self.n_ok = self.n_fail = self.samples = 0
-        self.peak_pending_bytes = 0; self.max_gather_bytes = 0
-        self.batches_done = 0; self.busy_s = 0.0; self.gather_s = 0.0
+        self.peak_pending_bytes = 0; self.max_gather_bytes = 0; self._pending_bytes = 0
+        self.batches_done = 0; self.busy_s = 0.0; self.gather_s = 0.0; self.format_s = 0.0
+        self.records_written = 0; self.text_bytes = 0
         self.error = False
+        self.failure = None          # the exception that aborted this rank, if any
+        self.stats = {}
         self.rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
-        # a peer posts its window with isend and goes on (dynamic balance would otherwise stop at every window: the writer only receives
-        # window k when its own batches of k are done); at most max_pending_windows windows of text wait in a rank's send queue
+        self.multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
         self.max_pending_windows = max_pending_windows
-        self._sends = []             # per posted window: [(work, tensor), ...]
+        self.group_bytes = group_bytes
+        if formatter is None:
+            from . import host as _host
+            formatter = _host.format_packed
+        self.formatter = formatter
+
+    # ---- main thread ----
+    def _file(self, w, chunk):
+        self.pending.setdefault(w, []).append(chunk)
+        self._pending_bytes += int(chunk[2].shape[0])
+        self.peak_pending_bytes = max(self.peak_pending_bytes, self._pending_bytes)
 
     def _collect_one(self):
         r = self.engine.collect()
         b = int(r["tag"]); w = int(self.window_of[b])
-        ords = r["ordinals"] if "ordinals" in r else self._tag_ords.pop(b)
-        pos = 0
-        recs = self.pending.setdefault(w, [])
-        for o, st, ln in zip(ords, r["status"], r["record_bytes"]):
-            if int(st) == 0:
-                recs.append((int(o), r["text"][pos:pos + int(ln)])); pos += int(ln); self.n_ok += 1
-            else:
-                self.n_fail += 1
+        ords = np.asarray(self._tag_ords.pop(b), np.int64)
+        if "packed_meta" in r:
+            m = np.asarray(r["packed_meta"], np.uint64).reshape(-1, 4)
+            if m.shape[0]:
+                self._file(w, (ords[m[:, 0].astype(np.int64)], m[:, 1:4], np.asarray(r["packed"], np.uint8)))
+            self.n_ok += int(m.shape[0]); self.n_fail += int(ords.shape[0] - m.shape[0])
+        else:
+            ok = np.asarray(r["status"]) == 0
+            ln = np.asarray(r["record_bytes"], np.int64)[ok]
+            if ln.shape[0]:
+                meta = np.zeros((ln.shape[0], 3), np.uint64); meta[:, 0] = ln; meta[:, 2] = PACK_TEXT
+                self._file(w, (ords[ok], meta, np.frombuffer(r["text"], np.uint8)))
+            self.n_ok += int(ok.sum()); self.n_fail += int((~ok).sum())
         self.open[w] -= 1
         self.batches_done += 1
         if self.release:
             self.release(r["batch"])
-        self.peak_pending_bytes = max(self.peak_pending_bytes, sum(len(x[1]) for v in self.pending.values() for x in v))
 
     def _flush_ready(self, final=False):
-        import time
         while self.flushed < self.n_windows and (final or self.flushed < self.frontier) and self.open.get(self.flushed, 0) == 0:
             w = self.flushed
-            recs = self.pending.pop(w, [])
-            t0 = time.perf_counter()
-            nbytes = sum(len(x[1]) for x in recs)
-            while len(self._sends) >= self.max_pending_windows:          # bound the text parked in this rank's send queue
-                for wk, _ in self._sends.pop(0):
-                    wk.wait()
-            posted = []
-            merged, err = gather_window(self.dist, [x[0] for x in recs], [x[1] for x in recs], dst=self.dst, device=self.device,
-                                        chunk_bytes=self.chunk, error=self.error, pending=posted if self.rank != self.dst else None)
-            if posted:
-                self._sends.append(posted)
-            self.gather_s += time.perf_counter() - t0
-            if merged is not None:
-                self.max_gather_bytes = max(self.max_gather_bytes, sum(len(x[1]) for x in merged))
-                self.error = self.error or bool(err)
-                if not self.error:
-                    self.write(merged)
-            else:
-                self.max_gather_bytes = max(self.max_gather_bytes, nbytes)
+            chunks = self.pending.pop(w, [])
+            n, blob = (0, np.zeros(0, np.uint8)) if self.error else build_blob(chunks)
+            self._pending_bytes -= sum(int(c[2].shape[0]) for c in chunks)
+            self._hand_over((w, n, blob, self.error))
             self.flushed += 1
+
+    def _hand_over(self, item):
+        import queue
+        while True:
+            try:
+                self._q.put(item, timeout=0.25)                   # bounded: at most max_pending_windows windows wait for the exchange
+                return
+            except queue.Full:
+                if not self._gt.is_alive():
+                    raise RuntimeError("gather thread died") from self._gather_exc
+
+    # ---- gather thread ----
+    def _gather_loop(self):
+        import time
+        try:
+            if self.device != "cpu":                             # the current device is per thread: take the driver's
+                import torch
+                d = torch.device(self.device)
+                if d.index is not None:
+                    torch.cuda.set_device(d)
+            for w in range(self.n_windows):
+                item = self._q.get()
+                assert item[0] == w
+                _, n, blob, err = item
+                t0 = time.perf_counter()
+                blobs, any_err = exchange_window(self.dist, self._keys, "%s/w%d" % (self.run_key, w), n, blob, err, dst=self.dst,
+                                                 device=self.device, chunk_bytes=self.chunk, stats=self.stats)
+                t1 = time.perf_counter()
+                self.gather_s += t1 - t0
+                if blobs is None:
+                    self.max_gather_bytes = max(self.max_gather_bytes, int(blob.shape[0]))
+                    continue
+                self.max_gather_bytes = max(self.max_gather_bytes, sum(int(b.shape[0]) for _, b in blobs))
+                self._writer_error = self._writer_error or bool(any_err)
+                if not self._writer_error:
+                    nrec, nb = format_window(blobs, self.formatter, self.write, self.group_bytes)
+                    self.records_written += nrec; self.text_bytes += nb
+                self.format_s += time.perf_counter() - t1
+        except BaseException as e:                               # noqa: BLE001 -- recorded, re-raised by run()
+            self._gather_exc = e
+            try:
+                if self._keys is not None:
+                    self._keys.set(self.run_key + "/dead", "1")
+            except Exception:
+                pass
 
     def run(self, prefetch=True):
         """prefetch: the NEXT batch is pulled and loaded by a helper thread while this one drives the engine (the loader reads the
-        container with all host cores; without it the GPU idles while a 600 MB batch comes off the disk)"""
+        container with all host cores; without it the GPU idles while a 600 MB batch comes off the disk).  Returns True when every
+        window was processed and (on the writer) written."""
+        import queue
+        import threading
         import time
         from concurrent.futures import ThreadPoolExecutor
         self._tag_ords = {}
+        self._q = queue.Queue(maxsize=max(1, self.max_pending_windows))
+        self._gather_exc = None
+        self._writer_error = False
+        self._keys = None
+        if self.multi:
+            from torch.distributed.distributed_c10d import _get_default_store
+            self._keys = StoreKeys(_get_default_store(), self.run_key + "/dead")
+        self._gt = threading.Thread(target=self._gather_loop, name="dn-gather", daemon=True)
+        self._gt.start()
         t_busy0 = time.perf_counter()
         pool = ThreadPoolExecutor(1) if prefetch else None
 
         def pull():
-            """next batch id of this rank -> (id, future / result of its load), or None when the counter is exhausted / the run aborted"""
-            if self.error or self.counter.aborted():
+            """next batch id of this rank -> (id, future / None), or None when the counter is exhausted / the run aborted.  The batch is
+            counted as OPEN in its window from this moment: the frontier may move past its window while it is still being loaded, and a
+            window must not be gathered without it (round-3 advisor: --inflight 1 lost the last batch of every window)."""
+            if self.error or self.counter.aborted() or self._gather_exc is not None:
                 self.error = True
                 return None
             b = self.counter.next()
             if b >= len(self.batches):
                 return None
-            self.frontier = max(self.frontier, int(self.window_of[b]))      # every batch of an earlier window has been handed out
+            w = int(self.window_of[b])
+            self.open[w] = self.open.get(w, 0) + 1
+            self.frontier = max(self.frontier, w)                # every batch of an earlier window has been handed out
             return b, (pool.submit(self.load, self.batches[b]) if pool else None)
 
-        nxt = pull()
-        while nxt is not None:
-            b, fut = nxt
-            w = int(self.window_of[b])
-            ords = self.batches[b]
-            try:
-                obj, accepted = fut.result() if fut is not None else self.load(ords)
-            except IOError:
-                self.error = True
-                self.counter.abort()
-                break
-            nxt = pull()                                       # ... and its load runs while this batch is submitted / older ones collected
-            keep = [int(o) for o, a in zip(ords, accepted) if a]
-            self.n_fail += len(ords) - len(keep)               # rejected by the reference's own filters: failed reads, not errors
-            if not keep:
-                if self.release:
-                    self.release(obj)
-                continue
-            while self.engine.full():
+        nxt = None
+        try:
+            nxt = pull()
+            while nxt is not None:
+                b, fut = nxt
+                w = int(self.window_of[b])
+                ords = self.batches[b]
+                try:
+                    obj, accepted = fut.result() if fut is not None else self.load(ords)
+                except BaseException:
+                    self.open[w] -= 1
+                    nxt = None
+                    raise
+                nxt = pull()                                       # ... and its load runs while this batch is submitted / older ones collected
+                keep = [int(o) for o, a in zip(ords, accepted) if a]
+                self.n_fail += len(ords) - len(keep)               # rejected by the reference's own filters: failed reads, not errors
+                if not keep:
+                    self.open[w] -= 1
+                    if self.release:
+                        self.release(obj)
+                    self._flush_ready()
+                    continue
+                while self.engine.full():
+                    self._collect_one()
+                    self._flush_ready()
+                self._tag_ords[b] = keep
+                try:
+                    self.engine.submit(obj, b)
+                except BaseException:
+                    self.open[w] -= 1; self._tag_ords.pop(b, None)
+                    raise
+                self._flush_ready()
+            self.frontier = self.n_windows
+            while self.engine.in_flight():
                 self._collect_one()
                 self._flush_ready()
-            self._tag_ords[b] = keep
-            self.open[w] = self.open.get(w, 0) + 1
-            self.engine.submit(obj, b)
-            self._flush_ready()
+        except BaseException as e:                               # noqa: BLE001 -- IOError of the loader, DnError of the engine, anything
+            self.error = True
+            self.failure = e
+            try:
+                self.counter.abort()
+            except Exception:
+                pass
+            while True:                                            # drain what is in flight, best effort; its results are dropped
+                try:
+                    if not self.engine.in_flight():
+                        break
+                    self._collect_one()
+                except BaseException:                              # noqa: BLE001
+                    break
         if nxt is not None and nxt[1] is not None:             # aborted with a load in flight: let it finish, drop it
             try:
                 obj, _ = nxt[1].result()
                 if self.release:
                     self.release(obj)
-            except IOError:
+            except BaseException:                                  # noqa: BLE001
                 pass
         if pool:
             pool.shutdown(wait=True)
+        if self.error or self.counter.aborted():
+            self.error = True
         self.frontier = self.n_windows
-        while self.engine.in_flight():
-            self._collect_one()
-            self._flush_ready()
-        self.busy_s = time.perf_counter() - t_busy0 - self.gather_s
-        self._flush_ready(final=True)                          # every rank walks ALL windows: the gathers always pair up
-        for posted in self._sends:
-            for wk, _ in posted:
-                wk.wait()
-        self._sends = []
+        self.open = {}
+        self.busy_s = time.perf_counter() - t_busy0
+        try:
+            self._flush_ready(final=True)                          # every rank walks ALL windows: the exchanges always pair up
+        except RuntimeError:
+            self.error = True
+        self._gt.join()
+        if self._gather_exc is not None:
+            self.error = True
+            if self.failure is None:
+                self.failure = self._gather_exc
+        if self._writer_error:
+            self.error = True
         return not self.error
