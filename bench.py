@@ -51,71 +51,98 @@ def cnn_macs(desc):
            sum(o["k"] * o["c"] for o in desc["ops"] if o["op"] == "dwconv") + 47040 + 64 * 3
 
 
-def cpu_baseline(model, n_bases, seed0, full, budget_reads):
-    """The oracle (CPU restatement of the reference path) with OpenMP, one read per thread, schedule(dynamic) -- the shape of the
-    reference's own loop (detect.cpp:852) -- over a bounded sample of the workload's reads.  full: + eventalign, and the CNN's
-    cost from the stock-PyTorch CPU rendering of the same model description (fp32, all cores) on a sample of the positions."""
+def _cnn_worker(args):
+    """one process of the CPU baseline's CNN leg: render the same slice of positions again and again for `seconds`; returns the positions done"""
+    ref, core, resid, sig, seconds = args
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cnn_torch_ref
+    import torch
+    torch.set_num_threads(1)
+    t0 = time.time(); done = 0
+    while time.time() - t0 < seconds or done == 0:
+        cnn_torch_ref.run(ref, core, resid, sig)
+        done += core.shape[0]
+    return done, time.time() - t0
+
+
+def cpu_baseline(model, n_bases, seed0, full, reads_per_thread=2, cnn_seconds=10.0):
+    """The oracle (CPU restatement of the reference path) on ALL host cores, measured, nothing extrapolated (round-3 verdict):
+      * normaliseEvents (+ eventalign): OpenMP, one read per thread, schedule(dynamic) -- the shape of the reference's own loop
+        (detect.cpp:852) -- over reads_per_thread x cores reads of the workload;
+      * the CNN (full scope): the stock-PyTorch CPU fp32 rendering of the same model description, ONE PROCESS PER CORE at once, each
+        rendering one read's positions single-threaded (the reference runs one TF_SessionRun per read from every OpenMP thread,
+        detect.cpp:653) for ~cnn_seconds: the aggregate positions/s of the loaded box, memory bandwidth contention included.
+    value = samples of the sample / (oracle seconds + its positions / measured aggregate CNN rate).  Must run BEFORE the process touches
+    the GPU (the CNN leg forks)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
+    from concurrent.futures import ThreadPoolExecutor
     from dnascent_amd import synth
     cores = os.cpu_count() or 1
-    # the reference's loop hands reads to threads one at a time (schedule(dynamic), detect.cpp:852): with one read per thread nothing is
-    # ever scheduled (round-2 verdict), so the sample holds reads_per_thread reads for every thread -- on FEWER threads when the budget of
-    # reads would not cover all cores (the per-thread rate is what scales to the box; the value reported is rate x cores)
-    reads_per_thread = 4
-    threads = max(1, min(cores, budget_reads // reads_per_thread))
-    n = threads * reads_per_thread
-    reads = [synth.make_read(seed0 + i, n_bases, model=model, is_reverse=bool(i & 1), sub_rate=0.002, ins_rate=0.001, del_rate=0.001)
-             for i in range(n)]
-    secs, samples, positions, ok = po.bench_reads(reads, model, full, threads)
-    what = "oracle normaliseEvents%s, OpenMP schedule(dynamic), %d reads on %d threads (%d per thread): %.1f s" % (
-        " + eventalign" if full else "", n, threads, reads_per_thread, secs)
-    cnn_s = 0.0
-    if full and positions:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import cnn_torch_ref
-        import torch
+    cnn_rate = None
+    what_cnn = ""
+    first = synth.make_read(seed0, n_bases, model=model, is_reverse=False, sub_rate=0.002, ins_rate=0.001, del_rate=0.001)
+    if full:
+        import multiprocessing as mp
         from dnascent_amd import cnn_model
-        # one read per thread like the reference (one TF_SessionRun per read from every OpenMP thread, detect.cpp:653): the
-        # rendering is timed on ONE thread and credited with perfect scaling over the cores -- generous to the CPU (a 256-thread
-        # intra-op run of these small convolutions is two orders of magnitude slower than that)
-        torch.set_num_threads(1)
-        o = po.OracleRead(reads[0], model)
+        o = po.OracleRead(first, model)
         assert o.normalise() == 0 and o.eventalign() == 0
         pos = o.positions()
         o.free()
-        k = min(len(pos["core"]), 20000)
+        k = min(len(pos["core"]), 12000)
         ref = cnn_model.default_model()[2]
-        t0 = time.time()
-        reps = 0
-        while time.time() - t0 < 4.0 or reps < 2:
-            cnn_torch_ref.run(ref, pos["core"][:k], pos["residual"][:k], pos["signal"][:k])
-            reps += 1
-        pos_per_s = reps * k / (time.time() - t0)
-        cnn_s = positions / (pos_per_s * threads)
-        what += "; CNN: PyTorch CPU fp32 rendering, %.0f positions/s on one thread, credited x %d threads: %d positions of the sample -> %.1f s" % (
-            pos_per_s, threads, positions, cnn_s)
-    per_thread = samples / (secs + cnn_s) / 1e6 / threads
-    return {"value": per_thread * cores, "unit": "Msamples/s", "cores": cores, "kind": "port", "threads_timed": threads,
-            "Msamples_per_s_per_thread": per_thread, "per_thread_without_cnn": samples / secs / 1e6 / threads,
+        job = (ref, np.ascontiguousarray(pos["core"][:k]), np.ascontiguousarray(pos["residual"][:k]), np.ascontiguousarray(pos["signal"][:k]), cnn_seconds)
+        with mp.get_context("fork").Pool(cores) as pool:               # before any OpenMP team exists in this process
+            t0 = time.time()
+            res = pool.map(_cnn_worker, [job] * cores, chunksize=1)
+            wall = time.time() - t0
+        cnn_rate = sum(r[0] for r in res) / max(r[1] for r in res)
+        what_cnn = "; CNN: PyTorch CPU fp32 rendering, %d processes x 1 thread at once, %d positions per call, %.1f s: %.0f positions/s aggregate (%.0f per core)" % (
+            cores, k, wall, cnn_rate, cnn_rate / cores)
+    n = cores * reads_per_thread
+    with ThreadPoolExecutor(min(cores, 32)) as ex:                       # the generator is C behind ctypes: threads do run in parallel
+        reads = [first] + list(ex.map(lambda i: synth.make_read(seed0 + i, n_bases, model=model, is_reverse=bool(i & 1), sub_rate=0.002, ins_rate=0.001,
+                                                                  del_rate=0.001), range(1, n)))
+    secs, samples, positions, ok = po.bench_reads(reads, model, full, cores)
+    what = "oracle normaliseEvents%s, OpenMP schedule(dynamic), %d reads on %d threads (%d per thread): %.1f s" % (
+        " + eventalign" if full else "", n, cores, reads_per_thread, secs)
+    cnn_s = positions / cnn_rate if (full and cnn_rate) else 0.0
+    if full:
+        what_cnn += "; the sample's %d positions at that rate: %.1f s" % (positions, cnn_s)
+    return {"value": samples / (secs + cnn_s) / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port", "threads_timed": cores,
+            "Msamples_per_s_per_thread": samples / (secs + cnn_s) / 1e6 / cores, "per_thread_without_cnn": samples / secs / 1e6 / cores,
+            "oracle_s": secs, "cnn_s": cnn_s, "cnn_positions_per_s_all_cores": cnn_rate,
             "reference_probe_per_thread": "0.15-0.20 Msamples/s (SURVEY.md s6: the real reference, one thread, normaliseEvents + eventalign)",
-            "sample": "%d of the %d-base reads of the workload (%d pass QC); %s; value = per-thread rate x %d cores" % (n, n_bases, ok, what, cores)}
+            "sample": "%d of the %d-base reads of the workload (%d pass QC); %s%s; value = samples / (oracle s + CNN s), every leg measured with all %d "
+                      "hardware threads loaded" % (n, n_bases, ok, what, what_cnn, cores)}
 
 
-def load_pmc(reads_per_step, bases, what):
-    """The committed counter passes (tools/r03_profile.sh -> tools/r03_collect.py -> profiles/r03_pmc_*.json): HBM bytes per launch and per
-    step, vector instructions of k2_fill, MFMA busy cycles.  Only used when they were taken at THIS workload's shape."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % ("banded" if what == "banded" else "bench"))
-    if not os.path.exists(path):
-        return None
-    try:
-        d = json.load(open(path))
-    except ValueError:
-        return None
-    w = d.get("workload", {})
-    if w.get("reads_per_step") != reads_per_step or w.get("bases") != bases or (what != "banded" and w.get("cnn_math") != what):
-        return None
-    return d
+def load_pmc(reads_per_step, bases, what, inflight=None):
+    """The committed counter passes (tools/r04_profile.sh -> tools/r04_collect.py -> profiles/r04_pmc_*.json; round 3's as a fall-back): HBM
+    bytes per launch and per step, vector instructions of k2_fill, MFMA busy cycles.  Only used when they were taken at THIS workload's shape;
+    the number of batches in flight during the counter pass is part of the shape for the chip-level figures (round-3 advisor): the caller
+    gets it back as d["workload"]["inflight"] and labels `roofline_chip` with it."""
+    for rnd in ("r04", "r03"):
+        path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, "banded" if what == "banded" else "bench"))
+        if not os.path.exists(path):
+            continue
+        try:
+            d = json.load(open(path))
+        except ValueError:
+            continue
+        w = d.get("workload", {})
+        if w.get("reads_per_step") != reads_per_step or w.get("bases") != bases or (what != "banded" and w.get("cnn_math") != what):
+            continue
+        d["source"] = os.path.basename(path)
+        d["inflight_matches"] = inflight is not None and w.get("inflight") == inflight
+        return d
+    return None
+
+
+def shard_plan(lens, args):
+    """the product driver's plan (shard.plan_windows) for reads of the given lengths in bases; sizes planned at 12.5 samples per base"""
+    from dnascent_amd import shard
+    return shard.plan_windows(lens * 12.5, args.window_batches * args.batch_samples, args.batch_samples, 2000)
 
 
 def _hbm_info():
@@ -136,9 +163,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scope", choices=["full", "banded"], default="full",
+    ap.add_argument("--scope", choices=["full", "banded", "mixed"], default="full",
                     help="full = BASELINE configs[2] (default): streamed 50 kb reads, whole pipeline, H2D to results on host; "
-                         "banded = configs[1]: 1 000 x 20 kb resident batch, normaliseEvents only (CNN stubbed)")
+                         "banded = configs[1]: 1 000 x 20 kb resident batch, normaliseEvents only (CNN stubbed); "
+                         "mixed = configs[4]'s read-length law on one GPU: --reads reads of clip(exp(N(ln 20 000, 0.9^2)), 1 000, 200 000) bases "
+                         "(seed 2025) cut into length-bucketed batches by shard.plan_windows (the product driver's plan), whole pipeline")
+    ap.add_argument("--reads", type=int, default=12000, help="mixed scope: reads of the workload")
+    ap.add_argument("--batch-samples", type=float, default=300e6, help="mixed scope: sample budget of a batch (run_detect's default)")
+    ap.add_argument("--window-batches", type=float, default=4.0, help="mixed scope: batches per window of consecutive reads")
+    ap.add_argument("--order", choices=["plan", "long-first"], default="plan",
+                    help="mixed scope: batch order -- plan = window by window (input order of the windows, longest batch of a window first: what the "
+                         "ordered writer needs); long-first = all batches of the run by descending read length (the LPT order of a shared queue)")
     ap.add_argument("--reads-per-step", type=int, default=None, help="reads per batch (default 500 full / 1000 banded)")
     ap.add_argument("--bases", type=int, default=None, help="bases per read (default 50000 full / 20000 banded)")
     ap.add_argument("--inflight", type=int, default=None,
@@ -151,7 +186,8 @@ def main():
     ap.add_argument("--fp32-steps", type=int, default=4, help="full scope, 1 GPU: after the run, this many steps again with the CNN in exact fp32 MFMA "
                                                               "arithmetic (value_fp32: the headline metric without the 16-bit split); 0 = off")
     args = ap.parse_args()
-    full = args.scope == "full"
+    mixed = args.scope == "mixed"
+    full = args.scope in ("full", "mixed")
     rps = args.reads_per_step or (500 if full else 1000)
     bases = args.bases or (50000 if full else 20000)
     inflight = args.inflight or 8                          # full, one session (round 3, gpurun_out/r3i): 6 -> 665, 8 -> 675, 10 -> 659 Msamples/s; 8 x 21 GB of workspaces + 4 CNN lanes = 238 of 309 GB
@@ -160,6 +196,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu_base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # FIRST, before this process touches the GPU: its CNN leg forks one worker per core
+        from dnascent_amd import synth as _synth
+        cpu_base = cpu_baseline(_synth.pore_model(), 30000 if mixed else bases, 1000003, full)
+        if mixed:
+            cpu_base["sample"] += " (mixed scope: 30 kb reads, the mean of the length law)"
     dist = None
     torch = None
     if world > 1:
@@ -182,6 +225,19 @@ def main():
     dev = (local_rank % max(1, hip.lib().dn_device_count())) if world > 1 else 0
     red_dev = "cuda" if (dist is not None and os.environ.get("DN_BENCH_BACKEND", "nccl") == "nccl") else "cpu"
     cnn_desc, cnn_blob, _ = cnn_model.default_model()
+    mix = None
+    if mixed:
+        # BASELINE configs[4]'s length law on ONE GPU through the product driver's plan (shard.plan_windows: windows of consecutive reads, each cut
+        # into length-bucketed batches, longest first); sizes are planned from the bases (x the generator's 12.5 samples per base)
+        rng = np.random.default_rng(2025 + rank)
+        lens = np.clip(np.exp(rng.normal(np.log(20000.0), 0.9, args.reads)), 1000, 200000).astype(np.int64)
+        plan, window_of = shard_plan(lens, args)
+        if args.order == "long-first":
+            order = sorted(range(len(plan)), key=lambda i: -int(lens[plan[i]].max()))
+            plan = [plan[i] for i in order]; window_of = window_of[order]
+        mix = dict(lens=lens, plan=plan, window_of=window_of)
+        args.steps = len(plan)
+        args.warmup = min(args.warmup, len(plan))
     n_batches = (args.warmup + args.steps) if full else 1
     nctx = max(1, min(inflight, args.steps if not full else n_batches))
     ctxs = [hip.Context(dev) for _ in range(nctx)]
@@ -199,9 +255,18 @@ def main():
     batches = []
     for b in range(n_batches):
         B = host.ReadBatch()
-        got = B.fill_synth(model, seed_base + b * rps, rps, bases)
-        assert got == rps, (got, rps)
+        if mixed:                                              # the warm-up replays the plan's first batches (same objects: an upload does not modify a batch)
+            if b < args.warmup:
+                continue
+            idx = mix["plan"][b - args.warmup]
+            got = B.fill_synth_list(model, 2 * (seed_base + idx.astype(np.int64)) + (idx & 1), mix["lens"][idx])
+            assert got == len(idx), (got, len(idx))
+        else:
+            got = B.fill_synth(model, seed_base + b * rps, rps, bases)
+            assert got == rps, (got, rps)
         batches.append(B)
+    if mixed:
+        batches = batches[:args.warmup] + batches
     t_gen = time.perf_counter() - t_gen
     if args.pin and full:
         for B in batches:
@@ -431,7 +496,7 @@ def main():
                     f_[q] += k_[q]
                 f_["kernels"][name] = k_
             k3_ms = sum(f_["ms"] for f_ in fam.values()) or 1.0
-            pmc = load_pmc(rps, bases, cnn_math)
+            pmc = None if mixed else load_pmc(rps, bases, cnn_math, inflight=nctx)
 
             def roof(label, d, solo_key=None):
                 secs = d["ms"] / 1e3
@@ -440,7 +505,11 @@ def main():
                 r = {"kernel": label, "launches": d["launches"], "mean_launch_ms": d["ms"] / d["launches"], "share_of_network_time": d["ms"] / k3_ms,
                      "algorithmic_flops_per_launch": d["flops"] / d["launches"], "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                      "flop_per_byte": inten, "ridge_flop_per_byte": ridge, "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "mfma_TFLOPs": tf,
-                     "mfma_frac": tf / peak, "mfma_issued_frac": issued * tf / peak, "traffic": None}
+                     "mfma_frac": tf / peak, "mfma_issued_frac": issued * tf / peak, "traffic": None,
+                     # the family's algorithmic work of the WHOLE timed run over the run's wall time: the launches of four CNN lanes overlap, so
+                     # their summed launch time exceeds the step and the per-launch `frac` is diluted; this one cannot be (round-3 verdict)
+                     "work_per_step_over_step_time": {"TFLOPs": d["flops"] / dt / 1e12, "GBs": d["bytes"] / dt / 1e9,
+                                                      "frac": (d["flops"] / dt / 1e12 / peak) if inten >= ridge else (d["bytes"] / dt / 1e9 / HBM_PEAK_GBS)}}
                 if inten >= ridge:
                     r.update(bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak)
                 else:
@@ -466,11 +535,11 @@ def main():
             note = ("achieved = algorithmic work of the launches (per-position figures x positions processed) / summed launch time, HIP events around every launch "
                     "in the timed region on the stream it runs on; a launch shares the chip with the other CNN lanes and the per-read stages of the batches in flight. "
                     "bound: flop/byte of the family against the ridge (%.0f flop/B for %s at %g issued products per fp32 product). traffic: HBM bytes per launch from the "
-                    "committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r03_pmc_bench.json) when they match this workload, else null" % (ridge, cnn_math, issued))
+                    "committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r0N_pmc_bench.json) when they match this workload, else null" % (ridge, cnn_math, issued))
             if fams:
                 out["roofline"] = dict(fams[0], note=note)
                 out["roofline_families"] = [{q: f_[q] for q in ("kernel", "share_of_network_time", "launches", "mean_launch_ms", "bound", "achieved", "peak", "unit", "frac",
-                                                               "hbm_frac", "mfma_frac", "mfma_issued_frac", "traffic")} for f_ in fams]
+                                                               "hbm_frac", "mfma_frac", "mfma_issued_frac", "traffic", "work_per_step_over_step_time")} for f_ in fams]
             mac = cnn_macs(cnn_desc)
             cnn_ms, cnn_n = prof.get("k3_cnn", (0.0, 0))
             flops = 2.0 * mac * positions / max(cnn_n, 1)
@@ -504,6 +573,8 @@ def main():
                 mf = issued * 2.0 * mac * positions / args.steps / (dt / args.steps) / 1e12
                 out["roofline_chip"] = {"hbm_bytes_per_step": stp["write_bytes"] + stp["fetch_bytes_corrected"], "hbm_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS,
                                         "mfma_issued_TFLOPs": mf, "mfma_issued_frac": mf / peak, "mfma_util_counter": stp.get("mfma_util"),
+                                        "counter_pass": {"source": pmc.get("source"), "inflight": pmc.get("workload", {}).get("inflight"), "this_run_inflight": nctx,
+                                                         "same_inflight": bool(pmc.get("inflight_matches"))},
                                         "note": "whole chip over one step of THIS run: HBM bytes of all kernels of a step (PMC passes at this workload's shape: "
                                                 "FETCH_SIZE x 2 + WRITE_SIZE) / ms_per_step / 8 TB/s; issued 16-bit MFMA flops of the network per step / ms_per_step / "
                                                 "the dense peak; mfma_util_counter = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of the counter pass"}
@@ -538,8 +609,28 @@ def main():
                              "reads_passing_qc": int(np.sum(summ["status"] == 0)),
                              "parallelism": "reads sharded, %d rank(s), %d batches in flight per GPU, one host thread per rank" % (world, nctx)}
             out["roofline"] = roof_banded
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, bases, seed_base, full, budget_reads=128)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
+        if mixed:
+            lens = mix["lens"]
+            per_batch = []
+            for idx in mix["plan"]:
+                l_ = lens[idx].astype(np.float64)
+                per_batch.append(dict(reads=int(len(idx)), bases=int(l_.sum()), longest=int(l_.max()), shortest=int(l_.min()),
+                                      lane_utilisation=float(l_.mean() / l_.max())))
+            wsum = float(sum(b_["bases"] for b_ in per_batch))
+            out["metric"] += " -- mixed read lengths (configs[4]'s law) on one GPU"
+            out["config"]["workload"] = ("%d synthetic R10.4.1 reads of clip(exp(N(ln 20 000, 0.9^2)), 1 000, 200 000) bases (seed 2025; %d .. %d, median %d, mean %d), "
+                                         "%d length-bucketed batches of <= %.0f M samples in %d windows (shard.plan_windows, order: %s), full pipeline (%s)" % (
+                                             args.reads, int(lens.min()), int(lens.max()), int(np.median(lens)), int(lens.mean()), len(per_batch), args.batch_samples / 1e6,
+                                             int(mix["window_of"].max()) + 1, args.order, cnn_math))
+            out["mixed"] = {"reads": int(args.reads), "batches": len(per_batch), "order": args.order,
+                            "lane_utilisation_weighted": float(sum(b_["lane_utilisation"] * b_["bases"] for b_ in per_batch) / wsum),
+                            "longest_read_share_of_serial_kernels": float(1.0 - sum(b_["lane_utilisation"] * b_["bases"] for b_ in per_batch) / wsum),
+                            "note": "k1 / k2_fill / k2_chase / k2b_eventalign run one wavefront (or workgroup) per read and are serial chains as long as the read: a batch "
+                                    "holds its SIMDs for its LONGEST read.  lane_utilisation = mean / longest read length of a batch (bases-weighted over the batches); "
+                                    "1 - that = the share of those kernels' wavefront-time spent waiting for the longest read",
+                            "per_batch": per_batch}
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()

@@ -88,20 +88,25 @@ static std::mutex g_lane_mu;
 static CnnLane *g_lane[64][DN_MAX_LANES] = { { nullptr } };
 static unsigned g_ctx_seq = 0;
 static unsigned g_dev_ctx[64] = { 0 };                  // live contexts per device: the last one to go takes the device's lanes with it
-// caller holds g_lane_mu; no dn_run_* of the device may be in progress (contexts are single-producer, the last one is being destroyed
-// or the host called dn_shutdown between runs)
-static void lanes_free_device(int dev) {
-    if (dev < 0 || dev >= 64) return;
+// caller holds g_lane_mu.  A lane whose mutex is held -- a CNN pass of another host thread is being enqueued on it right now (cnn_execute
+// holds L->mu, not g_lane_mu, for the whole enqueue) -- is left alone and counted: freeing it would pull the stream, the mutex and the
+// activation buffers from under that pass (round-3 advisor).  Returns the number of lanes that were busy.
+static int lanes_free_device(int dev) {
+    if (dev < 0 || dev >= 64) return 0;
+    int busy = 0;
     for (unsigned l = 0; l < DN_MAX_LANES; l++) {
         CnnLane *L = g_lane[dev][l];
         if (!L) continue;
+        if (!L->mu.try_lock()) { busy++; continue; }
         (void)hipSetDevice(dev);
         if (L->stream) { (void)hipStreamSynchronize(L->stream); (void)hipStreamDestroy(L->stream); }
         for (DevBuf &b : L->buf) if (b.p) (void)hipFree(b.p);
         for (DevBuf *b : { &L->valid, &L->enclen, &L->enchist, &L->permsrc, &L->permrow, &L->live }) if (b->p) (void)hipFree(b->p);
-        delete L;
-        g_lane[dev][l] = nullptr;
+        g_lane[dev][l] = nullptr;                        // nobody can find the lane any more (lookups go through g_lane under g_lane_mu) ...
+        L->mu.unlock();
+        delete L;                                        // ... so nobody can be waiting on its mutex
     }
+    return busy;
 }
 static size_t lanes_bytes_device(int dev) {
     size_t n = 0;
@@ -374,13 +379,14 @@ const char *dn_kernel_name(int k) { return (k >= 0 && k < DN_K_COUNT) ? KNAMES[k
 static void ctx_unregister(dn_ctx *c) {
     std::lock_guard<std::mutex> lk(g_lane_mu);
     if (c->device < 0 || c->device >= 64 || g_dev_ctx[c->device] == 0) return;
-    if (--g_dev_ctx[c->device] == 0) lanes_free_device(c->device);
+    if (--g_dev_ctx[c->device] == 0) (void)lanes_free_device(c->device);
 }
 
 int dn_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_lane_mu);
-    for (int d = 0; d < 64; d++) lanes_free_device(d);
-    return DN_OK;
+    int busy = 0;
+    for (int d = 0; d < 64; d++) busy += lanes_free_device(d);
+    return busy ? DN_ERR_STATE : DN_OK;                  // a dn_run_cnn / dn_cnn_infer of another host thread was in progress: its lane stays, call again
 }
 
 int dn_ctx_create(int device, void *hip_stream, dn_ctx **out) {
@@ -862,12 +868,13 @@ int dn_get_align_rows(dn_ctx *c, uint32_t *n_rows) {
     return DN_OK;
 }
 
-int dn_get_align_table(dn_ctx *c, uint32_t read, uint32_t n_rows, uint32_t *coord, uint32_t *ref_pos, double *value, uint8_t *kind) {
+int dn_get_align_table(dn_ctx *c, uint32_t read, uint32_t cap, uint32_t *coord, uint32_t *ref_pos, double *value, uint8_t *kind) {
     int rc = need(c, 6, "dn_get_align_table"); if (rc) return rc;
     if (read >= (uint32_t)c->B.n_reads) return DN_ERR_ARG;
     if (!c->have_align) return fail(c, DN_ERR_STATE, "dn_set_align_table(ctx, 1) must precede dn_run_eventalign");
     const unsigned long long a0 = c->h_al_off[read];
-    if (a0 + n_rows > c->h_al_off[read + 1]) return fail(c, DN_ERR_ARG, "dn_get_align_table: read %u has at most %llu rows", read, c->h_al_off[read + 1] - a0);
+    const unsigned long long n_rows = c->h_al_off[read + 1] - a0;          // the library's own count (dn_get_align_rows reports it), like every other tap
+    if (n_rows > cap) return fail(c, DN_ERR_ARG, "dn_get_align_table: read %u has %llu rows, the caller's arrays hold %u", read, n_rows, cap);
     if (n_rows == 0) return DN_OK;
     if (coord) HIPCHK(c, hipMemcpyAsync(coord, (unsigned *)c->al_coord.p + a0, n_rows * 4ull, hipMemcpyDeviceToHost, c->stream));
     if (ref_pos) HIPCHK(c, hipMemcpyAsync(ref_pos, (unsigned *)c->al_rpos.p + a0, n_rows * 4ull, hipMemcpyDeviceToHost, c->stream));

@@ -113,7 +113,13 @@ void ReadBatch::unpin() {
     pinned.clear();
 }
 
-int ReadBatch::add(const ReadInput &in) {
+// what add() derives from one read before anything is appended: the signal slice, the flattened CIGAR maps, the strand-direction sequences
+namespace {
+struct Prepared {
+    bool ok = false; size_t lo = 0, hi = 0; int refLen = 0;
+    std::vector<uint32_t> r2q; std::vector<int32_t> q2r; std::vector<uint8_t> r2d; std::string bc, rs;
+};
+void prepareRead(const ReadInput &in, Prepared &P) {
     // ---- signal slice (pod5.cpp:75-93) ----
     size_t lo = 0, hi = in.n_adc;
     if (in.signalLength > 0) {
@@ -121,25 +127,63 @@ int ReadBatch::add(const ReadInput &in) {
         else { lo = (size_t)in.signalTrim; hi = (size_t)in.signalLength; }
         hi = std::min(hi, in.n_adc); lo = std::min(lo, hi);
     }
-    if (hi - lo < 16 || in.querySeq.size() < DN_KMER + 1) return -1;
-    std::vector<uint32_t> r2q; std::vector<int32_t> q2r; std::vector<uint8_t> r2d;
-    const int refLen = parseCigar(in.cigarOp, in.cigarLen, in.isReverse, in.querySeq.size(), r2q, q2r, r2d);
-    if (refLen < DN_KMER || (size_t)refLen != in.refSlice.size()) return -1;
+    P.ok = false; P.lo = lo; P.hi = hi;
+    if (hi - lo < 16 || in.querySeq.size() < DN_KMER + 1) return;
+    P.refLen = parseCigar(in.cigarOp, in.cigarLen, in.isReverse, in.querySeq.size(), P.r2q, P.q2r, P.r2d);
+    if (P.refLen < DN_KMER || (size_t)P.refLen != in.refSlice.size()) return;
     // ---- sequencing direction (reads.h:280-286) ----
-    const std::string bc = in.isReverse ? reverseComplement(in.querySeq) : in.querySeq;
-    const std::string rs = in.isReverse ? reverseComplement(in.refSlice) : in.refSlice;
+    P.bc = in.isReverse ? reverseComplement(in.querySeq) : in.querySeq;
+    P.rs = in.isReverse ? reverseComplement(in.refSlice) : in.refSlice;
+    P.ok = true;
+}
+}  // namespace
 
-    readID.push_back(in.readID); contig.push_back(in.contig);
-    adc.insert(adc.end(), in.adc + lo, in.adc + hi); adc_off.push_back(adc.size());
-    cal_offset.push_back(in.cal_offset); cal_scale.push_back(in.cal_scale);
-    basecall.insert(basecall.end(), bc.begin(), bc.end()); basecall_off.push_back(basecall.size());
-    refseq.insert(refseq.end(), rs.begin(), rs.end()); refseq_off.push_back(refseq.size());
-    ref2query.insert(ref2query.end(), r2q.begin(), r2q.end());
-    ref2del.insert(ref2del.end(), r2d.begin(), r2d.end());
-    query2ref.insert(query2ref.end(), q2r.begin(), q2r.end());               // queryLen + 1 entries
-    ref_start.push_back(in.refStart); ref_end.push_back(in.refStart + refLen);
-    is_reverse.push_back(in.isReverse ? 1 : 0);
-    return (int)readID.size() - 1;
+int ReadBatch::add(const ReadInput &in) {
+    const ReadInput *one = &in;
+    uint8_t took = 0;
+    addMany(&one, 1, &took);
+    return took ? (int)readID.size() - 1 : -1;
+}
+
+// n reads at once: the per-read work of add() -- CIGAR flattening (htsInterface.cpp:59-157: three arrays of the read's reference length),
+// reverse complements, the copies of a 1 MB signal -- runs on the host's threads; only the offset bookkeeping is serial.  A 500 x 50 kb batch
+// read by read took 0.35-0.45 s of ONE thread, more than the GPU needs for it: the product driver's loader was what the GPU waited for
+// (round 4: run_detect 497 Msamples/s against the bench's 720 on pre-built batches).  Returns the reads accepted; accepted[i] = 1 / 0.
+size_t ReadBatch::addMany(const ReadInput *const *in, size_t n, uint8_t *accepted) {
+    std::vector<Prepared> P(n);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(hostThreads()) if (n > 1)
+    for (long i = 0; i < (long)n; i++) prepareRead(*in[i], P[(size_t)i]);
+    // offsets of every accepted read in the flat arrays
+    std::vector<size_t> o_adc(n), o_bc(n), o_rs(n), o_q2r(n), slot(n);
+    size_t a = adc.size(), b = basecall.size(), r = refseq.size(), q = query2ref.size(), k = readID.size(), taken = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (accepted) accepted[i] = P[i].ok ? 1 : 0;
+        if (!P[i].ok) continue;
+        o_adc[i] = a; o_bc[i] = b; o_rs[i] = r; o_q2r[i] = q; slot[i] = k + taken;
+        a += P[i].hi - P[i].lo; b += P[i].bc.size(); r += P[i].rs.size(); q += P[i].q2r.size();
+        adc_off.push_back(a); basecall_off.push_back(b); refseq_off.push_back(r);
+        taken++;
+    }
+    if (!taken) return 0;
+    readID.resize(k + taken); contig.resize(k + taken); cal_offset.resize(k + taken); cal_scale.resize(k + taken);
+    ref_start.resize(k + taken); ref_end.resize(k + taken); is_reverse.resize(k + taken);
+    adc.resize(a); basecall.resize(b); refseq.resize(r); ref2query.resize(r); ref2del.resize(r); query2ref.resize(q);     // ref2query / ref2del: one entry per reference base
+#pragma omp parallel for schedule(dynamic, 1) num_threads(hostThreads()) if (n > 1)
+    for (long i = 0; i < (long)n; i++) {
+        const Prepared &p = P[(size_t)i];
+        if (!p.ok) continue;
+        const ReadInput &x = *in[i];
+        const size_t s_ = slot[(size_t)i];
+        readID[s_] = x.readID; contig[s_] = x.contig; cal_offset[s_] = x.cal_offset; cal_scale[s_] = x.cal_scale;
+        ref_start[s_] = x.refStart; ref_end[s_] = x.refStart + p.refLen; is_reverse[s_] = x.isReverse ? 1 : 0;
+        memcpy(adc.data() + o_adc[(size_t)i], x.adc + p.lo, (p.hi - p.lo) * sizeof(int16_t));
+        memcpy(basecall.data() + o_bc[(size_t)i], p.bc.data(), p.bc.size());
+        memcpy(refseq.data() + o_rs[(size_t)i], p.rs.data(), p.rs.size());
+        memcpy(ref2query.data() + o_rs[(size_t)i], p.r2q.data(), p.r2q.size() * sizeof(uint32_t));
+        memcpy(ref2del.data() + o_rs[(size_t)i], p.r2d.data(), p.r2d.size());
+        memcpy(query2ref.data() + o_q2r[(size_t)i], p.q2r.data(), p.q2r.size() * sizeof(int32_t));               // queryLen + 1 entries
+    }
+    return taken;
 }
 
 dn_batch_desc ReadBatch::desc() const {
@@ -833,12 +877,13 @@ int64_t dnh_container_load_at(void *b, const char *path, const uint64_t *offsets
 #pragma omp for schedule(dynamic, 4)
             for (long j = 0; j < (long)m; j++) ok[(size_t)j] = open_ok && r.seek(offsets[c0 + (uint64_t)j]) && r.next(rd[(size_t)j]);
         }
-        for (uint64_t j = 0; j < m; j++) {
-            if (!ok[(size_t)j]) { io_bad = true; break; }
-            const bool took = B->add(rd[(size_t)j].in) >= 0;
-            if (accepted) accepted[c0 + j] = took ? 1 : 0;
-            got += took;
-        }
+        for (uint64_t j = 0; j < m; j++) if (!ok[(size_t)j]) { io_bad = true; break; }
+        if (io_bad) break;
+        std::vector<const ReadInput *> ptr((size_t)m);
+        std::vector<uint8_t> took((size_t)m, 0);
+        for (uint64_t j = 0; j < m; j++) ptr[(size_t)j] = &rd[(size_t)j].in;
+        got += (int64_t)B->addMany(ptr.data(), (size_t)m, took.data());
+        if (accepted) memcpy(accepted + c0, took.data(), (size_t)m);
     }
     if (io_bad) {                                            // all or nothing: a half-loaded batch would shift every later ordinal
         if (first == 0) B->clear();
@@ -964,9 +1009,10 @@ int dnh_detect_write(void *ctx, void *b, const char *path, const char *header) {
 // n_reads synthetic reads (dn_synth.c: seeds seed0 .. seed0 + n - 1, every odd one on the reverse strand) generated on all host
 // cores and added to the batch in seed order -- the bench's 10 000 x 50 kb stream would take minutes read by read from Python.
 // Returns the number of reads the batch accepted.
-int dnh_batch_fill_synth(void *b, const double *model_mean, uint64_t seed0, uint32_t n_reads, uint32_t n_bases, double noise_pa,
-                         double sub_rate, double ins_rate, double del_rate) {
-    ReadBatch *B = (ReadBatch *)b;
+}  // extern "C"
+template <typename Sink>
+static int synthReads(Sink &&sink, const double *model_mean, uint32_t n_reads, const uint64_t *seeds, const uint32_t *bases, const uint8_t *rev, double noise_pa,
+                      double sub_rate, double ins_rate, double del_rate) {
     struct Gen { std::vector<char> ref, bc; std::vector<uint32_t> op, len; std::vector<int16_t> adc; dns_read_out o; int rc; };
     int accepted = 0;
     const uint32_t chunk = 64;                              // reads generated at a time (bounds the temporary memory)
@@ -976,8 +1022,9 @@ int dnh_batch_fill_synth(void *b, const double *model_mean, uint64_t seed0, uint
 #pragma omp parallel for schedule(dynamic, 1)
         for (long i = 0; i < (long)m; i++) {
             Gen &G = g[(size_t)i];
+            const uint32_t n_bases = bases[c0 + i];
             dns_read_spec sp; memset(&sp, 0, sizeof sp);
-            sp.seed = seed0 + c0 + (uint64_t)i; sp.n_bases = n_bases; sp.ref_start = 1000; sp.is_reverse = (int)((c0 + i) & 1u);
+            sp.seed = seeds[c0 + i]; sp.n_bases = n_bases; sp.ref_start = 1000; sp.is_reverse = (int)rev[c0 + i];
             sp.noise_pa = noise_pa; sp.mean_dwell = 11.5; sp.sub_rate = sub_rate; sp.ins_rate = ins_rate; sp.del_rate = del_rate;
             const size_t capq = 2 * (size_t)n_bases + 8;
             G.ref.resize(n_bases); G.bc.resize(capq); G.op.resize(capq); G.len.resize(capq); G.adc.resize(dns_max_samples(n_bases));
@@ -988,7 +1035,7 @@ int dnh_batch_fill_synth(void *b, const double *model_mean, uint64_t seed0, uint
         for (uint32_t i = 0; i < m; i++) {
             Gen &G = g[i];
             if (G.rc) continue;
-            char id[64]; snprintf(id, sizeof id, "synth-%016llx", (unsigned long long)(seed0 + c0 + i));
+            char id[64]; snprintf(id, sizeof id, "synth-%016llx", (unsigned long long)seeds[c0 + i]);
             ReadInput in;
             in.readID = id; in.contig = "chrSynth";
             in.adc = G.adc.data(); in.n_adc = G.o.n_samples; in.cal_offset = G.o.cal_offset; in.cal_scale = G.o.cal_scale;
@@ -998,10 +1045,39 @@ int dnh_batch_fill_synth(void *b, const double *model_mean, uint64_t seed0, uint
             in.refSlice = G.o.is_reverse ? DNAscent::reverseComplement(rf) : rf;
             in.cigarOp.assign(G.op.data(), G.op.data() + G.o.n_cigar); in.cigarLen.assign(G.len.data(), G.len.data() + G.o.n_cigar);
             in.refStart = G.o.ref_start; in.isReverse = G.o.is_reverse != 0;
-            if (B->add(in) >= 0) accepted++;
+            if (sink(in)) accepted++;
         }
     }
     return accepted;
+}
+extern "C" {
+static int fillSynth(ReadBatch *B, const double *model_mean, uint32_t n_reads, const uint64_t *seeds, const uint32_t *bases, const uint8_t *rev, double noise_pa,
+                     double sub_rate, double ins_rate, double del_rate) {
+    return synthReads([B](const ReadInput &in) { return B->add(in) >= 0; }, model_mean, n_reads, seeds, bases, rev, noise_pa, sub_rate, ins_rate, del_rate);
+}
+// n_reads synthetic reads of n_bases straight into a binary read container (the product driver's input at BASELINE configs[2] size is 10 000 x
+// 50 kb = 11.5 GB: generated on all host cores, 64 reads at a time).  Returns the reads written or -1.
+int64_t dnh_container_write_synth(const char *path, const double *model_mean, uint64_t seed0, uint32_t n_reads, uint32_t n_bases) {
+    DNAscent::ReadContainerWriter w;
+    if (!w.open(path)) return -1;
+    std::vector<uint64_t> seeds(n_reads); std::vector<uint32_t> bases(n_reads, n_bases); std::vector<uint8_t> rev(n_reads);
+    for (uint32_t i = 0; i < n_reads; i++) { seeds[i] = seed0 + i; rev[i] = (uint8_t)(i & 1u); }
+    bool ok = true;
+    const int n = synthReads([&](const ReadInput &in) { ok = ok && w.add(in); return ok; }, model_mean, n_reads, seeds.data(), bases.data(), rev.data(), 1.6, 0.002, 0.001, 0.001);
+    return (w.close() && ok) ? n : -1;
+}
+int dnh_batch_fill_synth(void *b, const double *model_mean, uint64_t seed0, uint32_t n_reads, uint32_t n_bases, double noise_pa,
+                         double sub_rate, double ins_rate, double del_rate) {
+    std::vector<uint64_t> seeds(n_reads); std::vector<uint32_t> bases(n_reads, n_bases); std::vector<uint8_t> rev(n_reads);
+    for (uint32_t i = 0; i < n_reads; i++) { seeds[i] = seed0 + i; rev[i] = (uint8_t)(i & 1u); }      // every odd read of the call is reverse
+    return fillSynth((ReadBatch *)b, model_mean, n_reads, seeds.data(), bases.data(), rev.data(), noise_pa, sub_rate, ins_rate, del_rate);
+}
+// the same with a seed and a length PER READ (mixed-length workloads: BASELINE configs[4]'s 1-200 kb law); strand = seed parity
+int dnh_batch_fill_synth_list(void *b, const double *model_mean, uint32_t n_reads, const uint64_t *seeds, const uint32_t *bases, double noise_pa,
+                              double sub_rate, double ins_rate, double del_rate) {
+    std::vector<uint8_t> rev(n_reads);
+    for (uint32_t i = 0; i < n_reads; i++) rev[i] = (uint8_t)(seeds[i] & 1u);
+    return fillSynth((ReadBatch *)b, model_mean, n_reads, seeds, bases, rev.data(), noise_pa, sub_rate, ins_rate, del_rate);
 }
 
 int dnh_stream_detect(void **ctxs, int n_ctx, void **batches, int n_batches, int emit, const char *out_path, const char *header,

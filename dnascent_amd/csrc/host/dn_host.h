@@ -49,6 +49,8 @@ public:
     // returns the index of the read in the batch, or -1 if the read is rejected (empty signal / too short), mirroring
     // the reference's filters (detect.cpp:839, pod5.cpp:64)
     int add(const ReadInput &in);
+    // n reads at once, their per-read preparation (CIGAR flattening, reverse complements, copies) on the host's threads; accepted[i] = 1 / 0
+    size_t addMany(const ReadInput *const *in, size_t n, uint8_t *accepted);
     size_t size() const { return readID.size(); }
     dn_batch_desc desc() const;
     uint64_t totalSamples() const { return adc_off.empty() ? 0 : adc_off.back(); }

@@ -70,6 +70,10 @@ def lib():
                                         C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64]
         L.dnh_batch_fill_synth.restype = C.c_int
         L.dnh_batch_fill_synth.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.dnh_batch_fill_synth_list.restype = C.c_int
+        L.dnh_batch_fill_synth_list.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.dnh_container_write_synth.restype = C.c_int64
+        L.dnh_container_write_synth.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]
         L.dnh_stream_detect.restype = C.c_int
         L.dnh_stream_detect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(StreamStats), C.c_void_p]
         L.dnh_keep_new.restype = C.c_void_p
@@ -181,6 +185,15 @@ def write_container(path, synth_reads, signal_length=-1, signal_trim=0, signal_s
         raise IOError(path)
 
 
+def write_synth_container(path, model, seed0, n_reads, n_bases):
+    """n_reads synthetic reads (seeds seed0 .., every odd one reverse: ReadBatch.fill_synth's reads) into a container, generated on all host cores"""
+    m = np.ascontiguousarray(model, np.float64)
+    n = int(lib().dnh_container_write_synth(path.encode(), m.ctypes.data, seed0, n_reads, n_bases))
+    if n < 0:
+        raise IOError(path)
+    return n
+
+
 def container_count(path):
     return int(lib().dnh_container_count(path.encode()))
 
@@ -244,6 +257,13 @@ class ReadBatch:
         The batch does not keep SynthRead objects for them (self.reads stays as it was)."""
         m = np.ascontiguousarray(model, np.float64)
         return int(lib().dnh_batch_fill_synth(self.h, m.ctypes.data, seed0, n_reads, n_bases, noise_pa, sub_rate, ins_rate, del_rate))
+
+    def fill_synth_list(self, model, seeds, bases, noise_pa=1.6, sub_rate=0.002, ins_rate=0.001, del_rate=0.001):
+        """one synthetic read per (seed, length in bases) pair, strand by seed parity; generated on all host cores"""
+        m = np.ascontiguousarray(model, np.float64)
+        sd = np.ascontiguousarray(seeds, np.uint64); nb = np.ascontiguousarray(bases, np.uint32)
+        assert sd.shape == nb.shape
+        return int(lib().dnh_batch_fill_synth_list(self.h, m.ctypes.data, sd.shape[0], sd.ctypes.data, nb.ctypes.data, noise_pa, sub_rate, ins_rate, del_rate))
 
     def add_container(self, path, first=0, count=1 << 62):
         """reads [first, first + count) of a binary read container; returns how many were accepted (-1: malformed file)"""

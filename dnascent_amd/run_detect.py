@@ -43,6 +43,7 @@ import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # the host library's OpenMP teams must SLEEP between their loops: spinning threads starve the HIP runtime's callback thread (dn_host.cpp hostThreads)
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("DN_CNN_ROWS", str(4 << 20))         # activation rows resident per CNN pass and lane (bench.py's setting: 2 Mi -6 %, 8 Mi -3 %)
 if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "DN_HOST_THREADS" not in os.environ:
     # N ranks share the host's cores: each rank's loader / packer / formatter loops take their share (dn_host.cpp hostThreads)
     os.environ["DN_HOST_THREADS"] = str(max(4, min(64, (os.cpu_count() or 64) // int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"])))))
@@ -132,7 +133,19 @@ def main(argv=None):
 
     drv = shard.StreamDriver(dist, batches, window_of, engine, load, write, release=free.append, dst=0, device=dev_t,
                              chunk_bytes=a.gather_chunk_mb << 20)
+    # set-up, not part of the stream: every context gets its workspace now (a first upload is a 10+ GB hipMalloc) by uploading the plan's
+    # first batch -- window 0's longest reads -- once to each; later batches of the same budget fit the grow-only slabs
+    if len(batches):
+        b0, _ = load(batches[0])
+        if b0.size():
+            for c in ctxs:
+                b0.upload(c)
+                c.sync()
+        free.append(b0)
+    t_setup = time.time() - t0
+    t_stream = time.time()
     ok = drv.run()
+    t_stream = time.time() - t_stream
     st = engine.stats()
     tot = shard.reduce_counters(dist, [drv.n_ok, drv.n_fail, int(st.samples), 0 if ok else 1], device=dev_t)
     if drv.failure is not None:
@@ -152,13 +165,14 @@ def main(argv=None):
         else:
             busy = [p["busy_s"] for p in per_rank]
             print("run_detect: %d reads ok, %d failed, %.1f M samples, %d rank(s), %d batches in %d window(s), %.2f s (%.1f Msamples/s incl. "
-                  "ingestion); per-rank busy %.2f .. %.2f s, gather %.2f s max, writer formatting %.2f s, at most %.1f MB of packed results "
+                  "indexing, context set-up and ingestion; the stream itself -- first batch loaded to last record written -- %.2f s = %.1f Msamples/s); per-rank busy %.2f .. %.2f s, gather %.2f s max, writer formatting %.2f s, at most %.1f MB of packed results "
                   "buffered on a rank" %
-                  (tot[0], tot[1], tot[2] / 1e6, world, len(batches), drv.n_windows, dt, tot[2] / 1e6 / dt, min(busy), max(busy),
+                  (tot[0], tot[1], tot[2] / 1e6, world, len(batches), drv.n_windows, dt, tot[2] / 1e6 / dt, t_stream, tot[2] / 1e6 / t_stream, min(busy), max(busy),
                    max(p["gather_s"] for p in per_rank), drv.format_s, max(p["peak_buffered_bytes"] for p in per_rank) / 1e6))
         if a.stats:
             json.dump(dict(world=world, batches=len(batches), windows=drv.n_windows, seconds=dt, samples=tot[2], Msamples_per_s=tot[2] / 1e6 / dt,
                            reads_ok=tot[0], reads_failed=tot[1], text_bytes=int(drv.text_bytes), index_s=round(t_index, 3), inflight=len(ctxs),
+                           setup_s=round(t_setup, 3), stream_s=round(t_stream, 3), Msamples_per_s_stream=tot[2] / 1e6 / t_stream,
                            recv_groups=drv.stats.get("recv_groups", []), ranks=per_rank, failed=failed), open(a.stats, "w"))
     engine.close()
     for c in ctxs:

@@ -144,7 +144,8 @@ int dn_cnn_infer(dn_ctx *ctx, uint32_t n_seq, const uint32_t *len, const float *
  * scaled sample (raw - shift) / scale, kind (0 match, 1 insertion).  The text of a record is host work (k-mers, "%f"). */
 int dn_set_align_table(dn_ctx *ctx, int on);
 int dn_get_align_rows(dn_ctx *ctx, uint32_t *n_rows /* [n_reads] */);
-int dn_get_align_table(dn_ctx *ctx, uint32_t read, uint32_t n_rows, uint32_t *coord, uint32_t *ref_pos, double *value, uint8_t *kind);
+/* cap: rows EACH of the caller's arrays holds; the read's own row count (dn_get_align_rows) is what is written, DN_ERR_ARG if it exceeds cap */
+int dn_get_align_table(dn_ctx *ctx, uint32_t read, uint32_t cap /* rows */, uint32_t *coord, uint32_t *ref_pos, double *value, uint8_t *kind);
 
 /* ---- `detect --HMM` (detect.cpp:885): llAcrossRead (detect.cpp:393-574) + sequenceProbability (:235-378) ----
  * Fit models (config.h:53-54, import_poreModel_fitStdv data_IO.cpp:192): (mean, std) per 9-mer in kmer2index order.
@@ -239,7 +240,8 @@ const char *dn_kernel_name(int kernel);
 size_t dn_device_bytes(const dn_ctx *ctx);      /* HBM currently held by the context + the CNN lanes of its device (shared by its contexts) */
 /* Frees the process-wide CNN lanes (streams + activation buffers) of every device.  dn_ctx_destroy of the LAST context of a device does
  * it for that device by itself; dn_shutdown is for hosts that keep contexts alive but want the lanes' HBM back between runs.  The
- * lanes come back on the next dn_run_cnn. */
+ * lanes come back on the next dn_run_cnn.  A lane on which another host thread is enqueueing a pass at that moment (dn_run_cnn,
+ * dn_cnn_infer, dn_collect's repeat) is left alone: the call then returns DN_ERR_STATE after freeing the others -- call it again. */
 int dn_shutdown(void);
 
 #ifdef __cplusplus

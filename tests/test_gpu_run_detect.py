@@ -44,3 +44,37 @@ def test_two_ranks_write_the_same_file_as_one(model, tmp_path):
     assert bt.detect_write(ctx, ref, header="#hdr\n") == 13
     assert open(ref, "rb").read() == a
     ctx.close()
+
+
+def test_inflight_one_loses_nothing(model, tmp_path):
+    """`run_detect --inflight 1` (round-3 advisor: the prefetched batch's window used to be gathered without it) writes the file the default depth writes"""
+    reads = [synth.make_read(8900 + i, 2000 + 500 * (i % 4), model=model, is_reverse=bool(i & 1), sub_rate=0.002) for i in range(12)]
+    cont = str(tmp_path / "reads.dnrc")
+    host.write_container(cont, reads)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    outs = []
+    for depth in ("1", "3"):
+        out = str(tmp_path / ("d%s.detect" % depth)); outs.append(out)
+        r = subprocess.run([sys.executable, "-m", "dnascent_amd.run_detect", "--container", cont, "--out", out, "--batch-samples", "50000", "--inflight", depth,
+                            "--window-batches", "2"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    a, b = open(outs[0], "rb").read(), open(outs[1], "rb").read()
+    assert a == b and a.count(b">") == 12
+
+
+def test_bench_two_ranks_gloo():
+    """bench.py's N > 1 path -- static shard, per-rank streams, gather_calls / gather_stats / reduce_max inside and after the timed region -- on the
+    one GPU with the gloo backend (DN_BENCH_BACKEND): what the driver's 8-GPU SCALE command runs over RCCL must not execute for the first time there"""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), DN_BENCH_BACKEND="gloo", DN_CNN_ROWS=str(1 << 20))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reads-per-step", "40", "--bases", "5000", "--inflight", "2"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1, r.stdout[-2000:]
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert len(d["ranks"]["per_rank"]) == 2 and d["ranks"]["gather_s_max"] >= 0.0 and "gather_s" in d["host"]
+    assert d["config"]["samples_per_gpu"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d          # the CPU leg runs at N = 1 only

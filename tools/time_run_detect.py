@@ -1,0 +1,32 @@
+"""GPU: the PRODUCT driver timed at BASELINE configs[2] size (round-3 verdict item 3): a binary read container of N synthetic 50 kb reads is
+written to --dir (11.5 GB at N = 10 000), then `python -m dnascent_amd.run_detect` ingests it (index, plan, loader thread, DetectStream, packed
+gather to the gather thread, C++ formatter, ordered write) into a .detect file.  Prints run_detect's own summary line and writes its --stats JSON.
+    python tools/time_run_detect.py --reads 10000 --stats gpurun_out/run_detect_stats.json"""
+import argparse, json, os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--reads", type=int, default=10000)
+ap.add_argument("--bases", type=int, default=50000)
+ap.add_argument("--dir", default="/tmp")
+ap.add_argument("--inflight", type=int, default=8)
+ap.add_argument("--stats", default=None)
+ap.add_argument("--keep", action="store_true")
+a, extra = ap.parse_known_args()
+from dnascent_amd import host, synth
+cont = os.path.join(a.dir, "bench_reads.dnrc"); out = os.path.join(a.dir, "bench_reads.detect")
+t0 = time.time()
+n = host.write_synth_container(cont, synth.pore_model(), 1000003, a.reads, a.bases)
+print("container: %d reads, %.2f GB, written in %.1f s" % (n, os.path.getsize(cont) / 1e9, time.time() - t0), flush=True)
+env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), DN_CNN_ROWS=str(4 << 20))
+cmd = [sys.executable, "-m", "dnascent_amd.run_detect", "--container", cont, "--out", out, "--inflight", str(a.inflight)] + (["--stats", a.stats] if a.stats else []) + extra
+t0 = time.time()
+r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True)
+print(r.stdout[-3000:]); print(r.stderr[-3000:], file=sys.stderr)
+print("run_detect wall (process start to exit, incl. library load, context + CNN-lane allocation): %.1f s, rc %d, output %.2f GB" % (
+    time.time() - t0, r.returncode, os.path.getsize(out) / 1e9 if os.path.exists(out) else 0.0))
+if not a.keep:
+    for f in (cont, out):
+        if os.path.exists(f):
+            os.unlink(f)
+sys.exit(r.returncode)
