@@ -284,7 +284,13 @@ def main():
         warm, timed = batches[:args.warmup], batches[args.warmup:]
         # set-up, not a step: every context the warm-up batches will not reach gets its workspace now (a first upload is a
         # 10+ GB hipMalloc; with --warmup 2 and 4 contexts two of those used to land inside the timed region: 513 against 605)
-        for c in ctxs[len(warm):]:
+        if mixed:
+            # the batches differ in shape (28 .. 1 900 reads, 2 .. 200 kb): every context gets the workspace of the LARGEST of them now
+            # (dn_ctx_reserve) -- regrowing a slab in the middle of the stream frees the old one, and hipFree waits for the whole device
+            need = max(ctxs[0].workspace_bytes(B.desc()) for B in timed)
+            for c in ctxs:
+                c.reserve(int(need * 1.02), collect_bytes=int(args.batch_samples / 12.5 * 0.3 * 29 * 1.3))
+        for c in ctxs[len(warm):] if not mixed else ctxs:
             batches[0].upload(c)
             c.sync()
         if warm:

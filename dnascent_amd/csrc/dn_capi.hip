@@ -156,7 +156,8 @@ struct dn_ctx {
     uint32_t n_batch = 0;                               // reads of the resident batch (what the host functions loop over)
     // dn_collect: device-side compaction + page-locked result block
     unsigned *d_call_cnt = nullptr; unsigned long long *d_call_off = nullptr;
-    DevBuf col_dev; void *col_host = nullptr; size_t col_host_cap = 0;
+    DevBuf col_dev; void *col_host = nullptr; size_t col_host_cap = 0, col_reserve = 0;
+    size_t last_need = 0; bool measure_only = false;      // dn_batch_workspace_bytes: the sizing pass of dn_batch_upload alone
     unsigned long long *p_call_off = nullptr; dn_read_summary *p_summary = nullptr;
     bool upload_pinned = false;
     bool keep_k1 = false;                               // dn_debug_keep_k1
@@ -255,8 +256,12 @@ static int fit_slab(dn_ctx *c, size_t need) {
     c->slabs.push_back({ (char *)q, cap, 0 }); c->dev_bytes += cap;
     return DN_OK;
 }
+// grow-only side buffer.  Growth is GEOMETRIC with a floor: hipFree waits for the whole device, so with several batches in flight every regrowth
+// drains the pipeline -- on mixed read lengths (28 .. 1 900 reads per batch) a context used to regrow its per-read tables batch after batch
+// (round 4: 5.5 s of a 9.7 s run inside dn_batch_upload).  The per-read tables are a few bytes per read: 64 KiB covers any batch at once.
 static int dgrow(dn_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap) return DN_OK;
+    bytes = std::max<size_t>(std::max<size_t>(bytes + bytes / 2, 2 * b.cap), 64u << 10);
     if (b.p) { hipFree(b.p); c->dev_bytes -= b.cap; }
     b.p = nullptr; b.cap = 0;
     hipError_t e = hipMalloc(&b.p, bytes);
@@ -607,7 +612,7 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     if (n > c->p_cap) {                                   // page-locked mirrors for the stream-ordered host functions
         if (c->p_res) { hipHostFree(c->p_res); hipHostFree(c->p_bandc); hipHostFree(c->p_vit); hipHostFree(c->p_call_off); hipHostFree(c->p_summary); }
         c->p_res = nullptr; c->p_bandc = nullptr; c->p_vit = nullptr; c->p_call_off = nullptr; c->p_summary = nullptr; c->p_cap = 0;
-        const size_t cap = (size_t)n + n / 4 + 16;
+        const size_t cap = std::max<size_t>((size_t)n + n / 2 + 16, 4096);     // hipHostFree waits for the device too: sized once for any batch up to 4 096 reads
         HIPCHK(c, hipHostMalloc((void **)&c->p_res, cap * sizeof(ReadRes), hipHostMallocDefault));
         HIPCHK(c, hipHostMalloc((void **)&c->p_bandc, cap * sizeof(BandConstsH), hipHostMallocDefault));
         HIPCHK(c, hipHostMalloc((void **)&c->p_vit, cap * sizeof(VitReadH), hipHostMallocDefault));
@@ -657,6 +662,8 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     rc = place();
     c->measuring = false;
     if (rc) return rc;
+    c->last_need = c->measured;
+    if (c->measure_only) return DN_OK;                     // dn_batch_workspace_bytes: nothing allocated, nothing copied; the context holds no batch
     if ((rc = fit_slab(c, c->measured))) return rc;
     dfree_all(c);
     if ((rc = place())) return rc;
@@ -682,6 +689,27 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     c->h_res.assign(n, ReadRes{});
     c->n_batch = n; c->async_err = 0;
     c->have_batch = true; c->stage = 1;
+    return DN_OK;
+}
+
+int dn_batch_workspace_bytes(dn_ctx *c, const dn_batch_desc *d, uint64_t *bytes) {
+    if (!c || !d || !bytes) return DN_ERR_ARG;
+    c->measure_only = true;
+    const int rc = dn_batch_upload(c, d);
+    c->measure_only = false;
+    c->have_batch = false; c->stage = 0;
+    *bytes = rc ? 0 : (uint64_t)c->last_need;
+    return rc;
+}
+
+int dn_ctx_reserve(dn_ctx *c, uint64_t workspace_bytes, uint64_t collect_bytes) {
+    if (!c) return DN_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_batch = false; c->stage = 0;
+    dfree_all(c);
+    if (workspace_bytes) { const int rc = fit_slab(c, (size_t)workspace_bytes); if (rc) return rc; }
+    c->col_reserve = std::max(c->col_reserve, (size_t)collect_bytes);
     return DN_OK;
 }
 
@@ -957,7 +985,7 @@ int dn_collect(dn_ctx *c, dn_result_batch *out) {
     if (bytes > c->col_host_cap) {
         if (c->col_host) hipHostFree(c->col_host);
         c->col_host = nullptr; c->col_host_cap = 0;
-        const size_t want = bytes + bytes / 4;
+        const size_t want = std::max(bytes + bytes / 2, c->col_reserve);
         HIPCHK(c, hipHostMalloc(&c->col_host, want, hipHostMallocDefault));
         c->col_host_cap = want;
     }
@@ -1295,7 +1323,7 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned
     if (n > c->cnn_meta_cap) {
         if (c->p_cnn_rowoff) { hipHostFree(c->p_cnn_rowoff); hipHostFree(c->p_cnn_iooff); }
         c->p_cnn_rowoff = nullptr; c->p_cnn_iooff = nullptr; c->cnn_meta_cap = 0;
-        const size_t m = (size_t)n + n / 4 + 16;
+        const size_t m = std::max<size_t>((size_t)n + n / 2 + 16, 4096);
         HIPCHK(c, hipHostMalloc((void **)&c->p_cnn_rowoff, m * sizeof(unsigned), hipHostMallocDefault));
         HIPCHK(c, hipHostMalloc((void **)&c->p_cnn_iooff, m * sizeof(uint64_t), hipHostMallocDefault));
         c->cnn_meta_cap = m;

@@ -18,7 +18,7 @@ for _i, _n in enumerate(K_NAMES):
 
 # every symbol include/dnascent_hip.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = ["dn_abi_version", "dn_device_count", "dn_ctx_create", "dn_ctx_destroy", "dn_last_error", "dn_sync",
-           "dn_load_pore_model", "dn_batch_upload", "dn_host_alloc", "dn_host_free", "dn_host_register", "dn_host_unregister", "dn_run_detect", "dn_collect", "dn_debug_emission", "dn_debug_keep_k1", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded",
+           "dn_load_pore_model", "dn_batch_upload", "dn_host_alloc", "dn_host_free", "dn_host_register", "dn_host_unregister", "dn_run_detect", "dn_collect", "dn_batch_workspace_bytes", "dn_ctx_reserve", "dn_debug_emission", "dn_debug_keep_k1", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded",
            "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_set_align_table", "dn_get_align_rows", "dn_get_align_table", "dn_load_cnn", "dn_cnn_set_math", "dn_cnn_range_escalations", "dn_run_cnn", "dn_get_probabilities", "dn_cnn_infer", "dn_load_fit_models", "dn_run_hmm", "dn_get_hmm_calls", "dn_get_summaries", "dn_get_prefix_sums",
            "dn_get_tstats", "dn_get_scrappie_events", "dn_get_events", "dn_get_kmer_ranks", "dn_get_alignment",
            "dn_get_cleaned", "dn_get_trace", "dn_get_positions", "dn_get_windows", "dn_profile_enable", "dn_profile_get",
@@ -111,6 +111,8 @@ def lib():
         L.dn_get_probabilities.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
         L.dn_get_summaries.argtypes = [C.c_void_p, C.c_void_p]
         L.dn_collect.argtypes = [C.c_void_p, C.POINTER(ResultBatch)]
+        L.dn_batch_workspace_bytes.argtypes = [C.c_void_p, C.POINTER(BatchDesc), C.POINTER(C.c_uint64)]
+        L.dn_ctx_reserve.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
         L.dn_debug_emission.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dn_debug_keep_k1.argtypes = [C.c_void_p, C.c_int]
         L.dn_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
@@ -233,6 +235,16 @@ class Context:
         out = np.zeros(self.n_reads, SUMMARY_DTYPE)
         self._chk(lib().dn_get_summaries(self.h, out.ctypes.data), "dn_get_summaries")
         return out
+
+    def workspace_bytes(self, desc):
+        """dn_batch_workspace_bytes: the device workspace a batch of this shape needs (sizing pass only; the context holds no batch afterwards)"""
+        b = C.c_uint64(0)
+        self._chk(lib().dn_batch_workspace_bytes(self.h, C.byref(desc), C.byref(b)), "dn_batch_workspace_bytes")
+        return int(b.value)
+
+    def reserve(self, workspace_bytes, collect_bytes=0):
+        """dn_ctx_reserve: make the workspace slab hold at least workspace_bytes now (no regrowth -- a device-wide wait -- in the middle of a stream)"""
+        self._chk(lib().dn_ctx_reserve(self.h, C.c_uint64(int(workspace_bytes)), C.c_uint64(int(collect_bytes))), "dn_ctx_reserve")
 
     def collect(self):
         """dn_collect: the bulk result of the batch as numpy COPIES: summary [n_reads], call_off [n_reads + 1], and per call

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 3
+#define DN_ABI_VERSION 4
 #define DN_KMER 9            /* config.h:45 */
 #define DN_NKMER 262144      /* 4^9, data_IO.cpp:177 */
 #define DN_BANDWIDTH 100     /* config.h:41 AdaptiveBanded_Params.bandwidth */
@@ -198,6 +198,15 @@ typedef struct {
     const char *kmer9;                /* [n_calls * 9] strand 9-mer, not NUL-terminated */
 } dn_result_batch;
 int dn_collect(dn_ctx *ctx, dn_result_batch *out);
+
+/* ---- sizing a context ahead of its batches (hosts whose batches differ in shape: mixed read lengths) ----
+ * A context's workspace is one grow-only slab sized by its largest batch so far; growing it frees the old slab, and hipFree waits for
+ * the WHOLE device -- with several contexts in flight every regrowth drains the pipeline.  dn_batch_workspace_bytes runs the sizing pass
+ * of dn_batch_upload alone (nothing is allocated or copied; the context holds no batch afterwards); dn_ctx_reserve makes the slab hold at
+ * least workspace_bytes now and lets the first dn_collect allocate at least collect_bytes of page-locked result space.  Call both between
+ * batches (the context's stream is waited for).  The reference has no counterpart: its per-read buffers are malloc'ed per read. */
+int dn_batch_workspace_bytes(dn_ctx *ctx, const dn_batch_desc *batch, uint64_t *bytes);
+int dn_ctx_reserve(dn_ctx *ctx, uint64_t workspace_bytes, uint64_t collect_bytes);
 
 /* ---- intermediate taps (parity tests; NULL pointers are skipped) ----
  * Every tap takes `cap`: how many records (samples / events / k-mers / pairs / bands / positions / windows) EACH of the caller's arrays

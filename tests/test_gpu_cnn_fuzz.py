@@ -22,6 +22,7 @@ from dnascent_amd import hip
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+torch.set_num_threads(4)           # the renderings are tiny tensors: on a 256-thread host the default intra-op pool makes them 50x slower
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

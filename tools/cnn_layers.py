@@ -21,7 +21,7 @@ for r in last:
     dt = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; tot += dt
     if "k3_sep" in r["Kernel_Name"]:
         pw = ops[i + 1]
-        kind = "ws" if "k3_sep_ws" in r["Kernel_Name"] else "  "
+        kind = "ws" if "k3_sep_ws" in r["Kernel_Name"] else "un" if "k3_sep_uni" in r["Kernel_Name"] else "  "
         key = "sep%s k%-2d %3d->%3d" % (kind, o["k"], pw["cin"], pw["cout"]); fl = 2 * (pw["cin"] * pw["cout"] + o["k"] * o["c"]) * npos
         a = agg.setdefault(key, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += dt; a[2] += fl; a[3] += npos * (pw["cin"] + pw["cout"]) * 4
         i += 2; continue

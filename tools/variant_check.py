@@ -44,7 +44,7 @@ base = run({})
 print("default        ", base)
 ok = True
 for name, env in (("conv BM=128", {"DN_CNN_BM256": "0"}),
-                  ("sep no-ws", {"DN_CNN_SEP_WS": "0"}), ("sep unfused", {"DN_CNN_FUSE": "0"}), ("theilsen full", {"DN_TS_FULL": "1"})):
+                  ("sep no-ws", {"DN_CNN_SEP_WS": "0"}), ("sep uni", {"DN_CNN_SEP_UNI": "1"}), ("sep unfused", {"DN_CNN_FUSE": "0"}), ("theilsen full", {"DN_TS_FULL": "1"})):
     d = run(env)
     print("%-15s" % name, d, "same" if d == base else "DIFFERENT")
     ok = ok and d == base
