@@ -65,7 +65,7 @@ def _cnn_worker(args):
     return done, time.time() - t0
 
 
-def cpu_baseline(model, n_bases, seed0, full, reads_per_thread=2, cnn_seconds=10.0):
+def cpu_baseline(model, n_bases, seed0, full, reads_per_thread=2, cnn_seconds=6.0):
     """The oracle (CPU restatement of the reference path) on ALL host cores, measured, nothing extrapolated (round-3 verdict):
       * normaliseEvents (+ eventalign): OpenMP, one read per thread, schedule(dynamic) -- the shape of the reference's own loop
         (detect.cpp:852) -- over reads_per_thread x cores reads of the workload;
@@ -89,7 +89,7 @@ def cpu_baseline(model, n_bases, seed0, full, reads_per_thread=2, cnn_seconds=10
         assert o.normalise() == 0 and o.eventalign() == 0
         pos = o.positions()
         o.free()
-        k = min(len(pos["core"]), 12000)
+        k = min(len(pos["core"]), 4000)                     # ~2 s per call per core with every core loaded
         ref = cnn_model.default_model()[2]
         job = (ref, np.ascontiguousarray(pos["core"][:k]), np.ascontiguousarray(pos["residual"][:k]), np.ascontiguousarray(pos["signal"][:k]), cnn_seconds)
         with mp.get_context("fork").Pool(cores) as pool:               # before any OpenMP team exists in this process
@@ -142,7 +142,7 @@ def load_pmc(reads_per_step, bases, what, inflight=None):
 def shard_plan(lens, args):
     """the product driver's plan (shard.plan_windows) for reads of the given lengths in bases; sizes planned at 12.5 samples per base"""
     from dnascent_amd import shard
-    return shard.plan_windows(lens * 12.5, args.window_batches * args.batch_samples, args.batch_samples, 2000)
+    return shard.plan_windows(lens * 12.5, args.window_batches * args.batch_samples, args.batch_samples, 4096)
 
 
 def _hbm_info():
@@ -168,7 +168,7 @@ def main():
                          "banded = configs[1]: 1 000 x 20 kb resident batch, normaliseEvents only (CNN stubbed); "
                          "mixed = configs[4]'s read-length law on one GPU: --reads reads of clip(exp(N(ln 20 000, 0.9^2)), 1 000, 200 000) bases "
                          "(seed 2025) cut into length-bucketed batches by shard.plan_windows (the product driver's plan), whole pipeline")
-    ap.add_argument("--reads", type=int, default=12000, help="mixed scope: reads of the workload")
+    ap.add_argument("--reads", type=int, default=36000, help="mixed scope: reads of the workload")
     ap.add_argument("--batch-samples", type=float, default=300e6, help="mixed scope: sample budget of a batch (run_detect's default)")
     ap.add_argument("--window-batches", type=float, default=4.0, help="mixed scope: batches per window of consecutive reads")
     ap.add_argument("--order", choices=["plan", "long-first"], default="plan",

@@ -1173,7 +1173,7 @@ int dn_get_windows(dn_ctx *c, uint32_t read, uint64_t cap, uint32_t *ref_index, 
 }
 
 int dn_load_cnn(dn_ctx *c, const dn_cnn_op *ops, uint32_t n_ops, const float *weights, uint64_t n_weights, uint32_t n_buffers) {
-    if (!c || !ops || !weights || n_ops == 0 || n_buffers == 0 || n_buffers > 8) return DN_ERR_ARG;
+    if (!c || !ops || !weights || n_ops == 0 || n_ops > 1024 || n_buffers == 0 || n_buffers > 8) return DN_ERR_ARG;     // 1024: the range report block has two words per op
     HIPCHK(c, hipSetDevice(c->device));
     // the encoder is what marks a pass's live rows (validity bytes): every later epilogue masks by them
     if (ops[0].op != DN_CNN_ENCODE_GRU) return fail(c, DN_ERR_ARG, "cnn op 0 must be ENCODE_GRU (it writes the row validity mask every later op reads)");
@@ -1275,7 +1275,10 @@ int dn_load_cnn(dn_ctx *c, const dn_cnn_op *ops, uint32_t n_ops, const float *we
     HIPCHK(c, hipMalloc((void **)&c->d_cnn_wh, std::max<size_t>(wh.size(), 8) * 2));
     c->cnn_nwh = wh.size(); c->dev_bytes += wh.size() * 2;
     HIPCHK(c, hipMemcpyAsync(c->d_cnn_wh, wh.data(), wh.size() * 2, hipMemcpyHostToDevice, c->stream));
-    if (!c->d_cnn_flag) HIPCHK(c, hipMalloc((void **)&c->d_cnn_flag, sizeof(unsigned)));
+    if (!c->d_cnn_flag) {                                 // the range report block of a pass: word 0 for the host, two words per op (k3_cnn.hip range_report)
+        HIPCHK(c, hipMalloc((void **)&c->d_cnn_flag, (2 + 2 * 1024) * sizeof(unsigned)));
+        HIPCHK(c, hipMemsetAsync(c->d_cnn_flag, 0, (2 + 2 * 1024) * sizeof(unsigned), c->stream));
+    }
     HIPCHK(c, hipMemsetAsync(c->d_cnn_flag, 0, sizeof(unsigned), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cnn_wh_off = wh_off; c->cnn_post = post; c->cnn_one.assign(n_ops, 1.0f);

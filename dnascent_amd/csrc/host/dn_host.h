@@ -17,12 +17,26 @@
 #pragma once
 #include <stdint.h>
 
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "dnascent_hip.h"
 
 namespace DNAscent {
+
+// std::allocator whose construct() DEFAULT-initialises: resize() of the big sample / map arrays does not write zeros that the copies behind it
+// overwrite at once (600 MB of int16 per batch: ~0.1 s of one thread per batch in the product driver's loader)
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using RawVec = std::vector<T, NoInitAlloc<T>>;
 
 struct ReadInput {                     // what reads.h:210-287 + pod5.cpp:24-93 extract from BAM + POD5 + FASTA
     std::string readID, contig;
@@ -64,11 +78,11 @@ public:
     ReadBatch &operator=(const ReadBatch &) = delete;
 
     std::vector<std::string> readID, contig;
-    std::vector<int16_t> adc; std::vector<uint64_t> adc_off{0};
+    RawVec<int16_t> adc; std::vector<uint64_t> adc_off{0};
     std::vector<float> cal_offset, cal_scale;
     std::vector<char> basecall; std::vector<uint64_t> basecall_off{0};
     std::vector<char> refseq; std::vector<uint64_t> refseq_off{0};
-    std::vector<uint32_t> ref2query; std::vector<int32_t> query2ref; std::vector<uint8_t> ref2del;
+    RawVec<uint32_t> ref2query; RawVec<int32_t> query2ref; RawVec<uint8_t> ref2del;
     std::vector<int32_t> ref_start, ref_end; std::vector<uint8_t> is_reverse;
     std::vector<dn_read_summary> summary;               // filled by normaliseEvents / eventalign
 private:
@@ -83,7 +97,7 @@ private:
 //   record  str readID, str contig (u32 length + bytes); f32 cal_offset, cal_scale; i32 signalLength, signalTrim,
 //           signalStartCoord; u8 isSplit, isReverse; i32 refStart; str querySeq; str refSlice;
 //           u32 n_cigar, u32 op[n], u32 len[n]; u64 n_adc, i16 adc[n]
-struct OwnedRead { ReadInput in; std::vector<int16_t> adc; };             // in.adc points into adc
+struct OwnedRead { ReadInput in; RawVec<int16_t> adc; };                  // in.adc points into adc
 class ReadContainerWriter {
 public:
     bool open(const std::string &path);

@@ -75,7 +75,7 @@ public:
     explicit Pod5Cache(size_t maxOpen = 64) : cap(maxOpen) { pod5_init(); }
     ~Pod5Cache() { for (auto &e : open) pod5_close_and_free_reader(e.second); pod5_terminate(); }
     // the complete stored signal of (file, batch, row) + its calibration   pod5.cpp:36-60
-    bool fetch(const std::string &path, size_t batchIndex, size_t row, std::vector<int16_t> &adc, float &calOffset, float &calScale) {
+    bool fetch(const std::string &path, size_t batchIndex, size_t row, DNAscent::RawVec<int16_t> &adc, float &calOffset, float &calScale) {
         Pod5FileReader_t *f = reader(path);
         if (!f) return false;
         Pod5ReadRecordBatch_t *batch = nullptr;

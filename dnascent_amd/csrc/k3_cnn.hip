@@ -621,6 +621,33 @@ template <int NP> __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+// What a split-mode kernel reports about the values it split, once per wavefront: rf[0] |= 1 when one of them does not fit fp16 (> 65 504),
+// rf[1] = max(rf[1], largest |value|) (non-negative floats order like their bit patterns; the slot is read first, so after the first
+// workgroups almost no wavefront issues the atomic).  rf = the op's pair of words in the pass's report block; k3_range_check folds the
+// block into the one word the host looks at: bit 0 overflow, bit 1 UNDERFLOW -- a layer whose largest split value is below 2^-6.  Below
+// 2^-3 the low fp16 piece is subnormal and the split keeps an absolute 2^-25 instead of a relative 2^-22; that is harmless while the
+// layer's values are O(1) (3e-8 against sums of O(1)) and catastrophic when the whole layer is tiny and its weights correspondingly large
+// (round 4's precision fuzz, family tiny_act: activations ~1e-5 -> P off by 0.26).  The host then repeats the pass with bf16 pieces
+// (fp32's exponent range), exactly as for an overflow.
+__device__ __forceinline__ void range_report(float amax, unsigned *rf, int lane) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
+    if (lane == 0) {
+        if (amax > 65504.0f) atomicOr(rf, 1u);
+        const unsigned b = __float_as_uint(amax);
+        if (b > *(volatile unsigned *)(rf + 1)) atomicMax(rf + 1, b);
+    }
+}
+#define CNN_RANGE_WORDS(n_ops) (2 + 2 * (n_ops))
+__global__ __launch_bounds__(64) void k3_range_check(unsigned *R, int n_ops) {
+    for (int op = threadIdx.x; op < n_ops; op += 64) {
+        const unsigned f = R[2 + 2 * op], a = R[3 + 2 * op];
+        if (f) atomicOr(R, 1u);
+        if (a != 0u && a < 0x3c800000u) atomicOr(R, 2u);                  // 0 < largest |value| < 2^-6 (an all-zero layer -- no live rows -- says nothing)
+        R[2 + 2 * op] = 0u; R[3 + 2 * op] = 0u;                           // clean for the next pass
+    }
+}
+
 // Loop order: input-channel block outermost, taps inside.  The A tile of a channel block (128 + k - 1 rows) is split and
 // staged ONCE and every tap reads it at a row offset, so a k-tap layer converts each activation once instead of k times;
 // only the B tile changes per step.  Weights are laid out [channel block][tap][piece][cout][32] to match.
@@ -805,7 +832,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
         tap = lastTap ? 0 : tap + 1;
         cb += lastTap ? 1 : 0;
     }
-    if (NP == 2 && __any(amax > 65504.0f) && lane == 0) atomicOr(range_flag, 1u);    // out of fp16 range: the host repeats the pass in bf16x6
+    if (NP == 2) range_report(amax, range_flag, lane);     // out of fp16's range (either way): the host repeats the pass in bf16x6
     // the epilogue's thread coordinates are RE-DERIVED from the hardware id behind an opaque move: kept live across the step loop they
     // were three of the 256-row form's spilled registers (it runs under a 128-register cap)
     int tid_e = (int)threadIdx.x;
@@ -1021,7 +1048,7 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
         }
         conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, tile_m0(it), n0, wm, wn, lane, cout, relu, post);
     }
-    if (NP == 2 && __any(amax > 65504.0f) && lane == 0) atomicOr(range_flag, 1u);
+    if (NP == 2) range_report(amax, range_flag, lane);
 }
 
 // (Round 3: k3_sep_pair -- two consecutive 9-tap 128 -> 128 separable layers in one launch, the intermediate activations in LDS, 120-row
@@ -1228,7 +1255,7 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
         depthwise(1, 1);                                   // the last step (nb - 1, odd)
         __syncthreads();
         __syncthreads();
-        if (NP == 2 && __any(amax > 65504.0f) && lane == 0) atomicOr(range_flag, 1u);
+        if (NP == 2) range_report(amax, range_flag, lane);
         return;
     }
     constexpr int CJ = BN / 128;                           // consumer = ALL 128 rows x BN / 4 columns (CJ column blocks of 32): a weight fragment is
@@ -1458,9 +1485,12 @@ __global__ __launch_bounds__(512) void k3_sep_uni(const float *__restrict__ X, f
     // step g + 2 (set S1 for even g, S0 for odd g), read it back into x[], request step g + 4's into that set.  The workgroup's last step filters a repeat
     // of itself into planes nobody reads any more (the load stream stays on the last step): no branch inside the slots.
     constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
+#ifndef UNI_ABL
+#define UNI_ABL 0                                          /* experiment builds (timing only, wrong results): 1 = no filter FMAs, 2 = no MFMAs, 3 = neither */
+#endif
 #define UNI_MFMA(M, A, B) do { constexpr int r_ = (M) % 12, t_ = r_ / 4, i_ = (r_ % 4) / 2, j_ = r_ % 2; \
-        acc[i_][j_] = mfma16<NP>(A[i_][PA2[t_]], B[j_][PB2[t_]], acc[i_][j_]); } while (0)
-#define UNI_SLOT(M, A, B, P0, P1, EXTRA) do { UNI_MFMA(M, A, B); uni_fmas<P0, P1>(x, w, o); EXTRA; __builtin_amdgcn_sched_barrier(0); } while (0)
+        if (!(UNI_ABL & 2)) acc[i_][j_] = mfma16<NP>(A[i_][PA2[t_]], B[j_][PB2[t_]], acc[i_][j_]); } while (0)
+#define UNI_SLOT(M, A, B, P0, P1, EXTRA) do { UNI_MFMA(M, A, B); if (!(UNI_ABL & 1)) uni_fmas<P0, P1>(x, w, o); EXTRA; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define UNI_STEP(CUR, SET, G)                                                                                                            \
     do {                                                                                                                                  \
         readW((CUR) ^ 1); loadA(a0, CUR, 0); loadB(b1, 2 * (G) + 1);                                                                      \
@@ -1497,7 +1527,7 @@ __global__ __launch_bounds__(512) void k3_sep_uni(const float *__restrict__ X, f
 #undef UNI_STEP
 #undef UNI_SLOT
 #undef UNI_MFMA
-    if (__any(amax > 65504.0f) && lane == 0) atomicOr(range_flag, 1u);
+    range_report(amax, range_flag, lane);
 }
 
 // (Round 3: k3_sep_ts -- the same layer TIME-SLICED instead of wave-specialised: all eight wavefronts filter 128 input channels (rows straight
@@ -1614,7 +1644,7 @@ struct CnnRun {
     const int64_t *wb_off;            // host: per op offset into wts_split (in elements)
     int pieces;                       // 3: bf16x6, 2: f16x3
     const float *post;                // host, per op: inverse of the power of two the fp16 weights were scaled by (1 for bf16)
-    unsigned *range_flag;             // device: set by the fp16 path when an activation does not fit fp16
+    unsigned *range_flag;             // device: the pass's range report block (CNN_RANGE_WORDS(n_ops) words; word 0 is what the host reads)
     unsigned n_pass_pos;              // positions of the sequences [r0, r1)
     uint8_t *enc_len; unsigned *enc_hist; uint64_t *perm_src; unsigned *perm_row;   // device scratch of the encoder's counting sort
     // profiling (null = off): HIP event pairs around every launch of the network's dominant kernel, the 17-tap separable layer
@@ -1674,7 +1704,7 @@ static int k3_launch_sep(const CnnRun &c, int i, const float *in, float *out, co
     const dn_cnn_op &d = c.ops[i], &o = c.ops[i + 1];
     const unsigned rows = c.rows.rows;
 #define SEP_ARGS in, out, c.wts + d.w, c.wts_split + c.wb_off[i + 1], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, c.live, \
-        o.cin, o.cout, o.relu, c.post[i + 1], c.range_flag
+        o.cin, o.cout, o.relu, c.post[i + 1], c.range_flag + 2 + 2 * i
 #define SEP_GO(KW_) hipLaunchKernelGGL((k3_sep_split<BN, KW_, ADD, NP>), dim3(o.cout == BN ? min(conv_grid(rows, o.cout, BN), k3_sep_wgs(BN, NP)) : conv_grid(rows, o.cout, BN)), dim3(256), 0, st, SEP_ARGS)
     if (k3_takes_ws(NP, d, o) && k3_sep_uni_enabled()) {
         hipLaunchKernelGGL((k3_sep_uni<ADD>), dim3(min(conv_grid(rows, o.cout, 256), k3_cu_count())), dim3(512), 0, st, SEP_ARGS);
@@ -1749,10 +1779,10 @@ int k3_run(const CnnRun &c, hipStream_t st) {
         pb[o.src], pb[o.dst], c.wts + o.w, c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, c.live, o.k, o.cin, o.cout, o.relu)
 #define CONV_GO_SP(BN_, ADD_, NP_) hipLaunchKernelGGL((k3_conv_split<BN_, ADD_, NP_>), dim3(conv_grid(rows, o.cout, BN_)), dim3(256), 0, st, \
         pb[o.src], pb[o.dst], c.wts_split + c.wb_off[i], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, c.live, o.k, o.cin, o.cout, o.relu, \
-        c.post[i], c.range_flag)
+        c.post[i], c.range_flag + 2 + 2 * i)
 #define CONV_GO_BM(BN_, ADD_) hipLaunchKernelGGL((k3_conv_split<BN_, ADD_, 2, 256>), dim3(conv_grid(rows, o.cout, BN_, 256)), dim3(512), 0, st, \
         pb[o.src], pb[o.dst], c.wts_split + c.wb_off[i], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, c.live, o.k, o.cin, o.cout, o.relu, \
-        c.post[i], c.range_flag)
+        c.post[i], c.range_flag + 2 + 2 * i)
 #define CONV_GO_BF(BN_, ADD_) do { if (c.pieces == 3) CONV_GO_SP(BN_, ADD_, 3); else if (BN_ == 128 && k3_takes_bm256(c.pieces, o, rows)) CONV_GO_BM(128, ADD_); \
         else CONV_GO_SP(BN_, ADD_, 2); } while (0)
                 if (c.wts_split) {
@@ -1789,6 +1819,7 @@ int k3_run(const CnnRun &c, hipStream_t st) {
             default: return -1;
         }
     }
+    if (c.pieces == 2 && c.range_flag) hipLaunchKernelGGL(k3_range_check, dim3(1), dim3(64), 0, st, c.range_flag, c.n_ops);
     return 0;
 }
 

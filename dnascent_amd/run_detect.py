@@ -13,7 +13,7 @@ reads (detect.cpp:821-907), never "load everything, run, gather everything":
      consecutive reads (--window-batches x world x --batch-samples samples), each cut into length-bucketed batches (shard.plan_windows);
   2. the ranks PULL batch ids from one shared counter (shard.WorkCounter: a TCPStore add, no collective) -- the reference's
      `schedule(dynamic)` (detect.cpp:852): a rank whose reads fail QC early, or are short, takes more batches;
-  3. a rank holds at most --inflight + 2 batches on the host: the next one is loaded (all cores, direct seeks) while --inflight of
+  3. a rank holds at most --inflight + 3 batches on the host: the next two are loaded (all cores, direct seeks) while --inflight of
      them are on the GPU (DNAscent::DetectStream: upload, normaliseEvents, eventalign, CNN, dn_collect, records formatted);
   4. when a rank has collected its last batch of a window, the window's PACKED per-call results (16 bytes per call: coordinate, P(EdU),
      P(BrdU), 9-mer; ~40 % of the text's bytes) go to the writer rank: sizes through the process group's store, bytes in ONE grouped
@@ -77,10 +77,11 @@ def main(argv=None):
     ap.add_argument("--pore-model", default=None)
     ap.add_argument("--inflight", type=int, default=4)
     ap.add_argument("--batch-samples", type=float, default=300e6, help="sample budget of one batch")
-    ap.add_argument("--batch-reads", type=int, default=2000)
-    ap.add_argument("--window-batches", type=float, default=4.0,
+    ap.add_argument("--batch-reads", type=int, default=4096)
+    ap.add_argument("--window-batches", type=float, default=2.0,
                     help="a window (the unit of the ordered gather + write) holds about this many batches PER RANK")
     ap.add_argument("--gather-chunk-mb", type=int, default=256)
+    ap.add_argument("--prefetch", type=int, default=3, help="batches loaded ahead of the one being submitted (loader threads)")
     ap.add_argument("--backend", default=os.environ.get("DN_BACKEND", "nccl"))
     ap.add_argument("--header", default=None, help="text written before the records (e.g. DNAscent::writeDetectHeader)")
     ap.add_argument("--stats", default=None, help="rank 0 writes a JSON with per-rank busy / gather seconds, batches, peak buffered bytes")
@@ -117,8 +118,11 @@ def main(argv=None):
     engine = host.DetectStream(ctxs, emit="packed")
     free = []
 
-    def load(ords):
-        b = free.pop() if free else host.ReadBatch()
+    def load(ords):                                            # runs on the driver's loader threads (two at a time)
+        try:
+            b = free.pop()
+        except IndexError:
+            b = host.ReadBatch()
         b.clear()
         return b, b.add_container_at(a.container, offsets[ords])
 
@@ -148,7 +152,7 @@ def main(argv=None):
         free.append(b0)
     t_setup = time.time() - t0
     t_stream = time.time()
-    ok = drv.run()
+    ok = drv.run(prefetch=a.prefetch)
     t_stream = time.time() - t_stream
     st = engine.stats()
     tot = shard.reduce_counters(dist, [drv.n_ok, drv.n_fail, int(st.samples), 0 if ok else 1], device=dev_t)
@@ -157,7 +161,7 @@ def main(argv=None):
     per_rank = shard.gather_stats(dist, dict(rank=rank, batches=drv.batches_done, busy_s=round(drv.busy_s, 3), gather_s=round(drv.gather_s, 3),
                                              format_s=round(drv.format_s, 3), peak_buffered_bytes=int(drv.peak_pending_bytes),
                                              max_gather_bytes=int(drv.max_gather_bytes), reads_ok=drv.n_ok, reads_failed=drv.n_fail,
-                                             upload_s=round(st.seconds_upload, 3), collect_wait_s=round(st.seconds_collect, 3),
+                                             upload_s=round(st.seconds_upload, 3), collect_wait_s=round(st.seconds_collect, 3), load_wait_s=round(drv.load_wait_s, 3),
                                              pack_s=round(st.seconds_emit, 3)), device=dev_t)
     failed = tot[3] > 0
     if rank == 0:

@@ -524,28 +524,33 @@ class StreamDriver:
             except Exception:
                 pass
 
-    def run(self, prefetch=True):
-        """prefetch: the NEXT batch is pulled and loaded by a helper thread while this one drives the engine (the loader reads the
-        container with all host cores; without it the GPU idles while a 600 MB batch comes off the disk).  Returns True when every
-        window was processed and (on the writer) written."""
+    def run(self, prefetch=2):
+        """prefetch: how many batches AHEAD of the one being submitted are pulled and loaded by helper threads while this one drives the engine
+        (the loader reads the container with the host's cores; without it the GPU idles while a 600 MB batch comes off the disk; one ahead
+        was not enough at 750 Msamples/s: round 4).  0 / False: load in line.  Returns True when every window was processed and (on the
+        writer) written."""
         import queue
         import threading
         import time
+        from collections import deque
         from concurrent.futures import ThreadPoolExecutor
+        prefetch = int(prefetch)
         self._tag_ords = {}
         self._q = queue.Queue(maxsize=max(1, self.max_pending_windows))
         self._gather_exc = None
         self._writer_error = False
         self._keys = None
+        self.load_wait_s = 0.0
         if self.multi:
             from torch.distributed.distributed_c10d import _get_default_store
             self._keys = StoreKeys(_get_default_store(), self.run_key + "/dead")
         self._gt = threading.Thread(target=self._gather_loop, name="dn-gather", daemon=True)
         self._gt.start()
         t_busy0 = time.perf_counter()
-        pool = ThreadPoolExecutor(1) if prefetch else None
+        pool = ThreadPoolExecutor(prefetch) if prefetch > 0 else None
+        ahead = deque()                                          # batches pulled and being loaded, oldest first
 
-        def pull():
+        def pull_one():
             """next batch id of this rank -> (id, future / None), or None when the counter is exhausted / the run aborted.  The batch is
             counted as OPEN in its window from this moment: the frontier may move past its window while it is still being loaded, and a
             window must not be gathered without it (round-3 advisor: --inflight 1 lost the last batch of every window)."""
@@ -560,6 +565,18 @@ class StreamDriver:
             self.frontier = max(self.frontier, w)                # every batch of an earlier window has been handed out
             return b, (pool.submit(self.load, self.batches[b]) if pool else None)
 
+        state = {"dry": False}
+
+        def pull():
+            """the oldest batch pulled ahead (after topping the look-ahead up), or None at the end"""
+            while not state["dry"] and len(ahead) < max(1, prefetch):
+                item = pull_one()
+                if item is None:
+                    state["dry"] = True
+                    break
+                ahead.append(item)
+            return ahead.popleft() if ahead else None
+
         nxt = None
         try:
             nxt = pull()
@@ -568,7 +585,9 @@ class StreamDriver:
                 w = int(self.window_of[b])
                 ords = self.batches[b]
                 try:
+                    t_l = time.perf_counter()
                     obj, accepted = fut.result() if fut is not None else self.load(ords)
+                    self.load_wait_s += time.perf_counter() - t_l
                 except BaseException:
                     self.open[w] -= 1
                     nxt = None
@@ -610,13 +629,16 @@ class StreamDriver:
                     self._collect_one()
                 except BaseException:                              # noqa: BLE001
                     break
-        if nxt is not None and nxt[1] is not None:             # aborted with a load in flight: let it finish, drop it
+        for item in ([nxt] if nxt is not None else []) + list(ahead):     # aborted with loads in flight: let them finish, drop them
+            if item[1] is None:
+                continue
             try:
-                obj, _ = nxt[1].result()
+                obj, _ = item[1].result()
                 if self.release:
                     self.release(obj)
             except BaseException:                                  # noqa: BLE001
                 pass
+        ahead.clear()
         if pool:
             pool.shutdown(wait=True)
         if self.error or self.counter.aborted():

@@ -123,9 +123,10 @@ int dn_load_cnn(dn_ctx *ctx, const dn_cnn_op *ops, uint32_t n_ops, const float *
  *   BF16X6  fp32 operands split exactly into three bf16 pieces, the six significant products accumulated in fp32 on the
  *           bf16 matrix cores (fp32-equivalent: dropped terms < 2^-24);
  *   F16X3   (default) two fp16 pieces, three products (dropped terms < 2^-22; half the matrix work of BF16X6).  fp16 has a
- *           narrow exponent range: a pass in which some activation exceeds 65504 is detected on the device and repeated in
- *           BF16X6 automatically, and the context then stays on BF16X6 until the next dn_load_cnn / dn_cnn_set_math;
- *           dn_cnn_range_escalations counts those repeats. */
+ *           narrow exponent range: a pass in which some activation exceeds 65504 -- or in which a whole layer's activations are
+ *           below 2^-6, where the low pieces are subnormal and the split keeps an absolute 2^-25 instead of a relative 2^-22 --
+ *           is detected on the device and repeated in BF16X6 automatically, and the context then stays on BF16X6 until the next
+ *           dn_load_cnn / dn_cnn_set_math; dn_cnn_range_escalations counts those repeats. */
 enum { DN_CNN_MATH_FP32 = 0, DN_CNN_MATH_BF16X6 = 1, DN_CNN_MATH_F16X3 = 2 };
 int dn_cnn_set_math(dn_ctx *ctx, int mode);
 uint64_t dn_cnn_range_escalations(dn_ctx *ctx);

@@ -65,6 +65,10 @@ def test_precision_fuzz(family):
         assert esc["fp32"] == 0 and esc["bf16x6"] == 0
         if esc["f16x3"]:                                    # out of fp16's range: repeated with bf16 pieces, and then it IS the bf16x6 answer
             assert np.array_equal(got["f16x3"], got["bf16x6"])
+        if family == "tiny_act":                            # every layer's inputs ~1e-5: the UNDERFLOW guard must fire (without it P was off by 0.26: round 4)
+            assert esc["f16x3"] == 1
+        if family in ("gaussian", "student_t", "bn_wide", "cancelling"):
+            assert esc["f16x3"] == 0                        # ... and must not on models whose activations are O(1)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "cnn_fuzz_table.txt"), "a") as f:
         for r in rows:

@@ -164,3 +164,26 @@ def test_page_locked_batch_uploads_asynchronously_with_the_same_result(model):
         assert hip.lib().dn_host_unregister(desc.adc) == 0
     for x in (a, c, d):
         x.close()
+
+
+def test_reserve_sizes_the_workspace_once(model):
+    """dn_batch_workspace_bytes + dn_ctx_reserve (ABI 4): a context reserved for the largest batch of a plan does not regrow its slab when batches of
+    other shapes arrive (regrowth = hipFree = a device-wide wait in the middle of a stream), and the results are those of an unreserved context"""
+    small = host.ReadBatch(); big = host.ReadBatch()
+    for i in range(6):
+        assert small.add_synth(synth.make_read(5200 + i, 1500, model=model)) >= 0
+    for i in range(3):
+        assert big.add_synth(synth.make_read(5300 + i, 9000, model=model, is_reverse=bool(i & 1))) >= 0
+    ctx = hip.Context(0); ctx.load_pore_model(model, 0.14)
+    need_small, need_big = ctx.workspace_bytes(small.desc()), ctx.workspace_bytes(big.desc())
+    assert need_big > need_small > 0
+    ctx.reserve(need_big)
+    held = ctx.device_bytes()
+    for b in (small, big, small):
+        b.upload(ctx); ctx.run("normalise"); ctx.sync()
+        assert ctx.device_bytes() == held                                   # nothing regrown
+    got = ctx.summaries()
+    ref = hip.Context(0); ref.load_pore_model(model, 0.14)
+    small.upload(ref); ref.run("normalise"); ref.sync()
+    assert got.tobytes() == ref.summaries().tobytes()
+    ctx.close(); ref.close()

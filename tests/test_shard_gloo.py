@@ -226,7 +226,7 @@ def test_streamed_dynamic_two_ranks(depth):
         assert res[1][run][4] > res[0][run][4]                              # the faster rank pulled more batches (dynamic balance)
         total_text = sum(len(r) for _, r in expect)
         for r in (0, 1):
-            assert res[r][run][7] <= depth + 2                              # at most depth + 2 batches alive on a host
+            assert res[r][run][7] <= depth + 3                              # at most depth + 1 + the look-ahead (2) batches alive on a host
             assert res[r][run][5] < 0.6 * total_text and res[r][run][6] < 0.75 * total_text   # buffered / gathered bytes are bounded by the window, not the run
 
 
@@ -245,7 +245,7 @@ def test_streamed_one_rank_matches():
     """world 1 (no process group): same records, same order, windows flushed as they complete; depth 1 and 2"""
     n = _sizes(600)
     batches, window_of = shard.plan_windows(n, window_samples=2 * 20e6, batch_samples=20e6, batch_reads=64)
-    for depth, prefetch in ((2, False), (1, True), (1, False)):
+    for depth, prefetch in ((2, 0), (1, 2), (1, 1), (1, 0)):
         written = []
         eng = _FakeEngine(depth=depth, delay=0.0)
         drv = shard.StreamDriver(None, batches, window_of, eng, lambda ords: ([int(o) for o in ords if o % 17 != 3], np.array([o % 17 != 3 for o in ords], np.uint8)),

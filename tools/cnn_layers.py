@@ -7,7 +7,7 @@ desc, _, _ = cnn_model.default_model()
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k3_" in r["Kernel_Name"]]
 is_sort = lambda r: "k3_encode_len" in r["Kernel_Name"] or "k3_encode_perm" in r["Kernel_Name"]
 sort_us = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if is_sort(r))
-rows = [r for r in rows if not is_sort(r) and "k3_layout" not in r["Kernel_Name"]]      # the encoder's counting sort (two small kernels) is reported on its own line
+rows = [r for r in rows if not is_sort(r) and "k3_layout" not in r["Kernel_Name"] and "k3_range_check" not in r["Kernel_Name"]]      # the encoder's counting sort (two small kernels) is reported on its own line
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 npos = int(sys.argv[2]); ops = desc["ops"]
 # kernels of one run: walk the op list backwards from the end of the trace

@@ -46,7 +46,7 @@ int main(int argc, char **argv) {
     (void)hipMalloc(&b.X, act * 4); (void)hipMalloc(&b.Y, act * 4); (void)hipMalloc(&b.Y2, act * 4);
     (void)hipMalloc(&b.Wd, 17 * 256 * 4); (void)hipMalloc(&b.scale, 1024); (void)hipMalloc(&b.shift, 1024);
     const size_t nwb = (size_t)17 * 8 * 2 * 256 * 32;        // enough for 17 taps x 256 channels x 2 pieces x 256 outputs
-    (void)hipMalloc(&b.Wb, nwb * 2); (void)hipMalloc(&b.valid, rows + 1024); (void)hipMalloc(&b.live, 4); (void)hipMalloc(&b.flag, 4);
+    (void)hipMalloc(&b.Wb, nwb * 2); (void)hipMalloc(&b.valid, rows + 1024); (void)hipMalloc(&b.live, 4); (void)hipMalloc(&b.flag, 64);
     {
         std::vector<float> h(act);
         for (size_t i = 0; i < act; i++) h[i] = frand() * 2.0f;
@@ -58,7 +58,7 @@ int main(int argc, char **argv) {
         std::vector<uint16_t> wb(nwb); for (auto &v : wb) v = f16bits(frand() * 0.1f);
         (void)hipMemcpy(b.Wb, wb.data(), nwb * 2, hipMemcpyHostToDevice);
         (void)hipMemset(b.valid, 1, rows + 1024);
-        (void)hipMemcpy(b.live, &rows, 4, hipMemcpyHostToDevice); (void)hipMemset(b.flag, 0, 4);
+        (void)hipMemcpy(b.live, &rows, 4, hipMemcpyHostToDevice); (void)hipMemset(b.flag, 0, 64);
     }
     hipStream_t s1, s2; (void)hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
     hipEvent_t ev1, ev2; (void)hipEventCreateWithFlags(&ev1, hipEventDisableTiming); (void)hipEventCreateWithFlags(&ev2, hipEventDisableTiming);
