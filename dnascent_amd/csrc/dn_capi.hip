@@ -901,7 +901,11 @@ int dn_get_align_table(dn_ctx *c, uint32_t read, uint32_t cap, uint32_t *coord, 
     if (read >= (uint32_t)c->B.n_reads) return DN_ERR_ARG;
     if (!c->have_align) return fail(c, DN_ERR_STATE, "dn_set_align_table(ctx, 1) must precede dn_run_eventalign");
     const unsigned long long a0 = c->h_al_off[read];
-    const unsigned long long n_rows = c->h_al_off[read + 1] - a0;          // the library's own count (dn_get_align_rows reports it), like every other tap
+    unsigned cnt = 0;                                                      // the library's own count (what dn_get_align_rows reports), like every other tap
+    HIPCHK(c, hipMemcpyAsync(&cnt, (unsigned *)c->al_n.p + read, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const unsigned long long n_rows = cnt;
+    if (a0 + n_rows > c->h_al_off[read + 1]) return fail(c, DN_ERR_STATE, "dn_get_align_table: read %u reports %llu rows, its slice holds %llu", read, n_rows, c->h_al_off[read + 1] - a0);
     if (n_rows > cap) return fail(c, DN_ERR_ARG, "dn_get_align_table: read %u has %llu rows, the caller's arrays hold %u", read, n_rows, cap);
     if (n_rows == 0) return DN_OK;
     if (coord) HIPCHK(c, hipMemcpyAsync(coord, (unsigned *)c->al_coord.p + a0, n_rows * 4ull, hipMemcpyDeviceToHost, c->stream));

@@ -359,7 +359,7 @@ static std::string formatDetectCalls(const std::string &readID, const std::strin
 // else (IUPAC codes in a reference) travels as its formatted TEXT instead (flag DN_PACK_TEXT): the writer passes it through, so the file
 // is the same bytes whatever the alphabet.
 static inline int packBase(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : c == 'N' ? 4 : -1; }
-void packCalls(const ReadBatch &batch, const dn_result_batch &res, std::vector<uint64_t> &meta, std::vector<uint8_t> &payload) {
+void packCalls(const ReadBatch &batch, const dn_result_batch &res, std::vector<uint64_t> &meta, RawVec<uint8_t> &payload) {
     const long n = (long)batch.size();
     std::vector<std::string> hdr((size_t)n);
     std::vector<uint8_t> as_text((size_t)n, 0), ok((size_t)n, 0);

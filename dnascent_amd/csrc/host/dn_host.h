@@ -157,7 +157,7 @@ void formatCalls(const ReadBatch &batch, const dn_result_batch &res, bool humanR
 // f32 P(BrdU), u32 strand 9-mer at 3 bits per base}.  A read whose 9-mers hold anything but A C G T N travels as its formatted text
 // (DN_PACK_TEXT: count = text bytes, header bytes = 0).  formatPacked is the writer's half: same bytes as formatCalls' records.
 enum { DN_PACK_REVERSE = 1, DN_PACK_TEXT = 2 };
-void packCalls(const ReadBatch &batch, const dn_result_batch &res, std::vector<uint64_t> &meta /* [passing reads][4] */, std::vector<uint8_t> &payload);
+void packCalls(const ReadBatch &batch, const dn_result_batch &res, std::vector<uint64_t> &meta /* [passing reads][4] */, RawVec<uint8_t> &payload);
 void formatPacked(size_t n, const uint64_t *meta3 /* [n][3]: count, header bytes, flags */, const uint8_t *const *read_ptr /* [n] */, std::string &text,
                   uint64_t *record_bytes /* [n] or null */);
 
@@ -189,7 +189,7 @@ public:
         std::vector<uint64_t> record_bytes;                 // per read: length of its .detect record (0: failed read / emit off)
         std::string text;                                   // the records of the passing reads, batch order (emit == EMIT_TEXT)
         std::vector<uint64_t> packed_meta;                  // emit == EMIT_PACKED: packCalls' meta rows ...
-        std::vector<uint8_t> packed;                        // ... and payload (the multi-rank driver gathers these; the writer rank formats)
+        RawVec<uint8_t> packed;                             // ... and payload (the multi-rank driver gathers these; the writer rank formats)
     };
     enum { EMIT_NONE = 0, EMIT_TEXT = 1, EMIT_PACKED = 2 };
     DetectStream(dn_ctx **ctxs, int n_ctx, int emit);

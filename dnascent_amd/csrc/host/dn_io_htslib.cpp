@@ -125,7 +125,7 @@ long containerFromBam(const std::string &bamPath, const std::map<std::string, st
     Pod5Cache pod5;
     bam1_t *rec = bam_init1();
     long written = 0;
-    std::vector<int16_t> adc;
+    DNAscent::RawVec<int16_t> adc;
     while (sam_read1(bam, hdr, rec) >= 0) {
         if (rec->core.tid < 0 || rec->core.qual < minQuality || rec->core.l_qseq == 0) continue;
         if ((unsigned)(bam_endpos(rec) - rec->core.pos) < minLength) continue;                   // detect.cpp:839

@@ -433,11 +433,27 @@ class DetectStream:
             self._fail("DetectStream.submit", rc)
         self._batches[int(tag)] = batch
 
+    class _Owner:
+        """keeps a C++ Result (the packed payload of one collected batch) alive while numpy views point into it"""
+
+        def __init__(self, h):
+            self.h = h
+
+        def __del__(self):
+            try:
+                if self.h:
+                    lib().dnh_result_free(self.h); self.h = None
+            except Exception:
+                pass
+
     def collect(self, calls=False):
         """-> dict(tag, batch, status [n_reads], record_bytes [n_reads], text (bytes: the records of the passing reads, batch order));
-        calls=True adds read_calls / coord / p_edu / p_brdu (copies of the dn_result_batch arrays)"""
+        calls=True adds read_calls / coord / p_edu / p_brdu (copies of the dn_result_batch arrays).  emit == "packed": packed_meta [k][4] and
+        packed (uint8) are VIEWS into a C++ result object of their own, kept alive by out["owner"] (no copy of ~190 MB per batch)."""
         tag = C.c_uint64(); n = C.c_uint32(); rb = C.c_void_p(); tx = C.c_void_p(); tb = C.c_uint64(); res = _hip.ResultBatch()
-        rc = lib().dnh_stream_collect(self.h, self.res, C.byref(tag), C.byref(n), C.byref(rb), C.byref(tx), C.byref(tb), C.byref(res))
+        resh = C.c_void_p(lib().dnh_result_new()) if self.emit == 2 else self.res
+        rc = lib().dnh_stream_collect(self.h, resh, C.byref(tag), C.byref(n), C.byref(rb), C.byref(tx), C.byref(tb), C.byref(res))
+        owner = DetectStream._Owner(resh) if self.emit == 2 else None
         if rc != 0:
             self._fail("DetectStream.collect", rc)
         nr = int(n.value)
@@ -452,9 +468,15 @@ class DetectStream:
                    record_bytes=arr(rb.value, np.uint64, nr), text=C.string_at(tx.value, tb.value) if tb.value else b"")
         if self.emit == 2:
             mp = C.c_void_p(); pp = C.c_void_p(); pb = C.c_uint64()
-            k = int(lib().dnh_result_packed(self.res, C.byref(mp), C.byref(pp), C.byref(pb)))
-            out["packed_meta"] = arr(mp.value, np.uint64, 4 * k).reshape(k, 4)        # rows: index in the batch, count, header bytes, flags
-            out["packed"] = arr(pp.value, np.uint8, int(pb.value))
+            k = int(lib().dnh_result_packed(resh, C.byref(mp), C.byref(pp), C.byref(pb)))
+
+            def view(ptr, dtype, cnt):
+                if cnt == 0 or not ptr:
+                    return np.zeros(0, dtype)
+                return np.frombuffer((C.c_char * (cnt * np.dtype(dtype).itemsize)).from_address(ptr), dtype=dtype)
+            out["packed_meta"] = view(mp.value, np.uint64, 4 * k).reshape(k, 4)       # rows: index in the batch, count, header bytes, flags
+            out["packed"] = view(pp.value, np.uint8, int(pb.value))
+            out["owner"] = owner
         if calls:
             k = int(res.n_calls)
             off = arr(res.call_off, np.uint64, nr + 1 if nr else 0)

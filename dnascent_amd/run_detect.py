@@ -138,7 +138,7 @@ def main(argv=None):
     drv = shard.StreamDriver(dist, batches, window_of, engine, load, write, release=free.append, dst=0, device=dev_t,
                              chunk_bytes=a.gather_chunk_mb << 20)
     # set-up, not part of the stream: every context gets its workspace now (a 10+ GB hipMalloc), sized from the plan's first batch -- window 0's
-    # longest reads at the full sample budget -- scaled to the largest planned batch, + 10 % for batches of other composition (more, shorter
+    # longest reads at the full sample budget -- scaled to the largest planned batch, + 4 % for batches of other composition (more, shorter
     # reads): regrowing a slab later frees the old one, and hipFree waits for the WHOLE device, i.e. drains every batch in flight
     if len(batches):
         b0, _ = load(batches[0])
@@ -146,7 +146,7 @@ def main(argv=None):
             per_sample = ctxs[0].workspace_bytes(b0.desc()) / max(1, b0.samples())
             biggest = max(int(sizes[b].sum()) for b in batches)
             for c in ctxs:
-                c.reserve(int(per_sample * biggest * 1.10), collect_bytes=int(biggest / 12.5 * 0.3 * 29 * 1.3))
+                c.reserve(int(per_sample * biggest * 1.04), collect_bytes=int(biggest / 12.5 * 0.3 * 29 * 1.3))
                 b0.upload(c)                                   # the side tables (per-read mirrors, CNN lane buffers) take their size from a real batch
                 c.sync()
         free.append(b0)

@@ -47,16 +47,18 @@ def make_batches(sample_counts, max_samples, max_reads=4096):
     """
     n = np.asarray(sample_counts, dtype=np.int64)
     order = sorted(range(n.shape[0]), key=lambda i: (-int(n[i]), i))
-    # BALANCED groups: ceil(total / max_samples) of them, each closed once it holds its share -- a window of 4.02 batch budgets is cut into
-    # five batches of ~0.8 budgets, not four full ones and a 2 % remainder whose kernels cannot fill the chip (round 4: the product driver's
-    # 10 000 x 50 kb plan had 5 such stubs among 24 batches)
-    total = int(n.sum())
-    groups = max(1, -(-total // max(1, int(max_samples))))
-    target = total / groups
-    out, cur, load = [], [], 0
+    # BALANCED groups: ceil(total / max_samples) of them, each closed once it holds its share of what was LEFT when it was opened (a
+    # group that stopped short because its next read would not fit is made up for by the next ones, and nothing is left over for a stub batch
+    # whose kernels cannot fill the chip -- round 4: the product driver's 10 000 x 50 kb plan had 5 such stubs among 24 batches, the mixed-length
+    # plan a 48-read batch in every window)
+    left = int(n.sum())                                       # samples not yet in a closed group
+
+    def share(rest):                                          # a group's share of what is left when it is opened
+        return rest / max(1, -(-rest // max(1, int(max_samples))))
+    out, cur, load, target = [], [], 0, share(left)
     for i in order:
         if cur and (load + int(n[i]) > max_samples or len(cur) >= max_reads or load >= target):
-            out.append(np.array(sorted(cur), dtype=np.int64)); cur, load = [], 0
+            out.append(np.array(sorted(cur), dtype=np.int64)); left -= load; cur, load, target = [], 0, share(left)
         cur.append(i); load += int(n[i])
     if cur:
         out.append(np.array(sorted(cur), dtype=np.int64))
@@ -193,7 +195,7 @@ def plan_windows(sample_counts, window_samples, batch_samples, batch_reads=4096)
     lo, w = 0, 0
     while lo < n.shape[0]:
         hi, load = lo, 0
-        while hi < n.shape[0] and (hi == lo or load + int(n[hi]) <= window_samples):
+        while hi < n.shape[0] and (hi == lo or load + int(n[hi]) <= 0.98 * window_samples):     # 2 % slack: k budgets' worth of reads must cut into k batches, not k + 1
             load += int(n[hi]); hi += 1
         for idx in make_batches(n[lo:hi], batch_samples, batch_reads):
             batches.append(idx + lo); window_of.append(w)
@@ -364,13 +366,20 @@ def exchange_window(dist, keys, key, n, blob, error, dst=0, device="cpu", chunk_
 
 
 def format_window(blobs, formatter, write, group_bytes=256 << 20):
-    """the writer's half: the reads of every rank's blob merged by input ordinal, formatted in groups of bounded text size (the C++
-    formatter on the host's threads), handed to write(text, ordinals, record_bytes) in INPUT order.  Returns (reads, text bytes)."""
+    """the writer's half: the reads of every rank's share merged by input ordinal, formatted in groups of bounded text size (the C++
+    formatter on the host's threads), handed to write(text, ordinals, record_bytes) in INPUT order.  blobs: [(n, blob)] as exchange_window
+    returns them, or [(ordinals, meta, payload)] triples (one rank: the collected chunks as they are, no copy).  Returns (reads, text bytes)."""
     os_, ms_, ps_ = [], [], []
-    for n, blob in blobs:
-        if n == 0:
-            continue
-        o, m, pay = split_blob(n, blob)
+    for item in blobs:
+        if len(item) == 2:
+            n, blob = item
+            if n == 0:
+                continue
+            o, m, pay = split_blob(n, blob)
+        else:
+            o, m, pay = np.asarray(item[0], np.int64), np.asarray(item[1], np.uint64).reshape(-1, 3), item[2]
+            if o.shape[0] == 0:
+                continue
         sz = payload_sizes(m)
         off = np.concatenate([[0], np.cumsum(sz)[:-1]]).astype(np.uint64)
         os_.append(o); ms_.append(m); ps_.append(np.uint64(pay.ctypes.data) + off)
@@ -456,7 +465,7 @@ class StreamDriver:
         if "packed_meta" in r:
             m = np.asarray(r["packed_meta"], np.uint64).reshape(-1, 4)
             if m.shape[0]:
-                self._file(w, (ords[m[:, 0].astype(np.int64)], m[:, 1:4], np.asarray(r["packed"], np.uint8)))
+                self._file(w, (ords[m[:, 0].astype(np.int64)], m[:, 1:4], np.asarray(r["packed"], np.uint8), r.get("owner")))   # views: the owner keeps them alive
             self.n_ok += int(m.shape[0]); self.n_fail += int(ords.shape[0] - m.shape[0])
         else:
             ok = np.asarray(r["status"]) == 0
@@ -474,9 +483,8 @@ class StreamDriver:
         while self.flushed < self.n_windows and (final or self.flushed < self.frontier) and self.open.get(self.flushed, 0) == 0:
             w = self.flushed
             chunks = self.pending.pop(w, [])
-            n, blob = (0, np.zeros(0, np.uint8)) if self.error else build_blob(chunks)
             self._pending_bytes -= sum(int(c[2].shape[0]) for c in chunks)
-            self._hand_over((w, n, blob, self.error))
+            self._hand_over((w, [] if self.error else chunks, self.error))     # the gather thread builds the wire blob (or, alone, formats the chunks as they are)
             self.flushed += 1
 
     def _hand_over(self, item):
@@ -501,16 +509,23 @@ class StreamDriver:
             for w in range(self.n_windows):
                 item = self._q.get()
                 assert item[0] == w
-                _, n, blob, err = item
+                _, chunks, err = item
                 t0 = time.perf_counter()
-                blobs, any_err = exchange_window(self.dist, self._keys, "%s/w%d" % (self.run_key, w), n, blob, err, dst=self.dst,
-                                                 device=self.device, chunk_bytes=self.chunk, stats=self.stats)
+                if self.multi:
+                    n, blob = build_blob(chunks)
+                    del chunks, item
+                    blobs, any_err = exchange_window(self.dist, self._keys, "%s/w%d" % (self.run_key, w), n, blob, err, dst=self.dst,
+                                                     device=self.device, chunk_bytes=self.chunk, stats=self.stats)
+                    nbytes = int(blob.shape[0])
+                else:                                             # one rank: nothing to exchange, nothing to copy
+                    blobs, any_err = [c[:3] for c in chunks], bool(err)
+                    nbytes = sum(int(c[2].shape[0]) for c in chunks)
                 t1 = time.perf_counter()
                 self.gather_s += t1 - t0
                 if blobs is None:
-                    self.max_gather_bytes = max(self.max_gather_bytes, int(blob.shape[0]))
+                    self.max_gather_bytes = max(self.max_gather_bytes, nbytes)
                     continue
-                self.max_gather_bytes = max(self.max_gather_bytes, sum(int(b.shape[0]) for _, b in blobs))
+                self.max_gather_bytes = max(self.max_gather_bytes, nbytes if not self.multi else sum(int(b.shape[0]) for _, b in blobs))
                 self._writer_error = self._writer_error or bool(any_err)
                 if not self._writer_error:
                     nrec, nb = format_window(blobs, self.formatter, self.write, self.group_bytes)
