@@ -911,12 +911,21 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
     const int nb = my_tiles * cblocks;                     // steps of this workgroup
     const int l_r = tid >> 2, l_k = (tid & 3) * 8;        // B loader: 64 rows x 4 chunks of 8 elements per pass
     const int dq = tid & 7, dr = (tid >> 3) * 4;          // depthwise: channels 4 dq .. 4 dq + 3, output rows dr .. dr + 3
-    f32x4 rx[NLD]; bool pin[NLD];
+    // SEP_NSET register sets of raw rows + taps.  With ONE set a raw tile is stored one step after its loads were issued: a step cannot be shorter
+    // than the memory latency under load, and a CU holds one tile per workgroup in flight (35-50 KB: Little's law gives the 4.5-5.2 TB/s these
+    // layers reach, from HBM and from the Infinity Cache alike -- profiles/r04_infinity_cache_experiment.txt).  With TWO sets (experiment build
+    // -DSEP_NSET=2) a tile is stored two steps after its loads.
+#ifndef SEP_NSET
+#define SEP_NSET 1
+#endif
+    constexpr int NSET = (SEP_NSET == 2 && BN == 128 && NP == 2) ? 2 : 1;     // the 64-column form would drop from three workgroups per CU to two (179 registers)
+    struct RawT { f32x4 rx[NLD]; bool pin[NLD]; f32x4 rw; };
+    RawT T0, T1;
+    T0.rw = f32x4{0.f, 0.f, 0.f, 0.f}; T1.rw = T0.rw;
     u32x4 rb[NP][NBQ];
-    f32x4 rw = {0.f, 0.f, 0.f, 0.f};
     float amax = 0.0f;
     int ld_it = 0, ld_cb = 0;                              // the raw tiles are requested in step order: position of that stream
-    auto gloadX = [&]() {                                   // past the last step it stays on the last one (harmless)
+    auto gloadX = [&](RawT &T) {                            // past the last step it stays on the last one (harmless)
         const int cb = ld_cb, m0 = tile_m0(ld_it);
         if (ld_cb + 1 < cblocks) ld_cb++; else if (ld_it + 1 < my_tiles) { ld_cb = 0; ld_it++; }
 #pragma unroll
@@ -924,18 +933,18 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
             const int f = tid + 256 * p, rr = f >> 3, q = f & 7;
             const int src = m0 - half + rr;
             const bool in = rr < XROWS && src >= 0 && src < rows;
-            rx[p] = *reinterpret_cast<const f32x4 *>(X + (size_t)(in ? src : m0) * cin + (cb << 5) + q * 4);
-            pin[p] = in;
+            T.rx[p] = *reinterpret_cast<const f32x4 *>(X + (size_t)(in ? src : m0) * cin + (cb << 5) + q * 4);
+            T.pin[p] = in;
         }
-        if (tid < KW * 8) rw = *reinterpret_cast<const f32x4 *>(Wd + (size_t)(tid >> 3) * cin + (cb << 5) + (tid & 7) * 4);
+        if (tid < KW * 8) T.rw = *reinterpret_cast<const f32x4 *>(Wd + (size_t)(tid >> 3) * cin + (cb << 5) + (tid & 7) * 4);
     };
-    auto lstoreX = [&]() {                                  // raw tile + the depthwise taps of the same channel block
+    auto lstoreX = [&](RawT &T) {                           // raw tile + the depthwise taps of the same channel block
 #pragma unroll
         for (int p = 0; p < NLD; p++) {
             const int f = tid + 256 * p, rr = f >> 3, q = f & 7;
-            if (rr < XROWS) *reinterpret_cast<f32x4 *>(&Xr[rr * SEP_XP + q * 4]) = pin[p] ? rx[p] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rr < XROWS) *reinterpret_cast<f32x4 *>(&Xr[rr * SEP_XP + q * 4]) = T.pin[p] ? T.rx[p] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (tid < KW * 8) *reinterpret_cast<f32x4 *>(&Wl[(tid >> 3) * 32 + (tid & 7) * 4]) = rw;
+        if (tid < KW * 8) *reinterpret_cast<f32x4 *>(&Wl[(tid >> 3) * 32 + (tid & 7) * 4]) = T.rw;
     };
     auto gloadB = [&](int cb) {
 #pragma unroll
@@ -996,10 +1005,12 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
             }
         }
     };
-    gloadX(); gloadB(0);
-    lstoreX(); lstoreB();
+    gloadX(T0); gloadB(0);
+    lstoreX(T0); lstoreB();
     __syncthreads();
-    gloadX(); gloadB(1 % cblocks);
+    gloadX(T0);                                            // tile 1
+    if (NSET == 2) gloadX(T1);                             // tile 2: tile k travels in T0 for odd k, T1 for even k (cblocks is even: parity of k = parity of its block)
+    gloadB(1 % cblocks);
     depthwise();
     const int fm = lane & 31, fk = (lane >> 5) * 8;
     for (int it = 0; it < my_tiles; it++) {
@@ -1012,8 +1023,12 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
         for (int cb = 0; cb < cblocks; cb++) {
             const int g = it * cblocks + cb;
             __syncthreads();                               // A planes of step g complete; the raw tile is free
-            lstoreX();                                     // raw tile of step g + 1 (loaded during the previous step)
-            gloadX();                                      // ... of step g + 2
+            if (NSET == 2) {                               // raw tile of step g + 1 (requested two steps ago), then the request for step g + 3 into the same set
+                if (cb & 1) { lstoreX(T1); gloadX(T1); } else { lstoreX(T0); gloadX(T0); }      // wave-uniform
+            } else {
+                lstoreX(T0);                               // raw tile of step g + 1 (loaded during the previous step)
+                gloadX(T0);                                // ... of step g + 2
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k16 = 0; k16 < 2; k16++) {

@@ -140,8 +140,9 @@ def main(argv=None):
     # set-up, not part of the stream: every context gets its workspace now (a 10+ GB hipMalloc), sized from the plan's first batch -- window 0's
     # longest reads at the full sample budget -- scaled to the largest planned batch, + 4 % for batches of other composition (more, shorter
     # reads): regrowing a slab later frees the old one, and hipFree waits for the WHOLE device, i.e. drains every batch in flight
+    pre = {}
     if len(batches):
-        b0, _ = load(batches[0])
+        b0, acc0 = load(batches[0])
         if b0.size():
             per_sample = ctxs[0].workspace_bytes(b0.desc()) / max(1, b0.samples())
             biggest = max(int(sizes[b].sum()) for b in batches)
@@ -149,8 +150,9 @@ def main(argv=None):
                 c.reserve(int(per_sample * biggest * 1.04), collect_bytes=int(biggest / 12.5 * 0.3 * 29 * 1.3))
                 b0.upload(c)                                   # the side tables (per-read mirrors, CNN lane buffers) take their size from a real batch
                 c.sync()
-        free.append(b0)
+        pre[0] = (b0, acc0)                                    # whichever rank pulls batch 0 submits this copy instead of reading it again
     t_setup = time.time() - t0
+    drv.preloaded = pre
     t_stream = time.time()
     ok = drv.run(prefetch=a.prefetch)
     t_stream = time.time() - t_stream

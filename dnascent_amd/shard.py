@@ -403,6 +403,16 @@ def format_window(blobs, formatter, write, group_bytes=256 << 20):
 _RUN_SEQ = [0]
 
 
+class _Done:
+    """a finished 'future': a batch that was loaded before the stream started"""
+
+    def __init__(self, value):
+        self.value = value
+
+    def result(self):
+        return self.value
+
+
 class StreamDriver:
     """One rank's loop of the streamed, dynamically balanced run (the product driver, dnascent_amd/run_detect.py, and the CPU tests
     with a stand-in engine):
@@ -447,6 +457,7 @@ class StreamDriver:
         self.multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
         self.max_pending_windows = max_pending_windows
         self.group_bytes = group_bytes
+        self.preloaded = {}          # batch id -> (batch object, accepted mask): loaded by the caller before run()
         if formatter is None:
             from . import host as _host
             formatter = _host.format_packed
@@ -578,6 +589,8 @@ class StreamDriver:
             w = int(self.window_of[b])
             self.open[w] = self.open.get(w, 0) + 1
             self.frontier = max(self.frontier, w)                # every batch of an earlier window has been handed out
+            if b in self.preloaded:                              # loaded during set-up (run_detect sizes its contexts from batch 0): not read twice
+                return b, _Done(self.preloaded.pop(b))
             return b, (pool.submit(self.load, self.batches[b]) if pool else None)
 
         state = {"dry": False}
