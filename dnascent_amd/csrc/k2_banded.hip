@@ -325,9 +325,17 @@ __device__ __forceinline__ void f6_band(F6State &st, const int b, const int E, c
 #define F6_ARGS st, E, K, lane2, xs_c, mu_c, in, fc, lp_step, lp_stay, rows32, best, best_e, found
 #define F6_BAND(FAST_, PH_, b_) f6_band<FAST_, PH_>(st, (b_), E, K, lane2, xs_c, mu_c, in, fc, lp_step, lp_stay, rows32, best, best_e, found)
 
-__global__ __launch_bounds__(64) void k2_fill6(BatchDev B, const BandConsts *bc, FillConsts fc) {
-    const int r = blockIdx.x;
-    const int lane = threadIdx.x, lane2 = 2 * lane;
+// K2_FILL_W reads (= wavefronts: a read is one wavefront, they share nothing) per WORKGROUP.  The dispatcher places a workgroup on ONE CU, so W > 1 packs the
+// batch's 500 long-lived wavefronts onto n / W CUs instead of spreading one over every CU: the network's kernels are sized to own a CU's registers (the
+// 256-row convolution: two workgroups x 128 registers x 2 wavefronts per SIMD = all 512), and a single foreign wavefront of 48 registers on one SIMD
+// keeps the second workgroup off that whole CU for as long as it lives (round 4).
+#ifndef K2_FILL_W
+#define K2_FILL_W 1
+#endif
+__global__ __launch_bounds__(64 * K2_FILL_W) void k2_fill6(BatchDev B, const BandConsts *bc, FillConsts fc) {
+    const int r = K2_FILL_W > 1 ? __builtin_amdgcn_readfirstlane((int)(blockIdx.x * K2_FILL_W + (threadIdx.x >> 6))) : (int)blockIdx.x;     // wave-uniform, and the compiler must know it
+    if (r >= B.n_reads) return;
+    const int lane = threadIdx.x & 63, lane2 = 2 * lane;
     ReadRes &R = B.res[r];
     if (R.status != 0) return;
     const int E = __builtin_amdgcn_readfirstlane((int)R.n_events), K = __builtin_amdgcn_readfirstlane((int)R.n_kq);   // wave-uniform: keep them scalar
@@ -718,7 +726,7 @@ int k2_selftest_run(hipStream_t st) {
 }
 void k2_launch_fill(const BatchDev &B, const void *bc, const void *fc, hipStream_t st) {
     const FillConsts f = *reinterpret_cast<const FillConsts *>(fc);
-    hipLaunchKernelGGL(k2_fill6, dim3(B.n_reads), dim3(64), 0, st, B, (const BandConsts *)bc, f);
+    hipLaunchKernelGGL(k2_fill6, dim3((B.n_reads + K2_FILL_W - 1) / K2_FILL_W), dim3(64 * K2_FILL_W), 0, st, B, (const BandConsts *)bc, f);
 }
 void k2_launch_chase(const BatchDev &B, uint8_t *path_from, hipStream_t st) {
     hipLaunchKernelGGL(k2_chase, dim3(B.n_reads), dim3(64), 0, st, B);

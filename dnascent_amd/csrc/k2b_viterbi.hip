@@ -148,17 +148,36 @@ extern "C" int dn_debug_k2b_trace(unsigned long long *out, int reset) {
 #else
 #define K2B_T(k) do { } while (0)
 #endif
+// K2B_W reads (= wavefronts; they share nothing) per WORKGROUP -- see K2_FILL_W in k2_banded.hip: packing the batch's long-lived wavefronts onto n / W
+// CUs leaves the others to the network's kernels whole.  Every wavefront owns its slice of the shared arrays; the kernel's barriers only ever ordered
+// ONE wavefront's LDS traffic, so they are wave-level fences here (the wavefronts of a workgroup walk different reads and leave at different times).
+#ifndef K2B_W
+#define K2B_W 1
+#endif
+#if K2B_W > 1
+#define K2B_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
+#define K2B_SYNC() __syncthreads()
+#endif
+template <int TMAX> struct K2bLds {
+    double xs[TMAX];                                      // scaled observations of the window
+    unsigned tk_start[TMAX], tk_len[TMAX];                // raw span of each taken event (event.raw, reads.h:68-72)
+    unsigned ev_slot[TMAX], ev_cnt0[TMAX];                // label pass: position slot of an M-labelled event / samples before it
+    unsigned ps_p[VT_NS], ps_cnt[VT_NS];                  // positions created by this window: lattice position, sample count
+    unsigned ev_aoff[TMAX];                               // align table: first row of each printed event (0xffffffff: not printed)
+    unsigned short evlab[TMAX];                           // label of the state that emitted observation t: state << 8 | position
+    unsigned char bt[(TMAX + 1) * VT_NS];                 // backtrace codes: I 2 bits | M 3 bits | D 2 bits
+};
 template <int TMAX>
-__global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const VitRead *vrs, VitConsts vc, int mode) {
-    __shared__ double xs[TMAX];                           // scaled observations of the window
-    __shared__ unsigned tk_start[TMAX], tk_len[TMAX];     // raw span of each taken event (event.raw, reads.h:68-72)
-    __shared__ unsigned ev_slot[TMAX], ev_cnt0[TMAX];     // label pass: position slot of an M-labelled event / samples before it
-    __shared__ unsigned ps_p[VT_NS], ps_cnt[VT_NS];           // positions created by this window: lattice position, sample count
-    __shared__ unsigned short evlab[TMAX];                // label of the state that emitted observation t: state << 8 | position
-    __shared__ unsigned char bt[(TMAX + 1) * VT_NS];      // backtrace codes: I 2 bits | M 3 bits | D 2 bits
-    __shared__ unsigned ev_aoff[TMAX];                    // align table: first row of each printed event (0xffffffff: not printed)
-    const int r = blockIdx.x;
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * (TMAX <= VT_TFAST ? K2B_W : 1)) void k2b_eventalign(BatchDev B, EaDev O, const VitRead *vrs, VitConsts vc, int mode) {
+    constexpr int WPB = TMAX <= VT_TFAST ? K2B_W : 1;     // the 512-observation lattice holds 50 KB: one per workgroup as before (it runs for a handful of windows)
+    __shared__ __attribute__((aligned(16))) K2bLds<TMAX> lds_[WPB];
+    K2bLds<TMAX> &L_ = lds_[WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0];
+    double *xs = L_.xs; unsigned *tk_start = L_.tk_start, *tk_len = L_.tk_len, *ev_slot = L_.ev_slot, *ev_cnt0 = L_.ev_cnt0, *ps_p = L_.ps_p, *ps_cnt = L_.ps_cnt;
+    unsigned short *evlab = L_.evlab; unsigned char *bt = L_.bt; unsigned *ev_aoff = L_.ev_aoff;
+    const int r = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WPB + (threadIdx.x >> 6))) : (int)blockIdx.x;     // wave-uniform, and the compiler must know it
+    if (r >= B.n_reads) return;
+    const int lane = threadIdx.x & 63;
     if (mode != 0 && O.redo[r] != mode) return;           // later passes: only the reads the pass before handed over
     ReadRes &R = B.res[r];
     const VitRead vr = vrs[r];
@@ -259,7 +278,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             fail = 6; break;                                                  // points at its first event: gathering it again gives the same events)
         }
         const int T = __builtin_amdgcn_readfirstlane((int)nt);
-        __syncthreads();
+        K2B_SYNC();
         K2B_T(1);
         const int coord0 = is_rev ? (ref_end - ri - DN_K / 2) : (ref_start + ri + DN_K / 2);
 
@@ -312,7 +331,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             sI1 = shl_prev_z(I1); sM1 = shl_prev_z(M1); sD1 = shl_prev_z(D1);
             xq = shl_prev_d(xq, x0n, lane);
         }
-        __syncthreads();
+        K2B_SYNC();
         K2B_T(2);
         // ---- termination (:446-476) ----
         double fD, fM, fI;
@@ -384,7 +403,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             // a walk that stopped inside a group of 64 (only in an all-log(0) lattice) still leaves what it labelled
             if (last_ob > 0 && (last_ob & 63) != 0 && lane >= (last_ob & 63)) evlab[(last_ob & ~63) + lane] = (unsigned short)lab;
         }
-        __syncthreads();
+        K2B_SYNC();
         K2B_T(3);
         // ---- window log ----
         if (lane == 0) {
@@ -452,7 +471,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
             }
             npos += carry_slots;
             const int n_new = (int)carry_slots;
-            __syncthreads();
+            K2B_SYNC();
             K2B_T(8);
             // samples: one lane per event.  14 k of a window's 162 k ticks, and it is the HBM latency of the raw samples (untouched since
             // K1): round 3 tried all of an event's samples requested first (20 loads in flight: 18.5 k, the fp64 division then runs for the
@@ -495,7 +514,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
                 if (in) ev_aoff[e] = emit ? (al_rows + carry + run - len) : 0xffffffffu;
                 carry += (unsigned)__builtin_amdgcn_readlane((int)run, 63);
             }
-            __syncthreads();
+            K2B_SYNC();
             const unsigned long long A0 = O.al_off[r];
             for (int e = lane; e < T; e += 64) {
                 const unsigned off = ev_aoff[e];
@@ -520,7 +539,7 @@ __global__ __launch_bounds__(64) void k2b_eventalign(BatchDev B, EaDev O, const 
 #endif
         readHead += (unsigned)lastM_ev + 1u;                // :739-740
         ri += lastM_ref + 1;
-        __syncthreads();
+        K2B_SYNC();
         if (mode == 1) { park(2); return; }                 // the one oversized window is done: back to the small lattice
     }
 #ifdef DN_K2B_TRACE
@@ -586,9 +605,10 @@ void k2b_launch(const BatchDev &B, const void *ea, const void *vr, const void *v
     const EaDev O = *reinterpret_cast<const EaDev *>(ea);
     const VitConsts V = *reinterpret_cast<const VitConsts *>(vc);
     hipMemsetAsync(O.redo, 0, (size_t)B.n_reads, st);
-    hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, dim3(B.n_reads), dim3(64), 0, st, B, O, (const VitRead *)vr, V, 0);
+    const dim3 gf((B.n_reads + K2B_W - 1) / K2B_W), bf(64 * K2B_W);
+    hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, gf, bf, 0, st, B, O, (const VitRead *)vr, V, 0);
     hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), 0, st, B, O, (const VitRead *)vr, V, 1);
-    hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, dim3(B.n_reads), dim3(64), 0, st, B, O, (const VitRead *)vr, V, 2);
+    hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, gf, bf, 0, st, B, O, (const VitRead *)vr, V, 2);
     hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), 0, st, B, O, (const VitRead *)vr, V, 3);
     hipLaunchKernelGGL(k2b_features, dim3((max_ref + 255) / 256, B.n_reads), dim3(256), 0, st, B, O);
 }

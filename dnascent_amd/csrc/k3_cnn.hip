@@ -1712,7 +1712,14 @@ static bool k3_can_fuse(const CnnRun &c, int i) {
 // output channels: one workgroup covers ALL 256 columns, so the filter is applied once per row tile); the short filters of the
 // narrow layers are memory-side and run better as k3_sep_split with 2-3 workgroups per CU.
 static bool k3_takes_ws(int np, const dn_cnn_op &d, const dn_cnn_op &o) { return np == 2 && d.k == 17 && o.cout == 256 && o.cin % 64 == 0 && k3_sep_ws_enabled(); }
-static bool k3_takes_bm256(int pieces, const dn_cnn_op &o, unsigned rows) { return pieces == 2 && o.cout % 128 == 0 && o.k >= 9 && o.cin >= 128 && rows % 256 == 0 && k3_bm256_enabled(); }
+static int k3_env_int(const char *name, int dflt) { const char *e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
+// which convolutions take the 256-row form: >= DN_CNN_BM256_MINK taps and >= DN_CNN_BM256_MINCIN input channels.  Round 2 measured the 3-tap layers 8 % SLOWER in
+// this form (it spilled 18 registers under its 128-register cap) and kept it to >= 9 taps x >= 128 channels; without the spills (round 4) 3 x 256 -> 256 runs 1 206
+// against 1 439 us, 3 x 256 -> 128 618 against 714, 9 x 64 -> 128 509 against 582 (gpurun_out/r4l): every 128-column convolution takes it now.
+static bool k3_takes_bm256(int pieces, const dn_cnn_op &o, unsigned rows) {
+    static const int mink = k3_env_int("DN_CNN_BM256_MINK", 3), mincin = k3_env_int("DN_CNN_BM256_MINCIN", 64);
+    return pieces == 2 && o.cout % 128 == 0 && o.k >= mink && o.cin >= mincin && rows % 256 == 0 && k3_bm256_enabled();
+}
 
 template <int BN, bool ADD, int NP>
 static int k3_launch_sep(const CnnRun &c, int i, const float *in, float *out, const float *add, hipStream_t st) {

@@ -375,20 +375,37 @@ def stream_detect(ctxs, batches, emit=True, out_path=None, header=None, keep=Fal
 PACK_REVERSE, PACK_TEXT = 1, 2          # DNAscent::DN_PACK_* (flags of a packed read's meta row)
 
 
+class _TextOwner:
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().dnh_text_free(self.h); self.h = None
+        except Exception:
+            pass
+
+
 def format_packed(meta3, read_ptr):
     """DNAscent::formatPacked: the writer rank's formatter.  meta3 uint64 [n][3] (count, header bytes, flags), read_ptr uint64 [n] (address
-    of every read's payload, output order) -> (text bytes of the n records laid end to end, record_bytes uint64 [n])."""
+    of every read's payload, output order) -> (text of the n records laid end to end -- a memoryview of the C++ buffer, bytes when empty --,
+    record_bytes uint64 [n])."""
     m = np.ascontiguousarray(meta3, np.uint64); p = np.ascontiguousarray(read_ptr, np.uint64)
     n = p.shape[0]
     rb = np.zeros(max(n, 1), np.uint64)
     if n == 0:
         return b"", rb[:0]
     t = C.c_void_p(lib().dnh_format_packed(n, m.ctypes.data, p.ctypes.data, rb.ctypes.data))
-    try:
-        text = C.string_at(lib().dnh_text_data(t), lib().dnh_text_size(t))
-    finally:
+    size = int(lib().dnh_text_size(t))
+    if size == 0:
         lib().dnh_text_free(t)
-    return text, rb[:n]
+        return b"", rb[:n]
+    # a VIEW of the C++ string, not a copy: C.string_at would memcpy 200-400 MB per window while holding the GIL, i.e. with the thread that drives
+    # the GPU locked out (round 4: ~1 s of a 9 s run); file.write() takes the view as it is and releases the GIL for the system call
+    buf = (C.c_char * size).from_address(lib().dnh_text_data(t))
+    buf._owner = _TextOwner(t)                           # freed when the last view of the buffer goes
+    return memoryview(buf).cast("B"), rb[:n]
 
 
 class DetectStream:
