@@ -330,7 +330,7 @@ __device__ __forceinline__ void f6_band(F6State &st, const int b, const int E, c
 // 256-row convolution: two workgroups x 128 registers x 2 wavefronts per SIMD = all 512), and a single foreign wavefront of 48 registers on one SIMD
 // keeps the second workgroup off that whole CU for as long as it lives (round 4).
 #ifndef K2_FILL_W
-#define K2_FILL_W 1
+#define K2_FILL_W 4                                          /* round 4, one session (gpurun_out/r4m, r4n): W = 1 760-764 Msamples/s, 4 with K2B_W 4: 782; 8 / 6: 775-781; 16 / 4: no gain; 2 / 2: none */
 #endif
 __global__ __launch_bounds__(64 * K2_FILL_W) void k2_fill6(BatchDev B, const BandConsts *bc, FillConsts fc) {
     const int r = K2_FILL_W > 1 ? __builtin_amdgcn_readfirstlane((int)(blockIdx.x * K2_FILL_W + (threadIdx.x >> 6))) : (int)blockIdx.x;     // wave-uniform, and the compiler must know it
@@ -423,10 +423,22 @@ __device__ __forceinline__ unsigned trace_code(const uint8_t *tile, int row, int
     return ((unsigned)(w[0] >> l) & 1u) | (((unsigned)(w[1] >> l) & 1u) << 1);
 }
 
-__global__ __launch_bounds__(64) void k2_chase(BatchDev B) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[2][CH_ROWS * DN_TROW];
-    const int r = blockIdx.x;
-    const int lane = threadIdx.x;
+// K2_CHASE_W reads (= wavefronts) per workgroup, as K2_FILL_W: every wavefront has its own pair of tiles, and the barriers (which only ever ordered one
+// wavefront's LDS traffic) are wave-level fences
+#ifndef K2_CHASE_W
+#define K2_CHASE_W 1
+#endif
+#if K2_CHASE_W > 1
+#define K2C_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
+#define K2C_SYNC() __syncthreads()
+#endif
+__global__ __launch_bounds__(64 * K2_CHASE_W) void k2_chase(BatchDev B) {
+    __shared__ __attribute__((aligned(16))) uint8_t tiles_[K2_CHASE_W][2][CH_ROWS * DN_TROW];
+    uint8_t (*tile)[CH_ROWS * DN_TROW] = tiles_[K2_CHASE_W > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0];
+    const int r = K2_CHASE_W > 1 ? __builtin_amdgcn_readfirstlane((int)(blockIdx.x * K2_CHASE_W + (threadIdx.x >> 6))) : (int)blockIdx.x;
+    if (r >= B.n_reads) return;
+    const int lane = threadIdx.x & 63;
     ReadRes &R = B.res[r];
     if (R.status != 0) return;
     const int K = (int)R.n_kq;
@@ -457,7 +469,7 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B) {
     int cur = 0;
     int nlo = lo - CH_ROWS; if (nlo < 0) nlo = 0;
     if (lo > 0) load_tile(nlo, regs);
-    __syncthreads();
+    K2C_SYNC();
 
     unsigned step = 0;
     int bad = 0;
@@ -491,7 +503,7 @@ __global__ __launch_bounds__(64) void k2_chase(BatchDev B) {
             lo = nlo;
             nlo = lo - CH_ROWS; if (nlo < 0) nlo = 0;
             if (lo > 0) load_tile(nlo, regs);
-            __syncthreads();
+            K2C_SYNC();
         }
         const int bi = b - lo;
         if (bi >= 6 && e >= 4 && k >= 4 && step + 4u <= cap) {
@@ -729,7 +741,7 @@ void k2_launch_fill(const BatchDev &B, const void *bc, const void *fc, hipStream
     hipLaunchKernelGGL(k2_fill6, dim3((B.n_reads + K2_FILL_W - 1) / K2_FILL_W), dim3(64 * K2_FILL_W), 0, st, B, (const BandConsts *)bc, f);
 }
 void k2_launch_chase(const BatchDev &B, uint8_t *path_from, hipStream_t st) {
-    hipLaunchKernelGGL(k2_chase, dim3(B.n_reads), dim3(64), 0, st, B);
+    hipLaunchKernelGGL(k2_chase, dim3((B.n_reads + K2_CHASE_W - 1) / K2_CHASE_W), dim3(64 * K2_CHASE_W), 0, st, B);
     hipLaunchKernelGGL(k2_expand, dim3(B.n_reads), dim3(256), 0, st, B, path_from);
 }
 void k2_launch_post(const BatchDev &B, const uint8_t *path_from, float *path_lp, const void *fc, hipStream_t st) {

@@ -152,7 +152,7 @@ extern "C" int dn_debug_k2b_trace(unsigned long long *out, int reset) {
 // CUs leaves the others to the network's kernels whole.  Every wavefront owns its slice of the shared arrays; the kernel's barriers only ever ordered
 // ONE wavefront's LDS traffic, so they are wave-level fences here (the wavefronts of a workgroup walk different reads and leave at different times).
 #ifndef K2B_W
-#define K2B_W 1
+#define K2B_W 4
 #endif
 #if K2B_W > 1
 #define K2B_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
