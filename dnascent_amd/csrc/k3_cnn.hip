@@ -847,6 +847,18 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
 // MFMA load the clock settles at 1.5-1.8 GHz and the matrix pipe then delivers 1.5-1.9 PFLOP/s of dense fp16, not 2.5; the 17-tap layer's
 // 1.30 PFLOP/s of issued products is already 70-85 % of that.  Removing barriers and staging instructions does not buy what a second
 // workgroup per CU does)
+#if defined(DN_WS_TRACE) || defined(DN_SPLIT_TRACE)       /* experiment builds only (tools/ws_trace.py, tools/split_trace.py): shader-clock stamps of one workgroup's phases */
+#ifndef DN_WS_TRACE
+#define DN_WS_TRACE DN_SPLIT_TRACE
+#endif
+__device__ unsigned long long ws_trace[16][64];
+#define WS_T(i) do { if (blockIdx.x == DN_WS_TRACE && lane == 0) ws_trace[wave][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define WS_TRACE_TILE 2                                   /* the workgroup's third tile: steady state */
+extern "C" int dn_debug_ws_trace(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ws_trace), sizeof(ws_trace)); }
+#else
+#define WS_T(i) do { } while (0)
+#define WS_TRACE_TILE (-1)
+#endif
 // ---------------------------------------------------------------------------------------------------------
 // k3_sep_split: SeparableConv1D in ONE kernel -- the depthwise filter is applied while the A tile of the pointwise GEMM is
 // staged, so its output never goes to HBM (as two kernels the pair moves 4 x rows x C x 4 bytes, fused 2 x; the 29 separable
@@ -1022,13 +1034,21 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
                 for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
         for (int cb = 0; cb < cblocks; cb++) {
             const int g = it * cblocks + cb;
+#ifdef DN_SPLIT_TRACE
+#define SP_T(i) do { if (BN == 128 && KW == 9 && it == WS_TRACE_TILE) WS_T(i); } while (0)
+#else
+#define SP_T(i) do { } while (0)
+#endif
+            SP_T(2 + 6 * cb);
             __syncthreads();                               // A planes of step g complete; the raw tile is free
+            SP_T(3 + 6 * cb);
             if (NSET == 2) {                               // raw tile of step g + 1 (requested two steps ago), then the request for step g + 3 into the same set
                 if (cb & 1) { lstoreX(T1); gloadX(T1); } else { lstoreX(T0); gloadX(T0); }      // wave-uniform
             } else {
                 lstoreX(T0);                               // raw tile of step g + 1 (loaded during the previous step)
                 gloadX(T0);                                // ... of step g + 2
             }
+            SP_T(4 + 6 * cb);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k16 = 0; k16 < 2; k16++) {
@@ -1054,14 +1074,18 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            SP_T(5 + 6 * cb);
             if (g + 1 < nb) {                              // wave-uniform
                 __syncthreads();                           // every wavefront is done with the planes and the B tile; raw tile of g + 1 visible
+                SP_T(6 + 6 * cb);
                 lstoreB();
                 gloadB((g + 2) % cblocks);
                 depthwise();                               // A planes of step g + 1 (the next tile's first block after a tile's last)
+                SP_T(7 + 6 * cb);
             }
         }
         conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, tile_m0(it), n0, wm, wn, lane, cout, relu, post);
+        SP_T(40);
     }
     if (NP == 2) range_report(amax, range_flag, lane);
 }
@@ -1069,15 +1093,6 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
 // (Round 3: k3_sep_pair -- two consecutive 9-tap 128 -> 128 separable layers in one launch, the intermediate activations in LDS, 120-row
 // tiles, HBM bytes per pair 0.52 x -- is in tools/k3_sep_pair_experiment.hip: bit-identical, and slower (746 us per pair against 2 x 262):
 // one phase-locked 512-thread workgroup per CU loses to two independent k3_sep_split workgroups that overlap each other's phases.)
-#ifdef DN_WS_TRACE       /* experiment build only (tools/ws_trace.py): shader-clock stamps of one workgroup's phases */
-__device__ unsigned long long ws_trace[16][64];
-#define WS_T(i) do { if (blockIdx.x == DN_WS_TRACE && lane == 0) ws_trace[wave][i] = __builtin_amdgcn_s_memtime(); } while (0)
-#define WS_TRACE_TILE 2                                   /* the workgroup's third tile: steady state */
-extern "C" int dn_debug_ws_trace(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ws_trace), sizeof(ws_trace)); }
-#else
-#define WS_T(i) do { } while (0)
-#define WS_TRACE_TILE (-1)
-#endif
 // ---------------------------------------------------------------------------------------------------------
 // k3_sep_ws: the fused SeparableConv1D with WAVE SPECIALISATION.  In k3_sep_split a workgroup alternates between its
 // depthwise phase (vector unit + LDS) and its pointwise phase (matrix cores); the two never overlap inside the workgroup, and
