@@ -75,7 +75,7 @@ def main(argv=None):
     ap.add_argument("--out", required=True)
     ap.add_argument("--model", default=None, help="CNN description prefix (tools/convert_savedmodel.py); default: synthetic weights")
     ap.add_argument("--pore-model", default=None)
-    ap.add_argument("--inflight", type=int, default=4)
+    ap.add_argument("--inflight", type=int, default=8, help="batches in flight on the GPU (one context each: ~21 GB of HBM per 300 M samples; 8 measured best, bench.py)")
     ap.add_argument("--batch-samples", type=float, default=300e6, help="sample budget of one batch")
     ap.add_argument("--batch-reads", type=int, default=4096)
     ap.add_argument("--window-batches", type=float, default=2.0,
