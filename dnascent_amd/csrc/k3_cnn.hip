@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
 #define SEP_NSET 1
 #endif
     constexpr int NSET = (SEP_NSET == 2 && BN == 128 && NP == 2) ? 2 : 1;     // the 64-column form would drop from three workgroups per CU to two (179 registers)
-    struct RawT { f32x4 rx[NLD]; bool pin[NLD]; f32x4 rw; };
+    struct RawT { f32x4 rx[NLD]; unsigned pin; f32x4 rw; };       // pin: bit p = load p was inside the pass (one register instead of NLD predicates)
     RawT T0, T1;
     T0.rw = f32x4{0.f, 0.f, 0.f, 0.f}; T1.rw = T0.rw;
     u32x4 rb[NP][NBQ];
@@ -1023,13 +1023,14 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
     auto gloadX = [&](RawT &T) {                            // past the last step it stays on the last one (harmless)
         const int cb = ld_cb, m0 = tile_m0(ld_it);
         if (ld_cb + 1 < cblocks) ld_cb++; else if (ld_it + 1 < my_tiles) { ld_cb = 0; ld_it++; }
+        T.pin = 0u;
 #pragma unroll
         for (int p = 0; p < NLD; p++) {
             const int f = tid + 256 * p, rr = f >> 3, q = f & 7;
             const int src = m0 - half + rr;
             const bool in = rr < XROWS && src >= 0 && src < rows;
             T.rx[p] = *reinterpret_cast<const f32x4 *>(X + (size_t)(in ? src : m0) * cin + (cb << 5) + q * 4);
-            T.pin[p] = in;
+            T.pin |= in ? (1u << p) : 0u;
         }
         if (tid < KW * 8) T.rw = *reinterpret_cast<const f32x4 *>(Wd + (size_t)(tid >> 3) * cin + (cb << 5) + (tid & 7) * 4);
     };
@@ -1037,7 +1038,7 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
 #pragma unroll
         for (int p = 0; p < NLD; p++) {
             const int f = tid + 256 * p, rr = f >> 3, q = f & 7;
-            if (rr < XROWS) *reinterpret_cast<f32x4 *>(&Xr[rr * SEP_XP + q * 4]) = T.pin[p] ? T.rx[p] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rr < XROWS) *reinterpret_cast<f32x4 *>(&Xr[rr * SEP_XP + q * 4]) = ((T.pin >> p) & 1u) ? T.rx[p] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (tid < KW * 8) *reinterpret_cast<f32x4 *>(&Wl[(tid >> 3) * 32 + (tid & 7) * 4]) = T.rw;
     };
