@@ -106,6 +106,8 @@ def lib():
         L.dnh_text_size.restype = C.c_uint64
         L.dnh_text_size.argtypes = [C.c_void_p]
         L.dnh_text_free.argtypes = [C.c_void_p]
+        L.dnh_pwrite_parallel.restype = C.c_int
+        L.dnh_pwrite_parallel.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_uint64]
         L.dnh_batch_pin.argtypes = [C.c_void_p]
         L.dnh_batch_unpin.argtypes = [C.c_void_p]
         L.dnh_revcomp.restype = C.c_int
@@ -373,6 +375,19 @@ def stream_detect(ctxs, batches, emit=True, out_path=None, header=None, keep=Fal
 
 
 PACK_REVERSE, PACK_TEXT = 1, 2          # DNAscent::DN_PACK_* (flags of a packed read's meta row)
+
+
+def pwrite_parallel(fd, buf, offset):
+    """buf (bytes or a memoryview / ctypes view of the formatter's text) to file descriptor fd at `offset`, written in pieces by several host threads"""
+    n = len(buf)
+    if n == 0:
+        return
+    if isinstance(buf, (bytes, bytearray)):
+        addr = C.cast(C.c_char_p(bytes(buf)), C.c_void_p).value if isinstance(buf, bytearray) else C.cast(C.c_char_p(buf), C.c_void_p).value
+    else:
+        addr = C.addressof(C.c_char.from_buffer(buf)) if not buf.readonly else np.frombuffer(buf, np.uint8).ctypes.data
+    if lib().dnh_pwrite_parallel(int(fd), C.c_void_p(addr), n, int(offset)) != 0:
+        raise IOError("short write to the output file")
 
 
 class _TextOwner:

@@ -127,13 +127,19 @@ def main(argv=None):
         return b, b.add_container_at(a.container, offsets[ords])
 
     out_f = None
+    out_pos = [0]
+    write_s = [0.0]
     if rank == 0:
         out_f = open(a.out, "wb")
         if a.header:
-            out_f.write(a.header.encode())
+            out_f.write(a.header.encode()); out_f.flush()
+            out_pos[0] = out_f.tell()
 
-    def write(text, ordinals, record_bytes):
-        out_f.write(text)
+    def write(text, ordinals, record_bytes):                   # on the writer's gather thread: the group's text, by several threads at once (host.pwrite_parallel)
+        t_w = time.time()
+        host.pwrite_parallel(out_f.fileno(), text, out_pos[0])
+        out_pos[0] += len(text)
+        write_s[0] += time.time() - t_w
 
     drv = shard.StreamDriver(dist, batches, window_of, engine, load, write, release=free.append, dst=0, device=dev_t,
                              chunk_bytes=a.gather_chunk_mb << 20)
@@ -161,7 +167,7 @@ def main(argv=None):
     if drv.failure is not None:
         print("run_detect: rank %d aborted: %r" % (rank, drv.failure), file=sys.stderr)
     per_rank = shard.gather_stats(dist, dict(rank=rank, batches=drv.batches_done, busy_s=round(drv.busy_s, 3), gather_s=round(drv.gather_s, 3),
-                                             format_s=round(drv.format_s, 3), peak_buffered_bytes=int(drv.peak_pending_bytes),
+                                             format_s=round(drv.format_s - write_s[0], 3), write_s=round(write_s[0], 3), peak_buffered_bytes=int(drv.peak_pending_bytes),
                                              max_gather_bytes=int(drv.max_gather_bytes), reads_ok=drv.n_ok, reads_failed=drv.n_fail,
                                              upload_s=round(st.seconds_upload, 3), collect_wait_s=round(st.seconds_collect, 3), load_wait_s=round(drv.load_wait_s, 3),
                                              pack_s=round(st.seconds_emit, 3)), device=dev_t)

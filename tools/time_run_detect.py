@@ -12,6 +12,9 @@ ap.add_argument("--dir", default="/tmp")
 ap.add_argument("--inflight", type=int, default=8)
 ap.add_argument("--stats", default=None)
 ap.add_argument("--keep", action="store_true")
+ap.add_argument("--ranks", type=int, default=1, help="> 1: under torch.distributed.run with the gloo backend, the ranks SHARING this GPU (what the 8-GPU node runs over RCCL, "
+                                                     "exercised at full payload size; not a throughput figure)")
+ap.add_argument("--sha", action="store_true", help="print the SHA-256 of the .detect file (1- and N-rank runs must agree)")
 a, extra = ap.parse_known_args()
 from dnascent_amd import host, synth
 cont = os.path.join(a.dir, "bench_reads.dnrc"); out = os.path.join(a.dir, "bench_reads.detect")
@@ -19,12 +22,26 @@ t0 = time.time()
 n = host.write_synth_container(cont, synth.pore_model(), 1000003, a.reads, a.bases)
 print("container: %d reads, %.2f GB, written in %.1f s" % (n, os.path.getsize(cont) / 1e9, time.time() - t0), flush=True)
 env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), DN_CNN_ROWS=str(4 << 20))
-cmd = [sys.executable, "-m", "dnascent_amd.run_detect", "--container", cont, "--out", out, "--inflight", str(a.inflight)] + (["--stats", a.stats] if a.stats else []) + extra
+tail = ["--container", cont, "--out", out, "--inflight", str(a.inflight)] + (["--stats", a.stats] if a.stats else []) + extra
+if a.ranks > 1:
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.ranks), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "-m", "dnascent_amd.run_detect", "--backend", "gloo"] + tail
+else:
+    cmd = [sys.executable, "-m", "dnascent_amd.run_detect"] + tail
 t0 = time.time()
 r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True)
 print(r.stdout[-3000:]); print(r.stderr[-3000:], file=sys.stderr)
 print("run_detect wall (process start to exit, incl. library load, context + CNN-lane allocation): %.1f s, rc %d, output %.2f GB" % (
     time.time() - t0, r.returncode, os.path.getsize(out) / 1e9 if os.path.exists(out) else 0.0))
+if a.sha and os.path.exists(out):
+    import hashlib
+    h = hashlib.sha256()
+    with open(out, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    print("sha256 %s  %d bytes  (%d rank(s))" % (h.hexdigest(), os.path.getsize(out), a.ranks))
 if not a.keep:
     for f in (cont, out):
         if os.path.exists(f):
