@@ -65,7 +65,7 @@ def _cnn_worker(args):
     return done, time.time() - t0
 
 
-def cpu_baseline(model, n_bases, seed0, full, reads_per_thread=2, cnn_seconds=6.0):
+def cpu_baseline(model, n_bases, seed0, full, reads_per_thread=None, cnn_seconds=6.0):
     """The oracle (CPU restatement of the reference path) on ALL host cores, measured, nothing extrapolated (round-3 verdict):
       * normaliseEvents (+ eventalign): OpenMP, one read per thread, schedule(dynamic) -- the shape of the reference's own loop
         (detect.cpp:852) -- over reads_per_thread x cores reads of the workload;
@@ -77,8 +77,12 @@ def cpu_baseline(model, n_bases, seed0, full, reads_per_thread=2, cnn_seconds=6.
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     from concurrent.futures import ThreadPoolExecutor
-    from dnascent_amd import synth
-    cores = os.cpu_count() or 1
+    from dnascent_amd import host as _host, synth
+    # the CPUs this process can keep busy, not the hardware threads it can see: the pool's hosts show 256 and grant 16 (cgroup cpu.max); threads
+    # beyond the quota only get the whole process frozen for the rest of each 100 ms period (host.usable_cpus; round 4)
+    cores = _host.usable_cpus()
+    if reads_per_thread is None:
+        reads_per_thread = max(2, min(16, 256 // cores))     # ~10-30 s of oracle work whatever the quota
     cnn_rate = None
     what_cnn = ""
     first = synth.make_read(seed0, n_bases, model=model, is_reverse=False, sub_rate=0.002, ins_rate=0.001, del_rate=0.001)
@@ -111,10 +115,10 @@ def cpu_baseline(model, n_bases, seed0, full, reads_per_thread=2, cnn_seconds=6.
         what_cnn += "; the sample's %d positions at that rate: %.1f s" % (positions, cnn_s)
     return {"value": samples / (secs + cnn_s) / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port", "threads_timed": cores,
             "Msamples_per_s_per_thread": samples / (secs + cnn_s) / 1e6 / cores, "per_thread_without_cnn": samples / secs / 1e6 / cores,
-            "oracle_s": secs, "cnn_s": cnn_s, "cnn_positions_per_s_all_cores": cnn_rate,
+            "oracle_s": secs, "cnn_s": cnn_s, "cnn_positions_per_s_all_cores": cnn_rate, "hardware_threads_visible": os.cpu_count(),
             "reference_probe_per_thread": "0.15-0.20 Msamples/s (SURVEY.md s6: the real reference, one thread, normaliseEvents + eventalign)",
             "sample": "%d of the %d-base reads of the workload (%d pass QC); %s%s; value = samples / (oracle s + CNN s), every leg measured with all %d "
-                      "hardware threads loaded" % (n, n_bases, ok, what, what_cnn, cores)}
+                      "usable CPUs loaded (%d hardware threads visible; the cgroup's CPU quota is the limit)" % (n, n_bases, ok, what, what_cnn, cores, os.cpu_count() or 0)}
 
 
 def load_pmc(reads_per_step, bases, what, inflight=None):
@@ -209,7 +213,8 @@ def main():
         # the host side (read generation, record formatting) is OpenMP over reads: the ranks of a node share its cores
         # (torch.distributed.run exports OMP_NUM_THREADS=1 for its workers: the per-rank share replaces that launcher default)
         if os.environ.get("OMP_NUM_THREADS", "1") == "1":
-            os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // world))
+            from dnascent_amd import host as _h
+            os.environ["OMP_NUM_THREADS"] = str(max(1, _h.usable_cpus() // world))
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -604,7 +609,7 @@ def main():
                                 "note": "busy_s: a rank's own stream (first upload to its last records on the host); gather_s: its part of the RCCL gather of the "
                                         "per-call results to rank 0, inside the timed region"}
             out["hbm"] = _hbm_info()
-            out["host"] = {"datagen_s": t_gen, "upload_s": st.seconds_upload, "collect_wait_s": st.seconds_collect, "emit_s": st.seconds_emit,
+            out["host"] = {"datagen_s": t_gen, "upload_s": st.seconds_upload, "enqueue_s": st.seconds_run, "collect_wait_s": st.seconds_collect, "emit_s": st.seconds_emit,
                            "gather_s": gather_s, "emission": {"records_per_s": st.calls / st.seconds_emit if st.seconds_emit > 0 else None,
                                                               "MB_per_s": st.bytes_out / st.seconds_emit / 1e6 if st.seconds_emit > 0 else None,
                                                               "bytes": int(st.bytes_out)}}

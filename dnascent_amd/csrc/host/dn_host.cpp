@@ -5,6 +5,8 @@
 #include <math.h>
 #include <stdio.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <string.h>
 #include <time.h>
 
@@ -14,16 +16,39 @@
 
 namespace DNAscent {
 
-// Threads of the host-side parallel loops (record formatting, container reads).  NOT every hardware thread: on the 256-thread hosts of the
-// pool a 256-wide team that spin-waits after its loop (libgomp's default wait policy) starves the HIP runtime's callback thread -- the one
-// that computes the per-read libm constants between two stream operations -- and formats SLOWER: 1.63 s against 0.30 s of emission per
-// 8 000 reads, 657-667 against 704 Msamples/s end to end (round 3, gpurun_out/r3t).  DN_HOST_THREADS overrides; the Python drivers also
-// export OMP_WAIT_POLICY=passive before the library loads.
+// Threads of the host-side parallel loops (record formatting, container reads).  NOT every hardware thread: min(64, the CPUs the process may
+// actually USE).  The hosts of the pool show 256 hardware threads, but their containers run under a cgroup CPU quota (cpu.max = 16 CPUs):
+// a 64-wide team burns the 100 ms period's quota in 25 ms and the kernel then freezes EVERY thread of the process for the rest of the
+// period -- the one that drives the GPU included (round 4: dn_run_detect, 2 ms of launches, took 80-130 ms per batch inside run_detect, and
+// cpu.stat counted 307 throttled periods of 681; round 3 had seen the same thing as "a 256-wide team formats slower than a 64-wide one").
+// DN_HOST_THREADS overrides; the Python drivers also export OMP_WAIT_POLICY=passive before the library loads.
+static int cgroupCpus() {                                    // CPUs' worth of quota: cgroup v2 cpu.max "quota period" | v1 cfs_quota_us / cfs_period_us; 0 = unlimited / unknown
+    long q = -1, per = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char a[64] = {0};
+        if (fscanf(f, "%63s %ld", a, &per) == 2 && strcmp(a, "max") != 0) q = atol(a);
+        fclose(f);
+    } else {
+        FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (fq && fp && fscanf(fq, "%ld", &q) == 1 && fscanf(fp, "%ld", &per) == 1) {} else q = -1;
+        if (fq) fclose(fq);
+        if (fp) fclose(fp);
+    }
+    return (q > 0 && per > 0) ? (int)((q + per - 1) / per) : 0;
+}
 int hostThreads() {
     static const int n = [] {
         const char *e = getenv("DN_HOST_THREADS");
-        const int want = e ? atoi(e) : 64;
-        return std::max(1, std::min(want > 0 ? want : 64, omp_get_max_threads()));
+        int want = e ? atoi(e) : 0;
+        if (want > 0) return std::max(1, std::min(want, omp_get_thread_limit()));      // said explicitly: taken as it is (the loops carry num_threads())
+        want = std::min(64, omp_get_num_procs());
+        const int quota = cgroupCpus();
+        if (quota > 0) want = std::min(want, quota);
+        // OMP_NUM_THREADS is honoured when it asks for a team; "1" is what torch.distributed.run exports to every worker by default and would
+        // make each rank of a multi-GPU run load, pack and format on ONE thread -- the Python drivers set DN_HOST_THREADS to the rank's share instead
+        const int omp = omp_get_max_threads();
+        if (omp > 1) want = std::min(want, omp);
+        return std::max(1, want);
     }();
     return n;
 }
@@ -150,7 +175,21 @@ int ReadBatch::add(const ReadInput &in) {
 // reverse complements, the copies of a 1 MB signal -- runs on the host's threads; only the offset bookkeeping is serial.  A 500 x 50 kb batch
 // read by read took 0.35-0.45 s of ONE thread, more than the GPU needs for it: the product driver's loader was what the GPU waited for
 // (round 4: run_detect 497 Msamples/s against the bench's 720 on pre-built batches).  Returns the reads accepted; accepted[i] = 1 / 0.
-size_t ReadBatch::addMany(const ReadInput *const *in, size_t n, uint8_t *accepted) {
+size_t ReadBatch::addMany(const ReadInput *const *in, size_t n, uint8_t *accepted) { return addManyFromFile(in, n, accepted, -1, nullptr, nullptr); }
+
+namespace {
+bool preadAll(int fd, void *dst, size_t bytes, uint64_t off) {
+    char *d = (char *)dst;
+    while (bytes) {
+        const ssize_t k = pread(fd, d, bytes, (off_t)off);
+        if (k <= 0) return false;
+        d += k; off += (uint64_t)k; bytes -= (size_t)k;
+    }
+    return true;
+}
+}  // namespace
+
+size_t ReadBatch::addManyFromFile(const ReadInput *const *in, size_t n, uint8_t *accepted, int fd, const uint64_t *adcFileOff, bool *ioFailed) {
     std::vector<Prepared> P(n);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(hostThreads()) if (n > 1)
     for (long i = 0; i < (long)n; i++) prepareRead(*in[i], P[(size_t)i]);
@@ -169,7 +208,8 @@ size_t ReadBatch::addMany(const ReadInput *const *in, size_t n, uint8_t *accepte
     readID.resize(k + taken); contig.resize(k + taken); cal_offset.resize(k + taken); cal_scale.resize(k + taken);
     ref_start.resize(k + taken); ref_end.resize(k + taken); is_reverse.resize(k + taken);
     adc.resize(a); basecall.resize(b); refseq.resize(r); ref2query.resize(r); ref2del.resize(r); query2ref.resize(q);     // ref2query / ref2del: one entry per reference base
-#pragma omp parallel for schedule(dynamic, 1) num_threads(hostThreads()) if (n > 1)
+    int bad_io = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(hostThreads()) reduction(| : bad_io) if (n > 1)
     for (long i = 0; i < (long)n; i++) {
         const Prepared &p = P[(size_t)i];
         if (!p.ok) continue;
@@ -177,13 +217,15 @@ size_t ReadBatch::addMany(const ReadInput *const *in, size_t n, uint8_t *accepte
         const size_t s_ = slot[(size_t)i];
         readID[s_] = x.readID; contig[s_] = x.contig; cal_offset[s_] = x.cal_offset; cal_scale[s_] = x.cal_scale;
         ref_start[s_] = x.refStart; ref_end[s_] = x.refStart + p.refLen; is_reverse[s_] = x.isReverse ? 1 : 0;
-        memcpy(adc.data() + o_adc[(size_t)i], x.adc + p.lo, (p.hi - p.lo) * sizeof(int16_t));
+        if (fd >= 0) { if (!preadAll(fd, adc.data() + o_adc[(size_t)i], (p.hi - p.lo) * sizeof(int16_t), adcFileOff[i] + p.lo * sizeof(int16_t))) bad_io = 1; }
+        else memcpy(adc.data() + o_adc[(size_t)i], x.adc + p.lo, (p.hi - p.lo) * sizeof(int16_t));
         memcpy(basecall.data() + o_bc[(size_t)i], p.bc.data(), p.bc.size());
         memcpy(refseq.data() + o_rs[(size_t)i], p.rs.data(), p.rs.size());
         memcpy(ref2query.data() + o_rs[(size_t)i], p.r2q.data(), p.r2q.size() * sizeof(uint32_t));
         memcpy(ref2del.data() + o_rs[(size_t)i], p.r2d.data(), p.r2d.size());
         memcpy(query2ref.data() + o_q2r[(size_t)i], p.q2r.data(), p.q2r.size() * sizeof(int32_t));               // queryLen + 1 entries
     }
+    if (ioFailed) *ioFailed = bad_io != 0;
     return taken;
 }
 
@@ -273,7 +315,7 @@ bool ReadContainerReader::skip(uint64_t *nSamples) {     // the next record's sa
     seen++;
     return true;
 }
-bool ReadContainerReader::next(OwnedRead &o) {
+bool ReadContainerReader::nextHeader(OwnedRead &o, uint64_t *adcFileOff) {
     FILE *fp = (FILE *)f; if (!fp || seen >= n) return false;
     ReadInput &in = o.in;
     uint8_t split = 0, rev = 0; int32_t sl = 0, st = 0, sc = 0, rs = 0; uint32_t nc = 0; uint64_t na = 0;
@@ -282,10 +324,23 @@ bool ReadContainerReader::next(OwnedRead &o) {
               getStr(fp, in.refSlice, 1u << 30) && get(fp, nc) && nc <= (1u << 28);
     if (ok) { in.cigarOp.resize(nc); in.cigarLen.resize(nc); ok = nc == 0 || (fread(in.cigarOp.data(), 4, nc, fp) == nc && fread(in.cigarLen.data(), 4, nc, fp) == nc); }
     ok = ok && get(fp, na) && na <= (1ull << 33);
-    if (ok) { o.adc.resize((size_t)na); ok = na == 0 || fread(o.adc.data(), 2, (size_t)na, fp) == na; }
     if (!ok) { bad = true; return false; }
     in.signalLength = sl; in.signalTrim = st; in.signalStartCoord = sc; in.isSplit = split != 0; in.isReverse = rev != 0; in.refStart = rs;
-    in.adc = o.adc.data(); in.n_adc = o.adc.size();
+    in.adc = nullptr; in.n_adc = (size_t)na;
+    if (adcFileOff) {                                        // the caller fetches the samples itself (pread): step over them
+        *adcFileOff = (uint64_t)ftello(fp);
+        if (fseeko(fp, (off_t)(na * 2), SEEK_CUR) != 0) { bad = true; return false; }
+        seen++;
+    }
+    return true;
+}
+bool ReadContainerReader::next(OwnedRead &o) {
+    if (!nextHeader(o, nullptr)) return false;
+    FILE *fp = (FILE *)f;
+    const size_t na = o.in.n_adc;
+    o.adc.resize(na);
+    if (na && fread(o.adc.data(), 2, na, fp) != na) { bad = true; return false; }
+    o.in.adc = o.adc.data();
     seen++;
     return true;
 }
@@ -416,20 +471,47 @@ void packCalls(const ReadBatch &batch, const dn_result_batch &res, std::vector<u
 }
 
 // the writer rank's half: reads in the order given (pointers into the gathered payloads), formatted in parallel, laid end to end
-void formatPacked(size_t n, const uint64_t *meta3 /* [n][3]: count, header bytes, flags */, const uint8_t *const *read_ptr, std::string &text,
+// Two passes, nothing intermediate: the first sizes every record exactly (a line is digits(coord) + the two "%f" fields + 13 bytes), the second
+// formats each record in its final place in ONE uninitialised buffer.  (Until round 4 every read went through a zero-filled 128-bytes-per-call
+// string of its own and was copied once more into a zero-filled std::string of the window's 400 MB: three passes over memory the formatter did
+// not need, on a host whose cgroup gives the process 16 CPUs.)  Returns false if a record did not come out at its computed size (cannot happen;
+// checked, because the offsets of every later record depend on it).
+static inline size_t prob_len(float pf) {
+    const double p = (double)pf;
+    if (!(p >= 0.0 && p <= 1.0) || signbit(p)) return (size_t)snprintf(nullptr, 0, "%f", p);
+    return 8;
+}
+static inline size_t u32_len(uint32_t v) {
+    return v < 10u ? 1 : v < 100u ? 2 : v < 1000u ? 3 : v < 10000u ? 4 : v < 100000u ? 5 : v < 1000000u ? 6 : v < 10000000u ? 7 : v < 100000000u ? 8 : v < 1000000000u ? 9 : 10;
+}
+bool formatPacked(size_t n, const uint64_t *meta3 /* [n][3]: count, header bytes, flags */, const uint8_t *const *read_ptr, RawVec<char> &text,
                   uint64_t *record_bytes /* [n] */) {
-    std::vector<std::string> rec(n);
+    std::vector<uint64_t> off(n + 1, 0);
 #pragma omp parallel for schedule(dynamic, 4) num_threads(hostThreads())
     for (long r = 0; r < (long)n; r++) {
         const uint64_t cnt = meta3[3 * r], hb = meta3[3 * r + 1], fl = meta3[3 * r + 2];
+        if (fl & DN_PACK_TEXT) { off[(size_t)r + 1] = cnt; continue; }
+        const uint8_t *p = read_ptr[r] + hb;
+        size_t len = (size_t)hb + (size_t)cnt * 13;
+        for (uint64_t i = 0; i < cnt; i++) {
+            uint32_t w[3]; float e, b;
+            memcpy(w, p + 16 * i, 12); memcpy(&e, &w[1], 4); memcpy(&b, &w[2], 4);
+            len += u32_len(w[0]) + prob_len(e) + prob_len(b);
+        }
+        off[(size_t)r + 1] = len;
+    }
+    for (size_t r = 0; r < n; r++) { if (record_bytes) record_bytes[r] = off[r + 1]; off[r + 1] += off[r]; }
+    text.resize(off[n] + 64);                                // + slack: put_prob's snprintf branch is given 48 bytes of room
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(hostThreads()) reduction(| : bad)
+    for (long r = 0; r < (long)n; r++) {
+        const uint64_t cnt = meta3[3 * r], hb = meta3[3 * r + 1], fl = meta3[3 * r + 2];
         const uint8_t *p = read_ptr[r];
-        std::string &out = rec[(size_t)r];
-        if (fl & DN_PACK_TEXT) { out.assign((const char *)p, (size_t)cnt); continue; }
+        char *o = text.data() + off[(size_t)r];
+        if (fl & DN_PACK_TEXT) { memcpy(o, p, (size_t)cnt); continue; }
         const bool rev = (fl & DN_PACK_REVERSE) != 0;
-        out.assign((const char *)p, (size_t)hb);
-        out.resize((size_t)hb + (size_t)cnt * 128);
-        char *o = &out[(size_t)hb];
-        p += hb;
+        memcpy(o, p, (size_t)hb);
+        o += hb; p += hb;
         for (uint64_t q = 0; q < cnt; q++) {
             const uint64_t i = rev ? cnt - 1 - q : q;
             uint32_t w[4]; float e, b;
@@ -438,13 +520,10 @@ void formatPacked(size_t n, const uint64_t *meta3 /* [n][3]: count, header bytes
             for (int z = 0; z < 9; z++) km[z] = "ACGTN???"[(w[3] >> (3 * z)) & 7u];
             o = put_call(o, w[0], e, b, km, rev);
         }
-        out.resize((size_t)(o - out.data()));
+        if ((uint64_t)(o - text.data()) != off[(size_t)r + 1]) bad = 1;
     }
-    std::vector<uint64_t> off(n + 1, 0);
-    for (size_t r = 0; r < n; r++) { off[r + 1] = off[r] + rec[r].size(); if (record_bytes) record_bytes[r] = rec[r].size(); }
     text.resize(off[n]);
-#pragma omp parallel for schedule(static) num_threads(hostThreads())
-    for (long r = 0; r < (long)n; r++) memcpy(&text[off[(size_t)r]], rec[(size_t)r].data(), rec[(size_t)r].size());
+    return !bad;
 }
 
 std::string formatDetectRecord(const std::string &readID, const std::string &contig, int refStart, int refEnd, bool isReverse,
@@ -541,8 +620,10 @@ int DetectStream::submit(ReadBatch *batch, uint64_t tag) {
     const dn_batch_desc d = batch->desc();
     int rc = dn_batch_upload(ctx[(size_t)slot], &d);
     if (rc) return rc;
-    S.seconds_upload += now_s() - a;
+    const double b = now_s();
+    S.seconds_upload += b - a;
     if ((rc = dn_run_detect(ctx[(size_t)slot]))) return rc;
+    S.seconds_run += now_s() - b;
     slot_batch[(size_t)slot] = batch; slot_tag[(size_t)slot] = tag;
     inflight++;
     return DN_OK;
@@ -865,27 +946,39 @@ int64_t dnh_container_load_at(void *b, const char *path, const uint64_t *offsets
     ReadBatch *B = (ReadBatch *)b;
     int64_t got = 0;
     bool io_bad = false;
-    const uint64_t chunk = 256;
+    const uint64_t chunk = 1024;
     const size_t first = B->size();
+    const int fd = ::open(path, O_RDONLY);
+    struct stat sb;
+    if (fd < 0 || fstat(fd, &sb) != 0) { if (fd >= 0) ::close(fd); return -1; }
     for (uint64_t c0 = 0; c0 < n && !io_bad; c0 += chunk) {
         const uint64_t m = std::min(chunk, n - c0);
+        // the records' headers (ids, sequences, CIGAR: ~0.1 MB per 50 kb read) by all host cores, one FILE per thread; the samples stay in the file ...
         std::vector<DNAscent::OwnedRead> rd((size_t)m);
+        std::vector<uint64_t> adc_at((size_t)m, 0);
         std::vector<uint8_t> ok((size_t)m, 0);
 #pragma omp parallel num_threads(DNAscent::hostThreads())
         {
             DNAscent::ReadContainerReader r;
             const bool open_ok = r.open(path);
 #pragma omp for schedule(dynamic, 4)
-            for (long j = 0; j < (long)m; j++) ok[(size_t)j] = open_ok && r.seek(offsets[c0 + (uint64_t)j]) && r.next(rd[(size_t)j]);
+            for (long j = 0; j < (long)m; j++)
+                ok[(size_t)j] = open_ok && r.seek(offsets[c0 + (uint64_t)j]) && r.nextHeader(rd[(size_t)j], &adc_at[(size_t)j]) &&
+                                adc_at[(size_t)j] + rd[(size_t)j].in.n_adc * 2 <= (uint64_t)sb.st_size;          // a truncated payload is an I/O error, found before anything is appended
         }
         for (uint64_t j = 0; j < m; j++) if (!ok[(size_t)j]) { io_bad = true; break; }
         if (io_bad) break;
+        // ... and go from the page cache straight to their place in the batch (addManyFromFile): a 500 x 50 kb batch was 0.23 s with an intermediate
+        // 1 MB vector per read (fresh pages + a second copy), and three loaders at once competed with the engine's own host threads (round 4)
         std::vector<const ReadInput *> ptr((size_t)m);
         std::vector<uint8_t> took((size_t)m, 0);
         for (uint64_t j = 0; j < m; j++) ptr[(size_t)j] = &rd[(size_t)j].in;
-        got += (int64_t)B->addMany(ptr.data(), (size_t)m, took.data());
+        bool pread_bad = false;
+        got += (int64_t)B->addManyFromFile(ptr.data(), (size_t)m, took.data(), fd, adc_at.data(), &pread_bad);
+        if (pread_bad) { ::close(fd); B->clear(); return -1; }   // the file changed under us / EIO: nothing of this batch can be trusted
         if (accepted) memcpy(accepted + c0, took.data(), (size_t)m);
     }
+    ::close(fd);
     if (io_bad) {                                            // all or nothing: a half-loaded batch would shift every later ordinal
         if (first == 0) B->clear();
         return -1;
@@ -932,9 +1025,9 @@ uint64_t dnh_pack_calls(void *batch, const dn_result_batch *res, void *result) {
 }
 // the writer rank's formatter: n reads in output order, read_ptr[i] = address of read i's payload; returns a text handle
 void *dnh_format_packed(uint64_t n, const uint64_t *meta3, const uint64_t *read_ptr, uint64_t *record_bytes) {
-    std::string *t = new std::string();
+    DNAscent::RawVec<char> *t = new DNAscent::RawVec<char>();
     static_assert(sizeof(uint64_t) == sizeof(const uint8_t *), "64-bit host");
-    DNAscent::formatPacked((size_t)n, meta3, (const uint8_t *const *)read_ptr, *t, record_bytes);
+    if (!DNAscent::formatPacked((size_t)n, meta3, (const uint8_t *const *)read_ptr, *t, record_bytes)) { delete t; return nullptr; }
     return t;
 }
 // n bytes to file descriptor fd at offset off, in pieces written by the host's threads at once (pwrite): a single write() of a window's 400 MB of text
@@ -955,10 +1048,11 @@ int dnh_pwrite_parallel(int fd, const void *buf, uint64_t n, uint64_t off) {
     }
     return bad ? -1 : 0;
 }
-const char *dnh_text_data(void *t) { return ((std::string *)t)->data(); }
-uint64_t dnh_text_size(void *t) { return ((std::string *)t)->size(); }
-void dnh_text_free(void *t) { delete (std::string *)t; }
+const char *dnh_text_data(void *t) { return ((DNAscent::RawVec<char> *)t)->data(); }
+uint64_t dnh_text_size(void *t) { return ((DNAscent::RawVec<char> *)t)->size(); }
+void dnh_text_free(void *t) { delete (DNAscent::RawVec<char> *)t; }
 void dnh_stream_stats(void *s, DNAscent::StreamStats *st) { *st = ((DNAscent::DetectStream *)s)->stats(); }
+int dnh_host_threads(void) { return DNAscent::hostThreads(); }                    // what the parallel loops of this library use (cgroup quota applied)
 int dnh_batch_pin(void *b) { return ((ReadBatch *)b)->pin(); }
 void dnh_batch_unpin(void *b) { ((ReadBatch *)b)->unpin(); }
 
@@ -1038,7 +1132,7 @@ static int synthReads(Sink &&sink, const double *model_mean, uint32_t n_reads, c
     for (uint32_t c0 = 0; c0 < n_reads; c0 += chunk) {
         const uint32_t m = std::min(chunk, n_reads - c0);
         std::vector<Gen> g(m);
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(DNAscent::hostThreads())
         for (long i = 0; i < (long)m; i++) {
             Gen &G = g[(size_t)i];
             const uint32_t n_bases = bases[c0 + i];

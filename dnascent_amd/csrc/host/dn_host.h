@@ -55,7 +55,7 @@ int parseCigar(const std::vector<uint32_t> &ops, const std::vector<uint32_t> &le
                std::vector<uint32_t> &ref2query, std::vector<int32_t> &query2ref, std::vector<uint8_t> &ref2del);
 
 std::string reverseComplement(const std::string &s);    // common.h:91
-int hostThreads();                                       // threads of the host-side parallel loops (DN_HOST_THREADS, default min(64, cores))
+int hostThreads();                                       // threads of the host-side parallel loops (DN_HOST_THREADS, default min(64, cores, the cgroup's CPU quota))
 
 class ReadBatch {
 public:
@@ -65,6 +65,10 @@ public:
     int add(const ReadInput &in);
     // n reads at once, their per-read preparation (CIGAR flattening, reverse complements, copies) on the host's threads; accepted[i] = 1 / 0
     size_t addMany(const ReadInput *const *in, size_t n, uint8_t *accepted);
+    // the same with the signals still IN A FILE: in[i]->adc is null, in[i]->n_adc the stored sample count, adcFileOff[i] the byte offset of
+    // the read's first stored sample in fd.  The accepted reads' slices are pread() straight to their place in the batch (no intermediate copy
+    // of a 1 MB signal per read).  *ioFailed is set when a pread came back short: the batch is then unusable (clear() it).
+    size_t addManyFromFile(const ReadInput *const *in, size_t n, uint8_t *accepted, int fd, const uint64_t *adcFileOff, bool *ioFailed);
     size_t size() const { return readID.size(); }
     dn_batch_desc desc() const;
     uint64_t totalSamples() const { return adc_off.empty() ? 0 : adc_off.back(); }
@@ -112,6 +116,7 @@ public:
     bool open(const std::string &path);                                    // false: missing file / bad magic / version
     uint64_t count() const { return n; }
     bool next(OwnedRead &out);                                             // false at the end or on a truncated record
+    bool nextHeader(OwnedRead &out, uint64_t *adcFileOff);                 // everything but the samples (out.in.adc = null, n_adc = their count), which are seeked over
     bool skip(uint64_t *nSamples);                                         // seek over the next record, reporting its sample count
     uint64_t tell() const;                                                 // file offset of the next record (for an index)
     bool seek(uint64_t offset);                                            // ... and back to it: next() then reads THAT record
@@ -158,7 +163,7 @@ void formatCalls(const ReadBatch &batch, const dn_result_batch &res, bool humanR
 // (DN_PACK_TEXT: count = text bytes, header bytes = 0).  formatPacked is the writer's half: same bytes as formatCalls' records.
 enum { DN_PACK_REVERSE = 1, DN_PACK_TEXT = 2 };
 void packCalls(const ReadBatch &batch, const dn_result_batch &res, std::vector<uint64_t> &meta /* [passing reads][4] */, RawVec<uint8_t> &payload);
-void formatPacked(size_t n, const uint64_t *meta3 /* [n][3]: count, header bytes, flags */, const uint8_t *const *read_ptr /* [n] */, std::string &text,
+bool formatPacked(size_t n, const uint64_t *meta3 /* [n][3]: count, header bytes, flags */, const uint8_t *const *read_ptr /* [n] */, RawVec<char> &text,
                   uint64_t *record_bytes /* [n] or null */);
 
 // The buffer-of-reads loop of detect.cpp:821-907 as a stream: batch i is uploaded to context i % n_ctx and its whole per-read
@@ -173,6 +178,7 @@ struct StreamKeep {                     // optional: the binary per-call results
 struct StreamStats {
     double seconds_total, seconds_upload, seconds_collect, seconds_emit;   // wall time of the call / spent inside uploads, collects, emission
     uint64_t reads, reads_ok, samples, calls, bytes_out, positions;        // positions: r.refCoordToAP entries of the passing reads (CNN rows)
+    double seconds_run;                                                    // spent enqueueing the per-read body (dn_run_detect): launches + whatever the queue makes them wait for
 };
 int streamDetect(dn_ctx **ctxs, int n_ctx, ReadBatch **batches, int n_batches, bool emit, const char *outPath, const char *header,
                  StreamStats *st, StreamKeep *keep = nullptr);

@@ -14,7 +14,7 @@ class StreamStats(C.Structure):
     """DNAscent::StreamStats"""
     _fields_ = [("seconds_total", C.c_double), ("seconds_upload", C.c_double), ("seconds_collect", C.c_double), ("seconds_emit", C.c_double),
                 ("reads", C.c_uint64), ("reads_ok", C.c_uint64), ("samples", C.c_uint64), ("calls", C.c_uint64), ("bytes_out", C.c_uint64),
-                ("positions", C.c_uint64)]
+                ("positions", C.c_uint64), ("seconds_run", C.c_double)]
 
 
 def lib():
@@ -402,6 +402,32 @@ class _TextOwner:
             pass
 
 
+def host_threads():
+    """threads of the library's parallel loops: min(64, cores, the cgroup CPU quota), or DN_HOST_THREADS"""
+    return int(lib().dnh_host_threads())
+
+
+def usable_cpus():
+    """CPUs this process can actually keep busy: the affinity mask, cut to the cgroup's CPU quota (cpu.max) when there is one.  The hosts of the GPU
+    pool show 256 hardware threads and grant 16 CPUs of quota: anything wider is frozen by the kernel for the rest of each 100 ms period."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def format_packed(meta3, read_ptr):
     """DNAscent::formatPacked: the writer rank's formatter.  meta3 uint64 [n][3] (count, header bytes, flags), read_ptr uint64 [n] (address
     of every read's payload, output order) -> (text of the n records laid end to end -- a memoryview of the C++ buffer, bytes when empty --,
@@ -412,6 +438,8 @@ def format_packed(meta3, read_ptr):
     if n == 0:
         return b"", rb[:0]
     t = C.c_void_p(lib().dnh_format_packed(n, m.ctypes.data, p.ctypes.data, rb.ctypes.data))
+    if not t:
+        raise _hip.DnError("dnh_format_packed: a record did not come out at its computed size")
     size = int(lib().dnh_text_size(t))
     if size == 0:
         lib().dnh_text_free(t)

@@ -46,7 +46,8 @@ os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 os.environ.setdefault("DN_CNN_ROWS", str(4 << 20))         # activation rows resident per CNN pass and lane (bench.py's setting: 2 Mi -6 %, 8 Mi -3 %)
 if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "DN_HOST_THREADS" not in os.environ:
     # N ranks share the host's cores: each rank's loader / packer / formatter loops take their share (dn_host.cpp hostThreads)
-    os.environ["DN_HOST_THREADS"] = str(max(4, min(64, (os.cpu_count() or 64) // int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"])))))
+    from dnascent_amd.host import usable_cpus as _usable                   # the cgroup's CPU quota, not the hardware threads in sight
+    os.environ["DN_HOST_THREADS"] = str(max(2, min(64, _usable() // int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"])))))
 
 
 def load_pore_model(path):
@@ -169,7 +170,7 @@ def main(argv=None):
     per_rank = shard.gather_stats(dist, dict(rank=rank, batches=drv.batches_done, busy_s=round(drv.busy_s, 3), gather_s=round(drv.gather_s, 3),
                                              format_s=round(drv.format_s - write_s[0], 3), write_s=round(write_s[0], 3), peak_buffered_bytes=int(drv.peak_pending_bytes),
                                              max_gather_bytes=int(drv.max_gather_bytes), reads_ok=drv.n_ok, reads_failed=drv.n_fail,
-                                             upload_s=round(st.seconds_upload, 3), collect_wait_s=round(st.seconds_collect, 3), load_wait_s=round(drv.load_wait_s, 3),
+                                             upload_s=round(st.seconds_upload, 3), enqueue_s=round(st.seconds_run, 3), collect_wait_s=round(st.seconds_collect, 3), load_wait_s=round(drv.load_wait_s, 3), load_s=round(drv.load_s, 3), driver_submit_s=round(drv.t_submit, 3), driver_collect_s=round(drv.t_collect, 3), driver_engine_collect_s=round(drv.t_engine_collect, 3), driver_hand_over_s=round(drv.t_hand_over, 3),
                                              pack_s=round(st.seconds_emit, 3)), device=dev_t)
     failed = tot[3] > 0
     if rank == 0:

@@ -470,7 +470,10 @@ class StreamDriver:
         self.peak_pending_bytes = max(self.peak_pending_bytes, self._pending_bytes)
 
     def _collect_one(self):
+        import time
+        t_c = time.perf_counter()
         r = self.engine.collect()
+        self.t_engine_collect += time.perf_counter() - t_c
         b = int(r["tag"]); w = int(self.window_of[b])
         ords = np.asarray(self._tag_ords.pop(b), np.int64)
         if "packed_meta" in r:
@@ -489,13 +492,17 @@ class StreamDriver:
         self.batches_done += 1
         if self.release:
             self.release(r["batch"])
+        self.t_collect += time.perf_counter() - t_c
 
     def _flush_ready(self, final=False):
         while self.flushed < self.n_windows and (final or self.flushed < self.frontier) and self.open.get(self.flushed, 0) == 0:
             w = self.flushed
             chunks = self.pending.pop(w, [])
             self._pending_bytes -= sum(int(c[2].shape[0]) for c in chunks)
+            import time
+            t_h = time.perf_counter()
             self._hand_over((w, [] if self.error else chunks, self.error))     # the gather thread builds the wire blob (or, alone, formats the chunks as they are)
+            self.t_hand_over += time.perf_counter() - t_h                      # > 0: the writer side (exchange, formatter, file) is what the stream waits for
             self.flushed += 1
 
     def _hand_over(self, item):
@@ -567,6 +574,18 @@ class StreamDriver:
         self._writer_error = False
         self._keys = None
         self.load_wait_s = 0.0
+        self.t_submit = self.t_collect = self.t_engine_collect = self.t_hand_over = 0.0      # where the driver thread's time went (run_detect --stats)
+        self.load_s = 0.0                                        # summed over the loader threads: what the loads cost, against load_wait_s = what the stream waited for them
+        load_lock = threading.Lock()
+        raw_load = self.load
+
+        def timed_load(ords):
+            t = time.perf_counter()
+            try:
+                return raw_load(ords)
+            finally:
+                with load_lock:
+                    self.load_s += time.perf_counter() - t
         if self.multi:
             from torch.distributed.distributed_c10d import _get_default_store
             self._keys = StoreKeys(_get_default_store(), self.run_key + "/dead")
@@ -591,7 +610,7 @@ class StreamDriver:
             self.frontier = max(self.frontier, w)                # every batch of an earlier window has been handed out
             if b in self.preloaded:                              # loaded during set-up (run_detect sizes its contexts from batch 0): not read twice
                 return b, _Done(self.preloaded.pop(b))
-            return b, (pool.submit(self.load, self.batches[b]) if pool else None)
+            return b, (pool.submit(timed_load, self.batches[b]) if pool else None)
 
         state = {"dry": False}
 
@@ -614,7 +633,7 @@ class StreamDriver:
                 ords = self.batches[b]
                 try:
                     t_l = time.perf_counter()
-                    obj, accepted = fut.result() if fut is not None else self.load(ords)
+                    obj, accepted = fut.result() if fut is not None else timed_load(ords)
                     self.load_wait_s += time.perf_counter() - t_l
                 except BaseException:
                     self.open[w] -= 1
@@ -634,7 +653,9 @@ class StreamDriver:
                     self._flush_ready()
                 self._tag_ords[b] = keep
                 try:
+                    t_s = time.perf_counter()
                     self.engine.submit(obj, b)
+                    self.t_submit += time.perf_counter() - t_s
                 except BaseException:
                     self.open[w] -= 1; self._tag_ords.pop(b, None)
                     raise

@@ -305,6 +305,8 @@ def test_packed_calls_format_like_text():
     coord = rng.integers(0, 2 ** 31, k).astype(np.uint32)
     pe = rng.random(k).astype(np.float32); pb = rng.random(k).astype(np.float32)
     pe[:4] = [0.0, 1.0, 0.9999995, 1e-7]
+    pe[4:10] = [np.nan, -0.0, 1.5, 1e30, -3.25, np.inf]                      # outside [0, 1]: "%f" of any width -- the formatter sizes every record before it writes it
+    pb[60:63] = [np.nan, 2.0 ** 100, -1e-9]; coord[:10] = [0, 9, 10, 99, 100, 999999, 1000000, 2 ** 31 - 1, 4294967295, 12345]
     km = rng.choice(list(b"ACGT"), (k, 9)).astype(np.uint8); km[:, 4] = ord("T")
     km[3, 0] = ord("N")                                                     # N packs
     km[int(off[4]) + 5, 7] = ord("R")                                       # an IUPAC code: read 4 must travel as text

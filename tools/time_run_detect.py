@@ -12,6 +12,7 @@ ap.add_argument("--dir", default="/tmp")
 ap.add_argument("--inflight", type=int, default=8)
 ap.add_argument("--stats", default=None)
 ap.add_argument("--keep", action="store_true")
+ap.add_argument("--reuse", action="store_true", help="do not rewrite the container if --dir already holds one (repeated timings in one session; implies --keep)")
 ap.add_argument("--ranks", type=int, default=1, help="> 1: under torch.distributed.run with the gloo backend, the ranks SHARING this GPU (what the 8-GPU node runs over RCCL, "
                                                      "exercised at full payload size; not a throughput figure)")
 ap.add_argument("--sha", action="store_true", help="print the SHA-256 of the .detect file (1- and N-rank runs must agree)")
@@ -19,8 +20,11 @@ a, extra = ap.parse_known_args()
 from dnascent_amd import host, synth
 cont = os.path.join(a.dir, "bench_reads.dnrc"); out = os.path.join(a.dir, "bench_reads.detect")
 t0 = time.time()
-n = host.write_synth_container(cont, synth.pore_model(), 1000003, a.reads, a.bases)
-print("container: %d reads, %.2f GB, written in %.1f s" % (n, os.path.getsize(cont) / 1e9, time.time() - t0), flush=True)
+if a.reuse and os.path.exists(cont) and host.container_count(cont) == a.reads:
+    print("container: reused (%d reads, %.2f GB)" % (a.reads, os.path.getsize(cont) / 1e9), flush=True)
+else:
+    n = host.write_synth_container(cont, synth.pore_model(), 1000003, a.reads, a.bases)
+    print("container: %d reads, %.2f GB, written in %.1f s" % (n, os.path.getsize(cont) / 1e9, time.time() - t0), flush=True)
 env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), DN_CNN_ROWS=str(4 << 20))
 tail = ["--container", cont, "--out", out, "--inflight", str(a.inflight)] + (["--stats", a.stats] if a.stats else []) + extra
 if a.ranks > 1:
@@ -42,8 +46,10 @@ if a.sha and os.path.exists(out):
         for blk in iter(lambda: f.read(1 << 24), b""):
             h.update(blk)
     print("sha256 %s  %d bytes  (%d rank(s))" % (h.hexdigest(), os.path.getsize(out), a.ranks))
-if not a.keep:
+if not a.keep and not a.reuse:
     for f in (cont, out):
         if os.path.exists(f):
             os.unlink(f)
+elif os.path.exists(out) and not a.keep:
+    os.unlink(out)
 sys.exit(r.returncode)
