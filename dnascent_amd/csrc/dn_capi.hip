@@ -1356,11 +1356,17 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned
     CnnLane *L = lane_get(c);
     if (!L) return fail(c, DN_ERR_HIP, "cannot create the CNN lane of device %d", c->device);
     std::lock_guard<std::mutex> lane_lock(L->mu);
+    // A pass of a streamed batch holds between (cap - the longest read) and cap rows: sized by what THIS batch needs, the lane's buffers were freed and
+    // reallocated every time a batch came a few rows closer to cap than any before it -- a hipFree (it waits for the whole device: every batch in flight
+    // drained) and a 16 GiB hipMalloc, 1.3-2.1 s each, nine times in the first seconds of bench.py --scope mixed (round 4, DN_TRACE_ENQUEUE).  A batch that
+    // fills a quarter of a pass gets the full pass allocated once; small calls (tests, dn_cnn_infer of a few reads) keep small buffers.
+    const uint64_t cap_rows = (cap + 255) / 256 * 256;
+    const uint64_t lane_rows = max_rows >= cap_rows / 4 ? std::max(max_rows, cap_rows) : max_rows;
     for (int b = 0; b < c->cnn_nbuf; b++)
-        if ((rc = lane_grow(c, L, L->buf[b], (size_t)max_rows * 256 * sizeof(float)))) return rc;
-    if ((rc = lane_grow(c, L, L->enclen, (size_t)max_rows)) || (rc = lane_grow(c, L, L->enchist, 64 * sizeof(unsigned))) ||
-        (rc = lane_grow(c, L, L->permsrc, (size_t)max_rows * sizeof(uint64_t))) || (rc = lane_grow(c, L, L->permrow, (size_t)max_rows * sizeof(unsigned))) ||
-        (rc = lane_grow(c, L, L->valid, (size_t)max_rows + 256)) || (rc = lane_grow(c, L, L->live, 256))) return rc;    // + 256: k3_sep_pair's 120-row tiles look up to 127 rows past the pass
+        if ((rc = lane_grow(c, L, L->buf[b], (size_t)lane_rows * 256 * sizeof(float)))) return rc;
+    if ((rc = lane_grow(c, L, L->enclen, (size_t)lane_rows)) || (rc = lane_grow(c, L, L->enchist, 64 * sizeof(unsigned))) ||
+        (rc = lane_grow(c, L, L->permsrc, (size_t)lane_rows * sizeof(uint64_t))) || (rc = lane_grow(c, L, L->permrow, (size_t)lane_rows * sizeof(unsigned))) ||
+        (rc = lane_grow(c, L, L->valid, (size_t)lane_rows + 256)) || (rc = lane_grow(c, L, L->live, 256))) return rc;    // + 256: k3_sep_pair's 120-row tiles look up to 127 rows past the pass
     if ((rc = dgrow(c, c->cnn_rowoff, n * sizeof(unsigned))) || (rc = dgrow(c, c->cnn_iooff, n * sizeof(uint64_t)))) return rc;
     if (!c->p_cnn_flag) HIPCHK(c, hipHostMalloc((void **)&c->p_cnn_flag, sizeof(unsigned), hipHostMallocDefault));
     // hand the batch over to the lane: everything the context's stream has enqueued so far (eventalign, the position counts)
@@ -1455,9 +1461,23 @@ int dn_run_cnn(dn_ctx *c) {
 
 int dn_run_detect(dn_ctx *c) {
     int rc;
+    static const bool trace = [] { const char *e = getenv("DN_TRACE_ENQUEUE"); return e && e[0] == '1'; }();   // which stage's ENQUEUE made the host wait (they should cost launches only)
+    if (!trace) {
+        if ((rc = dn_run_normalise(c))) return rc;
+        if ((rc = dn_run_eventalign(c))) return rc;
+        return dn_run_cnn(c);
+    }
+    auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
+    const double t0 = now();
     if ((rc = dn_run_normalise(c))) return rc;
+    const double t1 = now();
     if ((rc = dn_run_eventalign(c))) return rc;
-    return dn_run_cnn(c);
+    const double t2 = now();
+    rc = dn_run_cnn(c);
+    const double t3 = now();
+    if (t3 - t0 > 0.010) fprintf(stderr, "dn_run_detect: %d reads, max length %u: enqueue normalise %.1f ms, eventalign %.1f ms, cnn %.1f ms\n", c->B.n_reads, c->max_len,
+                                 (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3);
+    return rc;
 }
 
 int dn_cnn_infer(dn_ctx *c, uint32_t n_seq, const uint32_t *len, const float *core, const float *residual, const float *signal, float *probs) {
