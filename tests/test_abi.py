@@ -93,3 +93,25 @@ def test_struct_layouts_match_the_header(tmp_path):
     want = [hip.SUMMARY_DTYPE.fields[f][1] for f in fields_summary] + [getattr(hip.CnnOp, f).offset for f in fields_op] + \
            [getattr(hip.BatchDesc, f).offset for f in fields_batch]
     assert offs == want
+
+
+def test_host_threads_follow_the_cpus_the_process_may_use():
+    """hostThreads(): an explicit DN_HOST_THREADS is taken as it is; otherwise min(64, cores, cgroup CPU quota), and OMP_NUM_THREADS=1 -- what
+    torch.distributed.run exports to every worker -- does NOT reduce a rank's loader / formatter to one thread (round 4: it did).  Each case in its
+    own process (the value is read once)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def ask(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("DN_HOST_THREADS", "OMP_NUM_THREADS")}
+        e.update(env, PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", "from dnascent_amd import host; print(host.host_threads(), host.usable_cpus())"], env=e, capture_output=True,
+                             text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [int(x) for x in out.stdout.split()]
+    n, usable = ask()
+    assert 1 <= n <= 64 and n <= usable <= (os.cpu_count() or 1)
+    assert ask(OMP_NUM_THREADS="1")[0] == n                     # the launcher's default is not a request
+    assert ask(DN_HOST_THREADS="3", OMP_NUM_THREADS="1")[0] == 3
+    if n >= 2:
+        assert ask(OMP_NUM_THREADS="2")[0] == 2                 # an explicit team size is
