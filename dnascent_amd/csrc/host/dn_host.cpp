@@ -948,7 +948,7 @@ int64_t dnh_container_load_at(void *b, const char *path, const uint64_t *offsets
     bool io_bad = false;
     const uint64_t chunk = 1024;
     const size_t first = B->size();
-    const int fd = ::open(path, O_RDONLY);
+    const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
     struct stat sb;
     if (fd < 0 || fstat(fd, &sb) != 0) { if (fd >= 0) ::close(fd); return -1; }
     for (uint64_t c0 = 0; c0 < n && !io_bad; c0 += chunk) {
