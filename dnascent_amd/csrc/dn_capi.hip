@@ -380,11 +380,40 @@ int dn_device_count(void) {
 
 const char *dn_kernel_name(int k) { return (k >= 0 && k < DN_K_COUNT) ? KNAMES[k] : "?"; }
 
+// ---- front gate (experiment, DN_FRONT_DEPTH, default off): at most DEPTH batches of a device in their per-read stages at once ----
+struct FrontGate { hipEvent_t ev[64] = {}; uint64_t marked = 0; };
+static FrontGate g_front[64];
+static int front_depth() {
+    static const int d = [] { const char *e = getenv("DN_FRONT_DEPTH"); const int v = e ? atoi(e) : 0; return std::max(0, std::min(v, 32)); }();
+    return d;
+}
+static void front_wait(dn_ctx *c) {                      // before the first per-read kernel of a batch
+    const int depth = front_depth();
+    if (!depth || c->device < 0 || c->device >= 64) return;
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    FrontGate &g = g_front[c->device];
+    if (g.marked < (uint64_t)depth) return;
+    hipEvent_t e = g.ev[(g.marked - depth) % 64];
+    if (e) (void)hipStreamWaitEvent(c->stream, e, 0);
+}
+static void front_mark(dn_ctx *c) {                      // after the last per-read kernel (eventalign) of a batch has been enqueued
+    if (!front_depth() || c->device < 0 || c->device >= 64) return;
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    FrontGate &g = g_front[c->device];
+    hipEvent_t &e = g.ev[g.marked % 64];
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e = nullptr; return; }
+    if (hipEventRecord(e, c->stream) == hipSuccess) g.marked++;
+}
+static void front_free_device(int d) {                   // caller holds g_lane_mu
+    for (hipEvent_t &e : g_front[d].ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    g_front[d].marked = 0;
+}
+
 // one context less on its device; the last one frees the device's CNN lanes (round-2 advisor: lanes used to outlive every context)
 static void ctx_unregister(dn_ctx *c) {
     std::lock_guard<std::mutex> lk(g_lane_mu);
     if (c->device < 0 || c->device >= 64 || g_dev_ctx[c->device] == 0) return;
-    if (--g_dev_ctx[c->device] == 0) (void)lanes_free_device(c->device);
+    if (--g_dev_ctx[c->device] == 0) { (void)lanes_free_device(c->device); front_free_device(c->device); }
 }
 
 int dn_shutdown(void) {
@@ -548,8 +577,14 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     if (!c || !d) return DN_ERR_ARG;
     if (!c->have_model) return fail(c, DN_ERR_STATE, "dn_load_pore_model must be called first");
     HIPCHK(c, hipSetDevice(c->device));
+    static const bool up_trace = [] { const char *e = getenv("DN_TRACE_SUBMIT"); return e && e[0] == '1'; }();
+    auto up_now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
+    auto up_cpu = [] { timespec t; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
+    const double up_t0 = up_trace ? up_now() : 0.0, up_c0 = up_trace ? up_cpu() : 0.0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double up_t1 = up_trace ? up_now() : 0.0;
     prof_collect(c);
+    const double up_t2 = up_trace ? up_now() : 0.0;
     dfree_all(c);
     c->have_batch = false; c->stage = 0;
     // a batch that raised the fp16 range flag and was never collected must not leave it to the next one (round-2 advisor)
@@ -658,6 +693,7 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
         (rc = dalloc(c, &c->ea.resume, (size_t)n * 8))) return rc;
         return DN_OK;
     };
+    const double up_t3 = up_trace ? up_now() : 0.0;
     c->measuring = true; c->measured = 0;
     rc = place();
     c->measuring = false;
@@ -684,7 +720,10 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
         }
         (void)hipGetLastError();
         c->upload_pinned = pinned;
+        const double up_t4 = up_trace ? up_now() : 0.0;
         if (!c->upload_pinned) HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (up_trace) fprintf(stderr, "dn_batch_upload: first sync %.1f ms, profile events %.1f ms, host tables %.1f ms, copies issued %.1f ms, final sync %.1f ms; CPU time of this thread %.1f ms\n",
+                              (up_t1 - up_t0) * 1e3, (up_t2 - up_t1) * 1e3, (up_t3 - up_t2) * 1e3, (up_t4 - up_t3) * 1e3, (up_now() - up_t4) * 1e3, (up_cpu() - up_c0) * 1e3);
     }
     c->h_res.assign(n, ReadRes{});
     c->n_batch = n; c->async_err = 0;
@@ -1462,9 +1501,11 @@ int dn_run_cnn(dn_ctx *c) {
 int dn_run_detect(dn_ctx *c) {
     int rc;
     static const bool trace = [] { const char *e = getenv("DN_TRACE_ENQUEUE"); return e && e[0] == '1'; }();   // which stage's ENQUEUE made the host wait (they should cost launches only)
+    if (c->have_batch && c->B.n_reads) front_wait(c);
     if (!trace) {
         if ((rc = dn_run_normalise(c))) return rc;
         if ((rc = dn_run_eventalign(c))) return rc;
+        if (c->B.n_reads) front_mark(c);
         return dn_run_cnn(c);
     }
     auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
@@ -1472,6 +1513,7 @@ int dn_run_detect(dn_ctx *c) {
     if ((rc = dn_run_normalise(c))) return rc;
     const double t1 = now();
     if ((rc = dn_run_eventalign(c))) return rc;
+    if (c->B.n_reads) front_mark(c);
     const double t2 = now();
     rc = dn_run_cnn(c);
     const double t3 = now();

@@ -623,7 +623,10 @@ int DetectStream::submit(ReadBatch *batch, uint64_t tag) {
     const double b = now_s();
     S.seconds_upload += b - a;
     if ((rc = dn_run_detect(ctx[(size_t)slot]))) return rc;
-    S.seconds_run += now_s() - b;
+    const double e = now_s();
+    S.seconds_run += e - b;
+    static const bool trace = [] { const char *t = getenv("DN_TRACE_SUBMIT"); return t && t[0] == '1'; }();     // when each batch went in and what its upload cost the host thread
+    if (trace) fprintf(stderr, "submit tag %llu at %.3f s: upload %.1f ms, enqueue %.1f ms, %d in flight before it\n", (unsigned long long)tag, a - t_open, (b - a) * 1e3, (e - b) * 1e3, inflight);
     slot_batch[(size_t)slot] = batch; slot_tag[(size_t)slot] = tag;
     inflight++;
     return DN_OK;
