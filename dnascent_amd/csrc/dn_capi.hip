@@ -380,40 +380,11 @@ int dn_device_count(void) {
 
 const char *dn_kernel_name(int k) { return (k >= 0 && k < DN_K_COUNT) ? KNAMES[k] : "?"; }
 
-// ---- front gate (experiment, DN_FRONT_DEPTH, default off): at most DEPTH batches of a device in their per-read stages at once ----
-struct FrontGate { hipEvent_t ev[64] = {}; uint64_t marked = 0; };
-static FrontGate g_front[64];
-static int front_depth() {
-    static const int d = [] { const char *e = getenv("DN_FRONT_DEPTH"); const int v = e ? atoi(e) : 0; return std::max(0, std::min(v, 32)); }();
-    return d;
-}
-static void front_wait(dn_ctx *c) {                      // before the first per-read kernel of a batch
-    const int depth = front_depth();
-    if (!depth || c->device < 0 || c->device >= 64) return;
-    std::lock_guard<std::mutex> lk(g_lane_mu);
-    FrontGate &g = g_front[c->device];
-    if (g.marked < (uint64_t)depth) return;
-    hipEvent_t e = g.ev[(g.marked - depth) % 64];
-    if (e) (void)hipStreamWaitEvent(c->stream, e, 0);
-}
-static void front_mark(dn_ctx *c) {                      // after the last per-read kernel (eventalign) of a batch has been enqueued
-    if (!front_depth() || c->device < 0 || c->device >= 64) return;
-    std::lock_guard<std::mutex> lk(g_lane_mu);
-    FrontGate &g = g_front[c->device];
-    hipEvent_t &e = g.ev[g.marked % 64];
-    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e = nullptr; return; }
-    if (hipEventRecord(e, c->stream) == hipSuccess) g.marked++;
-}
-static void front_free_device(int d) {                   // caller holds g_lane_mu
-    for (hipEvent_t &e : g_front[d].ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-    g_front[d].marked = 0;
-}
-
 // one context less on its device; the last one frees the device's CNN lanes (round-2 advisor: lanes used to outlive every context)
 static void ctx_unregister(dn_ctx *c) {
     std::lock_guard<std::mutex> lk(g_lane_mu);
     if (c->device < 0 || c->device >= 64 || g_dev_ctx[c->device] == 0) return;
-    if (--g_dev_ctx[c->device] == 0) { (void)lanes_free_device(c->device); front_free_device(c->device); }
+    if (--g_dev_ctx[c->device] == 0) (void)lanes_free_device(c->device);
 }
 
 int dn_shutdown(void) {
@@ -1501,11 +1472,9 @@ int dn_run_cnn(dn_ctx *c) {
 int dn_run_detect(dn_ctx *c) {
     int rc;
     static const bool trace = [] { const char *e = getenv("DN_TRACE_ENQUEUE"); return e && e[0] == '1'; }();   // which stage's ENQUEUE made the host wait (they should cost launches only)
-    if (c->have_batch && c->B.n_reads) front_wait(c);
     if (!trace) {
         if ((rc = dn_run_normalise(c))) return rc;
         if ((rc = dn_run_eventalign(c))) return rc;
-        if (c->B.n_reads) front_mark(c);
         return dn_run_cnn(c);
     }
     auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
@@ -1513,7 +1482,6 @@ int dn_run_detect(dn_ctx *c) {
     if ((rc = dn_run_normalise(c))) return rc;
     const double t1 = now();
     if ((rc = dn_run_eventalign(c))) return rc;
-    if (c->B.n_reads) front_mark(c);
     const double t2 = now();
     rc = dn_run_cnn(c);
     const double t3 = now();
