@@ -481,77 +481,6 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][BN / 64], float *
     }
 }
 
-// (Round 4) the same epilogue with its stores THROUGH LDS: every 32 x 32 accumulator tile is written to a per-wavefront scratch in accumulator layout (lane =
-// column) and read back as 16-byte row pieces, so that a tile leaves as 4 x dwordx4 stores -- 8 rows x 128 bytes each -- instead of 16 x dword (2 rows x 128 bytes
-// each).  The CU's address unit takes a 64-lane store every ~16 clocks whatever its width: a 128 x 128 tile's 4 x 64 dword stores were a third of a k3_sep_split
-// tile under the tracer (profiles/r04_sep_split_phase_trace.txt).  Unlike round 3's swapped-operand form (lane = row: 32 bytes to each of 32 rows per
-// instruction, network 19.2 against 17.0 ms) every instruction here writes whole 128-byte row segments.  Same values, same bytes.  scr: PITCH floats per row,
-// 32 rows, private to the wavefront (LDS executes a wavefront's accesses in order: only the compiler has to be kept from reordering them).
-template <int BN, bool ADD, int PITCH>
-__device__ __forceinline__ void conv_epilogue_lds(f32x16 (&acc)[2][BN / 64], float *__restrict__ Y, const float *__restrict__ scale,
-                                                  const float *__restrict__ shift, const float *__restrict__ Add,
-                                                  const uint8_t *__restrict__ valid, int m0, int n0, int wm, int wn, int lane, int cout, int relu,
-                                                  float post, float *scr) {
-    constexpr int NJ = BN / 64;
-    const unsigned long long vmask = __ballot(valid[m0 + wm * 64 + lane] != 0);
-    const bool all_valid = vmask == ~0ull;                 // wave-uniform
-    const float floor_ = relu ? 0.0f : -3.402823466e38f;
-    const int colw = n0 + wn * (BN / 2);                   // the wavefront's first column
-    const int colb = colw + (lane & 31);
-    auto uniform_ptr = [](const void *p) {
-        const unsigned long long v = (unsigned long long)p;
-        return (void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
-    };
-    const size_t wbase = (size_t)(m0 + wm * 64) * cout;
-    const int wbytes = 64 * cout * 4;
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(Y + wbase), 0, wbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float *>(ADD ? Add + wbase : Y + wbase)), 0, wbytes, 0x00020000);
-    const int voff = (4 * (lane >> 5) * cout + colb) * 4;                       // accumulator layout (residual loads)
-    const int soff_w = ((lane >> 3) * cout + colw + (lane & 7) * 4) * 4;          // row-piece layout (stores): row lane >> 3 of a group of 8, 16-byte piece lane & 7
-    float *wr = scr + 4 * (lane >> 5) * PITCH + (lane & 31);
-    const float *rd = scr + (lane >> 3) * PITCH + (lane & 7) * 4;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned eu32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            const float sc = scale[colb + j * 32] * post, sh = shift[colb + j * 32];
-            float addv[16];
-            if (ADD) {
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int soff = __builtin_amdgcn_readfirstlane((i * 32 + (q & 3) + 8 * (q >> 2)) * cout * 4);
-                    addv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, voff + j * 128, soff, 0));
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 16; q += 2) {
-                const int row = i * 32 + (q & 3) + 8 * (q >> 2);
-                f32x2 y = __builtin_elementwise_fma(f32x2{acc[i][j][q], acc[i][j][q + 1]}, f32x2{sc, sc}, f32x2{sh, sh});
-                if (ADD) y += f32x2{addv[q], addv[q + 1]};
-                float y0 = fmaxf(y[0], floor_), y1 = fmaxf(y[1], floor_);
-                if (!all_valid) {
-                    const unsigned long long k0 = (((vmask >> row) & 1ull) ? 0x00000000ffffffffull : 0ull) | (((vmask >> (row + 4)) & 1ull) ? 0xffffffff00000000ull : 0ull);
-                    const unsigned long long k1 = (((vmask >> (row + 1)) & 1ull) ? 0x00000000ffffffffull : 0ull) | (((vmask >> (row + 5)) & 1ull) ? 0xffffffff00000000ull : 0ull);
-                    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(y0) : "v"(y0), "s"(k0));
-                    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(y1) : "v"(y1), "s"(k1));
-                }
-                wr[((q & 3) + 8 * (q >> 2)) * PITCH] = y0;
-                wr[((q & 3) + 8 * (q >> 2) + 1) * PITCH] = y1;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(rd + 8 * k * PITCH);
-                const int soff = __builtin_amdgcn_readfirstlane((i * 32 + 8 * k) * cout * 4);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(eu32x4, v), ry, soff_w + j * 128, soff, 0);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    }
-}
-
 // Workgroup numbering of the conv kernels (1-D grid): consecutive workgroup ids go round-robin to the 8 XCDs, each with its own
 // L2.  Id L runs on XCD L % 8; on one XCD consecutive ids walk the COLUMN tiles of one row tile before moving to the next row
 // tile, so the second (third, fourth) read of the same activation rows hits that XCD's L2 instead of HBM.
@@ -908,13 +837,6 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
     // were three of the 256-row form's spilled registers (it runs under a 128-register cap)
     int tid_e = (int)threadIdx.x;
     asm volatile("" : "+v"(tid_e));
-#ifndef CONV_EP_LDS
-#define CONV_EP_LDS 0                                      /* experiment: 1 = stores through LDS (conv_epilogue_lds), the dead A planes as scratch */
-#endif
-    if (CONV_EP_LDS) {                                      // every wavefront passed the step loop's last barrier: nobody reads the planes any more
-        float *scr = reinterpret_cast<float *>(&As[0][0]) + (tid_e >> 6) * (32 * 40);
-        conv_epilogue_lds<BN, ADD, 40>(acc, Y, scale, shift, Add, valid, m0, n0, tid_e >> 7, (tid_e >> 6) & 1, tid_e & 63, cout, relu, post, scr);
-    } else
     conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, m0, n0, tid_e >> 7, (tid_e >> 6) & 1, tid_e & 63, cout, relu, post);
 }
 
@@ -977,11 +899,6 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
     __shared__ __attribute__((aligned(16))) float Wl[KW * 32];
     __shared__ __attribute__((aligned(16))) uint16_t As[NP][CNN_BM * CNN_BP];
     __shared__ __attribute__((aligned(16))) uint16_t Bs[NP][BN * CNN_BP];
-#if defined(SEP_EP_LDS) && SEP_EP_LDS
-    __shared__ __attribute__((aligned(16))) float Ep[(BN == 128 && NP == 2) ? 4 * 32 * 32 : 4];
-#else
-    float *Ep = nullptr;
-#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // PERSISTENT where the layer has one column tile (cout == BN: every layer that takes this kernel by default): the grid is two
@@ -1168,11 +1085,7 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
                 SP_T(7 + 6 * cb);
             }
         }
-#ifndef SEP_EP_LDS
-#define SEP_EP_LDS 0                                      /* experiment: 1 = the 128-column form's stores through 16 KB of extra LDS (two workgroups per CU still fit) */
-#endif
-        if (SEP_EP_LDS && BN == 128 && NP == 2) conv_epilogue_lds<BN, ADD, 32>(acc, Y, scale, shift, Add, valid, tile_m0(it), n0, wm, wn, lane, cout, relu, post, Ep + wave * (32 * 32));
-        else conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, tile_m0(it), n0, wm, wn, lane, cout, relu, post);
+        conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, tile_m0(it), n0, wm, wn, lane, cout, relu, post);
         SP_T(40);
     }
     if (NP == 2) range_report(amax, range_flag, lane);
@@ -1447,207 +1360,6 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// k3_sep_uni (round 4): the 17-tap 256-column separable layer with UNIFORM roles -- every wavefront filters AND multiplies, and the two
-// instruction streams are interleaved INSIDE each wavefront.  What the round-3 micro-benchmarks say about this SIMD:
-//   * a vector instruction of ANOTHER wavefront beside a dense MFMA stream issues every ~46 ticks (k3_sep_ws's producers: ~260 instructions
-//     per step take 3.0-3.4 k ticks beside the consumers' MFMAs, 1.75 k alone);
-//   * from the SAME wavefront, six plain v_fma_f32 / v_cvt and three or four LDS reads ride for free in an MFMA's 32-cycle slot
-//     (tools/ubench_inwave.hip: 36 cycles per {MFMA + 6 v_fma_f32}, 45 with 8, 52 with 10; a v_pk_fma_f32 costs 17).
-// So: 8 wavefronts, each owns a 64 x 64 tile of the 128 x 256 output (24 MFMAs per 32-channel step) and filters 16 rows x 32 channels of
-// the NEXT step between them -- lane = (channel, group of 8 rows): 24 input rows and 17 taps as 4-byte LDS reads, 136 plain fmaf (taps in
-// ascending order per output: bit-identical to k3_dwconv and to k3_sep_ws's packed form), split into the two fp16 planes.  The step is
-// written as 24 SLOTS -- one MFMA, six or seven filter instructions, now and then an LDS access -- pinned with sched_barrier (left to the
-// scheduler, also with sched_group_barrier, the MFMAs bunch at the top of the block and the filter trails behind them).  The output rows'
-// chains are run in two halves (rows 0-3, then 4-7) so that the first half's split and plane stores sit under the second half's MFMAs.
-// Raw rows travel global -> registers (two sets in flight, stored two steps after their loads) -> the wavefront's PRIVATE 32-row slice of
-// LDS and are read back into registers before the step's barrier (the slice is private: no barrier between its store and its reads);
-// weight fragments come straight from L2, one k16 half ahead; planes and taps are double-buffered: ONE barrier per step.  Persistent
-// workgroups (one per CU) run their tiles' channel blocks as one stream of steps; the epilogue of a tile is the shared conv_epilogue.
-// Same sums in the same order as k3_sep_ws: results are bit-identical (tools/variant_check.py).
-// ---------------------------------------------------------------------------------------------------------
-#define UNI_SROWS 32                                       // raw rows a wavefront's 16 output rows need (16 + 17 - 1)
-// the filter's 136 FMAs in issue order: output rows 0-3 (input rows 0 .. 19), then 4-7 (input rows 4 .. 23); within an output row the taps ascend
-struct UniFma { int j, i; };
-static constexpr UniFma uni_fma(int p) {
-    int q = 0;
-    for (int h = 0; h < 2; h++)
-        for (int j = 4 * h; j < 4 * h + 20; j++)
-            for (int i = 4 * h; i < 4 * h + 4; i++) {
-                const int t = j - i;
-                if (t >= 0 && t < 17) { if (q == p) return UniFma{j, i}; q++; }
-            }
-    return UniFma{-1, -1};
-}
-template <int P0, int P1> __device__ __forceinline__ void uni_fmas(const float (&x)[24], const float (&w)[17], float (&o)[8]) {
-    if constexpr (P0 < P1 && P0 < 136) {
-        constexpr UniFma f = uni_fma(P0);
-        o[f.i] = __builtin_fmaf(x[f.j], w[f.j - f.i], o[f.i]);
-        uni_fmas<P0 + 1, P1>(x, w, o);
-    }
-}
-template <bool ADD>
-__global__ __launch_bounds__(512) void k3_sep_uni(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ Wd,
-                                                  const uint16_t *__restrict__ Wb, const float *__restrict__ scale,
-                                                  const float *__restrict__ shift, const float *__restrict__ Add,
-                                                  const uint8_t *__restrict__ valid, int rows, const int *__restrict__ live, int cin, int cout, int relu, float post,
-                                                  unsigned *range_flag) {
-    rows = min(rows, *live);
-    constexpr int KW = 17, NP = 2, half = 8, NLD = 4;      // float4 loads per lane for one raw slice (32 rows x 8)
-    __shared__ __attribute__((aligned(16))) float Xr[8][UNI_SROWS * SEP_XPW];
-    __shared__ __attribute__((aligned(16))) float Wl[2][KW * 32];
-    __shared__ __attribute__((aligned(16))) uint16_t As[2][NP][CNN_BM * CNN_BP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntiles = (rows + CNN_BM - 1) / CNN_BM;
-    const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-    if (my_tiles == 0) return;
-    const int cblocks = cin >> 5;
-    auto tile_m0 = [&](int it) { return ((int)blockIdx.x + it * (int)gridDim.x) * CNN_BM; };
-    const int wm = wave >> 2, wn = wave & 3;               // GEMM role: rows 64 wm .., columns 64 wn ..
-    const int fch = lane & 31, frg = lane >> 5;            // filter role: channel fch, output rows 16 wave + 8 frg .. + 7
-    struct RawSet { f32x4 rx[NLD]; bool pin[NLD]; f32x4 rw; bool edge; };
-    RawSet S0, S1;
-    S0.rw = f32x4{0.f, 0.f, 0.f, 0.f}; S1.rw = S0.rw;
-    float amax = 0.0f;
-    float *Xs = Xr[wave];
-    int ld_cb = 0, ld_it = 0;
-    auto uniform_ptr = [](const void *p) {
-        const unsigned long long v = (unsigned long long)p;
-        return (void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
-    };
-    int xoff[NLD];
-#pragma unroll
-    for (int p = 0; p < NLD; p++) { const int f = lane + 64 * p; xoff[p] = ((f >> 3) * cin + (f & 7) * 4) * 4; }
-    const int woff = ((tid >> 3) * cin + (tid & 7) * 4) * 4;
-    const __amdgpu_buffer_rsrc_t rtap = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float *>(Wd)), 0, KW * cin * 4, 0x00020000);
-    auto gloadX = [&](RawSet &S) {                          // the raw slice (and the taps) of the load stream's next step
-        const int cb = ld_cb, m0 = tile_m0(ld_it);
-        if (ld_cb + 1 < cblocks) ld_cb++; else if (ld_it + 1 < my_tiles) { ld_cb = 0; ld_it++; }
-        S.edge = m0 - half < 0 || m0 + CNN_BM + half > rows;
-        if (S.edge) {
-#pragma unroll
-            for (int p = 0; p < NLD; p++) {
-                const int f = lane + 64 * p, rr = f >> 3, q = f & 7;
-                const int src = m0 + 16 * wave - half + rr;
-                const bool in = src >= 0 && src < rows;
-                S.rx[p] = *reinterpret_cast<const f32x4 *>(X + (size_t)(in ? src : m0) * cin + (cb << 5) + q * 4);
-                S.pin[p] = in;
-            }
-        } else {
-            const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float *>(X + (size_t)(m0 + 16 * wave - half) * cin)), 0, UNI_SROWS * cin * 4, 0x00020000);
-#pragma unroll
-            for (int p = 0; p < NLD; p++) S.rx[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsl, xoff[p], cb << 7, 0));
-        }
-        if (tid < 192) S.rw = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rtap, woff, cb << 7, 0));   // wavefronts 0-2: the 17 x 8 float4 of a block's taps (lanes past them read zeros)
-    };
-    auto lstoreX = [&](RawSet &S, int wbuf) {
-        if (S.edge) {
-#pragma unroll
-            for (int p = 0; p < NLD; p++) S.rx[p] = S.pin[p] ? S.rx[p] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int p = 0; p < NLD; p++) {
-            const int f = lane + 64 * p, rr = f >> 3, q = f & 7;
-            *reinterpret_cast<f32x4 *>(&Xs[rr * SEP_XPW + q * 4]) = S.rx[p];
-        }
-        if (tid < KW * 8) *reinterpret_cast<f32x4 *>(&Wl[wbuf][(tid >> 3) * 32 + (tid & 7) * 4]) = S.rw;
-    };
-    float x[24], w[KW], o[8];
-    auto readX = [&]() {                                    // this lane's 24 input rows of the slice (private to the wavefront: no barrier needed after lstoreX)
-#pragma unroll
-        for (int j = 0; j < 24; j++) x[j] = Xs[(8 * frg + j) * SEP_XPW + fch];
-    };
-    auto readW = [&](int wbuf) {
-#pragma unroll
-        for (int t = 0; t < KW; t++) w[t] = Wl[wbuf][t * 32 + fch];
-    };
-    auto splitOut = [&](int abuf, int i) {                  // output row i of the lane: the two fp16 pieces into the planes
-        const int off = (16 * wave + 8 * frg + i) * CNN_BP + fch;
-        amax = __builtin_fmaxf(amax, __builtin_fabsf(o[i]));
-        const _Float16 h = (_Float16)o[i];
-        const _Float16 l = (_Float16)(o[i] - (float)h);
-        *reinterpret_cast<_Float16 *>(&As[abuf][0][off]) = h; *reinterpret_cast<_Float16 *>(&As[abuf][1][off]) = l;
-    };
-    // GEMM role
-    constexpr int NJ = 2;
-    f32x16 acc[2][NJ];
-    const int fm = lane & 31, fk = (lane >> 5) * 8;
-    const uint16_t *wlane = Wb + ((size_t)(wn * 64 + fm)) * 32 + fk;
-    auto loadB = [&](u32x4 (&b)[NJ][NP], int step2) {     // step2 = 2 * step + k16
-        const int cb = (step2 >> 1) % cblocks, k16 = step2 & 1;
-#pragma unroll
-        for (int pc = 0; pc < NP; pc++)
-#pragma unroll
-            for (int j = 0; j < NJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(wlane + ((size_t)(cb * NP + pc) * cout + j * 32) * 32 + k16 * 16);
-    };
-    auto loadA = [&](u32x4 (&a)[2][NP], int cur, int k16) {
-#pragma unroll
-        for (int pc = 0; pc < NP; pc++)
-#pragma unroll
-            for (int i = 0; i < 2; i++) a[i][pc] = *reinterpret_cast<const u32x4 *>(&As[cur][pc][(wm * 64 + i * 32 + fm) * CNN_BP + k16 * 16 + fk]);
-    };
-    u32x4 b0[NJ][NP], b1[NJ][NP], a0[2][NP], a1[2][NP];
-    // prologue: raw slices of steps 0 (stored at once), 1, 2 requested; the planes of step 0 filtered without any MFMA beside them
-    gloadX(S0); lstoreX(S0, 0); gloadX(S0); gloadX(S1);
-    loadB(b0, 0);
-    __syncthreads();
-    readX(); readW(0);
-#pragma unroll
-    for (int i = 0; i < 8; i++) o[i] = 0.0f;
-    uni_fmas<0, 136>(x, w, o);
-#pragma unroll
-    for (int i = 0; i < 8; i++) splitOut(0, i);
-    lstoreX(S0, 1); readX(); gloadX(S0);
-    __syncthreads();
-    // step g (channel block cb of tile it): multiply planes[g & 1] and filter step g + 1 into planes[(g + 1) & 1] in 24 slots; then store the raw slice of
-    // step g + 2 (set S1 for even g, S0 for odd g), read it back into x[], request step g + 4's into that set.  The workgroup's last step filters a repeat
-    // of itself into planes nobody reads any more (the load stream stays on the last step): no branch inside the slots.
-    constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
-#ifndef UNI_ABL
-#define UNI_ABL 0                                          /* experiment builds (timing only, wrong results): 1 = no filter FMAs, 2 = no MFMAs, 3 = neither */
-#endif
-#define UNI_MFMA(M, A, B) do { constexpr int r_ = (M) % 12, t_ = r_ / 4, i_ = (r_ % 4) / 2, j_ = r_ % 2; \
-        if (!(UNI_ABL & 2)) acc[i_][j_] = mfma16<NP>(A[i_][PA2[t_]], B[j_][PB2[t_]], acc[i_][j_]); } while (0)
-#define UNI_SLOT(M, A, B, P0, P1, EXTRA) do { UNI_MFMA(M, A, B); if (!(UNI_ABL & 1)) uni_fmas<P0, P1>(x, w, o); EXTRA; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define UNI_STEP(CUR, SET, G)                                                                                                            \
-    do {                                                                                                                                  \
-        readW((CUR) ^ 1); loadA(a0, CUR, 0); loadB(b1, 2 * (G) + 1);                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 8; i++) o[i] = 0.0f;                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                                                \
-        UNI_SLOT(0, a0, b0, 0, 7, (void)0);      UNI_SLOT(1, a0, b0, 7, 14, (void)0);    UNI_SLOT(2, a0, b0, 14, 21, (void)0);            \
-        UNI_SLOT(3, a0, b0, 21, 28, (void)0);    UNI_SLOT(4, a0, b0, 28, 35, loadA(a1, CUR, 1));                                          \
-        UNI_SLOT(5, a0, b0, 35, 42, (void)0);    UNI_SLOT(6, a0, b0, 42, 49, (void)0);   UNI_SLOT(7, a0, b0, 49, 56, (void)0);            \
-        UNI_SLOT(8, a0, b0, 56, 62, (void)0);    UNI_SLOT(9, a0, b0, 62, 68, (void)0);   UNI_SLOT(10, a0, b0, 68, 73, splitOut((CUR) ^ 1, 0)); \
-        UNI_SLOT(11, a0, b0, 73, 78, splitOut((CUR) ^ 1, 1));                                                                             \
-        loadB(b0, 2 * (G) + 2);                                                                                                           \
-        UNI_SLOT(12, a1, b1, 78, 83, splitOut((CUR) ^ 1, 2));  UNI_SLOT(13, a1, b1, 83, 88, splitOut((CUR) ^ 1, 3));                      \
-        UNI_SLOT(14, a1, b1, 88, 95, (void)0);   UNI_SLOT(15, a1, b1, 95, 102, (void)0);  UNI_SLOT(16, a1, b1, 102, 109, (void)0);        \
-        UNI_SLOT(17, a1, b1, 109, 116, (void)0); UNI_SLOT(18, a1, b1, 116, 123, (void)0); UNI_SLOT(19, a1, b1, 123, 130, (void)0);        \
-        UNI_SLOT(20, a1, b1, 130, 136, (void)0); UNI_SLOT(21, a1, b1, 136, 136, splitOut((CUR) ^ 1, 4); splitOut((CUR) ^ 1, 5));          \
-        UNI_SLOT(22, a1, b1, 136, 136, splitOut((CUR) ^ 1, 6)); UNI_SLOT(23, a1, b1, 136, 136, splitOut((CUR) ^ 1, 7));                   \
-        lstoreX(SET, CUR); readX(); gloadX(SET);                                                                                          \
-        __syncthreads();                                                                                                                  \
-    } while (0)
-    for (int it = 0; it < my_tiles; it++) {
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < NJ; j++)
-#pragma unroll
-                for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
-        for (int cb = 0; cb < cblocks; cb += 2) {          // cblocks is even: a step's parity is its channel block's
-            const int g = it * cblocks + cb;
-            UNI_STEP(0, S1, g);
-            UNI_STEP(1, S0, g + 1);
-        }
-        conv_epilogue<128, ADD>(acc, Y, scale, shift, Add, valid, tile_m0(it), (wn >> 1) * 128, wm, wn & 1, lane, cout, relu, post);
-    }
-#undef UNI_STEP
-#undef UNI_SLOT
-#undef UNI_MFMA
-    range_report(amax, range_flag, lane);
-}
-
 // (Round 3: k3_sep_ts -- the same layer TIME-SLICED instead of wave-specialised: all eight wavefronts filter 128 input channels (rows straight
 // from global memory into registers, taps in LDS, no MFMA in flight so the vector pipe runs at its full rate), then all eight multiply, four
 // barriers per tile -- is in tools/k3_sep_ts_experiment.hip with its phase traces: bit-identical, 4 018 us against 3 810 for the five
@@ -1789,7 +1501,6 @@ static unsigned k3_sep_wgs(int bn, int np = 2) {                       // persis
 }
 // the GRU products on the matrix cores whenever the convolutions are (split modes); DN_CNN_ENC_MFMA=0: the vector-unit encoder everywhere
 static bool k3_encode_mfma_enabled(const CnnRun &c) { static const bool on = !(getenv("DN_CNN_ENC_MFMA") && atoi(getenv("DN_CNN_ENC_MFMA")) == 0); return on && c.wts_split != nullptr; }
-static bool k3_sep_uni_enabled() { static const bool on = getenv("DN_CNN_SEP_UNI") && atoi(getenv("DN_CNN_SEP_UNI")) != 0; return on; }
 static bool k3_sep_ws_enabled() { static const bool on = !(getenv("DN_CNN_SEP_WS") && atoi(getenv("DN_CNN_SEP_WS")) == 0); return on; }
 static bool k3_bm256_enabled() { static const bool on = !(getenv("DN_CNN_BM256") && atoi(getenv("DN_CNN_BM256")) == 0); return on; }
 static bool k3_fuse_enabled() { static const bool on = !(getenv("DN_CNN_FUSE") && atoi(getenv("DN_CNN_FUSE")) == 0); return on; }
@@ -1831,10 +1542,6 @@ static int k3_launch_sep(const CnnRun &c, int i, const float *in, float *out, co
 #define SEP_ARGS in, out, c.wts + d.w, c.wts_split + c.wb_off[i + 1], c.wts + o.scale, c.wts + o.shift, add, c.valid, (int)rows, c.live, \
         o.cin, o.cout, o.relu, c.post[i + 1], c.range_flag + 2 + 2 * i
 #define SEP_GO(KW_) hipLaunchKernelGGL((k3_sep_split<BN, KW_, ADD, NP>), dim3(o.cout == BN ? min(conv_grid(rows, o.cout, BN), k3_sep_wgs(BN, NP)) : conv_grid(rows, o.cout, BN)), dim3(256), 0, st, SEP_ARGS)
-    if (k3_takes_ws(NP, d, o) && k3_sep_uni_enabled()) {
-        hipLaunchKernelGGL((k3_sep_uni<ADD>), dim3(min(conv_grid(rows, o.cout, 256), k3_cu_count())), dim3(512), 0, st, SEP_ARGS);
-        return 0;
-    }
     if (k3_takes_ws(NP, d, o)) {                            // BN == cout: one column tile
         hipLaunchKernelGGL((k3_sep_ws<256, 17, ADD, 2>), dim3(min(conv_grid(rows, o.cout, 256), k3_cu_count())), dim3(512), 0, st, SEP_ARGS);
         return 0;
@@ -1959,8 +1666,7 @@ int k3_describe(const CnnRun &c, int i, char *buf, size_t cap) {
     if (k3_can_fuse(c, i)) {
         const dn_cnn_op &pw = c.ops[i + 1];
         const char *add = pw.op == DN_CNN_CONV_ADD ? "true" : "false";
-        if (k3_takes_ws(np, o, pw) && k3_sep_uni_enabled()) snprintf(buf, cap, "k3_sep_uni<%s>", add);
-        else if (k3_takes_ws(np, o, pw)) snprintf(buf, cap, "k3_sep_ws<256, 17, %s, 2>", add);
+        if (k3_takes_ws(np, o, pw)) snprintf(buf, cap, "k3_sep_ws<256, 17, %s, 2>", add);
         else snprintf(buf, cap, "k3_sep_split<%d, %d, %s, %d>", pw.cout % 128 == 0 ? 128 : 64, o.k, add, np);
         return 1;
     }
