@@ -481,6 +481,14 @@ def main():
             def op_cost(i):
                 """algorithmic (flops, HBM bytes) per position of op i (fp32 activations in and out, + the residual read)"""
                 o = ops[i]
+                name_i = lay.get(i, [0, 0, ""])[2]
+                if name_i.startswith("k3_block64"):        # one launch = a whole residual block (13 ops), or its six separable layers (12): the work of all of them, the
+                    span = 13 if "true" in name_i else 12  # bytes of ONE pass over the activations (block input in, block output out; + the shortcut's second read of the input)
+                    fl = 0.0
+                    for j in range(i, i + span):
+                        q = ops[j]
+                        fl += 2.0 * (q["k"] * q["c"] if q["op"] == "dwconv" else q["k"] * q["cin"] * q["cout"])
+                    return fl, 4.0 * (64 + 64 + (64 if span == 13 else 0))
                 if o["op"] == "dwconv" and i + 1 < len(ops) and lay.get(i, [0, 0, ""])[2].startswith("k3_sep"):
                     p = ops[i + 1]
                     return 2.0 * (o["k"] * o["c"] + p["cin"] * p["cout"]), 4.0 * (p["cin"] + p["cout"] + (p["cout"] if p.get("add", -1) >= 0 else 0))

@@ -484,13 +484,13 @@ static inline size_t prob_len(float pf) {
 static inline size_t u32_len(uint32_t v) {
     return v < 10u ? 1 : v < 100u ? 2 : v < 1000u ? 3 : v < 10000u ? 4 : v < 100000u ? 5 : v < 1000000u ? 6 : v < 10000000u ? 7 : v < 100000000u ? 8 : v < 1000000000u ? 9 : 10;
 }
-bool formatPacked(size_t n, const uint64_t *meta3 /* [n][3]: count, header bytes, flags */, const uint8_t *const *read_ptr, RawVec<char> &text,
-                  uint64_t *record_bytes /* [n] */) {
-    std::vector<uint64_t> off(n + 1, 0);
+// the first pass on its own: the exact text length of every packed read (what a rank announces before anybody formats: with the lengths of a window's
+// reads every rank knows the file offset of each of its records -- round 5, the per-rank formatter of run_detect)
+void packedSizes(size_t n, const uint64_t *meta3, const uint8_t *const *read_ptr, uint64_t *record_bytes /* [n] */) {
 #pragma omp parallel for schedule(dynamic, 4) num_threads(hostThreads())
     for (long r = 0; r < (long)n; r++) {
         const uint64_t cnt = meta3[3 * r], hb = meta3[3 * r + 1], fl = meta3[3 * r + 2];
-        if (fl & DN_PACK_TEXT) { off[(size_t)r + 1] = cnt; continue; }
+        if (fl & DN_PACK_TEXT) { record_bytes[r] = cnt; continue; }
         const uint8_t *p = read_ptr[r] + hb;
         size_t len = (size_t)hb + (size_t)cnt * 13;
         for (uint64_t i = 0; i < cnt; i++) {
@@ -498,8 +498,13 @@ bool formatPacked(size_t n, const uint64_t *meta3 /* [n][3]: count, header bytes
             memcpy(w, p + 16 * i, 12); memcpy(&e, &w[1], 4); memcpy(&b, &w[2], 4);
             len += u32_len(w[0]) + prob_len(e) + prob_len(b);
         }
-        off[(size_t)r + 1] = len;
+        record_bytes[r] = len;
     }
+}
+bool formatPacked(size_t n, const uint64_t *meta3 /* [n][3]: count, header bytes, flags */, const uint8_t *const *read_ptr, RawVec<char> &text,
+                  uint64_t *record_bytes /* [n] */) {
+    std::vector<uint64_t> off(n + 1, 0);
+    packedSizes(n, meta3, read_ptr, off.data() + 1);
     for (size_t r = 0; r < n; r++) { if (record_bytes) record_bytes[r] = off[r + 1]; off[r + 1] += off[r]; }
     text.resize(off[n] + 64);                                // + slack: put_prob's snprintf branch is given 48 bytes of room
     int bad = 0;
@@ -1047,6 +1052,38 @@ int dnh_pwrite_parallel(int fd, const void *buf, uint64_t n, uint64_t off) {
             const ssize_t w = pwrite(fd, p, (size_t)left, (off_t)(off + a));
             if (w <= 0) { bad = 1; break; }
             p += w; a += (uint64_t)w; left -= (uint64_t)w;
+        }
+    }
+    return bad ? -1 : 0;
+}
+// the exact text length of n packed reads (DNAscent::packedSizes)
+void dnh_packed_sizes(uint64_t n, const uint64_t *meta3, const uint64_t *read_ptr, uint64_t *record_bytes) {
+    DNAscent::packedSizes((size_t)n, meta3, (const uint8_t *const *)read_ptr, record_bytes);
+}
+// n pieces of one buffer to their own places in the file: piece i = len[i] bytes at buf + src_off[i] -> file offset file_off[i] (pwrite, the host's threads at
+// once, pieces of more than 8 MB cut up).  What every rank of run_detect does with the records it formatted itself: they interleave with the other ranks'
+// records in input order, so a rank's text is contiguous in memory but not in the file.  Returns 0, or -1 on a short / failed write.
+int dnh_pwrite_scatter(int fd, const void *buf, uint64_t n, const uint64_t *src_off, const uint64_t *len, const uint64_t *file_off) {
+    const uint64_t piece = 8ull << 20;
+    struct Job { uint64_t src, dst, len; };
+    std::vector<Job> jobs;
+    for (uint64_t i = 0; i < n; i++) {
+        // neighbours in memory that are neighbours in the file too go out as one piece
+        if (!jobs.empty() && jobs.back().src + jobs.back().len == src_off[i] && jobs.back().dst + jobs.back().len == file_off[i] && jobs.back().len + len[i] <= piece) {
+            jobs.back().len += len[i];
+            continue;
+        }
+        for (uint64_t a = 0; a < len[i]; a += piece) jobs.push_back({src_off[i] + a, file_off[i] + a, std::min(piece, len[i] - a)});
+    }
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(std::min(16, DNAscent::hostThreads())) reduction(| : bad)
+    for (long j = 0; j < (long)jobs.size(); j++) {
+        const char *p = (const char *)buf + jobs[(size_t)j].src;
+        uint64_t left = jobs[(size_t)j].len, at = jobs[(size_t)j].dst;
+        while (left) {
+            const ssize_t w = pwrite(fd, p, (size_t)left, (off_t)at);
+            if (w <= 0) { bad = 1; break; }
+            p += w; at += (uint64_t)w; left -= (uint64_t)w;
         }
     }
     return bad ? -1 : 0;

@@ -163,6 +163,7 @@ void formatCalls(const ReadBatch &batch, const dn_result_batch &res, bool humanR
 // (DN_PACK_TEXT: count = text bytes, header bytes = 0).  formatPacked is the writer's half: same bytes as formatCalls' records.
 enum { DN_PACK_REVERSE = 1, DN_PACK_TEXT = 2 };
 void packCalls(const ReadBatch &batch, const dn_result_batch &res, std::vector<uint64_t> &meta /* [passing reads][4] */, RawVec<uint8_t> &payload);
+void packedSizes(size_t n, const uint64_t *meta3 /* [n][3] */, const uint8_t *const *read_ptr /* [n] */, uint64_t *record_bytes /* [n]: exact text length of every read */);
 bool formatPacked(size_t n, const uint64_t *meta3 /* [n][3]: count, header bytes, flags */, const uint8_t *const *read_ptr /* [n] */, RawVec<char> &text,
                   uint64_t *record_bytes /* [n] or null */);
 

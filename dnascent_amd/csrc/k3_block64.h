@@ -1,0 +1,403 @@
+// k3_block64.h -- included by k3_cnn.hip (needs its f32x16 / u32x4 / mfma16 / range_report / CNN_BP).
+//
+// k3_block64: a WHOLE 64-channel residual block of the network (SURVEY s2.3 layers 4-17 and 18-31; runCNN's graph, detect.cpp:577-675) in ONE launch:
+//     six SeparableConv1D (5 taps, 64 -> 64, folded BatchNorm, ReLU between them) + the shortcut Conv1D (5 taps, 64 -> 64, folded BatchNorm) + Add + ReLU.
+// Layer by layer these are 13 launches that each stream the whole pass through HBM (12 x 512 B + 768 B per position at 4.4-5.4 TB/s: the stage is
+// HBM-bound); here a position's activations enter the chip once and leave it once (HBM: 256 B in, 256 B out, + the shortcut's re-read of the input,
+// which comes from L2 / the Infinity Cache), and every value is computed ONCE -- no halo rows recomputed by neighbouring tiles, no weights re-fetched.
+//
+// Formulation: a DATAFLOW PIPELINE over 32-row chunks, one persistent 8-wavefront workgroup per CU walking a contiguous stripe of the pass's rows.
+//   wavefront = one LAYER (a pipeline stage), its weights resident in REGISTERS for the whole launch:
+//       stage l (6 of them): the 64 x 64 pointwise matrix as MFMA B fragments (2 channel blocks x 2 k16 x {hi, lo} x 2 column tiles = 64 registers),
+//                            its 5 depthwise taps, its folded BatchNorm;
+//       conv  c (2 of them): one 32-column tile of the 5 x 64 x 64 shortcut kernel (160 registers).
+//   step s: stage l works on chunk s - l, the shortcut on chunk s - 6; ONE workgroup barrier per step.  Between two stages the activations cross as
+//   fp32 rows in a double-buffered LDS ring (2 x 32 rows x 272 B per stage boundary): written by stage l's epilogue during step s, read by stage l + 1's
+//   depthwise filter during step s + 1.  Every layer's 5-tap filter needs 2 rows either side, so layer l's chunk grid is shifted up by 2 l rows: a stage
+//   can always produce its whole chunk from the chunk it was handed plus the LAST FOUR ROWS of the previous one, which it keeps itself (a private 4-row
+//   halo in LDS).  The fp16 hi / lo planes the matrix cores read (A operand) are private to a stage and hold one 32-channel block at a time (5 KB).
+//   A stripe starts with one warm-up chunk (outputs discarded) that fills the halos; the rows it gets wrong are exactly the ones the previous stripe's
+//   last chunk computes.
+//
+// Arithmetic, operand splits, K order, epilogue expressions and masks are those of k3_sep_split / k3_conv_split: results are bit-identical to the
+// layer-by-layer path (tools/k3_block64_check.hip compares the two on the device, tools/variant_check.py the whole pipeline).  f16x3 only; the other
+// arithmetics (and any description that does not have this block shape) run layer by layer.
+//
+// LDS (153 216 B of the CU's 163 840): rings 6 x 2 x 32 x 272, halos 6 x 4 x 272, A planes 6 x 2 x 32 x 80, shortcut planes 2 x 2 x 36 x 80.
+// One workgroup per CU, two wavefronts per SIMD: SIMD pairs (stage 0, stage 1), (stage 2, stage 3), (stage 4, shortcut tile 0), (stage 5, shortcut tile 1).
+#pragma once
+
+#define B64_RP 68                                           // ring pitch in floats: rows 8 apart start half a bank window apart (ds_read_b64 of two row quarters)
+#define B64_RING (32 * B64_RP)                              // floats of one ring buffer
+#define B64_APL (32 * CNN_BP)                               // elements of one stage A plane (one piece, one channel block)
+#define B64_CPL (36 * CNN_BP)                               // ... of one shortcut A plane (32 rows + 2 either side)
+
+struct B64Layer {
+    const float *wd;                                        // depthwise taps [5][64]
+    const uint16_t *wb;                                     // pointwise weights, pre-split fp16 pieces [channel block][piece][cout][32]
+    const float *scale, *shift;                             // folded BatchNorm + bias
+    unsigned *range;                                        // the layer's pair of words in the pass's range report block
+    float post; int relu;
+};
+struct B64Args {
+    const float *X; float *Y;                               // block input / output, [row][64] fp32
+    const uint8_t *valid; const int *live; int rows; int pad_;
+    B64Layer L[6];
+    const uint16_t *wc;                                     // shortcut kernel, pre-split [channel block][tap][piece][cout][32]
+    const float *cscale, *cshift; unsigned *crange; float cpost; int crelu;
+};
+
+#ifdef B64_TRACE                                            /* experiment builds only (tools/k3_block64_check.hip -DB64_TRACE=<workgroup>): shader-clock stamps of one step's phases */
+#ifndef B64_TRACE_STEP
+#define B64_TRACE_STEP 40
+#endif
+__device__ unsigned long long b64_trace[8][16];
+#define B64_T(role, i) do { if (blockIdx.x == B64_TRACE && s == B64_TRACE_STEP) { __builtin_amdgcn_sched_barrier(0); if (lane == 0) b64_trace[role][i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define B64_T(role, i) do { } while (0)
+#endif
+
+// The step barrier.  __syncthreads() is fence + barrier, and the fence waits for EVERY outstanding memory operation of the wavefront (s_waitcnt vmcnt(0)):
+// the rows requested a chunk ahead and the results just stored would have to finish before every barrier -- the prefetch would hide nothing.  What the
+// pipeline needs ordered across a step is LDS traffic only (rings, written before the barrier, read after it): wait for that, then s_barrier.  Global loads
+// stay in flight across it (MI355X_MICROARCH.md: barriers do not drain VMEM); the compiler still waits for each load before its first use.
+__device__ __forceinline__ void b64_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+typedef float b64f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 b64h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 b64h4 __attribute__((ext_vector_type(4)));
+typedef unsigned b64u2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ const void *b64_uniform_ptr(const void *p) {
+    const unsigned long long v = (unsigned long long)p;
+    return (const void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+}
+
+// Where the pipeline's stages start.  Wavefronts w and w + 4 share a SIMD and run the same program between the same barriers: left alone both filter at the
+// same time (vector pipe contended, matrix pipe idle) and then both multiply (the reverse).  -DB64_STAGGER=1 STAGGERS the second wavefront of a pair
+// (MI355X_MICROARCH.md, two waves per SIMD, item 9): stages 1 and 3 (wavefronts 4, 5) DEFER a chunk's epilogue to the start of the next step (its sums stay in
+// registers across the barrier), so that they filter while their partner multiplies and multiply while it filters; a deferred stage hands its chunk over one step
+// later, which the next stage's start absorbs.  Bit-identical, and no faster (see the switch): not the default.
+#ifndef B64_STAGGER
+#define B64_STAGGER 0                                       /* measured (gpurun_out/r5c, r5d): 520-544 us staggered against 512-542 us plain for 1.2 M rows: the phases that cost are vector + LDS on both partners, not matrix against vector; kept as a build switch */
+#endif
+#define B64_START(st) (B64_STAGGER ? ((st) + ((st) >= 2) + ((st) >= 4)) : (st))      /* 0 1 3 4 6 7 | 0 1 2 3 4 5 */
+#define B64_CONV_START (B64_START(5) + 1)
+#define B64_DEFERS(st) (B64_STAGGER && ((st) == 1 || (st) == 3))
+
+// the split of 8 filtered rows x 2 channels into the fp16 planes (+ the range report's largest |value|; MASKED: rows outside the pass do not count)
+template <bool MASKED>
+__device__ __forceinline__ void b64_split_store(const b64f2 (&o)[8], float &am, uint16_t *ap, const int g0, const int rows) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float m = __builtin_fmaxf(__builtin_fabsf(o[i][0]), __builtin_fabsf(o[i][1]));
+        if (MASKED) { const int g = g0 + i; m = (g >= 0 && g < rows) ? m : 0.0f; }
+        am = __builtin_fmaxf(am, m);
+        const b64h2 h = __builtin_convertvector(o[i], b64h2);
+        const b64f2 rest = o[i] - __builtin_convertvector(h, b64f2);
+        const b64h2 l = __builtin_convertvector(rest, b64h2);
+        *reinterpret_cast<b64h2 *>(ap + i * CNN_BP) = h; *reinterpret_cast<b64h2 *>(ap + B64_APL + i * CNN_BP) = l;
+    }
+}
+
+// a stage's epilogue: folded BatchNorm, ReLU, padding mask (MASKED: some row of the chunk is padding); accumulator register q of lane (n, hh) is row
+// (q & 3) + 8 (q >> 2) + 4 hh, column tile j is channel 2 n + j.  Rows go in pairs (q, q + 1): adjacent registers for the packed FMA.
+template <bool MASKED, bool TO_GLOBAL>
+__device__ __forceinline__ void b64_epilogue(const f32x16 (&acc)[2], const b64f2 sc, const b64f2 sh, const float floor_, const unsigned vml, float *wrow,
+                                             const __amdgpu_buffer_rsrc_t rY, const int ybase) {
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) {
+        const int rowq = (q & 3) + 8 * (q >> 2);
+        b64f2 y0 = __builtin_elementwise_fma(b64f2{acc[0][q], acc[0][q + 1]}, b64f2{sc[0], sc[0]}, b64f2{sh[0], sh[0]});
+        b64f2 y1 = __builtin_elementwise_fma(b64f2{acc[1][q], acc[1][q + 1]}, b64f2{sc[1], sc[1]}, b64f2{sh[1], sh[1]});
+        float a0 = __builtin_fmaxf(y0[0], floor_), a1 = __builtin_fmaxf(y1[0], floor_), b0 = __builtin_fmaxf(y0[1], floor_), b1 = __builtin_fmaxf(y1[1], floor_);
+        if (MASKED) {
+            const bool oka = (vml >> rowq) & 1u, okb = (vml >> (rowq + 1)) & 1u;
+            a0 = oka ? a0 : 0.0f; a1 = oka ? a1 : 0.0f; b0 = okb ? b0 : 0.0f; b1 = okb ? b1 : 0.0f;
+        }
+        if (TO_GLOBAL) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(b64u2, b64f2{a0, a1}), rY, ybase + rowq * 256, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(b64u2, b64f2{b0, b1}), rY, ybase + (rowq + 1) * 256, 0, 0);
+        } else {
+            float *r0 = wrow + rowq * B64_RP;
+            r0[0] = a0; r0[1] = a1; r0[B64_RP] = b0; r0[B64_RP + 1] = b1;
+        }
+    }
+}
+
+// One separable layer as a pipeline stage.  KIND 0: the block's first layer (its input comes from global memory, a chunk ahead in registers),
+// 1: a middle layer (LDS ring in, LDS ring out), 2: the last layer (ring in; out to the ring the shortcut joins from, or to global memory when the
+// shortcut runs as its own launch: CONV == false).  DEFER: the epilogue of a chunk runs at the start of the next step (see B64_START).
+template <int KIND, bool CONV, bool DEFER>
+__device__ __forceinline__ void b64_stage(const B64Args &A, const int st, const int t0, const int lane, const int S0, const int nch, const int nsteps, const int rows,
+                                          const float *rin, float *rout, float *hal, uint16_t *Ap) {
+    const B64Layer &P = A.L[st];
+    const int n = lane & 31, hh = lane >> 5;               // GEMM role: accumulator column pair n (channels 2 n, 2 n + 1), lane half
+    const int cpl = lane & 15, rq = lane >> 4;             // filter role: channel pair cpl of the channel block, row quarter rq (8 output rows)
+    // ---- resident operands ----
+    u32x4 bw[2][2][2][2];                                  // [channel block][k16][piece][column tile]: column tile j of lane n is output channel 2 n + j
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int k16 = 0; k16 < 2; k16++)
+#pragma unroll
+            for (int pc = 0; pc < 2; pc++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    bw[cb][k16][pc][j] = *reinterpret_cast<const u32x4 *>(P.wb + ((size_t)((cb * 2 + pc) * 64 + 2 * n + j)) * 32 + k16 * 16 + 8 * hh);
+    b64f2 tw[2][5];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int t = 0; t < 5; t++) tw[cb][t] = *reinterpret_cast<const b64f2 *>(P.wd + t * 64 + cb * 32 + 2 * cpl);
+    const b64f2 sc = {P.scale[2 * n] * P.post, P.scale[2 * n + 1] * P.post}, sh = {P.shift[2 * n], P.shift[2 * n + 1]};
+    const float floor_ = P.relu ? 0.0f : -3.402823466e38f;
+    float amax = 0.0f;
+    // ---- first stage: the input chunk travels global -> registers, requested one chunk ahead.  Lane (cpl, rq) of channel block cb needs rows
+    //      XC - 4 + 8 rq + j, j = 0 .. 11 (XC = first row of the input chunk): 8 bytes each, a 16-lane group reads 128 contiguous bytes of a row.
+    //      Rows outside [0, rows) fall outside the descriptor and read as the zeros 'same' padding wants.
+    b64u2 xp[2][12];
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b64_uniform_ptr(A.X)), 0, KIND == 0 ? rows * 256 : 0, 0x00020000);
+    const int xlane = ((8 * rq - 4) * 64 + 2 * cpl) * 4;
+    auto gloadX = [&](int c, int cb) {
+        const int base = xlane + ((S0 - 20 + 32 * c) * 64 + cb * 32) * 4;
+#pragma unroll
+        for (int j = 0; j < 12; j++) xp[cb][j] = __builtin_bit_cast(b64u2, __builtin_amdgcn_raw_buffer_load_b64(rX, base + j * 256, 0, 0));
+    };
+    if (KIND == 0) { gloadX(0, 0); gloadX(0, 1); }
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b64_uniform_ptr(A.Y)), 0, (KIND == 2 && !CONV) ? rows * 256 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b64_uniform_ptr(A.valid)), 0, rows, 0x00020000);
+    constexpr bool TO_GLOBAL = KIND == 2 && !CONV;
+    f32x16 acc[2];
+    // what a deferred epilogue needs of its chunk: the votes of its rows and where it goes
+    unsigned d_vm = 0; int d_c = -1;
+    auto epilogue = [&](const unsigned vm, const int c) {
+        const unsigned vml = hh ? vm >> 4 : vm;
+        float *wrow = rout + (c & 1) * B64_RING + 4 * hh * B64_RP + 2 * n;
+        const int ybase = ((S0 - 20 - 2 * (st + 1) + 32 * c + 4 * hh) * 64 + 2 * n) * 4;
+        if (TO_GLOBAL && c == 0) return;                   // the warm-up chunk's rows belong to the previous stripe
+        if (vm == 0xffffffffu) b64_epilogue<false, TO_GLOBAL>(acc, sc, sh, floor_, vml, wrow, rY, ybase);
+        else { asm volatile("; chunk with padding rows" ::: "memory"); b64_epilogue<true, TO_GLOBAL>(acc, sc, sh, floor_, vml, wrow, rY, ybase); }
+    };
+    for (int s = 0; s < nsteps; s++) {
+        const int c = s - t0;
+        B64_T(st, 0);
+        if (DEFER && d_c >= 0) { epilogue(d_vm, d_c); d_c = -1; }
+        if (c >= 0 && c < nch) {                           // wave-uniform
+            const int og0 = S0 - 20 - 2 * (st + 1) + 32 * c;          // first global row of this stage's output chunk
+            // validity of the 32 output rows: fetched now (both lane halves the same 32 bytes; rows outside [0, rows) fall outside the descriptor and read 0),
+            // voted on by the epilogue.  NO branch around the load: behind `if (in range)` the compiler waited for it (vmcnt(0): this byte and every row
+            // requested ahead) right where it was issued -- ~1 000 ticks at the top of every step of every stage in the first version's stamps
+            const unsigned vb = __builtin_amdgcn_raw_buffer_load_b8(rV, og0 + n, 0, 0);
+            const bool edge = og0 < 0 || og0 + 32 > rows;  // the chunk reaches outside the pass: those rows are masked out of the range report
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc[j][q] = 0.0f;
+            float am = 0.0f;
+            const float *rb = rin + (c & 1) * B64_RING;
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++) {
+                // ---- the filter's 12 input rows: in[j], j = 8 rq .. 8 rq + 11, where in[0 .. 3] = the halo (last four rows of the previous chunk), in[4 .. 35] = the chunk ----
+                b64f2 x[12];
+                if (KIND == 0) {
+#pragma unroll
+                    for (int j = 0; j < 12; j++) x[j] = __builtin_bit_cast(b64f2, xp[cb][j]);
+                } else {
+                    const float *p4 = rb + 8 * rq * B64_RP + cb * 32 + 2 * cpl;            // in[8 rq + 4] = row 8 rq of the chunk
+                    const float *pa = rq == 0 ? hal + cb * 32 + 2 * cpl : p4 - 4 * B64_RP; // in[8 rq]: the halo for row quarter 0, else four rows further up in the chunk
+#pragma unroll
+                    for (int j = 0; j < 4; j++) x[j] = *reinterpret_cast<const b64f2 *>(pa + j * B64_RP);
+#pragma unroll
+                    for (int j = 4; j < 12; j++) x[j] = *reinterpret_cast<const b64f2 *>(p4 + (j - 4) * B64_RP);
+                    if (rq == 3) {                         // the chunk's last four rows are the next chunk's halo (the reads above were issued first: LDS keeps a wavefront's order)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) *reinterpret_cast<b64f2 *>(hal + r * B64_RP + cb * 32 + 2 * cpl) = x[8 + r];
+                    }
+                }
+                B64_T(st, 1 + 4 * cb);
+                // ---- depthwise: output row 8 rq + i = sum over taps t of in[8 rq + i + t] w[t], taps ascending (k3_dwconv's order), packed over the channel pair ----
+                b64f2 o[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) o[i] = b64f2{0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 12; j++) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int t = j - i;
+                        if (t >= 0 && t < 5) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(o[i]) : "v"(x[j]), "v"(tw[cb][t]));
+                    }
+                }
+                B64_T(st, 2 + 4 * cb);
+                if (KIND == 0) gloadX(c + 1, cb);           // the same rows of the next chunk (past the stripe: loaded, never used)
+                // ---- split into the two fp16 pieces -> this stage's A planes ----
+                uint16_t *ap = Ap + 8 * rq * CNN_BP + 2 * cpl;
+                if (!edge) b64_split_store<false>(o, am, ap, 0, 0);
+                else { asm volatile("; chunk at an end of the pass" ::: "memory"); b64_split_store<true>(o, am, ap, og0 + 8 * rq, rows); }
+                B64_T(st, 3 + 4 * cb);
+                // ---- pointwise: 32 rows x 64 columns, K = this channel block; pieces l h', h l', h h' per k16 as in k3_sep_split ----
+#pragma unroll
+                for (int k16 = 0; k16 < 2; k16++) {
+                    const u32x4 ah = *reinterpret_cast<const u32x4 *>(Ap + n * CNN_BP + k16 * 16 + 8 * hh);
+                    const u32x4 al = *reinterpret_cast<const u32x4 *>(Ap + B64_APL + n * CNN_BP + k16 * 16 + 8 * hh);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[j] = mfma16<2>(al, bw[cb][k16][0][j], acc[j]);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[j] = mfma16<2>(ah, bw[cb][k16][1][j], acc[j]);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[j] = mfma16<2>(ah, bw[cb][k16][0][j], acc[j]);
+                }
+                B64_T(st, 4 + 4 * cb);
+            }
+            if (c > 0 || S0 == 0) amax = __builtin_fmaxf(amax, am);   // a later stripe's warm-up chunk filters rows it cannot know (the previous stripe reports them)
+            const unsigned vm = (unsigned)__ballot((vb & 0xffu) != 0);
+            if (DEFER) { d_vm = vm; d_c = c; }
+            else epilogue(vm, c);
+        }
+        B64_T(st, 9);
+        b64_barrier();
+        B64_T(st, 10);
+    }
+    range_report(amax, P.range, lane);
+}
+
+// The shortcut convolution + Add + ReLU as the pipeline's last stage: column tile ct (32 output channels) of chunk s - B64_CONV_START.
+__device__ __forceinline__ void b64_conv(const B64Args &A, const int ct, const int lane, const int S0, const int nch, const int nsteps, const int rows,
+                                         const float *r5, uint16_t *Ac) {
+    const int n = lane & 31, hh = lane >> 5;
+    u32x4 wc[2][5][2][2];                                  // [channel block][tap][k16][piece] of output channel 32 ct + n: 160 registers
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int tap = 0; tap < 5; tap++)
+#pragma unroll
+            for (int k16 = 0; k16 < 2; k16++)
+#pragma unroll
+                for (int pc = 0; pc < 2; pc++)
+                    wc[cb][tap][k16][pc] = *reinterpret_cast<const u32x4 *>(A.wc + ((size_t)(((cb * 5 + tap) * 2 + pc) * 64 + ct * 32 + n)) * 32 + k16 * 16 + 8 * hh);
+    const float sc = A.cscale[ct * 32 + n] * A.cpost, sh = A.cshift[ct * 32 + n];
+    const float floor_ = A.crelu ? 0.0f : -3.402823466e38f;
+    float amax = 0.0f;
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b64_uniform_ptr(A.X)), 0, rows * 256, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b64_uniform_ptr(A.Y)), 0, rows * 256, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b64_uniform_ptr(A.valid)), 0, rows, 0x00020000);
+    // the 36 input rows x 32 channels of a channel block are 288 float4: lane takes f = lane + 64 p, p = 0 .. 4 (the fifth only on lanes 0-31); both
+    // channel blocks of the NEXT chunk are requested while this one is multiplied (a whole step for the rows to arrive: the first version asked half a step
+    // ahead and its stamps showed the split waiting for them)
+    f32x4 xr[2][5];
+    auto gloadX = [&](int c, int cb) {
+        const int base = ((S0 - 32 + 32 * c - 2) * 64 + cb * 32) * 4;
+#pragma unroll
+        for (int p = 0; p < 5; p++) {
+            const int f = lane + 64 * p;
+            xr[cb][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, base + ((f >> 3) * 64 + (f & 7) * 4) * 4, 0, 0));
+        }
+    };
+    gloadX(1, 0); gloadX(1, 1);
+    for (int s = 0; s < nsteps; s++) {
+        const int c = s - B64_CONV_START;
+        B64_T(6 + ct, 0);
+        if (c >= 1 && c < nch) {                           // wave-uniform; chunk 0 is the stripe's warm-up chunk: nothing to join
+            const int G0 = S0 - 32 + 32 * c;
+            const unsigned vb = __builtin_amdgcn_raw_buffer_load_b8(rV, G0 + n, 0, 0);
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[q] = 0.0f;
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++) {
+#pragma unroll
+                for (int p = 0; p < 5; p++) {
+                    const int f = lane + 64 * p;
+                    if (p < 4 || lane < 32) {
+                        b64h4 h, l;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float x = xr[cb][p][e];
+                            amax = __builtin_fmaxf(amax, __builtin_fabsf(x));
+                            const _Float16 hv = (_Float16)x;
+                            h[e] = hv; l[e] = (_Float16)(x - (float)hv);
+                        }
+                        const int off = (f >> 3) * CNN_BP + (f & 7) * 4;
+                        *reinterpret_cast<b64h4 *>(Ac + off) = h; *reinterpret_cast<b64h4 *>(Ac + B64_CPL + off) = l;
+                    }
+                }
+                B64_T(6 + ct, 1 + 4 * cb);
+                gloadX(c + 1, cb);                          // the same channel block of the next chunk (past the stripe: loaded, never used)
+#pragma unroll
+                for (int tap = 0; tap < 5; tap++)
+#pragma unroll
+                    for (int k16 = 0; k16 < 2; k16++) {
+                        const u32x4 ah = *reinterpret_cast<const u32x4 *>(Ac + (n + tap) * CNN_BP + k16 * 16 + 8 * hh);
+                        const u32x4 al = *reinterpret_cast<const u32x4 *>(Ac + B64_CPL + (n + tap) * CNN_BP + k16 * 16 + 8 * hh);
+                        acc = mfma16<2>(al, wc[cb][tap][k16][0], acc);
+                        acc = mfma16<2>(ah, wc[cb][tap][k16][1], acc);
+                        acc = mfma16<2>(ah, wc[cb][tap][k16][0], acc);
+                    }
+                B64_T(6 + ct, 4 + 4 * cb);
+            }
+            const unsigned vm = (unsigned)__ballot((vb & 0xffu) != 0);
+            const unsigned vml = hh ? vm >> 4 : vm;
+            const float *rb = r5 + (c & 1) * B64_RING + 4 * hh * B64_RP + ct * 32 + n;
+            const int ybase = ((G0 + 4 * hh) * 64 + ct * 32 + n) * 4;
+            if (vm == 0xffffffffu) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int rowq = (q & 3) + 8 * (q >> 2);
+                    float y = __builtin_fmaf(acc[q], sc, sh);
+                    y += rb[rowq * B64_RP];
+                    y = __builtin_fmaxf(y, floor_);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rY, ybase + rowq * 256, 0, 0);
+                }
+            } else {
+                asm volatile("; chunk with padding rows" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int rowq = (q & 3) + 8 * (q >> 2);
+                    float y = __builtin_fmaf(acc[q], sc, sh);
+                    y += rb[rowq * B64_RP];
+                    y = __builtin_fmaxf(y, floor_);
+                    y = ((vml >> rowq) & 1u) ? y : 0.0f;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rY, ybase + rowq * 256, 0, 0);
+                }
+            }
+        }
+        B64_T(6 + ct, 9);
+        b64_barrier();
+        B64_T(6 + ct, 10);
+    }
+    range_report(amax, A.crange, lane);
+}
+
+template <bool CONV>
+__global__ __launch_bounds__(512, 2) void k3_block64(const B64Args A) {
+    __shared__ __attribute__((aligned(16))) float ring[6][2][B64_RING];
+    __shared__ __attribute__((aligned(16))) float halo[6][4 * B64_RP];
+    __shared__ __attribute__((aligned(16))) uint16_t Apl[6][2 * B64_APL];
+    __shared__ __attribute__((aligned(16))) uint16_t Acv[2][2 * B64_CPL];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rows = min(A.rows, *A.live);
+    // stripes: the pass's 32-row chunks dealt to the workgroups in contiguous runs
+    const int nct = rows >> 5;
+    const int per = (nct + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int c_lo = (int)blockIdx.x * per;
+    const int mych = min(per, nct - c_lo);
+    if (mych <= 0) return;
+    const int S0 = c_lo * 32, nch = mych + 1, nsteps = nch + (CONV ? B64_CONV_START : B64_START(5) + 1);     // (a deferred stage finishes a step after its last chunk: covered)
+    for (int i = tid; i < 6 * 4 * B64_RP; i += 512) (&halo[0][0])[i] = 0.0f;
+    __syncthreads();
+    // wavefronts w and w + 4 share a SIMD: stages (0, 1), (2, 3), (4, shortcut 0), (5, shortcut 1)
+    const int role = (int)((0x76315420u >> (4 * wave)) & 15u);
+    if (role < 6) {
+        const float *rin = &ring[role ? role - 1 : 0][0][0];
+        float *rout = &ring[role][0][0];
+        if (role == 0) b64_stage<0, CONV, false>(A, 0, B64_START(0), lane, S0, nch, nsteps, rows, rin, rout, &halo[0][0], &Apl[0][0]);
+        else if (role == 5) b64_stage<2, CONV, false>(A, 5, B64_START(5), lane, S0, nch, nsteps, rows, rin, rout, &halo[5][0], &Apl[5][0]);
+        else if (B64_DEFERS(1) && (role == 1 || role == 3)) b64_stage<1, CONV, true>(A, role, B64_START(role), lane, S0, nch, nsteps, rows, rin, rout, &halo[role][0], &Apl[role][0]);
+        else b64_stage<1, CONV, false>(A, role, B64_START(role), lane, S0, nch, nsteps, rows, rin, rout, &halo[role][0], &Apl[role][0]);
+    } else if (CONV) {
+        b64_conv(A, role - 6, lane, S0, nch, nsteps, rows, &ring[5][0][0], &Acv[role - 6][0]);
+    } else {
+        for (int s = 0; s < nsteps; s++) b64_barrier();
+    }
+}

@@ -1460,6 +1460,8 @@ __global__ __launch_bounds__(256) void k3_dense_softmax(const float *__restrict_
     }
 }
 
+#include "k3_block64.h"
+
 // ---------------------------------------------------------------------------------------------------------
 // host-side walker over the op list
 // ---------------------------------------------------------------------------------------------------------
@@ -1522,11 +1524,64 @@ static bool k3_can_fuse(const CnnRun &c, int i) {
     return true;
 }
 
+static int k3_env_int(const char *name, int dflt) { const char *e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
+// ---- a whole 64-channel residual block in one launch (k3_block64.h) ----
+// DN_CNN_BLOCK64: 2 (default) = six separable layers + shortcut convolution + join in one launch, 1 = the six separable layers only (the shortcut stays
+// its own launch), 0 = layer by layer.  k3_block64_force (>= 0) overrides the environment: tools/k3_block64_check.hip runs both paths in one process.
+int k3_block64_force = -1;
+static int k3_block64_mode() { static const int env = k3_env_int("DN_CNN_BLOCK64", 2); return k3_block64_force >= 0 ? k3_block64_force : env; }
+// Do the ops at i form such a block?  Returns the number of ops ONE launch covers (13: the whole block, 12: its separable layers), 0 if not:
+//   i + 2 j, i + 2 j + 1 (j = 0 .. 5): DWCONV 5 x 64 -> CONV 1 x 64 -> 64, each a fusable pair (k3_can_fuse: nothing else reads the depthwise output), chained,
+//   i + 12: CONV_ADD 5 x 64 -> 64 reading the block's input and adding the chain's result;
+//   no intermediate buffer is read after the block before it is overwritten (the one launch never materialises them).
+static int k3_block64_span(const CnnRun &c, int i) {
+    const int mode = k3_block64_mode();
+    if (mode <= 0 || c.pieces != 2 || !c.wts_split || !k3_fuse_enabled() || i < 0 || i + 12 >= c.n_ops) return 0;
+    if (c.rows.rows % 256 || (unsigned long long)c.rows.rows * 256ull >= (1ull << 31)) return 0;          // byte offsets of the buffer descriptors stay below 2^31
+    const int bX = c.ops[i].src;
+    int prev = bX;
+    for (int j = 0; j < 6; j++) {
+        if (!k3_can_fuse(c, i + 2 * j)) return 0;
+        const dn_cnn_op &d = c.ops[i + 2 * j], &p = c.ops[i + 2 * j + 1];
+        if (d.k != 5 || d.cin != 64 || p.op != DN_CNN_CONV || p.cin != 64 || p.cout != 64 || d.src != prev || d.dst == bX || p.dst == bX) return 0;
+        prev = p.dst;
+    }
+    const dn_cnn_op &sc = c.ops[i + 12];
+    if (sc.op != DN_CNN_CONV_ADD || sc.k != 5 || sc.cin != 64 || sc.cout != 64 || sc.src != bX || sc.a != prev || sc.dst == bX) return 0;
+    if (mode == 1) return 12;
+    for (int j = 0; j < 12; j++) {                         // every buffer the layer-by-layer path would have written on the way
+        const int b = c.ops[i + j].dst;
+        if (b == sc.dst) continue;
+        for (int q = i + 13; q < c.n_ops; q++) {
+            const dn_cnn_op &o = c.ops[q];
+            const bool reads = (o.op != DN_CNN_ENCODE_GRU && o.src == b) || ((o.op == DN_CNN_ADD_RELU || o.op == DN_CNN_CONV_ADD) && o.a == b) ||
+                               (o.op == DN_CNN_ADD_RELU && o.b == b);
+            if (reads) return 12;                          // still needed later: keep the shortcut (and with it the chain's result) materialised
+            if (o.dst == b) break;
+        }
+    }
+    return 13;
+}
+static void k3_launch_block64(const CnnRun &c, int i, int span, const float *x, float *y, hipStream_t st) {
+    B64Args a{};
+    a.X = x; a.Y = y; a.valid = c.valid; a.live = c.live; a.rows = (int)c.rows.rows;
+    for (int j = 0; j < 6; j++) {
+        const dn_cnn_op &d = c.ops[i + 2 * j], &p = c.ops[i + 2 * j + 1];
+        a.L[j].wd = c.wts + d.w; a.L[j].wb = c.wts_split + c.wb_off[i + 2 * j + 1]; a.L[j].scale = c.wts + p.scale; a.L[j].shift = c.wts + p.shift;
+        a.L[j].range = c.range_flag + 2 + 2 * (i + 2 * j); a.L[j].post = c.post[i + 2 * j + 1]; a.L[j].relu = p.relu;
+    }
+    const dn_cnn_op &sc = c.ops[i + 12];
+    a.wc = c.wts_split + c.wb_off[i + 12]; a.cscale = c.wts + sc.scale; a.cshift = c.wts + sc.shift; a.crange = c.range_flag + 2 + 2 * (i + 12);
+    a.cpost = c.post[i + 12]; a.crelu = sc.relu;
+    const unsigned grid = std::max(1u, std::min(k3_cu_count(), c.rows.rows / 32u));
+    if (span == 13) hipLaunchKernelGGL((k3_block64<true>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k3_block64<false>), dim3(grid), dim3(512), 0, st, a);
+}
+
 // Which fused kernel: the wave-specialised one pays off where the depthwise filter is long and the layer wide (17 taps, 256
 // output channels: one workgroup covers ALL 256 columns, so the filter is applied once per row tile); the short filters of the
 // narrow layers are memory-side and run better as k3_sep_split with 2-3 workgroups per CU.
 static bool k3_takes_ws(int np, const dn_cnn_op &d, const dn_cnn_op &o) { return np == 2 && d.k == 17 && o.cout == 256 && o.cin % 64 == 0 && k3_sep_ws_enabled(); }
-static int k3_env_int(const char *name, int dflt) { const char *e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
 // which convolutions take the 256-row form: >= DN_CNN_BM256_MINK taps and >= DN_CNN_BM256_MINCIN input channels.  Round 2 measured the 3-tap layers 8 % SLOWER in
 // this form (it spilled 18 registers under its 128-register cap) and kept it to >= 9 taps x >= 128 channels; without the spills (round 4) 3 x 256 -> 256 runs 1 206
 // against 1 439 us, 3 x 256 -> 128 618 against 714, 9 x 64 -> 128 509 against 582 (gpurun_out/r4l): every 128-column convolution takes it now.
@@ -1568,6 +1623,13 @@ int k3_run(const CnnRun &c, hipStream_t st) {
         // that the run itself says which kernel family dominates (bench.py); k3_describe names the kernel an op takes
         struct Mark { const CnnRun &c; int i; hipStream_t st; Mark(const CnnRun &c_, int i_, hipStream_t s_) : c(c_), i(i_), st(s_) { if (c.mark) c.mark(c.mark_who, 1, i, st); }
                       ~Mark() { if (c.mark) c.mark(c.mark_who, 0, i, st); } } mark_op(c, i, st);
+        if (const int span = k3_block64_span(c, i)) {
+            // a whole residual block (13 ops), or its six separable layers (12), in one launch: reads the block's input, writes the shortcut's destination
+            // (resp. the last pointwise op's); the buffers in between are never touched, so no logical buffers swap
+            k3_launch_block64(c, i, span, pb[o.src], span == 13 ? pb[c.ops[i + 12].dst] : pb[c.ops[i + 11].dst], st);
+            i += span - 1;
+            continue;
+        }
         if (k3_can_fuse(c, i)) {
             const dn_cnn_op &pw = c.ops[i + 1];
             const float *add = pw.op == DN_CNN_CONV_ADD ? pb[pw.a] : nullptr;
@@ -1651,7 +1713,9 @@ int k3_run(const CnnRun &c, hipStream_t st) {
             default: return -1;
         }
     }
+#ifndef K3_NO_RANGE_CHECK                                  /* tools/k3_block64_check.hip reads the per-op words itself */
     if (c.pieces == 2 && c.range_flag) hipLaunchKernelGGL(k3_range_check, dim3(1), dim3(64), 0, st, c.range_flag, c.n_ops);
+#endif
     return 0;
 }
 
@@ -1662,6 +1726,15 @@ int k3_describe(const CnnRun &c, int i, char *buf, size_t cap) {
     buf[0] = 0;
     const dn_cnn_op &o = c.ops[i];
     const int np = c.pieces;
+    for (int j = 0; j <= i;) {                             // k3_run's own walk up to op i: is it inside a block that one launch covers?
+        const int span = k3_block64_span(c, j);
+        if (span && i < j + span) {
+            if (j < i) return 0;
+            snprintf(buf, cap, "k3_block64<%s>", span == 13 ? "true" : "false");
+            return 1;
+        }
+        j += span ? span : (k3_can_fuse(c, j) ? 2 : 1);
+    }
     if (i > 0 && k3_can_fuse(c, i - 1)) return 0;
     if (k3_can_fuse(c, i)) {
         const dn_cnn_op &pw = c.ops[i + 1];

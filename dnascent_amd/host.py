@@ -108,6 +108,10 @@ def lib():
         L.dnh_text_free.argtypes = [C.c_void_p]
         L.dnh_pwrite_parallel.restype = C.c_int
         L.dnh_pwrite_parallel.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_uint64]
+        L.dnh_pwrite_scatter.restype = C.c_int
+        L.dnh_pwrite_scatter.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dnh_packed_sizes.restype = None
+        L.dnh_packed_sizes.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dnh_batch_pin.argtypes = [C.c_void_p]
         L.dnh_batch_unpin.argtypes = [C.c_void_p]
         L.dnh_revcomp.restype = C.c_int
@@ -377,17 +381,57 @@ def stream_detect(ctxs, batches, emit=True, out_path=None, header=None, keep=Fal
 PACK_REVERSE, PACK_TEXT = 1, 2          # DNAscent::DN_PACK_* (flags of a packed read's meta row)
 
 
+def _buffer_address(buf):
+    """(address, keep-alive object) of a bytes / bytearray / memoryview / ctypes buffer: the object returned must stay referenced for as long as the
+    address is used (round-4 advisor: the bytearray branch used to take the address of a temporary copy that nothing kept alive)"""
+    if isinstance(buf, bytes):
+        return C.cast(C.c_char_p(buf), C.c_void_p).value, buf
+    if isinstance(buf, bytearray):
+        hold = (C.c_char * len(buf)).from_buffer(buf)
+        return C.addressof(hold), hold
+    mv = memoryview(buf)
+    if mv.readonly:
+        arr = np.frombuffer(mv, np.uint8)                    # wraps the caller's buffer (no copy); `arr` keeps the view, the view keeps the buffer
+        return arr.ctypes.data, arr
+    hold = C.c_char.from_buffer(mv)
+    return C.addressof(hold), (hold, mv)
+
+
 def pwrite_parallel(fd, buf, offset):
     """buf (bytes or a memoryview / ctypes view of the formatter's text) to file descriptor fd at `offset`, written in pieces by several host threads"""
     n = len(buf)
     if n == 0:
         return
-    if isinstance(buf, (bytes, bytearray)):
-        addr = C.cast(C.c_char_p(bytes(buf)), C.c_void_p).value if isinstance(buf, bytearray) else C.cast(C.c_char_p(buf), C.c_void_p).value
-    else:
-        addr = C.addressof(C.c_char.from_buffer(buf)) if not buf.readonly else np.frombuffer(buf, np.uint8).ctypes.data
-    if lib().dnh_pwrite_parallel(int(fd), C.c_void_p(addr), n, int(offset)) != 0:
+    addr, hold = _buffer_address(buf)
+    rc = lib().dnh_pwrite_parallel(int(fd), C.c_void_p(addr), n, int(offset))
+    del hold
+    if rc != 0:
         raise IOError("short write to the output file")
+
+
+def pwrite_scatter(fd, buf, src_off, lens, file_off):
+    """pieces of one buffer to their own file offsets (dnh_pwrite_scatter): piece i = lens[i] bytes at buf[src_off[i]:] -> file offset file_off[i]"""
+    so = np.ascontiguousarray(src_off, np.uint64); ln = np.ascontiguousarray(lens, np.uint64); fo = np.ascontiguousarray(file_off, np.uint64)
+    n = int(ln.shape[0])
+    assert so.shape[0] == n and fo.shape[0] == n
+    if n == 0 or int(ln.sum()) == 0:
+        return
+    assert int((so + ln).max()) <= len(buf)
+    addr, hold = _buffer_address(buf)
+    rc = lib().dnh_pwrite_scatter(int(fd), C.c_void_p(addr), n, so.ctypes.data, ln.ctypes.data, fo.ctypes.data)
+    del hold
+    if rc != 0:
+        raise IOError("short write to the output file")
+
+
+def packed_sizes(meta3, read_ptr):
+    """DNAscent::packedSizes: the exact text length of every packed read (uint64 [n]), without formatting anything"""
+    m = np.ascontiguousarray(meta3, np.uint64); p = np.ascontiguousarray(read_ptr, np.uint64)
+    n = p.shape[0]
+    rb = np.zeros(max(n, 1), np.uint64)
+    if n:
+        lib().dnh_packed_sizes(n, m.ctypes.data, p.ctypes.data, rb.ctypes.data)
+    return rb[:n]
 
 
 class _TextOwner:

@@ -15,13 +15,14 @@ reads (detect.cpp:821-907), never "load everything, run, gather everything":
      `schedule(dynamic)` (detect.cpp:852): a rank whose reads fail QC early, or are short, takes more batches;
   3. a rank holds at most --inflight + 3 batches on the host: the next two are loaded (all cores, direct seeks) while --inflight of
      them are on the GPU (DNAscent::DetectStream: upload, normaliseEvents, eventalign, CNN, dn_collect, records formatted);
-  4. when a rank has collected its last batch of a window, the window's PACKED per-call results (16 bytes per call: coordinate, P(EdU),
-     P(BrdU), 9-mer; ~40 % of the text's bytes) go to the writer rank: sizes through the process group's store, bytes in ONE grouped
-     receive from all peers per window (pieces of --gather-chunk-mb), on a gather thread of every rank, so neither the sends nor the
-     receives hold up the thread that drives the GPU.  The writer formats them (the C++ formatter on its host threads) and writes them
-     in INPUT order while the GPUs work on the next window -- the file is byte-identical whatever the number of ranks (the reference
-     writes in completion order, detect.cpp:902-906; input order is what it produces with one thread).  No rank ever holds more than
-     a few windows' results;
+  4. THERE IS NO WRITER RANK (round 5; the reference funnels every record through one critical section, detect.cpp:902-906 -- the thing not to
+     copy: a central formatter has the CPU share of ONE rank for the text of all of them).  When a rank has collected its last batch of a window
+     it announces {ordinal, exact text length} of its reads through the process group's store (16 bytes per READ: a few KB per window, no
+     collective, nothing on the GPU); with every rank's announcement an exclusive scan in input order gives each record its offset in the
+     file; the rank then formats ITS OWN records (the C++ formatter on its share of the host's threads) and pwrite()s them in place -- one
+     node, one file system.  All of it on a gather thread, while the GPU works on the next window.  The file is byte-identical whatever the
+     number of ranks (input order is what the reference produces with one thread); --central-writer keeps round 4's form (packed calls
+     gathered to rank 0 in one grouped receive per window and formatted there);
   5. one all-reduce of the counters (reads ok / failed, samples) at the end.
 
 A read the reference's own filters reject (empty / too short signal, detect.cpp:839, pod5.cpp:64) counts as FAILED, as there.  A
@@ -84,6 +85,7 @@ def main(argv=None):
     ap.add_argument("--gather-chunk-mb", type=int, default=256)
     ap.add_argument("--prefetch", type=int, default=3, help="batches loaded ahead of the one being submitted (loader threads)")
     ap.add_argument("--backend", default=os.environ.get("DN_BACKEND", "nccl"))
+    ap.add_argument("--central-writer", action="store_true", help="round 4's form: packed results gathered to rank 0 and formatted there")
     ap.add_argument("--header", default=None, help="text written before the records (e.g. DNAscent::writeDetectHeader)")
     ap.add_argument("--stats", default=None, help="rank 0 writes a JSON with per-rank busy / gather seconds, batches, peak buffered bytes")
     a = ap.parse_args(argv)
@@ -128,41 +130,64 @@ def main(argv=None):
         return b, b.add_container_at(a.container, offsets[ords])
 
     out_f = None
-    out_pos = [0]
+    head = (a.header or "").encode()
+    out_pos = [len(head)]
     write_s = [0.0]
     if rank == 0:
         out_f = open(a.out, "wb")
-        if a.header:
-            out_f.write(a.header.encode()); out_f.flush()
-            out_pos[0] = out_f.tell()
+        if head:
+            out_f.write(head); out_f.flush()
+    if dist is not None:
+        dist.barrier()                                         # the file exists (and is empty but for the header) before anybody else opens it
+    if rank != 0 and not a.central_writer:
+        out_f = open(a.out, "r+b")                             # every rank writes its own records in place: same file, own descriptor
 
-    def write(text, ordinals, record_bytes):                   # on the writer's gather thread: the group's text, by several threads at once (host.pwrite_parallel)
+    def write(text, ordinals, record_bytes):                   # --central-writer: on the writer's gather thread, the group's text by several threads at once
         t_w = time.time()
         host.pwrite_parallel(out_f.fileno(), text, out_pos[0])
         out_pos[0] += len(text)
         write_s[0] += time.time() - t_w
 
+    def write_at(text, src_off, lens, file_off, ordinals):     # on EVERY rank's gather thread: its own records to their places in the file
+        t_w = time.time()
+        host.pwrite_scatter(out_f.fileno(), text, src_off, lens, file_off)
+        write_s[0] += time.time() - t_w
+
     drv = shard.StreamDriver(dist, batches, window_of, engine, load, write, release=free.append, dst=0, device=dev_t,
-                             chunk_bytes=a.gather_chunk_mb << 20)
+                             chunk_bytes=a.gather_chunk_mb << 20, write_at=None if a.central_writer else write_at, file_base=len(head))
     # set-up, not part of the stream: every context gets its workspace now (a 10+ GB hipMalloc), sized from the plan's first batch -- window 0's
     # longest reads at the full sample budget -- scaled to the largest planned batch, + 4 % for batches of other composition (more, shorter
     # reads): regrowing a slab later frees the old one, and hipFree waits for the WHOLE device, i.e. drains every batch in flight
     pre = {}
-    if len(batches):
-        b0, acc0 = load(batches[0])
-        if b0.size():
-            per_sample = ctxs[0].workspace_bytes(b0.desc()) / max(1, b0.samples())
-            biggest = max(int(sizes[b].sum()) for b in batches)
-            for c in ctxs:
-                c.reserve(int(per_sample * biggest * 1.04), collect_bytes=int(biggest / 12.5 * 0.3 * 29 * 1.3))
-                b0.upload(c)                                   # the side tables (per-read mirrors, CNN lane buffers) take their size from a real batch
-                c.sync()
-        pre[0] = (b0, acc0)                                    # whichever rank pulls batch 0 submits this copy instead of reading it again
+    setup_exc = None
+    try:
+        if len(batches):
+            b0, acc0 = load(batches[0])
+            if b0.size():
+                per_sample = ctxs[0].workspace_bytes(b0.desc()) / max(1, b0.samples())
+                biggest = max(int(sizes[b].sum()) for b in batches)
+                for c in ctxs:
+                    c.reserve(int(per_sample * biggest * 1.04), collect_bytes=int(biggest / 12.5 * 0.3 * 29 * 1.3))
+                    b0.upload(c)                               # the side tables (per-read mirrors, CNN lane buffers) take their size from a real batch
+                    c.sync()
+            pre[0] = (b0, acc0)                                # whichever rank pulls batch 0 submits this copy instead of reading it again
+    except BaseException as e:                                 # noqa: BLE001 -- a rank that cannot even set up raises the shared abort flag and still walks the windows:
+        setup_exc = e                                          # its peers stop at once instead of waiting for the store's timeout (round-4 advisor)
+        try:
+            drv.counter.abort()
+        except Exception:
+            pass
     t_setup = time.time() - t0
     drv.preloaded = pre
     t_stream = time.time()
     ok = drv.run(prefetch=a.prefetch)
     t_stream = time.time() - t_stream
+    for bl, _ in drv.preloaded.values():                       # batch 0 as loaded for the set-up, on the ranks that did not pull it: back to the pool
+        free.append(bl)
+    drv.preloaded = {}
+    if setup_exc is not None:
+        ok = False
+        drv.failure = drv.failure or setup_exc
     st = engine.stats()
     tot = shard.reduce_counters(dist, [drv.n_ok, drv.n_fail, int(st.samples), 0 if ok else 1], device=dev_t)
     if drv.failure is not None:
@@ -173,8 +198,9 @@ def main(argv=None):
                                              upload_s=round(st.seconds_upload, 3), enqueue_s=round(st.seconds_run, 3), collect_wait_s=round(st.seconds_collect, 3), load_wait_s=round(drv.load_wait_s, 3), load_s=round(drv.load_s, 3), driver_submit_s=round(drv.t_submit, 3), driver_collect_s=round(drv.t_collect, 3), driver_engine_collect_s=round(drv.t_engine_collect, 3), driver_hand_over_s=round(drv.t_hand_over, 3),
                                              pack_s=round(st.seconds_emit, 3)), device=dev_t)
     failed = tot[3] > 0
-    if rank == 0:
+    if out_f is not None:
         out_f.close()
+    if rank == 0:
         dt = time.time() - t0
         if failed:
             os.unlink(a.out)                                   # a partial file must not pass for a result
@@ -182,7 +208,7 @@ def main(argv=None):
         else:
             busy = [p["busy_s"] for p in per_rank]
             print("run_detect: %d reads ok, %d failed, %.1f M samples, %d rank(s), %d batches in %d window(s), %.2f s (%.1f Msamples/s incl. "
-                  "indexing, context set-up and ingestion; the stream itself -- first batch loaded to last record written -- %.2f s = %.1f Msamples/s); per-rank busy %.2f .. %.2f s, gather %.2f s max, writer formatting %.2f s, at most %.1f MB of packed results "
+                  "indexing, context set-up and ingestion; the stream itself -- first batch loaded to last record written -- %.2f s = %.1f Msamples/s); per-rank busy %.2f .. %.2f s, gather %.2f s max, formatting %.2f s (rank 0), at most %.1f MB of packed results "
                   "buffered on a rank" %
                   (tot[0], tot[1], tot[2] / 1e6, world, len(batches), drv.n_windows, dt, tot[2] / 1e6 / dt, t_stream, tot[2] / 1e6 / t_stream, min(busy), max(busy),
                    max(p["gather_s"] for p in per_rank), drv.format_s, max(p["peak_buffered_bytes"] for p in per_rank) / 1e6))

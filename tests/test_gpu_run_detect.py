@@ -1,7 +1,8 @@
 """GPU: the product path end to end across ranks: container in, .detect out.  `python -m dnascent_amd.run_detect` with one
 rank, and under torch.distributed.run with two ranks sharing the one GPU (gloo; the 8-GPU node runs the same code over RCCL):
-partition (assign_reads) -> length-bucketed batches -> streamed pipeline -> grouped send / recv of the per-read records to the
-writer -> ordered write.  The two files must be byte-identical, and equal to a plain single-context run of the same reads."""
+plan (plan_windows) -> length-bucketed batches pulled from a shared counter -> streamed pipeline -> every rank formats its own records and
+writes them at their offsets in the shared file (round 5: no writer rank; --central-writer = round 4's gather to rank 0).  The files must be
+byte-identical, and equal to a plain single-context run of the same reads."""
 import os
 import socket
 import subprocess
@@ -33,6 +34,14 @@ def test_two_ranks_write_the_same_file_as_one(model, tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     a, b = open(one, "rb").read(), open(two, "rb").read()
     assert a == b and a.startswith(b"#hdr\n") and a.count(b">") == 13                  # the noisy read fails the QC and is not written
+    # round 4's form (packed calls gathered to rank 0, formatted there) stays selectable and writes the same bytes
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cen = str(tmp_path / "central.detect")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "dnascent_amd.run_detect", "--out", cen, "--backend", "gloo", "--central-writer"] + common,
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert open(cen, "rb").read() == a
     # and both equal one plain batch on one context, records in input order
     ctx = hip.Context(0); ctx.load_pore_model(model, 0.14)
     desc, blob, _ = cnn_model.default_model(); ctx.load_cnn(desc, blob)

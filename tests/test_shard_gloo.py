@@ -164,6 +164,110 @@ def test_plan_has_no_stub_batches():
             assert len(sz) == int(wb) and max(sz) <= 300e6 and min(sz) >= 0.9 * max(sz), (w, sz)
 
 
+def _scatter_worker(rank, world, port, q, path, bad_at):
+    """the product driver's form (round 5): no writer rank -- every rank formats its own records and pwrite()s them into the shared file"""
+    import torch.distributed as dist
+    from dnascent_amd import host
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = _sizes(600)
+        batches, window_of = shard.plan_windows(n, window_samples=2 * world * 8e6, batch_samples=8e6, batch_reads=64)
+        head = b"#header line\n"
+        if rank == 0:
+            with open(path, "wb") as f:
+                f.write(head)
+        dist.barrier()
+        f = open(path, "r+b")
+        mine = []
+
+        def load(ords):
+            if bad_at is not None and bad_at in ords.tolist():
+                raise IOError("truncated record")
+            acc = np.array([0 if o % 17 == 3 else 1 for o in ords], np.uint8)
+            return [int(o) for o, a in zip(ords, acc) if a], acc
+
+        def write_at(text, src_off, lens, file_off, ordinals):
+            host.pwrite_scatter(f.fileno(), text, src_off, lens, file_off)
+            mine.extend(int(o) for o in ordinals)
+
+        eng = _FakeEngine(depth=3, delay=0.03 if rank == 0 else 0.003)
+        drv = shard.StreamDriver(dist, batches, window_of, eng, load, None, dst=0, write_at=write_at, file_base=len(head), group_bytes=2000)
+        dist.barrier()
+        ok = drv.run()
+        f.close()
+        tot = shard.reduce_counters(dist, [drv.n_ok, drv.n_fail, drv.batches_done, drv.records_written])
+        dist.barrier()
+        import traceback
+        fail = "".join(traceback.format_exception(type(drv.failure), drv.failure, drv.failure.__traceback__)) if drv.failure is not None else "None"
+        if drv.failure is not None and drv.failure.__cause__ is not None:
+            c_ = drv.failure.__cause__
+            fail += "caused by: " + "".join(traceback.format_exception(type(c_), c_, c_.__traceback__))
+        q.put((rank, ok, tot, sorted(mine), drv.max_gather_bytes, drv.format_s, drv.file_pos, drv.n_windows, fail))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_scatter(world, path, bad_at=None):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_scatter_worker, args=(r, world, port, q, path, bad_at)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in ps:
+        r = q.get(timeout=240)
+        res[r[0]] = r
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_no_writer_rank_three_ranks(tmp_path):
+    """round-4 verdict item 2: every rank formats its own records and writes them in place -- the file of 3 ranks is byte-identical to what one
+    rank writes (header + records in input order), only LENGTHS cross between the ranks, and every rank did format"""
+    expect = b"#header line\n" + b"".join(_record(o) for o in range(600) if not (o % 17 == 3 or o % 13 == 5))
+    n_expect = sum(1 for o in range(600) if not (o % 17 == 3 or o % 13 == 5))
+    path = str(tmp_path / "three.detect")
+    res = _run_scatter(3, path)
+    assert open(path, "rb").read() == expect
+    assert all(res[r][1] for r in range(3))
+    assert res[0][2][0] == n_expect and res[0][2][3] == n_expect                     # every record written exactly once, by somebody
+    owners = [set(res[r][3]) for r in range(3)]
+    assert all(owners) and not (owners[0] & owners[1]) and not (owners[0] & owners[2]) and not (owners[1] & owners[2])     # each by the rank that computed it
+    total_text = len(expect)
+    for r in range(3):
+        assert 0 < res[r][4] < 0.05 * total_text + 16 * 600 + 4096                   # what crossed: 16 bytes per read and a header per window, not the records
+        assert res[r][5] > 0                                                          # format_s: every rank formatted
+        assert res[r][6] == len(expect)                                               # every rank's running file position ends at the file's size
+    # one rank, no process group: same bytes
+    path1 = str(tmp_path / "one.detect")
+    with open(path1, "wb") as f:
+        f.write(b"#header line\n")
+    f = open(path1, "r+b")
+    from dnascent_amd import host
+    n = _sizes(600)
+    batches, window_of = shard.plan_windows(n, window_samples=2 * 20e6, batch_samples=20e6, batch_reads=64)
+    drv = shard.StreamDriver(None, batches, window_of, _FakeEngine(depth=2, delay=0.0),
+                             lambda ords: ([int(o) for o in ords if o % 17 != 3], np.array([o % 17 != 3 for o in ords], np.uint8)), None,
+                             write_at=lambda text, so, ln, fo, o: host.pwrite_scatter(f.fileno(), text, so, ln, fo), file_base=13)
+    assert drv.run() and drv.max_gather_bytes == 0
+    f.close()
+    assert open(path1, "rb").read() == expect
+
+
+def test_no_writer_rank_abort(tmp_path):
+    """a loader failure on one rank: every rank sees the error flag of that window's announcement, nobody writes from there on, nothing hangs"""
+    path = str(tmp_path / "abort.detect")
+    res = _run_scatter(2, path, bad_at=301)
+    assert not res[0][1] and not res[1][1]
+    assert res[0][2][3] < 560                                                          # not a complete file
+
+
 def _stream_worker(rank, world, port, q, bad_at, depth, fail_rank):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -11,7 +11,6 @@ rows = [r for r in rows if not is_sort(r) and "k3_layout" not in r["Kernel_Name"
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 npos = int(sys.argv[2]); ops = desc["ops"]
 # kernels of one run: walk the op list backwards from the end of the trace
-n_fused = sum(1 for r in rows if "k3_sep" in r["Kernel_Name"])
 runs = max(1, sum(1 for r in rows if "k3_encode(" in r["Kernel_Name"] or "k3_encode_mfma(" in r["Kernel_Name"]))
 per_run = len(rows) // runs
 last = rows[-per_run:]
@@ -19,6 +18,12 @@ tot = 0; agg = {}; i = 0
 for r in last:
     o = ops[i]
     dt = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; tot += dt
+    if "k3_block64" in r["Kernel_Name"]:                    # a whole residual block (13 ops) or its six separable layers (12) in one launch
+        span = 13 if "k3_block64<true>" in r["Kernel_Name"] or "ILb1E" in r["Kernel_Name"] else 12
+        fl = sum(2 * (q["k"] * q["c"] if q["op"] == "dwconv" else q["k"] * q["cin"] * q["cout"]) for q in ops[i:i + span]) * npos
+        key = "block k5 64 (%d ops)" % span
+        a = agg.setdefault(key, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += dt; a[2] += fl; a[3] += npos * (64 + 64 + (64 if span == 13 else 0)) * 4
+        i += span; continue
     if "k3_sep" in r["Kernel_Name"]:
         pw = ops[i + 1]
         kind = "ws" if "k3_sep_ws" in r["Kernel_Name"] else "un" if "k3_sep_uni" in r["Kernel_Name"] else "  "

@@ -1,6 +1,6 @@
 """GPU: the alternative kernel forms kept behind environment switches must give bit-identical results to the defaults:
 DN_CNN_BM256=0 (128-row
-workgroups on the long-K convolutions), DN_CNN_SEP_WS=0 (single-role fused separable kernel for the 17-tap layers), DN_TS_FULL=1
+workgroups on the long-K convolutions), DN_CNN_BLOCK64=0 / 1 (the 64-channel residual blocks layer by layer / only their separable layers in one launch), DN_CNN_SEP_WS=0 (single-role fused separable kernel for the 17-tap layers), DN_TS_FULL=1
 (Theil-Sen: the general first-level histogram path that a median slope outside [0.5, 2) takes).
 Each variant runs in its own process (the switches are read once per process)."""
 import hashlib, os, subprocess, sys
@@ -44,7 +44,8 @@ base = run({})
 print("default        ", base)
 ok = True
 for name, env in (("conv BM=128", {"DN_CNN_BM256": "0"}),
-                  ("sep no-ws", {"DN_CNN_SEP_WS": "0"}), ("sep unfused", {"DN_CNN_FUSE": "0"}), ("theilsen full", {"DN_TS_FULL": "1"})):
+                  ("sep no-ws", {"DN_CNN_SEP_WS": "0"}), ("sep unfused", {"DN_CNN_FUSE": "0"}), ("theilsen full", {"DN_TS_FULL": "1"}),
+                  ("block64 off", {"DN_CNN_BLOCK64": "0"}), ("block64 sep", {"DN_CNN_BLOCK64": "1"})):
     d = run(env)
     print("%-15s" % name, d, "same" if d == base else "DIFFERENT")
     ok = ok and d == base
