@@ -82,22 +82,24 @@ struct CnnLane {
     std::mutex mu;                                       // enqueue order == execution order
     DevBuf buf[8], valid, enclen, enchist, permsrc, permrow, live;
     size_t bytes = 0;
+    int users = 0;                                       // guarded by g_lane_mu: passes that hold `mu` or are about to take it (lane_get .. lane_put)
 };
 #define DN_MAX_LANES 16
 static std::mutex g_lane_mu;
 static CnnLane *g_lane[64][DN_MAX_LANES] = { { nullptr } };
 static unsigned g_ctx_seq = 0;
 static unsigned g_dev_ctx[64] = { 0 };                  // live contexts per device: the last one to go takes the device's lanes with it
-// caller holds g_lane_mu.  A lane whose mutex is held -- a CNN pass of another host thread is being enqueued on it right now (cnn_execute
-// holds L->mu, not g_lane_mu, for the whole enqueue) -- is left alone and counted: freeing it would pull the stream, the mutex and the
-// activation buffers from under that pass (round-3 advisor).  Returns the number of lanes that were busy.
+// caller holds g_lane_mu.  A lane in USE -- a CNN pass of another host thread has looked it up (lane_get counted it in, under g_lane_mu) and is
+// enqueueing on it or about to lock it -- is left alone and counted: freeing it would pull the stream, the mutex and the activation buffers from
+// under that pass (round-3 advisor).  The count closes the window the mutex alone left open (round-4 advisor): between lane_get returning the
+// pointer and the pass locking `mu`, a try_lock here succeeded and the pass went on to lock a deleted mutex.  Returns the number of busy lanes.
 static int lanes_free_device(int dev) {
     if (dev < 0 || dev >= 64) return 0;
     int busy = 0;
     for (unsigned l = 0; l < DN_MAX_LANES; l++) {
         CnnLane *L = g_lane[dev][l];
         if (!L) continue;
-        if (!L->mu.try_lock()) { busy++; continue; }
+        if (L->users > 0 || !L->mu.try_lock()) { busy++; continue; }
         (void)hipSetDevice(dev);
         if (L->stream) { (void)hipStreamSynchronize(L->stream); (void)hipStreamDestroy(L->stream); }
         for (DevBuf &b : L->buf) if (b.p) (void)hipFree(b.p);
@@ -145,6 +147,7 @@ struct dn_ctx {
     int stage = 0;   // 0 none, 1 uploaded, 2 segmented, 3 rough scaled, 4 banded, 5 theil-sen, 6 eventaligned
     std::vector<uint64_t> h_samp_off, h_base_off, h_ref_off, h_chunk_off, h_ev_off, h_aln_off, h_trace_off;
     unsigned max_samples = 0, max_chunks = 0, max_len = 0, max_evcap = 0;
+    unsigned ev_div = 2;                                  // the event workspace of a read holds samples / ev_div + 64 events (dn_ctx_set_event_bound)
     std::vector<ReadRes> h_res;
     uint8_t *d_path_from = nullptr; float *d_path_lp = nullptr;
     uint64_t *d_trace_off = nullptr;
@@ -166,6 +169,7 @@ struct dn_ctx {
     FillConstsH fc{};
     std::vector<int64_t> cnn_wb_off, cnn_wh_off; uint16_t *d_cnn_wb = nullptr, *d_cnn_wh = nullptr; size_t cnn_nwb = 0, cnn_nwh = 0; int cnn_math = DN_CNN_MATH_F16X3;
     std::vector<float> cnn_post, cnn_one; unsigned *d_cnn_flag = nullptr; uint64_t cnn_escalations = 0; bool cnn_f16_off = false;
+    unsigned cnn_underflow_streak = 0; bool cnn_bf16_once = false;        // see cnn_note_escalation
     std::vector<dn_cnn_op> cnn_ops; float *d_cnn_w = nullptr; size_t cnn_nw = 0; int cnn_nbuf = 0; DevBuf cnn_rowoff, cnn_npos, cnn_iooff, cnn_in[3], cnn_out;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;    // hand-over to / from the device's CNN lane
     unsigned lane_id = 0;
@@ -326,8 +330,19 @@ static CnnLane *lane_get(dn_ctx *c) {
         if (!made && hipStreamCreateWithPriority(&L->stream, hipStreamNonBlocking, lo) != hipSuccess) { delete L; return nullptr; }
         g_lane[c->device][c->lane_id] = L;
     }
+    g_lane[c->device][c->lane_id]->users++;               // counted in while g_lane_mu is held: from here on lanes_free_device leaves the lane alone
     return g_lane[c->device][c->lane_id];
 }
+static void lane_put(CnnLane *L) {
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    L->users--;
+}
+struct LaneUse {                                           // lane_get .. lane_put around a pass's enqueue
+    CnnLane *L;
+    explicit LaneUse(CnnLane *l) : L(l) {}
+    ~LaneUse() { if (L) lane_put(L); }
+    LaneUse(const LaneUse &) = delete; LaneUse &operator=(const LaneUse &) = delete;
+};
 
 // HIP event pairs around every op of the network (layer = index into the description's op list), profiling only
 static void cnn_mark(void *who, int begin, int layer, hipStream_t st) {
@@ -544,6 +559,7 @@ int dn_load_pore_model(dn_ctx *c, const double *mean, double sigma) {
     return DN_OK;
 }
 
+static void cnn_note_escalation(dn_ctx *c, unsigned flag);
 int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     if (!c || !d) return DN_ERR_ARG;
     if (!c->have_model) return fail(c, DN_ERR_STATE, "dn_load_pore_model must be called first");
@@ -561,7 +577,7 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     // a batch that raised the fp16 range flag and was never collected must not leave it to the next one (round-2 advisor)
     if (c->cnn_pending) {
         c->cnn_pending = false;
-        if (c->p_cnn_flag && *c->p_cnn_flag) { c->cnn_f16_off = true; c->cnn_escalations++; }      // the model does not fit fp16: remembered, the dropped batch is not repeated
+        if (c->p_cnn_flag && *c->p_cnn_flag) cnn_note_escalation(c, *c->p_cnn_flag);      // the pass did not fit fp16: remembered, the dropped batch is not repeated
     }
     if (c->p_cnn_flag) *c->p_cnn_flag = 0;
     if (c->d_cnn_flag) HIPCHK(c, hipMemsetAsync(c->d_cnn_flag, 0, sizeof(unsigned), c->stream));
@@ -596,7 +612,10 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
         if (ns < 16 || nb < DN_K + 1 || nr < DN_K) return fail(c, DN_ERR_ARG, "read %u too short (samples %llu, bases %llu, ref %llu)", r,
                                                                   (unsigned long long)ns, (unsigned long long)nb, (unsigned long long)nr);
         const uint64_t nch = (ns + DN_SEG_CHUNK - 1) / DN_SEG_CHUNK;
-        const uint64_t evcap = ns / 2 + 8;
+        // events of a read: the detector cannot place more than one peak per two samples (its shortest window is 3: event_detection.h:19-25), which is the
+        // default bound; a driver that retries a batch on DN_ERR_OVERFLOW (DNAscent::DetectStream) may ask for a tighter one (dn_ctx_set_event_bound: R10.4.1
+        // reads carry one event per 5-8 samples) -- event, alignment and trace arrays are sized from it: 13 of the 21 GB of a 500 x 50 kb batch
+        const uint64_t evcap = ns / c->ev_div + (c->ev_div > 2 ? 64 : 8);
         c->h_chunk_off[r + 1] = c->h_chunk_off[r] + nch;
         c->h_ev_off[r + 1] = c->h_ev_off[r] + evcap;
         c->h_aln_off[r + 1] = c->h_aln_off[r] + evcap + nb + 8;
@@ -711,6 +730,13 @@ int dn_batch_workspace_bytes(dn_ctx *c, const dn_batch_desc *d, uint64_t *bytes)
     *bytes = rc ? 0 : (uint64_t)c->last_need;
     return rc;
 }
+
+int dn_ctx_set_event_bound(dn_ctx *c, uint32_t samples_per_event) {
+    if (!c || samples_per_event < 2 || samples_per_event > 16) return DN_ERR_ARG;
+    c->ev_div = samples_per_event;
+    return DN_OK;
+}
+uint32_t dn_ctx_get_event_bound(const dn_ctx *c) { return c ? c->ev_div : 0; }
 
 int dn_ctx_reserve(dn_ctx *c, uint64_t workspace_bytes, uint64_t collect_bytes) {
     if (!c) return DN_ERR_ARG;
@@ -1298,7 +1324,7 @@ int dn_load_cnn(dn_ctx *c, const dn_cnn_op *ops, uint32_t n_ops, const float *we
     c->cnn_wh_off = wh_off; c->cnn_post = post; c->cnn_one.assign(n_ops, 1.0f);
     { const char *e = getenv("DN_CNN_MATH");
       if (e) c->cnn_math = strcmp(e, "fp32") == 0 ? DN_CNN_MATH_FP32 : strcmp(e, "bf16x6") == 0 ? DN_CNN_MATH_BF16X6 : DN_CNN_MATH_F16X3; }
-    c->cnn_f16_off = false;
+    c->cnn_f16_off = false; c->cnn_underflow_streak = 0;
     weights = wl.data();
     if (c->d_cnn_w) { hipFree(c->d_cnn_w); c->dev_bytes -= c->cnn_nw * sizeof(float); c->d_cnn_w = nullptr; }
     HIPCHK(c, hipMalloc((void **)&c->d_cnn_w, n_weights * sizeof(float)));
@@ -1320,8 +1346,24 @@ static uint64_t cnn_row_cap() {
 
 int dn_cnn_set_math(dn_ctx *c, int mode) {
     if (!c || (mode != DN_CNN_MATH_FP32 && mode != DN_CNN_MATH_BF16X6 && mode != DN_CNN_MATH_F16X3)) return DN_ERR_ARG;
-    c->cnn_math = mode; c->cnn_f16_off = false;
+    c->cnn_math = mode; c->cnn_f16_off = false; c->cnn_underflow_streak = 0;
     return DN_OK;
+}
+
+// A pass left fp16's range (word 0 of the range report: bit 0 = some split value > 65 504, bit 1 = a layer whose largest split value is < 2^-6) and is
+// repeated with bf16 pieces.  An OVERFLOW is a property of the model: the context stays on bf16 pieces.  An UNDERFLOW may be one odd batch (a tiny
+// batch, a layer that is nearly all zero after its ReLU): it is repeated on its own, and only a second one in a row switches the context over
+// (round-4 advisor: one such pass used to double the matrix work of every later batch).  Said once on stderr, with the reason.
+static void cnn_note_escalation(dn_ctx *c, unsigned flag) {
+    c->cnn_escalations++;
+    if (flag & 1u) c->cnn_f16_off = true;
+    else if (++c->cnn_underflow_streak >= 2) c->cnn_f16_off = true;
+    static bool said = false;
+    if (!said) {
+        said = true;
+        fprintf(stderr, "dnascent_hip: a CNN pass was repeated with bf16 pieces (%s); dn_cnn_range_escalations counts the repeats\n",
+                (flag & 1u) ? "an activation beyond fp16's range: the context stays on bf16 pieces" : "a whole layer below 2^-6: fp16's low pieces would be subnormal");
+    }
 }
 
 // the CNN over n sequences whose input tensors (core, residual, signal) are already on the device.
@@ -1365,6 +1407,7 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned
     { const uint64_t rr = (rows + 255) / 256 * 256; passes.push_back({ r0, n, (unsigned)rr, max_pos, pass_pos }); max_rows = std::max(max_rows, rr); }
     CnnLane *L = lane_get(c);
     if (!L) return fail(c, DN_ERR_HIP, "cannot create the CNN lane of device %d", c->device);
+    LaneUse lane_use(L);                                   // declared before the lock: released after it (a concurrent dn_shutdown sees the lane busy until then)
     std::lock_guard<std::mutex> lane_lock(L->mu);
     // A pass of a streamed batch holds between (cap - the longest read) and cap rows: sized by what THIS batch needs, the lane's buffers were freed and
     // reallocated every time a batch came a few rows closer to cap than any before it -- a hipFree (it waits for the whole device: every batch in flight
@@ -1404,7 +1447,7 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned
         run.row_off_w = (unsigned *)c->cnn_rowoff.p; run.live = (int *)L->live.p;
         // fp16 pieces are only valid while every activation fits fp16: the kernels raise range_flag otherwise and the pass is
         // repeated with bf16 pieces (same result contract, 2x the matrix work) -- never a silently wrong answer
-        for (int math = (c->cnn_math == DN_CNN_MATH_F16X3 && c->cnn_f16_off) ? DN_CNN_MATH_BF16X6 : c->cnn_math;;) {
+        for (int math = (c->cnn_math == DN_CNN_MATH_F16X3 && (c->cnn_f16_off || c->cnn_bf16_once)) ? DN_CNN_MATH_BF16X6 : c->cnn_math;;) {
             run.wts_split = math == DN_CNN_MATH_BF16X6 ? c->d_cnn_wb : math == DN_CNN_MATH_F16X3 ? c->d_cnn_wh : nullptr;
             run.wb_off = math == DN_CNN_MATH_F16X3 ? c->cnn_wh_off.data() : c->cnn_wb_off.data();
             run.pieces = math == DN_CNN_MATH_F16X3 ? 2 : 3;
@@ -1414,10 +1457,9 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned
             if (math != DN_CNN_MATH_F16X3 || !check_now) break;
             HIPCHK(c, hipMemcpyAsync(c->p_cnn_flag, c->d_cnn_flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
-            if (!*c->p_cnn_flag) break;
+            if (!*c->p_cnn_flag) { c->cnn_underflow_streak = 0; break; }
             HIPCHK(c, hipMemsetAsync(c->d_cnn_flag, 0, sizeof(unsigned), st));
-            c->cnn_escalations++;
-            c->cnn_f16_off = true;                          // this model's activations do not fit: stay on bf16 pieces from now on
+            cnn_note_escalation(c, *c->p_cnn_flag);
             math = DN_CNN_MATH_BF16X6;
         }
     }
@@ -1450,13 +1492,14 @@ static int cnn_settle(dn_ctx *c) {
     c->cnn_pending = false;
     if (c->p_cnn_flag && *c->p_cnn_flag) {
         HIPCHK(c, hipMemsetAsync(c->d_cnn_flag, 0, sizeof(unsigned), c->stream));
+        cnn_note_escalation(c, *c->p_cnn_flag);
         *c->p_cnn_flag = 0;
-        c->cnn_escalations++;
-        c->cnn_f16_off = true;
+        c->cnn_bf16_once = true;                               // this batch again with bf16 pieces, whatever the context does afterwards
         int rc = cnn_enqueue_batch(c);
+        c->cnn_bf16_once = false;
         if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
+    } else if (c->p_cnn_flag) c->cnn_underflow_streak = 0;
     return DN_OK;
 }
 

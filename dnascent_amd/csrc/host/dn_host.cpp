@@ -645,6 +645,15 @@ int DetectStream::collect(Result &out) {
     out.record_bytes.clear(); out.text.clear();
     const double a = now_s();
     int rc = dn_collect(c, &out.res);
+    if (rc == DN_ERR_OVERFLOW && dn_ctx_get_event_bound(c) > 2) {
+        // a read with more events than the tightened workspace bound holds (dn_ctx_set_event_bound): nothing was truncated silently -- the batch runs again on
+        // this context with the detector's own bound (one peak per two samples: cannot overflow), and the context keeps it.  Rare by construction; the
+        // regrown slab costs a device-wide wait once.
+        S.overflow_retries++;
+        const dn_batch_desc d = B.desc();
+        if ((rc = dn_ctx_set_event_bound(c, 2)) || (rc = dn_batch_upload(c, &d)) || (rc = dn_run_detect(c))) return rc;
+        rc = dn_collect(c, &out.res);
+    }
     if (rc) return rc;
     const double b = now_s();
     const dn_result_batch &res = out.res;

@@ -180,6 +180,7 @@ struct StreamStats {
     double seconds_total, seconds_upload, seconds_collect, seconds_emit;   // wall time of the call / spent inside uploads, collects, emission
     uint64_t reads, reads_ok, samples, calls, bytes_out, positions;        // positions: r.refCoordToAP entries of the passing reads (CNN rows)
     double seconds_run;                                                    // spent enqueueing the per-read body (dn_run_detect): launches + whatever the queue makes them wait for
+    uint64_t overflow_retries;                                             // batches run a second time with the detector's own event bound (dn_ctx_set_event_bound)
 };
 int streamDetect(dn_ctx **ctxs, int n_ctx, ReadBatch **batches, int n_batches, bool emit, const char *outPath, const char *header,
                  StreamStats *st, StreamKeep *keep = nullptr);

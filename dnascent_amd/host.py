@@ -14,7 +14,7 @@ class StreamStats(C.Structure):
     """DNAscent::StreamStats"""
     _fields_ = [("seconds_total", C.c_double), ("seconds_upload", C.c_double), ("seconds_collect", C.c_double), ("seconds_emit", C.c_double),
                 ("reads", C.c_uint64), ("reads_ok", C.c_uint64), ("samples", C.c_uint64), ("calls", C.c_uint64), ("bytes_out", C.c_uint64),
-                ("positions", C.c_uint64), ("seconds_run", C.c_double)]
+                ("positions", C.c_uint64), ("seconds_run", C.c_double), ("overflow_retries", C.c_uint64)]
 
 
 def lib():

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 4
+#define DN_ABI_VERSION 5
 #define DN_KMER 9            /* config.h:45 */
 #define DN_NKMER 262144      /* 4^9, data_IO.cpp:177 */
 #define DN_BANDWIDTH 100     /* config.h:41 AdaptiveBanded_Params.bandwidth */
@@ -208,6 +208,14 @@ int dn_collect(dn_ctx *ctx, dn_result_batch *out);
  * batches (the context's stream is waited for).  The reference has no counterpart: its per-read buffers are malloc'ed per read. */
 int dn_batch_workspace_bytes(dn_ctx *ctx, const dn_batch_desc *batch, uint64_t *bytes);
 int dn_ctx_reserve(dn_ctx *ctx, uint64_t workspace_bytes, uint64_t collect_bytes);
+/* ABI 5.  How many events a read's workspace holds: samples / samples_per_event + 64 (default 2: scrappie's detector cannot place more than one peak per
+ * two samples -- its shortest window is 3, event_detection.h:19-25 -- so that bound never overflows).  The event, alignment and trace arrays are sized from it
+ * (13 of the 21 GB of a 500 x 50 kb batch at the default); R10.4.1 reads carry one event per 5-8 samples, so a host that RETRIES may ask for 3 .. 16: a read
+ * with more events makes dn_collect return DN_ERR_OVERFLOW for its batch (nothing is truncated silently), and the host submits that batch again after
+ * dn_ctx_set_event_bound(ctx, 2) -- DNAscent::DetectStream::collect does exactly that.  Takes effect at the next dn_batch_upload.  The reference has no
+ * counterpart: event_detection.c:268-319 callocs per read. */
+int dn_ctx_set_event_bound(dn_ctx *ctx, uint32_t samples_per_event);
+uint32_t dn_ctx_get_event_bound(const dn_ctx *ctx);
 
 /* ---- intermediate taps (parity tests; NULL pointers are skipped) ----
  * Every tap takes `cap`: how many records (samples / events / k-mers / pairs / bands / positions / windows) EACH of the caller's arrays

@@ -5,11 +5,14 @@ over a large common offset) go through dn_cnn_infer -- the TF_SessionRun seam of
 MFMA, and are compared with a FLOAT64 rendering of the same raw parameters, so that the error of fp32 arithmetic itself (the stock-PyTorch
 fp32 rendering, and the device's exact-fp32 mode) is visible beside the split modes' instead of being mistaken for theirs.
 
-The bar of BASELINE.json is 1e-4 absolute on the probabilities against the reference's fp32 CPU path.  On the saturating families fp32
-itself is 5e-4 .. 9e-4 away from float64 (steep logits), so the assertion is: a split mode stays within 1e-4 of float64, OR within 1e-4 of
-what exact fp32 arithmetic does on the same model (the larger of the PyTorch fp32 rendering's and the device fp32 mode's own distance from
-float64) -- and when f16x3 leaves fp16's range the escalation must be counted and the answer must be bf16x6's, bit for bit.
-The observed table is printed (pytest -s) and written to gpurun_out/cnn_fuzz_table.txt for DESIGN.md s4b."""
+The bar of BASELINE.json is 1e-4 absolute on the probabilities against the reference's fp32 CPU path.  What is asserted (round-4 verdict item 5: "assert
+what north_star says, print what is true"), per (family, seed):
+  * the two fp32 renderings -- stock PyTorch fp32 on the CPU and the device's exact-fp32 MFMA mode, which differ only in summation order -- agree within
+    1e-4: the bar is DEFINED, and every split mode must be within 1e-4 of the PyTorch fp32 rendering.  No escape clause;
+  * they do not (saturating heads: fp32 itself moves by more than 1e-4 under re-association, so "within 1e-4 of the fp32 path" has no single answer):
+    reported as "bar undefined", and a split mode must then be no further from float64 than the worse of the two fp32 renderings is.
+When f16x3 leaves fp16's range the escalation must be counted and the answer must be bf16x6's, bit for bit.
+The observed table is printed (pytest -s) and written to gpurun_out/cnn_fuzz_table.txt for README.md / DESIGN.md s3."""
 import os
 
 import numpy as np
@@ -46,7 +49,8 @@ def test_precision_fuzz(family):
     for seed in (11, 12):
         desc, blob, ref = fz.build(family, seed, lens, core, resid, sig)
         want = _render(ref, lens, core, resid, sig, torch.float64)
-        e_t32 = float(np.abs(_render(ref, lens, core, resid, sig, torch.float32) - want).max())
+        t32 = _render(ref, lens, core, resid, sig, torch.float32)
+        e_t32 = float(np.abs(t32 - want).max())
         got, esc = {}, {}
         for math in ("fp32", "bf16x6", "f16x3"):
             ctx = hip.Context(0)
@@ -56,12 +60,16 @@ def test_precision_fuzz(family):
             esc[math] = ctx.cnn_range_escalations()
             ctx.close()
             assert np.isfinite(got[math]).all()
-        err = {m: float(np.abs(got[m] - want).max()) for m in got}
-        rows.append((family, seed, e_t32, err["fp32"], err["bf16x6"], err["f16x3"], esc["f16x3"]))
-        fp32_own = max(e_t32, err["fp32"])                 # what exact fp32 arithmetic itself does to this model
+        err = {m: float(np.abs(got[m] - want).max()) for m in got}            # distance from float64
+        vs_t32 = {m: float(np.abs(got[m] - t32).max()) for m in got}          # distance from the PyTorch fp32 rendering: what north_star's bar is about
+        defined = vs_t32["fp32"] <= TOL                     # do the two fp32 renderings agree?
+        rows.append((family, seed, e_t32, err["fp32"], err["bf16x6"], err["f16x3"], vs_t32["fp32"], vs_t32["bf16x6"], vs_t32["f16x3"],
+                     "defined" if defined else "UNDEFINED (fp32 itself moves by > 1e-4 under re-association)", esc["f16x3"]))
         for m in ("bf16x6", "f16x3"):
-            vs_fp32 = float(np.abs(got[m] - got["fp32"]).max())
-            assert err[m] <= TOL or vs_fp32 <= TOL or err[m] <= 1.5 * fp32_own, (family, seed, m, err, e_t32, vs_fp32)
+            if defined:
+                assert vs_t32[m] <= TOL, (family, seed, m, vs_t32, err)
+            else:
+                assert err[m] <= max(e_t32, err["fp32"]), (family, seed, m, err, e_t32)
         assert esc["fp32"] == 0 and esc["bf16x6"] == 0
         if esc["f16x3"]:                                    # out of fp16's range: repeated with bf16 pieces, and then it IS the bf16x6 answer
             assert np.array_equal(got["f16x3"], got["bf16x6"])
@@ -72,5 +80,6 @@ def test_precision_fuzz(family):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "cnn_fuzz_table.txt"), "a") as f:
         for r in rows:
-            line = "%-15s seed %d  max|dp| vs float64:  torch fp32 %.2e | device fp32 MFMA %.2e | bf16x6 %.2e | f16x3 %.2e  (f16x3 range escalations: %d)" % r
+            line = ("%-15s seed %d  max|dP| vs float64:  torch fp32 %.2e | device fp32 MFMA %.2e | bf16x6 %.2e | f16x3 %.2e   vs torch fp32:  device fp32 %.2e | "
+                    "bf16x6 %.2e | f16x3 %.2e   1e-4 bar %s  (f16x3 range escalations: %d)") % r
             print(line); f.write(line + "\n")

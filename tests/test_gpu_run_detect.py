@@ -87,3 +87,7 @@ def test_bench_two_ranks_gloo():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 3 and d["scaling"] == "weak"
     assert len(d["ranks"]["per_rank"]) == 2 and d["ranks"]["gather_s_max"] >= 0.0 and "gather_s" in d["host"]
     assert d["config"]["samples_per_gpu"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d          # the CPU leg runs at N = 1 only
+    # round-4 verdict item 6: K1's own roofline entry beside the banded one; at N > 1 a rank cycles through inflight + 2 distinct batches (4 steps here:
+    # all distinct) and says what generating them cost
+    assert d["roofline_k1"]["frac"] > 0 and d["roofline_k1"]["algorithmic_bytes_per_launch"] > 0 and 2.0 < d["roofline_k1"]["bytes_per_sample"] < 6.0
+    assert all(p["datagen_s"] > 0 and p["distinct_batches"] == 4 for p in d["ranks"]["per_rank"])
