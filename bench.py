@@ -249,6 +249,9 @@ def main():
     for c in ctxs:
         c.load_pore_model(model, 0.14)
         if full:
+            # event workspaces sized for one event per 4 samples instead of the detector's own bound of 2 (the synthetic R10.4.1 signal carries one per ~5.2;
+            # a batch that overflowed would be run again at 2 by DetectStream: `host.overflow_retries` below): 8 x 14.5 instead of 8 x 21 GB of HBM
+            c.set_event_bound(int(os.environ.get("DN_BENCH_EVENT_BOUND", "4")))
             c.load_cnn(cnn_desc, cnn_blob)
             if args.cnn_math:
                 c.cnn_set_math(args.cnn_math)
@@ -641,7 +644,7 @@ def main():
                                         "per-call results to rank 0, inside the timed region"}
             out["hbm"] = _hbm_info()
             out["host"] = {"datagen_s": t_gen, "upload_s": st.seconds_upload, "enqueue_s": st.seconds_run, "collect_wait_s": st.seconds_collect, "emit_s": st.seconds_emit,
-                           "gather_s": gather_s, "emission": {"records_per_s": st.calls / st.seconds_emit if st.seconds_emit > 0 else None,
+                           "gather_s": gather_s, "overflow_retries": int(st.overflow_retries), "emission": {"records_per_s": st.calls / st.seconds_emit if st.seconds_emit > 0 else None,
                                                               "MB_per_s": st.bytes_out / st.seconds_emit / 1e6 if st.seconds_emit > 0 else None,
                                                               "bytes": int(st.bytes_out)}}
         else:

@@ -16,7 +16,7 @@ HIP_SO = os.path.join(LIB, "libdnascent_hip.so")
 HOST_SO = os.path.join(LIB, "libdnascent_host.so")
 
 HIP_SOURCES = ["dn_capi.hip", "k1_segment.hip", "k2_banded.hip", "k_scaling.hip", "k2b_viterbi.hip", "k3_cnn.hip", "k_hmm.hip", "k_collect.hip"]
-HOST_SOURCES = ["host/dn_synth.c", "host/dn_host.cpp"]
+HOST_SOURCES = ["host/dn_synth.c", "host/dn_host.cpp", "host/dn_bam.cpp"]       # dn_bam.cpp: BGZF / BAM over zlib (libz is in the image; htslib is not)
 
 
 def _newer(target, deps):
@@ -72,7 +72,7 @@ def build_host(force=False):
         objs.append(o)
     # the host side calls the C-ABI: link it against libdnascent_hip.so sitting next to it
     _run(["g++", "-shared", "-fopenmp", "-o", HOST_SO] + objs +
-         ["-L", LIB, "-ldnascent_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-ldl"])
+         ["-L", LIB, "-ldnascent_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-ldl", "-lz"])
     return HOST_SO
 
 

@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include <memory>
+#include <map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -49,6 +50,63 @@ struct ReadInput {                     // what reads.h:210-287 + pod5.cpp:24-93 
     std::vector<uint32_t> cigarOp, cigarLen;            // BAM order
     int refStart = 0; bool isReverse = false;
 };
+
+// ---- BAM without htslib (host/dn_bam.cpp: BGZF + BAM records from the SAM/BAM specification, over zlib) ----
+struct BamRef { std::string name; uint32_t len; };
+class BgzfReader {
+public:
+    ~BgzfReader();
+    bool open(const std::string &path);
+    size_t read(void *dst, size_t n);                   // bytes of the uncompressed stream; short only at the end of the file or on a malformed block
+    bool failed() const { return bad; }
+    void close();
+private:
+    bool fill();
+    void *f = nullptr; std::vector<uint8_t> buf; size_t pos = 0; bool eof = false, bad = false;
+};
+class BgzfWriter {
+public:
+    ~BgzfWriter();
+    bool open(const std::string &path);
+    bool write(const void *src, size_t n);
+    bool close();                                        // flushes, appends the EOF marker block
+private:
+    bool block(const uint8_t *p, size_t n);
+    void *f = nullptr; std::vector<uint8_t> buf; bool ok = false;
+};
+struct BamRecord {                                       // one alignment record (SAMv1 s4.2)
+    std::vector<uint8_t> raw;                            // the record as stored, behind its block_size (passed through unchanged by BamWriter)
+    int32_t refID = -1, pos = -1, l_seq = 0; uint8_t mapq = 0; uint16_t flag = 0;
+    std::string qname, seq;                              // seq decoded from the 4-bit codes "=ACMGRSVTWYHKDBN"
+    std::vector<uint32_t> cigarOp, cigarLen;             // BAM operation codes M I D N S H P = X -> 0 .. 8; a CG:B,I tag (> 65 535 operations) is resolved
+    size_t aux_off = 0;                                  // where the auxiliary fields start in raw
+    long auxFind(const char *tag) const;                 // offset of the field's tag bytes in raw, -1 if absent
+    bool auxInt(const char *tag, int64_t &v) const;      // bam_aux2i: any of c C s S i I
+    bool auxStr(const char *tag, std::string &s) const;  // Z / H
+    int64_t refLength() const;                           // reference bases the CIGAR spans (bam_endpos - pos)
+};
+class BamReader {
+public:
+    bool open(const std::string &path);                  // magic, header text, reference dictionary
+    int next(BamRecord &r);                              // 1 a record, 0 end of file, -1 malformed
+    const std::string &headerText() const { return text_; }
+    const std::vector<BamRef> &refs() const { return refs_; }
+private:
+    BgzfReader z; std::string text_; std::vector<BamRef> refs_;
+};
+class BamWriter {                                        // detect.h:62-97 SamWriter: header, then records
+public:
+    bool open(const std::string &path, const std::string &headerText, const std::vector<BamRef> &refs);
+    bool writeRaw(const std::vector<uint8_t> &raw);
+    bool writeWithMods(const BamRecord &r, const std::string &mmFields, const std::vector<uint8_t> &ml);      // reads.h:453-512 writeModBamTag
+    bool close();
+private:
+    BgzfWriter z;
+};
+struct ReadInput;
+// reads.h:210-287: the record's fields -> ReadInput (no signal: in.adc stays null; fetchID = the POD5 read to fetch).  0 ok, -1 unmapped / empty, -2 not in
+// the reference, -3 a base other than A C G T N (htsInterface.cpp:160-178 throws)
+int readInputFromBam(const BamRecord &r, const std::vector<BamRef> &refs, const std::map<std::string, std::string> &reference, ReadInput &in, std::string &fetchID);
 
 // htsInterface.cpp:59-157 flattened: ref2query[refLen], ref2del[refLen], query2ref[queryLen+1] (-1 = absent key)
 int parseCigar(const std::vector<uint32_t> &ops, const std::vector<uint32_t> &lens, bool isReverse, size_t queryLen,

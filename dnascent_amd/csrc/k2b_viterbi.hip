@@ -168,10 +168,33 @@ template <int TMAX> struct K2bLds {
     unsigned short evlab[TMAX];                           // label of the state that emitted observation t: state << 8 | position
     unsigned char bt[(TMAX + 1) * VT_NS];                 // backtrace codes: I 2 bits | M 3 bits | D 2 bits
 };
+// K2B_WAVES_EU (round-4 verdict item 4): a register budget for this kernel.  With its LDS declared statically (88 KB per four-read workgroup) the compiler
+// knows one workgroup fits a CU, i.e. one wavefront per SIMD, and takes all the registers it likes (175; amdgpu_waves_per_eu / amdgpu_num_vgpr are ignored
+// against that bound); a budget only binds when the LDS is DYNAMIC (the compiler then cannot bound the occupancy by it) and __launch_bounds__ names the
+// wavefronts per SIMD.  Measured, bit-identical digests, one session (gpurun_out/r5g/ab.txt; 12 steps of the default bench, twice each):
+//     0  static LDS, no budget     175 registers, 133 spilled scalars    kernel alone 70.4 ms   pipeline 789.6 / 788.8 Msamples/s
+//     3  dynamic LDS, 168 budget   168 registers, 135 spilled scalars                 65.4                796.2 / 805.5   (+1.5 %)   <- default
+//     4  dynamic LDS, 128 budget   128 registers + 33 spilled to scratch (136 B per lane)  87.7           778.5 / 781.9
+// The verdict's 128-register form exists only with vector spills in the lattice loop: the kernel's real need is ~160 registers (12 constants + 15 lattice
+// states + the traceback's 24 block registers as fp64 / dword pairs, beside ~60 live pointers of BatchDev / EaDev that the scalar file cannot hold).
+#ifndef K2B_WAVES_EU
+#define K2B_WAVES_EU 3
+#endif
+#if K2B_WAVES_EU > 0
+#define K2B_BOUNDS(threads) __launch_bounds__(threads, K2B_WAVES_EU)
+#else
+#define K2B_BOUNDS(threads) __launch_bounds__(threads)
+#endif
+static_assert(sizeof(K2bLds<VT_TFAST>) * K2B_W <= 160 * 1024 && sizeof(K2bLds<VT_TMAX>) <= 160 * 1024, "K2B_W wavefronts' lattices must fit gfx950's 160 KB of LDS per CU");
 template <int TMAX>
-__global__ __launch_bounds__(64 * (TMAX <= VT_TFAST ? K2B_W : 1)) void k2b_eventalign(BatchDev B, EaDev O, const VitRead *vrs, VitConsts vc, int mode) {
+__global__ K2B_BOUNDS(64 * (TMAX <= VT_TFAST ? K2B_W : 1)) void k2b_eventalign(BatchDev B, EaDev O, const VitRead *vrs, VitConsts vc, int mode) {
     constexpr int WPB = TMAX <= VT_TFAST ? K2B_W : 1;     // the 512-observation lattice holds 50 KB: one per workgroup as before (it runs for a handful of windows)
+#if K2B_WAVES_EU > 0
+    extern __shared__ __attribute__((aligned(16))) unsigned char k2b_dyn_lds_[];
+    K2bLds<TMAX> *lds_ = reinterpret_cast<K2bLds<TMAX> *>(k2b_dyn_lds_);
+#else
     __shared__ __attribute__((aligned(16))) K2bLds<TMAX> lds_[WPB];
+#endif
     K2bLds<TMAX> &L_ = lds_[WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0];
     double *xs = L_.xs; unsigned *tk_start = L_.tk_start, *tk_len = L_.tk_len, *ev_slot = L_.ev_slot, *ev_cnt0 = L_.ev_cnt0, *ps_p = L_.ps_p, *ps_cnt = L_.ps_cnt;
     unsigned short *evlab = L_.evlab; unsigned char *bt = L_.bt; unsigned *ev_aoff = L_.ev_aoff;
@@ -606,9 +629,17 @@ void k2b_launch(const BatchDev &B, const void *ea, const void *vr, const void *v
     const VitConsts V = *reinterpret_cast<const VitConsts *>(vc);
     hipMemsetAsync(O.redo, 0, (size_t)B.n_reads, st);
     const dim3 gf((B.n_reads + K2B_W - 1) / K2B_W), bf(64 * K2B_W);
-    hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, gf, bf, 0, st, B, O, (const VitRead *)vr, V, 0);
-    hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), 0, st, B, O, (const VitRead *)vr, V, 1);
-    hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, gf, bf, 0, st, B, O, (const VitRead *)vr, V, 2);
-    hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), 0, st, B, O, (const VitRead *)vr, V, 3);
+    const size_t lf = K2B_WAVES_EU > 0 ? sizeof(K2bLds<VT_TFAST>) * K2B_W : 0, lm = K2B_WAVES_EU > 0 ? sizeof(K2bLds<VT_TMAX>) : 0;     // dynamic LDS of the budgeted build
+    if (K2B_WAVES_EU > 0) {
+        static const bool once = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k2b_eventalign<VT_TFAST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(K2bLds<VT_TFAST>) * K2B_W));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k2b_eventalign<VT_TMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K2bLds<VT_TMAX>));
+            return true; }();
+        (void)once;
+    }
+    hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, gf, bf, lf, st, B, O, (const VitRead *)vr, V, 0);
+    hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), lm, st, B, O, (const VitRead *)vr, V, 1);
+    hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, gf, bf, lf, st, B, O, (const VitRead *)vr, V, 2);
+    hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), lm, st, B, O, (const VitRead *)vr, V, 3);
     hipLaunchKernelGGL(k2b_features, dim3((max_ref + 255) / 256, B.n_reads), dim3(256), 0, st, B, O);
 }

@@ -86,10 +86,12 @@ def main(argv=None):
     ap.add_argument("--prefetch", type=int, default=3, help="batches loaded ahead of the one being submitted (loader threads)")
     ap.add_argument("--backend", default=os.environ.get("DN_BACKEND", "nccl"))
     ap.add_argument("--central-writer", action="store_true", help="round 4's form: packed results gathered to rank 0 and formatted there")
+    ap.add_argument("--event-bound", type=int, default=4, help="samples per event the workspaces are sized for (2 = the detector's own bound; a batch that overflows a tighter one is re-run at 2)")
     ap.add_argument("--header", default=None, help="text written before the records (e.g. DNAscent::writeDetectHeader)")
     ap.add_argument("--stats", default=None, help="rank 0 writes a JSON with per-rank busy / gather seconds, batches, peak buffered bytes")
     a = ap.parse_args(argv)
 
+    t_proc = time.time()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     dev_t = "cpu"
@@ -114,11 +116,31 @@ def main(argv=None):
         if rank == 0:
             print("run_detect: NO --model given: the CNN runs seeded RANDOM weights; the probabilities are synthetic", file=sys.stderr)
     ndev = max(1, hip.lib().dn_device_count())
+    t_ctx = time.time()
     ctxs = [hip.Context(local % ndev) for _ in range(max(1, min(a.inflight, max(1, len(batches)))))]
     for c in ctxs:
         c.load_pore_model(pore, 0.14)
         c.load_cnn(desc, blob)
-    engine = host.DetectStream(ctxs, emit="packed")
+        # a read's event workspace: samples / 4 + 64 instead of the detector's own bound samples / 2 (R10.4.1: one event per 5-8 samples) -- 14.5 instead of
+        # 21 GB per 300 M-sample context, less to hipMalloc before the first batch; a batch that does overflow is run again at the safe bound by DetectStream
+        c.set_event_bound(a.event_bound)
+    t_ctx = time.time() - t_ctx
+    import threading
+    ready = [threading.Event() for _ in ctxs]
+
+    class GatedStream:
+        """DetectStream whose later contexts may still be getting their workspace (a helper thread, below): submit() waits for the context the batch
+        lands on -- the k-th submission goes to context k mod n"""
+
+        def __init__(self, inner):
+            self.inner, self.k = inner, 0
+            self.full, self.in_flight, self.collect, self.stats, self.close = inner.full, inner.in_flight, inner.collect, inner.stats, inner.close
+
+        def submit(self, batch, tag):
+            ready[self.k % len(ready)].wait()
+            self.k += 1
+            self.inner.submit(batch, tag)
+    engine = GatedStream(host.DetectStream(ctxs, emit="packed"))
     free = []
 
     def load(ords):                                            # runs on the driver's loader threads (two at a time)
@@ -158,18 +180,45 @@ def main(argv=None):
     # set-up, not part of the stream: every context gets its workspace now (a 10+ GB hipMalloc), sized from the plan's first batch -- window 0's
     # longest reads at the full sample budget -- scaled to the largest planned batch, + 4 % for batches of other composition (more, shorter
     # reads): regrowing a slab later frees the old one, and hipFree waits for the WHOLE device, i.e. drains every batch in flight
+    # Round 5: only the FIRST context is prepared before the stream starts; the others get theirs from a helper thread while the first batches already run
+    # (hipMalloc does not drain the device -- only the hipFree of a regrowth did).  The stream's k-th submission waits for context k mod n (GatedStream).
     pre = {}
     setup_exc = None
+    bg_exc = []
+    bg = None
     try:
         if len(batches):
             b0, acc0 = load(batches[0])
             if b0.size():
                 per_sample = ctxs[0].workspace_bytes(b0.desc()) / max(1, b0.samples())
                 biggest = max(int(sizes[b].sum()) for b in batches)
-                for c in ctxs:
-                    c.reserve(int(per_sample * biggest * 1.04), collect_bytes=int(biggest / 12.5 * 0.3 * 29 * 1.3))
-                    b0.upload(c)                               # the side tables (per-read mirrors, CNN lane buffers) take their size from a real batch
+                want = (int(per_sample * biggest * 1.04), int(biggest / 12.5 * 0.3 * 29 * 1.3))
+
+                def prepare(c, bt):
+                    c.reserve(want[0], collect_bytes=want[1])
+                    bt.upload(c)                               # the side tables (per-read mirrors) take their size from a real batch
                     c.sync()
+                prepare(ctxs[0], b0)
+
+                def prepare_rest():
+                    try:
+                        bb, _ = load(batches[0])               # its own copy: batch 0 itself may be collected, released and refilled by the loader meanwhile
+                        for k in range(1, len(ctxs)):
+                            prepare(ctxs[k], bb)
+                            ready[k].set()
+                        free.append(bb)
+                    except BaseException as e:                 # noqa: BLE001
+                        bg_exc.append(e)
+                        try:
+                            drv.counter.abort()
+                        except Exception:
+                            pass
+                    finally:
+                        for ev in ready:
+                            ev.set()
+                if len(ctxs) > 1:
+                    bg = threading.Thread(target=prepare_rest, name="dn-prepare", daemon=True)
+                    bg.start()
             pre[0] = (b0, acc0)                                # whichever rank pulls batch 0 submits this copy instead of reading it again
     except BaseException as e:                                 # noqa: BLE001 -- a rank that cannot even set up raises the shared abort flag and still walks the windows:
         setup_exc = e                                          # its peers stop at once instead of waiting for the store's timeout (round-4 advisor)
@@ -177,6 +226,11 @@ def main(argv=None):
             drv.counter.abort()
         except Exception:
             pass
+    if bg is None:
+        for ev in ready:
+            ev.set()
+    else:
+        ready[0].set()
     t_setup = time.time() - t0
     drv.preloaded = pre
     t_stream = time.time()
@@ -185,10 +239,23 @@ def main(argv=None):
     for bl, _ in drv.preloaded.values():                       # batch 0 as loaded for the set-up, on the ranks that did not pull it: back to the pool
         free.append(bl)
     drv.preloaded = {}
+    if bg is not None:
+        bg.join()
+    if setup_exc is None and bg_exc:
+        setup_exc = bg_exc[0]
     if setup_exc is not None:
         ok = False
         drv.failure = drv.failure or setup_exc
     st = engine.stats()
+    hbm_info = None
+    try:                                                       # device memory in use at the end of the stream (every context, every CNN lane): hipMemGetInfo
+        import ctypes
+        rt = ctypes.CDLL("libamdhip64.so")
+        fr, totl = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        if rt.hipMemGetInfo(ctypes.byref(fr), ctypes.byref(totl)) == 0:
+            hbm_info = {"used_GB": round((totl.value - fr.value) / 1e9, 1), "total_GB": round(totl.value / 1e9, 1)}
+    except OSError:
+        pass
     tot = shard.reduce_counters(dist, [drv.n_ok, drv.n_fail, int(st.samples), 0 if ok else 1], device=dev_t)
     if drv.failure is not None:
         print("run_detect: rank %d aborted: %r" % (rank, drv.failure), file=sys.stderr)
@@ -214,15 +281,21 @@ def main(argv=None):
                    max(p["gather_s"] for p in per_rank), drv.format_s, max(p["peak_buffered_bytes"] for p in per_rank) / 1e6))
         if a.stats:
             json.dump(dict(world=world, batches=len(batches), windows=drv.n_windows, seconds=dt, samples=tot[2], Msamples_per_s=tot[2] / 1e6 / dt,
+                           imports_s=round(t0 - t_proc, 3), contexts_s=round(t_ctx, 3), event_bound=a.event_bound, overflow_retries=int(st.overflow_retries),
+                           hbm=hbm_info,
                            reads_ok=tot[0], reads_failed=tot[1], text_bytes=int(drv.text_bytes), index_s=round(t_index, 3), inflight=len(ctxs),
                            setup_s=round(t_setup, 3), stream_s=round(t_stream, 3), Msamples_per_s_stream=tot[2] / 1e6 / t_stream,
                            recv_groups=drv.stats.get("recv_groups", []), ranks=per_rank, failed=failed), open(a.stats, "w"))
+    t_close = time.time()
     engine.close()
     for c in ctxs:
         c.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and not failed:
+        print("run_detect: process %.2f s = imports %.2f + index / plan %.2f + contexts %.2f + first workspace %.2f + stream %.2f + close %.2f (+ counters, stats)" % (
+            time.time() - t_proc, t0 - t_proc, t_index, t_ctx, t_setup - t_index - t_ctx, t_stream, time.time() - t_close))
     return 1 if failed else 0
 
 

@@ -88,3 +88,43 @@ def test_kernel_variants_behind_switches_are_bit_identical():
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "variant_check.py")
     out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0 and "variants agree: True" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_event_bound_overflow_is_reported_and_retried(model):
+    """ABI 5 (dn_ctx_set_event_bound): a context whose event workspaces are sized tighter than the detector's own bound must never truncate silently --
+    dn_collect reports DN_ERR_OVERFLOW for the batch -- and DNAscent::DetectStream runs that batch again at the safe bound: same records as a context that
+    never had the tight bound, one retry counted, the context left at the safe bound."""
+    from dnascent_amd import cnn_model
+    desc, blob, _ = cnn_model.default_model()
+    reads = [synth.make_read(7300 + i, 3000 + 400 * i, model=model, is_reverse=bool(i & 1)) for i in range(5)]
+
+    def stream(bound):
+        ctx = hip.Context(0)
+        ctx.load_pore_model(model, 0.14); ctx.load_cnn(desc, blob)
+        if bound:
+            ctx.set_event_bound(bound)
+        b = host.ReadBatch()
+        for r in reads:
+            assert b.add_synth(r) >= 0
+        ds = host.DetectStream([ctx], emit=True)
+        ds.submit(b, 7)
+        out = ds.collect()
+        st = ds.stats()
+        ds.close()
+        left = int(hip.lib().dn_ctx_get_event_bound(ctx.h))
+        ctx.close()
+        return out["text"], out["status"].tolist(), int(st.overflow_retries), left
+    want, st_w, r_w, b_w = stream(0)
+    assert r_w == 0 and b_w == 2 and want.count(b">") == 5
+    got, st_g, r_g, b_g = stream(16)                        # samples / 16 + 64 events: these reads carry one event per ~5 samples
+    assert r_g == 1 and b_g == 2 and st_g == st_w and got == want
+    got4, _, r_4, b_4 = stream(4)                           # the drivers' bound: holds
+    assert r_4 == 0 and b_4 == 4 and got4 == want
+    # without a retrying host the overflow is an error, never a truncated result
+    ctx = hip.Context(0)
+    ctx.load_pore_model(model, 0.14); ctx.load_cnn(desc, blob); ctx.set_event_bound(16)
+    _batch(ctx, reads)
+    ctx.run("detect")
+    with pytest.raises(hip.DnError):
+        ctx.collect()
+    ctx.close()
