@@ -23,7 +23,7 @@
 // layer-by-layer path (tools/k3_block64_check.hip compares the two on the device, tools/variant_check.py the whole pipeline).  f16x3 only; the other
 // arithmetics (and any description that does not have this block shape) run layer by layer.
 //
-// LDS (153 216 B of the CU's 163 840): rings 6 x 2 x 32 x 272, halos 6 x 4 x 272, A planes 6 x 2 x 32 x 80, shortcut planes 2 x 2 x 36 x 80.
+// LDS (163 648 B of the CU's 163 840): rings 6 x 2 x 32 x 272, halos 5 x 4 x 272, A planes 6 x 2 x 32 x 80, shortcut planes 2 x 2 x 2 x 36 x 80.
 // One workgroup per CU, two wavefronts per SIMD: SIMD pairs (stage 0, stage 1), (stage 2, stage 3), (stage 4, shortcut tile 0), (stage 5, shortcut tile 1).
 #pragma once
 
@@ -47,6 +47,9 @@ struct B64Args {
     const float *cscale, *cshift; unsigned *crange; float cpost; int crelu;
 };
 
+#ifndef B64_ABL
+#define B64_ABL 0                                           /* experiment builds of tools/k3_block64_check.hip (TIMING ONLY, wrong results): 1 = no ring reads, 2 = no ring writes, 4 = the A planes' LDS round trip replaced by a register dependency */
+#endif
 #ifdef B64_TRACE                                            /* experiment builds only (tools/k3_block64_check.hip -DB64_TRACE=<workgroup>): shader-clock stamps of one step's phases */
 #ifndef B64_TRACE_STEP
 #define B64_TRACE_STEP 40
@@ -85,9 +88,40 @@ __device__ __forceinline__ const void *b64_uniform_ptr(const void *p) {
 #define B64_CONV_START (B64_START(5) + 1)
 #define B64_DEFERS(st) (B64_STAGGER && ((st) == 1 || (st) == 3))
 
-// the split of 8 filtered rows x 2 channels into the fp16 planes (+ the range report's largest |value|; MASKED: rows outside the pass do not count)
+// the split of 8 filtered rows x 2 channels into the fp16 planes (+ the range report's largest |value|; MASKED: rows outside the pass do not count).
+// B64_SPLIT_WIDE (default): the five steps of the split run ACROSS the eight rows -- eight independent instructions per step -- instead of row by row (the
+// compiler interleaved two rows: dependent vector instructions of one wavefront issue ~8 ticks apart, and the phase took 800-1 700 ticks for ~70 instructions).
+#ifndef B64_SPLIT_WIDE
+#define B64_SPLIT_WIDE 1
+#endif
 template <bool MASKED>
 __device__ __forceinline__ void b64_split_store(const b64f2 (&o)[8], float &am, uint16_t *ap, const int g0, const int rows) {
+    if (B64_SPLIT_WIDE) {
+        b64h2 h[8], l[8]; b64f2 back[8], rest[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) h[i] = __builtin_convertvector(o[i], b64h2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; i++) back[i] = __builtin_convertvector(h[i], b64f2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; i++) rest[i] = o[i] - back[i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; i++) l[i] = __builtin_convertvector(rest[i], b64h2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { *reinterpret_cast<b64h2 *>(ap + i * CNN_BP) = h[i]; *reinterpret_cast<b64h2 *>(ap + B64_APL + i * CNN_BP) = l[i]; }
+        float m0 = 0.0f, m1 = 0.0f;                        // two chains for the maximum
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            float m = __builtin_fmaxf(__builtin_fabsf(o[i][0]), __builtin_fabsf(o[i][1]));
+            if (MASKED) { const int g = g0 + i; m = (g >= 0 && g < rows) ? m : 0.0f; }
+            if (i & 1) m1 = __builtin_fmaxf(m1, m); else m0 = __builtin_fmaxf(m0, m);
+        }
+        am = __builtin_fmaxf(am, __builtin_fmaxf(m0, m1));
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         float m = __builtin_fmaxf(__builtin_fabsf(o[i][0]), __builtin_fabsf(o[i][1]));
@@ -153,6 +187,9 @@ __device__ __forceinline__ void b64_stage(const B64Args &A, const int st, const 
     const b64f2 sc = {P.scale[2 * n] * P.post, P.scale[2 * n + 1] * P.post}, sh = {P.shift[2 * n], P.shift[2 * n + 1]};
     const float floor_ = P.relu ? 0.0f : -3.402823466e38f;
     float amax = 0.0f;
+#ifdef B64_YOUNG_PRIO
+    if (st == 1 || st == 3) __builtin_amdgcn_s_setprio(B64_YOUNG_PRIO);      // experiment: wavefronts 4, 5 are the second-dispatched partners of stages 0, 2 and lose the issue arbitration by age (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+#endif
     // ---- first stage: the input chunk travels global -> registers, requested one chunk ahead.  Lane (cpl, rq) of channel block cb needs rows
     //      XC - 4 + 8 rq + j, j = 0 .. 11 (XC = first row of the input chunk): 8 bytes each, a 16-lane group reads 128 contiguous bytes of a row.
     //      Rows outside [0, rows) fall outside the descriptor and read as the zeros 'same' padding wants.
@@ -176,6 +213,13 @@ __device__ __forceinline__ void b64_stage(const B64Args &A, const int st, const 
         float *wrow = rout + (c & 1) * B64_RING + 4 * hh * B64_RP + 2 * n;
         const int ybase = ((S0 - 20 - 2 * (st + 1) + 32 * c + 4 * hh) * 64 + 2 * n) * 4;
         if (TO_GLOBAL && c == 0) return;                   // the warm-up chunk's rows belong to the previous stripe
+        if ((B64_ABL & 2) && !TO_GLOBAL) {                  // keep the sums alive without the ring stores
+            float keep = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; q++) keep += acc[0][q] * sc[0] + acc[1][q] * sc[1];
+            if (keep == 1234.5f) wrow[0] = keep;
+            return;
+        }
         if (vm == 0xffffffffu) b64_epilogue<false, TO_GLOBAL>(acc, sc, sh, floor_, vml, wrow, rY, ybase);
         else { asm volatile("; chunk with padding rows" ::: "memory"); b64_epilogue<true, TO_GLOBAL>(acc, sc, sh, floor_, vml, wrow, rY, ybase); }
     };
@@ -204,6 +248,10 @@ __device__ __forceinline__ void b64_stage(const B64Args &A, const int st, const 
 #pragma unroll
                     for (int j = 0; j < 12; j++) x[j] = __builtin_bit_cast(b64f2, xp[cb][j]);
                 } else {
+                    if (B64_ABL & 1) {
+#pragma unroll
+                        for (int j = 0; j < 12; j++) x[j] = tw[cb][j % 5] + b64f2{(float)s, (float)j};
+                    } else {
                     const float *p4 = rb + 8 * rq * B64_RP + cb * 32 + 2 * cpl;            // in[8 rq + 4] = row 8 rq of the chunk
                     const float *pa = rq == 0 ? hal + cb * 32 + 2 * cpl : p4 - 4 * B64_RP; // in[8 rq]: the halo for row quarter 0, else four rows further up in the chunk
 #pragma unroll
@@ -213,6 +261,7 @@ __device__ __forceinline__ void b64_stage(const B64Args &A, const int st, const 
                     if (rq == 3) {                         // the chunk's last four rows are the next chunk's halo (the reads above were issued first: LDS keeps a wavefront's order)
 #pragma unroll
                         for (int r = 0; r < 4; r++) *reinterpret_cast<b64f2 *>(hal + r * B64_RP + cb * 32 + 2 * cpl) = x[8 + r];
+                    }
                     }
                 }
                 B64_T(st, 1 + 4 * cb);
@@ -232,14 +281,30 @@ __device__ __forceinline__ void b64_stage(const B64Args &A, const int st, const 
                 if (KIND == 0) gloadX(c + 1, cb);           // the same rows of the next chunk (past the stripe: loaded, never used)
                 // ---- split into the two fp16 pieces -> this stage's A planes ----
                 uint16_t *ap = Ap + 8 * rq * CNN_BP + 2 * cpl;
+                if (B64_ABL & 4) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {              // the split's arithmetic without the planes: the pieces stay in o[] for the register "fragments"
+                        am = __builtin_fmaxf(am, __builtin_fmaxf(__builtin_fabsf(o[i][0]), __builtin_fabsf(o[i][1])));
+                        const b64h2 h = __builtin_convertvector(o[i], b64h2);
+                        const b64f2 rest = o[i] - __builtin_convertvector(h, b64f2);
+                        const b64h2 l = __builtin_convertvector(rest, b64h2);
+                        o[i] = b64f2{__builtin_bit_cast(float, h), __builtin_bit_cast(float, l)};
+                    }
+                } else
                 if (!edge) b64_split_store<false>(o, am, ap, 0, 0);
                 else { asm volatile("; chunk at an end of the pass" ::: "memory"); b64_split_store<true>(o, am, ap, og0 + 8 * rq, rows); }
                 B64_T(st, 3 + 4 * cb);
                 // ---- pointwise: 32 rows x 64 columns, K = this channel block; pieces l h', h l', h h' per k16 as in k3_sep_split ----
 #pragma unroll
                 for (int k16 = 0; k16 < 2; k16++) {
-                    const u32x4 ah = *reinterpret_cast<const u32x4 *>(Ap + n * CNN_BP + k16 * 16 + 8 * hh);
-                    const u32x4 al = *reinterpret_cast<const u32x4 *>(Ap + B64_APL + n * CNN_BP + k16 * 16 + 8 * hh);
+                    u32x4 ah, al;
+                    if (B64_ABL & 4) {
+                        ah = u32x4{__builtin_bit_cast(unsigned, o[4 * k16][0]), __builtin_bit_cast(unsigned, o[4 * k16 + 1][0]), __builtin_bit_cast(unsigned, o[4 * k16 + 2][0]), __builtin_bit_cast(unsigned, o[4 * k16 + 3][0])};
+                        al = u32x4{__builtin_bit_cast(unsigned, o[4 * k16][1]), __builtin_bit_cast(unsigned, o[4 * k16 + 1][1]), __builtin_bit_cast(unsigned, o[4 * k16 + 2][1]), __builtin_bit_cast(unsigned, o[4 * k16 + 3][1])};
+                    } else {
+                    ah = *reinterpret_cast<const u32x4 *>(Ap + n * CNN_BP + k16 * 16 + 8 * hh);
+                    al = *reinterpret_cast<const u32x4 *>(Ap + B64_APL + n * CNN_BP + k16 * 16 + 8 * hh);
+                    }
 #pragma unroll
                     for (int j = 0; j < 2; j++) acc[j] = mfma16<2>(al, bw[cb][k16][0][j], acc[j]);
 #pragma unroll
@@ -261,9 +326,13 @@ __device__ __forceinline__ void b64_stage(const B64Args &A, const int st, const 
     range_report(amax, P.range, lane);
 }
 
-// The shortcut convolution + Add + ReLU as the pipeline's last stage: column tile ct (32 output channels) of chunk s - B64_CONV_START.
+// The shortcut convolution + Add + ReLU as the pipeline's last stage: column tile ct (32 output channels) of chunk s - B64_CONV_START.  The two wavefronts
+// SHARE the fp16 planes of the 36 input rows (round 5, second version): wavefront ct splits channel block ct of the NEXT chunk's rows into the planes (double-
+// buffered by chunk parity; the step barrier orders the hand-over), and both multiply the current chunk out of the planes written a step earlier.  In the
+// first version each split all 64 channels for itself: its stamps showed the shortcut wavefronts at 6 300 ticks per step with every LDS round trip of the
+// separable stages ablated away -- they, not the stages, set the step -- and 2 x ~1 000 of those ticks were the split.
 __device__ __forceinline__ void b64_conv(const B64Args &A, const int ct, const int lane, const int S0, const int nch, const int nsteps, const int rows,
-                                         const float *r5, uint16_t *Ac) {
+                                         const float *r5, uint16_t *Acv) {
     const int n = lane & 31, hh = lane >> 5;
     u32x4 wc[2][5][2][2];                                  // [channel block][tap][k16][piece] of output channel 32 ct + n: 160 registers
 #pragma unroll
@@ -281,22 +350,45 @@ __device__ __forceinline__ void b64_conv(const B64Args &A, const int ct, const i
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b64_uniform_ptr(A.X)), 0, rows * 256, 0x00020000);
     const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b64_uniform_ptr(A.Y)), 0, rows * 256, 0x00020000);
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b64_uniform_ptr(A.valid)), 0, rows, 0x00020000);
-    // the 36 input rows x 32 channels of a channel block are 288 float4: lane takes f = lane + 64 p, p = 0 .. 4 (the fifth only on lanes 0-31); both
-    // channel blocks of the NEXT chunk are requested while this one is multiplied (a whole step for the rows to arrive: the first version asked half a step
-    // ahead and its stamps showed the split waiting for them)
-    f32x4 xr[2][5];
-    auto gloadX = [&](int c, int cb) {
-        const int base = ((S0 - 32 + 32 * c - 2) * 64 + cb * 32) * 4;
+    // the 36 input rows x 32 channels of this wavefront's channel block are 288 float4: lane takes f = lane + 64 p, p = 0 .. 4 (the fifth only on lanes 0-31),
+    // requested a whole step before they are split (two steps before they are multiplied)
+    f32x4 xr[5];
+    auto gloadX = [&](int c) {
+        const int base = ((S0 - 32 + 32 * c - 2) * 64 + ct * 32) * 4;
 #pragma unroll
         for (int p = 0; p < 5; p++) {
             const int f = lane + 64 * p;
-            xr[cb][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, base + ((f >> 3) * 64 + (f & 7) * 4) * 4, 0, 0));
+            xr[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, base + ((f >> 3) * 64 + (f & 7) * 4) * 4, 0, 0));
         }
     };
-    gloadX(1, 0); gloadX(1, 1);
+    gloadX(1);
+#ifdef B64_CONV_PRIO
+    __builtin_amdgcn_s_setprio(B64_CONV_PRIO);             // experiment: the shortcut wavefronts set the step; let them win the issue arbitration against their stage partner
+#endif
     for (int s = 0; s < nsteps; s++) {
         const int c = s - B64_CONV_START;
         B64_T(6 + ct, 0);
+        if (c >= 0 && c + 1 < nch) {                       // wave-uniform: channel block ct of chunk c + 1 -> planes [(c + 1) & 1][ct]
+            uint16_t *Ap = Acv + (((c + 1) & 1) * 2 + ct) * (2 * B64_CPL);
+#pragma unroll
+            for (int p = 0; p < 5; p++) {
+                const int f = lane + 64 * p;
+                if (p < 4 || lane < 32) {
+                    b64h4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float x = xr[p][e];
+                        amax = __builtin_fmaxf(amax, __builtin_fabsf(x));
+                        const _Float16 hv = (_Float16)x;
+                        h[e] = hv; l[e] = (_Float16)(x - (float)hv);
+                    }
+                    const int off = (f >> 3) * CNN_BP + (f & 7) * 4;
+                    *reinterpret_cast<b64h4 *>(Ap + off) = h; *reinterpret_cast<b64h4 *>(Ap + B64_CPL + off) = l;
+                }
+            }
+            gloadX(c + 2);                                  // (past the stripe: loaded, never used)
+        }
+        B64_T(6 + ct, 1);
         if (c >= 1 && c < nch) {                           // wave-uniform; chunk 0 is the stripe's warm-up chunk: nothing to join
             const int G0 = S0 - 32 + 32 * c;
             const unsigned vb = __builtin_amdgcn_raw_buffer_load_b8(rV, G0 + n, 0, 0);
@@ -305,24 +397,7 @@ __device__ __forceinline__ void b64_conv(const B64Args &A, const int ct, const i
             for (int q = 0; q < 16; q++) acc[q] = 0.0f;
 #pragma unroll
             for (int cb = 0; cb < 2; cb++) {
-#pragma unroll
-                for (int p = 0; p < 5; p++) {
-                    const int f = lane + 64 * p;
-                    if (p < 4 || lane < 32) {
-                        b64h4 h, l;
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const float x = xr[cb][p][e];
-                            amax = __builtin_fmaxf(amax, __builtin_fabsf(x));
-                            const _Float16 hv = (_Float16)x;
-                            h[e] = hv; l[e] = (_Float16)(x - (float)hv);
-                        }
-                        const int off = (f >> 3) * CNN_BP + (f & 7) * 4;
-                        *reinterpret_cast<b64h4 *>(Ac + off) = h; *reinterpret_cast<b64h4 *>(Ac + B64_CPL + off) = l;
-                    }
-                }
-                B64_T(6 + ct, 1 + 4 * cb);
-                gloadX(c + 1, cb);                          // the same channel block of the next chunk (past the stripe: loaded, never used)
+                const uint16_t *Ac = Acv + ((c & 1) * 2 + cb) * (2 * B64_CPL);
 #pragma unroll
                 for (int tap = 0; tap < 5; tap++)
 #pragma unroll
@@ -371,9 +446,9 @@ __device__ __forceinline__ void b64_conv(const B64Args &A, const int ct, const i
 template <bool CONV>
 __global__ __launch_bounds__(512, 2) void k3_block64(const B64Args A) {
     __shared__ __attribute__((aligned(16))) float ring[6][2][B64_RING];
-    __shared__ __attribute__((aligned(16))) float halo[6][4 * B64_RP];
+    __shared__ __attribute__((aligned(16))) float halo[5][4 * B64_RP];            // stages 1 .. 5 (stage 0 takes its rows from global memory)
     __shared__ __attribute__((aligned(16))) uint16_t Apl[6][2 * B64_APL];
-    __shared__ __attribute__((aligned(16))) uint16_t Acv[2][2 * B64_CPL];
+    __shared__ __attribute__((aligned(16))) uint16_t Acv[2][2][2 * B64_CPL];       // the shortcut's planes: [chunk parity][channel block][piece]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rows = min(A.rows, *A.live);
@@ -384,19 +459,19 @@ __global__ __launch_bounds__(512, 2) void k3_block64(const B64Args A) {
     const int mych = min(per, nct - c_lo);
     if (mych <= 0) return;
     const int S0 = c_lo * 32, nch = mych + 1, nsteps = nch + (CONV ? B64_CONV_START : B64_START(5) + 1);     // (a deferred stage finishes a step after its last chunk: covered)
-    for (int i = tid; i < 6 * 4 * B64_RP; i += 512) (&halo[0][0])[i] = 0.0f;
+    for (int i = tid; i < 5 * 4 * B64_RP; i += 512) (&halo[0][0])[i] = 0.0f;
     __syncthreads();
     // wavefronts w and w + 4 share a SIMD: stages (0, 1), (2, 3), (4, shortcut 0), (5, shortcut 1)
     const int role = (int)((0x76315420u >> (4 * wave)) & 15u);
     if (role < 6) {
         const float *rin = &ring[role ? role - 1 : 0][0][0];
         float *rout = &ring[role][0][0];
-        if (role == 0) b64_stage<0, CONV, false>(A, 0, B64_START(0), lane, S0, nch, nsteps, rows, rin, rout, &halo[0][0], &Apl[0][0]);
-        else if (role == 5) b64_stage<2, CONV, false>(A, 5, B64_START(5), lane, S0, nch, nsteps, rows, rin, rout, &halo[5][0], &Apl[5][0]);
-        else if (B64_DEFERS(1) && (role == 1 || role == 3)) b64_stage<1, CONV, true>(A, role, B64_START(role), lane, S0, nch, nsteps, rows, rin, rout, &halo[role][0], &Apl[role][0]);
-        else b64_stage<1, CONV, false>(A, role, B64_START(role), lane, S0, nch, nsteps, rows, rin, rout, &halo[role][0], &Apl[role][0]);
+        if (role == 0) b64_stage<0, CONV, false>(A, 0, B64_START(0), lane, S0, nch, nsteps, rows, rin, rout, &halo[0][0] /* unused */, &Apl[0][0]);
+        else if (role == 5) b64_stage<2, CONV, false>(A, 5, B64_START(5), lane, S0, nch, nsteps, rows, rin, rout, &halo[4][0], &Apl[5][0]);
+        else if (B64_DEFERS(1) && (role == 1 || role == 3)) b64_stage<1, CONV, true>(A, role, B64_START(role), lane, S0, nch, nsteps, rows, rin, rout, &halo[role - 1][0], &Apl[role][0]);
+        else b64_stage<1, CONV, false>(A, role, B64_START(role), lane, S0, nch, nsteps, rows, rin, rout, &halo[role - 1][0], &Apl[role][0]);
     } else if (CONV) {
-        b64_conv(A, role - 6, lane, S0, nch, nsteps, rows, &ring[5][0][0], &Acv[role - 6][0]);
+        b64_conv(A, role - 6, lane, S0, nch, nsteps, rows, &ring[5][0][0], &Acv[0][0][0]);
     } else {
         for (int s = 0; s < nsteps; s++) b64_barrier();
     }
