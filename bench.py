@@ -122,11 +122,11 @@ def cpu_baseline(model, n_bases, seed0, full, reads_per_thread=None, cnn_seconds
 
 
 def load_pmc(reads_per_step, bases, what, inflight=None):
-    """The committed counter passes (tools/r04_profile.sh -> tools/r04_collect.py -> profiles/r04_pmc_*.json; round 3's as a fall-back): HBM
+    """The committed counter passes (tools/r05_profile.sh -> tools/r05_collect.py -> profiles/r05_pmc_*.json; earlier rounds' as a fall-back): HBM
     bytes per launch and per step, vector instructions of k2_fill, MFMA busy cycles.  Only used when they were taken at THIS workload's shape;
     the number of batches in flight during the counter pass is part of the shape for the chip-level figures (round-3 advisor): the caller
     gets it back as d["workload"]["inflight"] and labels `roofline_chip` with it."""
-    for rnd in ("r04", "r03"):
+    for rnd in ("r05", "r04", "r03"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, "banded" if what == "banded" else "bench"))
         if not os.path.exists(path):
             continue

@@ -331,7 +331,7 @@ __device__ __forceinline__ void b64_stage(const B64Args &A, const int st, const 
 // buffered by chunk parity; the step barrier orders the hand-over), and both multiply the current chunk out of the planes written a step earlier.  In the
 // first version each split all 64 channels for itself: its stamps showed the shortcut wavefronts at 6 300 ticks per step with every LDS round trip of the
 // separable stages ablated away -- they, not the stages, set the step -- and 2 x ~1 000 of those ticks were the split.
-__device__ __forceinline__ void b64_conv(const B64Args &A, const int ct, const int lane, const int S0, const int nch, const int nsteps, const int rows,
+__device__ __forceinline__ void b64_conv(const B64Args &A, const int ct, const int t0, const int lane, const int S0, const int nch, const int nsteps, const int rows,
                                          const float *r5, uint16_t *Acv) {
     const int n = lane & 31, hh = lane >> 5;
     u32x4 wc[2][5][2][2];                                  // [channel block][tap][k16][piece] of output channel 32 ct + n: 160 registers
@@ -366,7 +366,7 @@ __device__ __forceinline__ void b64_conv(const B64Args &A, const int ct, const i
     __builtin_amdgcn_s_setprio(B64_CONV_PRIO);             // experiment: the shortcut wavefronts set the step; let them win the issue arbitration against their stage partner
 #endif
     for (int s = 0; s < nsteps; s++) {
-        const int c = s - B64_CONV_START;
+        const int c = s - t0;
         B64_T(6 + ct, 0);
         if (c >= 0 && c + 1 < nch) {                       // wave-uniform: channel block ct of chunk c + 1 -> planes [(c + 1) & 1][ct]
             uint16_t *Ap = Acv + (((c + 1) & 1) * 2 + ct) * (2 * B64_CPL);
@@ -443,12 +443,256 @@ __device__ __forceinline__ void b64_conv(const B64Args &A, const int ct, const i
     range_report(amax, A.crange, lane);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// Round 5, third version (B64_V3, the default when the shortcut is fused): THE FILTER RUNS IN THE ACCUMULATOR LAYOUT.
+// In the version above a chunk crosses LDS twice per layer: the epilogue writes fp32 rows to a ring, the next stage's filter reads them back in ITS lane
+// layout (lane = channel pair x row quarter), filters, splits and writes the fp16 planes, and the multiply reads those.  Here the wavefront that produced
+// layer l's sums ALSO filters them for layer l + 1, in the registers they are already in: after the epilogue lane (n, hh) holds channels (2 n, 2 n + 1) of
+// rows {0-3, 8-11, 16-19, 24-27} + 4 hh -- a 5-tap filter down the rows needs its neighbours' rows, and four rounds of v_permlane32_swap (the lane halves
+// exchange register halves; no LDS) turn that into 20 CONSECUTIVE rows per lane: rows -4 .. 15 in the lower half, 12 .. 31 in the upper, the first four of
+// the lower half being the chunk before's last four, which the wavefront keeps in registers.  Each half then filters 16 output rows (80 packed FMAs, taps
+// ascending as everywhere), splits them and stores layer l + 1's fp16 planes.  LDS per layer boundary: ONE crossing (planes written, planes read) instead of
+// two, 40 instructions instead of ~72; the fp32 rings and the halo rows are gone (only the last layer still hands fp32 rows to the shortcut's join).
+//
+//   wavefront l = 0 .. 4:   planes of layer l (chunk c)  -> 24 MFMAs -> BatchNorm / ReLU / mask -> exchange -> filter of layer l + 1 -> split -> planes of layer l + 1
+//   wavefront 5 ("ends"):   the block's FIRST filter (input rows from global memory, a chunk ahead in registers, in the lane layout of the version above)
+//                           and its LAST multiply (layer 5 -> the fp32 ring the shortcut joins from)
+//   wavefronts 6, 7:        the shortcut, as above
+//   step s: the first filter works on chunk s, wavefront l on chunk s - 1 - l, the last multiply on chunk s - 6, the shortcut on chunk s - 7.
+// The row grids are those of the version above (layer l's chunk c starts at row S0 - 20 - 2 (l + 1) + 32 c), so are the sums' order and every expression:
+// bit-identical again.  LDS: planes 6 x 2 x (2 channel blocks x 2 pieces x 32 x 80 B) + ring 2 x 32 x 272 + shortcut planes = 163 328 B.
+#ifndef B64_V3
+#define B64_V3 0                                             /* until tools/k3_block64_check.hip has passed on the device */
+#endif
+#define B64_V3_CONV_START 7
+
+// v_permlane32_swap on a channel pair: a's upper lane half <-> b's lower lane half.  (Components are copied to scalars first: __builtin_bit_cast straight
+// from a vector element, `bit_cast(unsigned, a[e])`, read element 0 for every e with this compiler -- the first build multiplied one column tile only.)
+__device__ __forceinline__ void b64_swap(b64f2 &a, b64f2 &b) {
+    const float ax = a[0], ay = a[1], bx = b[0], by = b[1];
+    const b64u2 r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ax), __float_as_uint(bx), false, false);
+    const b64u2 r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ay), __float_as_uint(by), false, false);
+    a = b64f2{__uint_as_float(r0[0]), __uint_as_float(r1[0])};
+    b = b64f2{__uint_as_float(r0[1]), __uint_as_float(r1[1])};
+}
+
+// the epilogue into registers: Y[q] = (channel 2 n, channel 2 n + 1) of row (q & 3) + 8 (q >> 2) + 4 hh
+template <bool MASKED>
+__device__ __forceinline__ void b64_epilogue_regs(const f32x16 (&acc)[2], const b64f2 sc, const b64f2 sh, const float floor_, const unsigned vml, b64f2 (&Y)[16]) {
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) {
+        const int rowq = (q & 3) + 8 * (q >> 2);
+        b64f2 y0 = __builtin_elementwise_fma(b64f2{acc[0][q], acc[0][q + 1]}, b64f2{sc[0], sc[0]}, b64f2{sh[0], sh[0]});
+        b64f2 y1 = __builtin_elementwise_fma(b64f2{acc[1][q], acc[1][q + 1]}, b64f2{sc[1], sc[1]}, b64f2{sh[1], sh[1]});
+        float a0 = __builtin_fmaxf(y0[0], floor_), a1 = __builtin_fmaxf(y1[0], floor_), b0 = __builtin_fmaxf(y0[1], floor_), b1 = __builtin_fmaxf(y1[1], floor_);
+        if (MASKED) {
+            const bool oka = (vml >> rowq) & 1u, okb = (vml >> (rowq + 1)) & 1u;
+            a0 = oka ? a0 : 0.0f; a1 = oka ? a1 : 0.0f; b0 = okb ? b0 : 0.0f; b1 = okb ? b1 : 0.0f;
+        }
+        Y[q] = b64f2{a0, a1}; Y[q + 1] = b64f2{b0, b1};
+    }
+}
+
+// the 24 MFMAs of one chunk out of a layer's planes [channel block][piece][32 x CNN_BP]
+__device__ __forceinline__ void b64_multiply(const uint16_t *Pb, const u32x4 (&bw)[2][2][2][2], const int n, const int hh, f32x16 (&acc)[2]) {
+    u32x4 ah[2][2], al[2][2];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int k16 = 0; k16 < 2; k16++) {
+            ah[cb][k16] = *reinterpret_cast<const u32x4 *>(Pb + cb * (2 * B64_APL) + n * CNN_BP + k16 * 16 + 8 * hh);
+            al[cb][k16] = *reinterpret_cast<const u32x4 *>(Pb + cb * (2 * B64_APL) + B64_APL + n * CNN_BP + k16 * 16 + 8 * hh);
+        }
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[j][q] = 0.0f;
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int k16 = 0; k16 < 2; k16++) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[j] = mfma16<2>(al[cb][k16], bw[cb][k16][0][j], acc[j]);
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[j] = mfma16<2>(ah[cb][k16], bw[cb][k16][1][j], acc[j]);
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[j] = mfma16<2>(ah[cb][k16], bw[cb][k16][0][j], acc[j]);
+        }
+}
+
+__device__ __forceinline__ void b64_load_bw(const B64Layer &P, const int n, const int hh, u32x4 (&bw)[2][2][2][2]) {
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int k16 = 0; k16 < 2; k16++)
+#pragma unroll
+            for (int pc = 0; pc < 2; pc++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    bw[cb][k16][pc][j] = *reinterpret_cast<const u32x4 *>(P.wb + ((size_t)((cb * 2 + pc) * 64 + 2 * n + j)) * 32 + k16 * 16 + 8 * hh);
+}
+
+// wavefront l = 0 .. 4: layer l's multiply + epilogue, layer l + 1's filter + split
+__device__ __forceinline__ void b64_v3_stage(const B64Args &A, const int st, const int lane, const int S0, const int nch, const int nsteps, const int rows,
+                                             const uint16_t *Pin, uint16_t *Pout) {
+    const B64Layer &P = A.L[st], &Q = A.L[st + 1];
+    const int n = lane & 31, hh = lane >> 5;
+    const int t0 = st + 1;
+    u32x4 bw[2][2][2][2];
+    b64_load_bw(P, n, hh, bw);
+    b64f2 tw[5];
+#pragma unroll
+    for (int t = 0; t < 5; t++) tw[t] = *reinterpret_cast<const b64f2 *>(Q.wd + t * 64 + 2 * n);
+    const b64f2 sc = {P.scale[2 * n] * P.post, P.scale[2 * n + 1] * P.post}, sh = {P.shift[2 * n], P.shift[2 * n + 1]};
+    const float floor_ = P.relu ? 0.0f : -3.402823466e38f;
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b64_uniform_ptr(A.valid)), 0, rows, 0x00020000);
+    float amax = 0.0f;
+    b64f2 carry[4];                                        // this layer's rows 28 .. 31 of the chunk before (upper lane half; the lower half's copy is never used)
+#pragma unroll
+    for (int i = 0; i < 4; i++) carry[i] = b64f2{0.f, 0.f};
+    uint16_t *const apl = Pout + (n >> 4) * (2 * B64_APL) + 16 * hh * CNN_BP + 2 * (n & 15);
+    for (int s = 0; s < nsteps; s++) {
+        const int c = s - t0;
+        B64_T(st, 0);
+        if (c >= 0 && c < nch) {                           // wave-uniform
+            const int og0 = S0 - 20 - 2 * (st + 1) + 32 * c;          // first row of layer st's chunk; layer st + 1's chunk starts two rows earlier
+            const unsigned vb = __builtin_amdgcn_raw_buffer_load_b8(rV, og0 + n, 0, 0);
+            const bool edge = og0 - 2 < 0 || og0 + 30 > rows;
+            f32x16 acc[2];
+            b64_multiply(Pin + (c & 1) * (4 * B64_APL), bw, n, hh, acc);
+            B64_T(st, 1);
+            const unsigned vm = (unsigned)__ballot((vb & 0xffu) != 0);
+            const unsigned vml = hh ? vm >> 4 : vm;
+            b64f2 Y[16];
+            if (vm == 0xffffffffu) b64_epilogue_regs<false>(acc, sc, sh, floor_, vml, Y);
+            else { asm volatile("; chunk with padding rows" ::: "memory"); b64_epilogue_regs<true>(acc, sc, sh, floor_, vml, Y); }
+            B64_T(st, 2);
+            // ---- 20 consecutive rows per lane: W[w] = row w - 4 (lower half) / row w + 12 (upper half) of the chunk ----
+            b64f2 W[20];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                b64f2 a = Y[i], b = Y[8 + i]; b64_swap(a, b); W[4 + i] = a; W[8 + i] = b;              // a: rows i | 16 + i,      b: rows 4 + i | 20 + i
+                b64f2 a2 = Y[4 + i], b2 = Y[12 + i]; b64_swap(a2, b2); W[12 + i] = a2; W[16 + i] = b2; // a2: rows 8 + i | 24 + i, b2: rows 12 + i | 28 + i
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                b64f2 p = carry[i], d = W[16 + i];
+                b64_swap(p, d);                             // p's upper half <- this chunk's rows 12 + i; d's lower half <- the previous chunk's rows 28 + i
+                W[i] = hh ? p : d;
+                carry[i] = W[16 + i];
+            }
+            B64_T(st, 3);
+            // ---- depthwise, taps ascending: output k = sum_t W[k + t] w[t] = row k - 2 (lower half) / k + 14 (upper half) of layer st's grid = plane row k / 16 + k ----
+            b64f2 o[2][8];
+#pragma unroll
+            for (int g = 0; g < 2; g++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) o[g][i] = b64f2{0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 20; w++) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int t = w - k;
+                    if (t >= 0 && t < 5) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(o[k >> 3][k & 7]) : "v"(W[w]), "v"(tw[t]));
+                }
+            }
+            B64_T(st, 4);
+            float am = 0.0f;
+            uint16_t *ap = apl + (c & 1) * (4 * B64_APL);
+            if (!edge) { b64_split_store<false>(o[0], am, ap, 0, 0); b64_split_store<false>(o[1], am, ap + 8 * CNN_BP, 0, 0); }
+            else {
+                asm volatile("; chunk at an end of the pass" ::: "memory");
+                b64_split_store<true>(o[0], am, ap, og0 - 2 + 16 * hh, rows); b64_split_store<true>(o[1], am, ap + 8 * CNN_BP, og0 - 2 + 16 * hh + 8, rows);
+            }
+            if (c > 0 || S0 == 0) amax = __builtin_fmaxf(amax, am);
+            B64_T(st, 5);
+        }
+        B64_T(st, 9);
+        b64_barrier();
+        B64_T(st, 10);
+    }
+    range_report(amax, Q.range, lane);
+}
+
+// wavefront 5: the block's first filter (chunk s) and its last multiply (chunk s - 6)
+__device__ __forceinline__ void b64_v3_ends(const B64Args &A, const int lane, const int S0, const int nch, const int nsteps, const int rows,
+                                            uint16_t *P0, const uint16_t *P5, float *r5) {
+    const B64Layer &F = A.L[0], &P = A.L[5];
+    const int n = lane & 31, hh = lane >> 5;
+    const int cpl = lane & 15, rq = lane >> 4;
+    u32x4 bw[2][2][2][2];
+    b64_load_bw(P, n, hh, bw);
+    b64f2 tw[2][5];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int t = 0; t < 5; t++) tw[cb][t] = *reinterpret_cast<const b64f2 *>(F.wd + t * 64 + cb * 32 + 2 * cpl);
+    const b64f2 sc = {P.scale[2 * n] * P.post, P.scale[2 * n + 1] * P.post}, sh = {P.shift[2 * n], P.shift[2 * n + 1]};
+    const float floor_ = P.relu ? 0.0f : -3.402823466e38f;
+    float amax = 0.0f;
+    b64u2 xp[2][12];
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b64_uniform_ptr(A.X)), 0, rows * 256, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b64_uniform_ptr(A.valid)), 0, rows, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000);
+    const int xlane = ((8 * rq - 4) * 64 + 2 * cpl) * 4;
+    auto gloadX = [&](int c, int cb) {
+        const int base = xlane + ((S0 - 20 + 32 * c) * 64 + cb * 32) * 4;
+#pragma unroll
+        for (int j = 0; j < 12; j++) xp[cb][j] = __builtin_bit_cast(b64u2, __builtin_amdgcn_raw_buffer_load_b64(rX, base + j * 256, 0, 0));
+    };
+    gloadX(0, 0); gloadX(0, 1);
+    for (int s = 0; s < nsteps; s++) {
+        B64_T(5, 0);
+        const int c5 = s - 6;
+        const int g5 = S0 - 32 + 32 * c5;                  // first row of layer 5's chunk
+        const unsigned vb = __builtin_amdgcn_raw_buffer_load_b8(rV, g5 + n, 0, 0);      // NO branch around it (see b64_stage); outside the pass it reads 0 and nobody looks
+        if (s < nch) {                                     // wave-uniform: the first filter, chunk s
+            const int og0 = S0 - 22 + 32 * s;
+            const bool edge = og0 < 0 || og0 + 32 > rows;
+            float am = 0.0f;
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++) {
+                b64f2 x[12];
+#pragma unroll
+                for (int j = 0; j < 12; j++) x[j] = __builtin_bit_cast(b64f2, xp[cb][j]);
+                b64f2 o[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) o[i] = b64f2{0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 12; j++) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int t = j - i;
+                        if (t >= 0 && t < 5) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(o[i]) : "v"(x[j]), "v"(tw[cb][t]));
+                    }
+                }
+                gloadX(s + 1, cb);                          // (past the stripe: loaded, never used)
+                uint16_t *ap = P0 + (s & 1) * (4 * B64_APL) + cb * (2 * B64_APL) + 8 * rq * CNN_BP + 2 * cpl;
+                if (!edge) b64_split_store<false>(o, am, ap, 0, 0);
+                else { asm volatile("; chunk at an end of the pass" ::: "memory"); b64_split_store<true>(o, am, ap, og0 + 8 * rq, rows); }
+            }
+            if (s > 0 || S0 == 0) amax = __builtin_fmaxf(amax, am);
+        }
+        B64_T(5, 1);
+        if (c5 >= 0 && c5 < nch) {                         // wave-uniform: the last multiply, chunk s - 6 -> the ring the shortcut joins from
+            f32x16 acc[2];
+            b64_multiply(P5 + (c5 & 1) * (4 * B64_APL), bw, n, hh, acc);
+            const unsigned vm = (unsigned)__ballot((vb & 0xffu) != 0);
+            const unsigned vml = hh ? vm >> 4 : vm;
+            float *wrow = r5 + (c5 & 1) * B64_RING + 4 * hh * B64_RP + 2 * n;
+            if (vm == 0xffffffffu) b64_epilogue<false, false>(acc, sc, sh, floor_, vml, wrow, rY, 0);
+            else { asm volatile("; chunk with padding rows" ::: "memory"); b64_epilogue<true, false>(acc, sc, sh, floor_, vml, wrow, rY, 0); }
+        }
+        B64_T(5, 9);
+        b64_barrier();
+        B64_T(5, 10);
+    }
+    range_report(amax, F.range, lane);
+}
+
 template <bool CONV>
 __global__ __launch_bounds__(512, 2) void k3_block64(const B64Args A) {
-    __shared__ __attribute__((aligned(16))) float ring[6][2][B64_RING];
-    __shared__ __attribute__((aligned(16))) float halo[5][4 * B64_RP];            // stages 1 .. 5 (stage 0 takes its rows from global memory)
-    __shared__ __attribute__((aligned(16))) uint16_t Apl[6][2 * B64_APL];
-    __shared__ __attribute__((aligned(16))) uint16_t Acv[2][2][2 * B64_CPL];       // the shortcut's planes: [chunk parity][channel block][piece]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rows = min(A.rows, *A.live);
@@ -458,21 +702,36 @@ __global__ __launch_bounds__(512, 2) void k3_block64(const B64Args A) {
     const int c_lo = (int)blockIdx.x * per;
     const int mych = min(per, nct - c_lo);
     if (mych <= 0) return;
-    const int S0 = c_lo * 32, nch = mych + 1, nsteps = nch + (CONV ? B64_CONV_START : B64_START(5) + 1);     // (a deferred stage finishes a step after its last chunk: covered)
-    for (int i = tid; i < 5 * 4 * B64_RP; i += 512) (&halo[0][0])[i] = 0.0f;
-    __syncthreads();
-    // wavefronts w and w + 4 share a SIMD: stages (0, 1), (2, 3), (4, shortcut 0), (5, shortcut 1)
+    const int S0 = c_lo * 32, nch = mych + 1;
+    // wavefronts w and w + 4 share a SIMD: roles (0, 1), (2, 3), (4, shortcut 0), (5, shortcut 1)
     const int role = (int)((0x76315420u >> (4 * wave)) & 15u);
-    if (role < 6) {
-        const float *rin = &ring[role ? role - 1 : 0][0][0];
-        float *rout = &ring[role][0][0];
-        if (role == 0) b64_stage<0, CONV, false>(A, 0, B64_START(0), lane, S0, nch, nsteps, rows, rin, rout, &halo[0][0] /* unused */, &Apl[0][0]);
-        else if (role == 5) b64_stage<2, CONV, false>(A, 5, B64_START(5), lane, S0, nch, nsteps, rows, rin, rout, &halo[4][0], &Apl[5][0]);
-        else if (B64_DEFERS(1) && (role == 1 || role == 3)) b64_stage<1, CONV, true>(A, role, B64_START(role), lane, S0, nch, nsteps, rows, rin, rout, &halo[role - 1][0], &Apl[role][0]);
-        else b64_stage<1, CONV, false>(A, role, B64_START(role), lane, S0, nch, nsteps, rows, rin, rout, &halo[role - 1][0], &Apl[role][0]);
-    } else if (CONV) {
-        b64_conv(A, role - 6, lane, S0, nch, nsteps, rows, &ring[5][0][0], &Acv[0][0][0]);
+    if constexpr (CONV && B64_V3) {
+        __shared__ __attribute__((aligned(16))) uint16_t Pl[6][2][4 * B64_APL];        // layer l's planes: [chunk parity][channel block][piece][32 x CNN_BP]
+        __shared__ __attribute__((aligned(16))) float ring5[2][B64_RING];              // layer 5's rows, for the shortcut's join
+        __shared__ __attribute__((aligned(16))) uint16_t Acv[2][2][2 * B64_CPL];       // the shortcut's planes: [chunk parity][channel block][piece]
+        const int nsteps = nch + B64_V3_CONV_START;
+        if (role < 5) b64_v3_stage(A, role, lane, S0, nch, nsteps, rows, &Pl[role][0][0], &Pl[role + 1][0][0]);
+        else if (role == 5) b64_v3_ends(A, lane, S0, nch, nsteps, rows, &Pl[0][0][0], &Pl[5][0][0], &ring5[0][0]);
+        else b64_conv(A, role - 6, B64_V3_CONV_START, lane, S0, nch, nsteps, rows, &ring5[0][0], &Acv[0][0][0]);
     } else {
-        for (int s = 0; s < nsteps; s++) b64_barrier();
+        __shared__ __attribute__((aligned(16))) float ring[6][2][B64_RING];
+        __shared__ __attribute__((aligned(16))) float halo[5][4 * B64_RP];            // stages 1 .. 5 (stage 0 takes its rows from global memory)
+        __shared__ __attribute__((aligned(16))) uint16_t Apl[6][2 * B64_APL];
+        __shared__ __attribute__((aligned(16))) uint16_t Acv[2][2][2 * B64_CPL];       // the shortcut's planes: [chunk parity][channel block][piece]
+        const int nsteps = nch + (CONV ? B64_CONV_START : B64_START(5) + 1);             // (a deferred stage finishes a step after its last chunk: covered)
+        for (int i = tid; i < 5 * 4 * B64_RP; i += 512) (&halo[0][0])[i] = 0.0f;
+        __syncthreads();
+        if (role < 6) {
+            const float *rin = &ring[role ? role - 1 : 0][0][0];
+            float *rout = &ring[role][0][0];
+            if (role == 0) b64_stage<0, CONV, false>(A, 0, B64_START(0), lane, S0, nch, nsteps, rows, rin, rout, &halo[0][0] /* unused */, &Apl[0][0]);
+            else if (role == 5) b64_stage<2, CONV, false>(A, 5, B64_START(5), lane, S0, nch, nsteps, rows, rin, rout, &halo[4][0], &Apl[5][0]);
+            else if (B64_DEFERS(1) && (role == 1 || role == 3)) b64_stage<1, CONV, true>(A, role, B64_START(role), lane, S0, nch, nsteps, rows, rin, rout, &halo[role - 1][0], &Apl[role][0]);
+            else b64_stage<1, CONV, false>(A, role, B64_START(role), lane, S0, nch, nsteps, rows, rin, rout, &halo[role - 1][0], &Apl[role][0]);
+        } else if (CONV) {
+            b64_conv(A, role - 6, B64_CONV_START, lane, S0, nch, nsteps, rows, &ring[5][0][0], &Acv[0][0][0]);
+        } else {
+            for (int s = 0; s < nsteps; s++) b64_barrier();
+        }
     }
 }
