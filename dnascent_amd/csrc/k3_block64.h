@@ -48,14 +48,15 @@ struct B64Args {
 };
 
 #ifndef B64_ABL
-#define B64_ABL 0                                           /* experiment builds of tools/k3_block64_check.hip (TIMING ONLY, wrong results): 1 = no ring reads, 2 = no ring writes, 4 = the A planes' LDS round trip replaced by a register dependency */
+#define B64_ABL 0                                           /* experiment builds of tools/k3_block64_check.hip (TIMING ONLY, wrong results): 1 = no ring reads, 2 = no ring writes, 4 = the A planes' LDS round trip replaced by a register dependency; third version: 8 = wavefronts 0-5 idle (first filter: 32), 16 = the shortcut wavefronts idle, 64 / 128 = the odd / even ones of wavefronts 0-4 idle */
 #endif
 #ifdef B64_TRACE                                            /* experiment builds only (tools/k3_block64_check.hip -DB64_TRACE=<workgroup>): shader-clock stamps of one step's phases */
 #ifndef B64_TRACE_STEP
 #define B64_TRACE_STEP 40
 #endif
 __device__ unsigned long long b64_trace[8][16];
-#define B64_T(role, i) do { if (blockIdx.x == B64_TRACE && s == B64_TRACE_STEP) { __builtin_amdgcn_sched_barrier(0); if (lane == 0) b64_trace[role][i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define B64_T(role, i) do { if (blockIdx.x == B64_TRACE && s == B64_TRACE_STEP) { __builtin_amdgcn_sched_barrier(0); if (lane == 0) b64_trace[role][i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } \
+                            if (blockIdx.x == B64_TRACE && (i) == 10 && (s == 0 || s == nsteps - 1) && lane == 0) { b64_trace[role][s == 0 ? 12 : 13] = __builtin_amdgcn_s_memtime(); b64_trace[role][14] = (unsigned long long)nsteps; } } while (0)
 #else
 #define B64_T(role, i) do { } while (0)
 #endif
@@ -94,44 +95,54 @@ __device__ __forceinline__ const void *b64_uniform_ptr(const void *p) {
 #ifndef B64_SPLIT_WIDE
 #define B64_SPLIT_WIDE 1
 #endif
+// what the fp16 rounding of a channel pair left over, o - (float) h, in ONE instruction per channel: v_fma_mix_f32 reads the fp16 half directly
+// (h x -1.0 + o, exact: the difference is representable), where conversion + subtraction are 3 instructions per pair.  B64_MIX=0: the plain expression.
+#ifndef B64_V3
+#define B64_V3 0                                            /* 1: the third version below (filter in the accumulator layout); bit-identical, 480 us per block against 467: not the default */
+#endif
+#ifndef B64_MIX
+#define B64_MIX (B64_V3 ? 0 : 1)                            /* measured in one session (gpurun_out/r5n, 1.2 M rows): second version 473 / 467 / 477 us with 0 / 1 / 2, third version 480 / 507 / 489 */
+#endif
+__device__ __forceinline__ b64f2 b64_rest(const b64h2 h, const b64f2 o) {
+    if (!B64_MIX) return o - __builtin_convertvector(h, b64f2);
+    float r0, r1;
+    const float o0 = o[0], o1 = o[1];
+    if (B64_MIX == 2) {                                    // two plain subtractions instead of the packed one the compiler forms
+        const b64f2 f = __builtin_convertvector(h, b64f2);
+        const float f0 = f[0], f1 = f[1];
+        asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r0) : "v"(o0), "v"(f0));
+        asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r1) : "v"(o1), "v"(f1));
+        return b64f2{r0, r1};
+    }
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(o0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(o1));
+    return b64f2{r0, r1};
+}
+
 template <bool MASKED>
 __device__ __forceinline__ void b64_split_store(const b64f2 (&o)[8], float &am, uint16_t *ap, const int g0, const int rows) {
-    if (B64_SPLIT_WIDE) {
-        b64h2 h[8], l[8]; b64f2 back[8], rest[8];
+    b64h2 h[8], l[8]; b64f2 rest[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) h[i] = __builtin_convertvector(o[i], b64h2);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < 8; i++) h[i] = __builtin_convertvector(o[i], b64h2);
+    if (B64_SPLIT_WIDE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 8; i++) back[i] = __builtin_convertvector(h[i], b64f2);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < 8; i++) rest[i] = b64_rest(h[i], o[i]);
+    if (B64_SPLIT_WIDE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 8; i++) rest[i] = o[i] - back[i];
-        __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < 8; i++) l[i] = __builtin_convertvector(rest[i], b64h2);
+    if (B64_SPLIT_WIDE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 8; i++) l[i] = __builtin_convertvector(rest[i], b64h2);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 8; i++) { *reinterpret_cast<b64h2 *>(ap + i * CNN_BP) = h[i]; *reinterpret_cast<b64h2 *>(ap + B64_APL + i * CNN_BP) = l[i]; }
-        float m0 = 0.0f, m1 = 0.0f;                        // two chains for the maximum
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            float m = __builtin_fmaxf(__builtin_fabsf(o[i][0]), __builtin_fabsf(o[i][1]));
-            if (MASKED) { const int g = g0 + i; m = (g >= 0 && g < rows) ? m : 0.0f; }
-            if (i & 1) m1 = __builtin_fmaxf(m1, m); else m0 = __builtin_fmaxf(m0, m);
-        }
-        am = __builtin_fmaxf(am, __builtin_fmaxf(m0, m1));
-        return;
-    }
+    for (int i = 0; i < 8; i++) { *reinterpret_cast<b64h2 *>(ap + i * CNN_BP) = h[i]; *reinterpret_cast<b64h2 *>(ap + B64_APL + i * CNN_BP) = l[i]; }
+    float m0 = am, m1 = 0.0f;                              // two chains of v_max3_f32 (m, |a|, |b|) for the range report's largest |value|
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        float m = __builtin_fmaxf(__builtin_fabsf(o[i][0]), __builtin_fabsf(o[i][1]));
-        if (MASKED) { const int g = g0 + i; m = (g >= 0 && g < rows) ? m : 0.0f; }
-        am = __builtin_fmaxf(am, m);
-        const b64h2 h = __builtin_convertvector(o[i], b64h2);
-        const b64f2 rest = o[i] - __builtin_convertvector(h, b64f2);
-        const b64h2 l = __builtin_convertvector(rest, b64h2);
-        *reinterpret_cast<b64h2 *>(ap + i * CNN_BP) = h; *reinterpret_cast<b64h2 *>(ap + B64_APL + i * CNN_BP) = l;
+        float &m = (i & 1) ? m1 : m0;
+        if (MASKED) {
+            const int g = g0 + i;
+            if (g >= 0 && g < rows) m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(o[i][0])), __builtin_fabsf(o[i][1]));
+        } else m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(o[i][0])), __builtin_fabsf(o[i][1]));
     }
+    am = __builtin_fmaxf(m0, m1);
 }
 
 // a stage's epilogue: folded BatchNorm, ReLU, padding mask (MASKED: some row of the chunk is padding); accumulator register q of lane (n, hh) is row
@@ -368,20 +379,18 @@ __device__ __forceinline__ void b64_conv(const B64Args &A, const int ct, const i
     for (int s = 0; s < nsteps; s++) {
         const int c = s - t0;
         B64_T(6 + ct, 0);
-        if (c >= 0 && c + 1 < nch) {                       // wave-uniform: channel block ct of chunk c + 1 -> planes [(c + 1) & 1][ct]
+        if (!(B64_ABL & 16) && c >= 0 && c + 1 < nch) {    // wave-uniform: channel block ct of chunk c + 1 -> planes [(c + 1) & 1][ct]
             uint16_t *Ap = Acv + (((c + 1) & 1) * 2 + ct) * (2 * B64_CPL);
 #pragma unroll
             for (int p = 0; p < 5; p++) {
                 const int f = lane + 64 * p;
                 if (p < 4 || lane < 32) {
-                    b64h4 h, l;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float x = xr[p][e];
-                        amax = __builtin_fmaxf(amax, __builtin_fabsf(x));
-                        const _Float16 hv = (_Float16)x;
-                        h[e] = hv; l[e] = (_Float16)(x - (float)hv);
-                    }
+                    const b64f2 xa = {xr[p][0], xr[p][1]}, xb = {xr[p][2], xr[p][3]};
+                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(xa[0])), __builtin_fabsf(xa[1]));
+                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(xb[0])), __builtin_fabsf(xb[1]));
+                    const b64h2 ha = __builtin_convertvector(xa, b64h2), hb = __builtin_convertvector(xb, b64h2);
+                    const b64h2 la = __builtin_convertvector(b64_rest(ha, xa), b64h2), lb = __builtin_convertvector(b64_rest(hb, xb), b64h2);
+                    const b64h4 h = {ha[0], ha[1], hb[0], hb[1]}, l = {la[0], la[1], lb[0], lb[1]};
                     const int off = (f >> 3) * CNN_BP + (f & 7) * 4;
                     *reinterpret_cast<b64h4 *>(Ap + off) = h; *reinterpret_cast<b64h4 *>(Ap + B64_CPL + off) = l;
                 }
@@ -389,7 +398,7 @@ __device__ __forceinline__ void b64_conv(const B64Args &A, const int ct, const i
             gloadX(c + 2);                                  // (past the stripe: loaded, never used)
         }
         B64_T(6 + ct, 1);
-        if (c >= 1 && c < nch) {                           // wave-uniform; chunk 0 is the stripe's warm-up chunk: nothing to join
+        if (!(B64_ABL & 16) && c >= 1 && c < nch) {        // wave-uniform; chunk 0 is the stripe's warm-up chunk: nothing to join
             const int G0 = S0 - 32 + 32 * c;
             const unsigned vb = __builtin_amdgcn_raw_buffer_load_b8(rV, G0 + n, 0, 0);
             f32x16 acc;
@@ -445,7 +454,7 @@ __device__ __forceinline__ void b64_conv(const B64Args &A, const int ct, const i
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
-// Round 5, third version (B64_V3, the default when the shortcut is fused): THE FILTER RUNS IN THE ACCUMULATOR LAYOUT.
+// Round 5, third version (-DB64_V3=1; bit-identical, NOT the default: it is no faster, see the end of this comment): THE FILTER RUNS IN THE ACCUMULATOR LAYOUT.
 // In the version above a chunk crosses LDS twice per layer: the epilogue writes fp32 rows to a ring, the next stage's filter reads them back in ITS lane
 // layout (lane = channel pair x row quarter), filters, splits and writes the fp16 planes, and the multiply reads those.  Here the wavefront that produced
 // layer l's sums ALSO filters them for layer l + 1, in the registers they are already in: after the epilogue lane (n, hh) holds channels (2 n, 2 n + 1) of
@@ -462,9 +471,13 @@ __device__ __forceinline__ void b64_conv(const B64Args &A, const int ct, const i
 //   step s: the first filter works on chunk s, wavefront l on chunk s - 1 - l, the last multiply on chunk s - 6, the shortcut on chunk s - 7.
 // The row grids are those of the version above (layer l's chunk c starts at row S0 - 20 - 2 (l + 1) + 32 c), so are the sums' order and every expression:
 // bit-identical again.  LDS: planes 6 x 2 x (2 channel blocks x 2 pieces x 32 x 80 B) + ring 2 x 32 x 272 + shortcut planes = 163 328 B.
-#ifndef B64_V3
-#define B64_V3 0                                             /* until tools/k3_block64_check.hip has passed on the device */
-#endif
+//
+// Measured (gpurun_out/r5m, r5n; 1.2 M rows, one session): 480 us per block against 473 for the second version with the same split, 467 with its default one.
+// The LDS instructions it removes were not what a step costs.  Its stamps and ablations (tools/k3_block64_check.hip -DB64_TRACE / -DB64_ABL): a step is ~5 800
+// ticks in both versions; with the shortcut wavefronts idle 389-422 us, with wavefronts 0-5 idle 304; ONE filtering wavefront per SIMD (its partner idle) takes
+// 3 900 ticks for a chunk -- 24 MFMAs (990 with the fragment reads) + ~320 vector instructions at 7-8 ticks each -- and two of them on a SIMD 5 500.  Cutting
+// the vector instructions (50 fewer per wavefront: b64_rest, v_max3_f32 for the range report) moved the block by 1 % in either direction depending on the
+// instruction chosen; the average clock under this kernel is 1.9 GHz against 2.2-2.3 for its lighter ablations.  NOTES.md has the table.
 #define B64_V3_CONV_START 7
 
 // v_permlane32_swap on a channel pair: a's upper lane half <-> b's lower lane half.  (Components are copied to scalars first: __builtin_bit_cast straight
@@ -555,7 +568,7 @@ __device__ __forceinline__ void b64_v3_stage(const B64Args &A, const int st, con
     for (int s = 0; s < nsteps; s++) {
         const int c = s - t0;
         B64_T(st, 0);
-        if (c >= 0 && c < nch) {                           // wave-uniform
+        if (!(B64_ABL & 8) && !((B64_ABL & 64) && (st & 1)) && !((B64_ABL & 128) && !(st & 1)) && c >= 0 && c < nch) {         // wave-uniform
             const int og0 = S0 - 20 - 2 * (st + 1) + 32 * c;          // first row of layer st's chunk; layer st + 1's chunk starts two rows earlier
             const unsigned vb = __builtin_amdgcn_raw_buffer_load_b8(rV, og0 + n, 0, 0);
             const bool edge = og0 - 2 < 0 || og0 + 30 > rows;
@@ -647,7 +660,7 @@ __device__ __forceinline__ void b64_v3_ends(const B64Args &A, const int lane, co
         const int c5 = s - 6;
         const int g5 = S0 - 32 + 32 * c5;                  // first row of layer 5's chunk
         const unsigned vb = __builtin_amdgcn_raw_buffer_load_b8(rV, g5 + n, 0, 0);      // NO branch around it (see b64_stage); outside the pass it reads 0 and nobody looks
-        if (s < nch) {                                     // wave-uniform: the first filter, chunk s
+        if (!(B64_ABL & 32) && s < nch) {                  // wave-uniform: the first filter, chunk s
             const int og0 = S0 - 22 + 32 * s;
             const bool edge = og0 < 0 || og0 + 32 > rows;
             float am = 0.0f;
@@ -675,7 +688,7 @@ __device__ __forceinline__ void b64_v3_ends(const B64Args &A, const int lane, co
             if (s > 0 || S0 == 0) amax = __builtin_fmaxf(amax, am);
         }
         B64_T(5, 1);
-        if (c5 >= 0 && c5 < nch) {                         // wave-uniform: the last multiply, chunk s - 6 -> the ring the shortcut joins from
+        if (!(B64_ABL & 8) && c5 >= 0 && c5 < nch) {       // wave-uniform: the last multiply, chunk s - 6 -> the ring the shortcut joins from
             f32x16 acc[2];
             b64_multiply(P5 + (c5 & 1) * (4 * B64_APL), bw, n, hh, acc);
             const unsigned vm = (unsigned)__ballot((vb & 0xffu) != 0);

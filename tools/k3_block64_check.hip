@@ -143,6 +143,7 @@ int main(int argc, char **argv) {
             for (int i = 0; i < 11; i++) printf(" %7lld", tr[r][i] ? (long long)(tr[r][i] - t0) : -1ll);
             printf("\n");
         }
+        printf("  workgroup %d: %llu steps in %llu ticks = %.0f ticks per step (first barrier to last)\n", (int)B64_TRACE, tr[0][14] - 1, tr[0][13] - tr[0][12], (double)(tr[0][13] - tr[0][12]) / (double)(tr[0][14] - 1));
     }
 #endif
     printf("speed-up of the block: %.2fx (whole block), %.2fx (separable layers fused, shortcut apart)\n", best[0] / best[1], best[0] / best[2]);
