@@ -607,13 +607,39 @@ __device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, bf16x8 
         h[q] = hh; m[q] = mm; l[q] = (__bf16)r2;
     }
 }
+// One channel PAIR split into its two fp16 pieces (+ the range report's running maximum), the way every f16x3 kernel below does it.  K3_SPLIT_MIX:
+//   0  element by element as first written: per pair v_cvt_pk_f16_f32, 2 x v_cvt_f32_f16, v_pk_add_f32 (or 2 x v_sub_f32), v_cvt_pk_f16_f32, and 2-3 v_max_f32
+//      for the maximum (fmaxf (amax, fabsf (x)) per element: the compiler quiets a possible NaN of every operand first);
+//   2  the maximum as ONE v_max3_f32 (amax, |x0|, |x1|) per pair;
+//   1  that, and the rest x - (float) h as ONE v_fma_mix_f32 per element, which reads the fp16 half in place (h x -1.0 + x: exact, the same value).
+// Same values in all three (tools/variant_check.py); what differs is the producers' instruction count, which is what the separable layers wait for.
+#ifndef K3_SPLIT_MIX
+#define K3_SPLIT_MIX 1
+#endif
+typedef _Float16 sp16x2 __attribute__((ext_vector_type(2)));
+typedef float spf32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(const float x0, const float x1, sp16x2 &h, sp16x2 &l, float &amax) {
+    if (K3_SPLIT_MIX == 0) {
+        amax = fmaxf(amax, fabsf(x0)); amax = fmaxf(amax, fabsf(x1));
+        const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+        h = sp16x2{h0, h1}; l = sp16x2{(_Float16)(x0 - (float)h0), (_Float16)(x1 - (float)h1)};
+        return;
+    }
+    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x0)), __builtin_fabsf(x1));
+    h = __builtin_convertvector(spf32x2{x0, x1}, sp16x2);
+    if (K3_SPLIT_MIX == 2) { l = __builtin_convertvector(spf32x2{x0, x1} - __builtin_convertvector(h, spf32x2), sp16x2); return; }
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x1));
+    l = __builtin_convertvector(spf32x2{r0, r1}, sp16x2);
+}
 __device__ __forceinline__ void split2(const f32x4 lo4, const f32x4 hi4, f16x8 &h, f16x8 &l, float &amax) {
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const float x = q < 4 ? lo4[q] : hi4[q - 4];
-        amax = fmaxf(amax, fabsf(x));
-        const _Float16 hh = (_Float16)x;
-        h[q] = hh; l[q] = (_Float16)(x - (float)hh);       // the difference is exact while |x| <= 65504
+    for (int q = 0; q < 8; q += 2) {
+        const float x0 = q < 4 ? lo4[q] : hi4[q - 4], x1 = q < 4 ? lo4[q + 1] : hi4[q - 3];
+        sp16x2 hp, lp;
+        split_pair(x0, x1, hp, lp, amax);                  // the difference is exact while |x| <= 65504
+        h[q] = hp[0]; h[q + 1] = hp[1]; l[q] = lp[0]; l[q + 1] = lp[1];
     }
 }
 template <int NP> __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
@@ -767,11 +793,10 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
                 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
                 f16x4 h, l;
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float x = rh[e];
-                    amax = fmaxf(amax, fabsf(x));
-                    const _Float16 hh = (_Float16)x;
-                    h[e] = hh; l[e] = (_Float16)(x - (float)hh);
+                for (int e = 0; e < 4; e += 2) {
+                    sp16x2 hp, lp;
+                    split_pair(rh[e], rh[e + 1], hp, lp, amax);
+                    h[e] = hp[0]; h[e + 1] = hp[1]; l[e] = lp[0]; l[e + 1] = lp[1];
                 }
                 *reinterpret_cast<f16x4 *>(&As[0][o]) = h; *reinterpret_cast<f16x4 *>(&As[1][o]) = l;
             }
@@ -1008,11 +1033,10 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
                 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
                 f16x4 h, l;
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float x = o[i][e];
-                    amax = fmaxf(amax, fabsf(x));
-                    const _Float16 hh = (_Float16)x;
-                    h[e] = hh; l[e] = (_Float16)(x - (float)hh);
+                for (int e = 0; e < 4; e += 2) {
+                    sp16x2 hp, lp;
+                    split_pair(o[i][e], o[i][e + 1], hp, lp, amax);
+                    h[e] = hp[0]; h[e + 1] = hp[1]; l[e] = lp[0]; l[e + 1] = lp[1];
                 }
                 *reinterpret_cast<f16x4 *>(&As[0][off]) = h; *reinterpret_cast<f16x4 *>(&As[1][off]) = l;
             }
@@ -1244,13 +1268,10 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
                 *reinterpret_cast<bf16x2 *>(&As[abuf][0][off]) = h; *reinterpret_cast<bf16x2 *>(&As[abuf][1][off]) = m;
                 *reinterpret_cast<bf16x2 *>(&As[abuf][NP - 1][off]) = l;
             } else {
-                // the pair at once: packed round-to-nearest conversions, packed subtraction (same values as element by element)
-                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-                amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(o[i][0]), __builtin_fabsf(o[i][1])));
-                const f16x2 h = __builtin_convertvector(o[i], f16x2);
-                const f32x2 rest = o[i] - __builtin_convertvector(h, f32x2);
-                const f16x2 l = __builtin_convertvector(rest, f16x2);
-                *reinterpret_cast<f16x2 *>(&As[abuf][0][off]) = h; *reinterpret_cast<f16x2 *>(&As[abuf][1][off]) = l;
+                // the pair at once (split_pair: packed round-to-nearest conversions; same values as element by element)
+                sp16x2 h, l;
+                split_pair(o[i][0], o[i][1], h, l, amax);
+                *reinterpret_cast<sp16x2 *>(&As[abuf][0][off]) = h; *reinterpret_cast<sp16x2 *>(&As[abuf][1][off]) = l;
             }
         }
     };
