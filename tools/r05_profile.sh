@@ -38,7 +38,12 @@ python3 tools/time_run_detect.py --reads 10000 --stats $OUT/run_detect_stats.jso
 python3 tools/time_run_detect.py --reads 10000 --stats $OUT/run_detect_stats_warm.json --reuse > $OUT/run_detect_warm.log 2>&1
 python3 tools/time_run_detect.py --reads 10000 --ranks 2 --sha --reuse --stats $OUT/run_detect_2ranks_gloo_stats.json > $OUT/run_detect_2ranks.log 2>&1
 python3 tools/time_run_detect.py --reads 10000 --sha --reuse > $OUT/run_detect_1rank_sha.log 2>&1
+DN_RUN_DETECT_SLOW_EXIT=1 python3 tools/time_run_detect.py --reads 10000 --reuse > $OUT/run_detect_slow_exit.log 2>&1
 #   (8) the fused 64-channel block against the 13 launches it replaces (bit for bit + time), with its phase stamps
 tools/_bin/k3_block64_check 1200128 5 > $OUT/k3_block64_check.txt 2>&1
-tools/_bin/k3_block64_trace 1200128 3 2>&1 | grep -E "phase|stage|conv" > $OUT/k3_block64_phase_trace.txt
+tools/_bin/k3_block64_trace 1200128 3 2>&1 | grep -E "phase|stage|conv|workgroup" > $OUT/k3_block64_phase_trace.txt
+#   (9) the third version of the block (filter in the accumulator layout), same session: bit for bit + time + stamps + ablations
+tools/_bin/k3_block64_check3 1200128 5 > $OUT/k3_block64_v3_check.txt 2>&1
+tools/_bin/k3_b64_v3t 1200128 3 2>&1 | grep -E "phase|stage|conv|workgroup" >> $OUT/k3_block64_v3_check.txt
+for b in k3_b64v3_abl40 k3_b64v3_abl48 k3_b64v3_abl16; do echo "== $b (timing only)" >> $OUT/k3_block64_v3_check.txt; tools/_bin/$b 1200128 3 2>&1 | grep "BLOCK64=2" >> $OUT/k3_block64_v3_check.txt; done
 ls $OUT | head -60; tail -1 $OUT/bench_default.json | cut -c1-300
