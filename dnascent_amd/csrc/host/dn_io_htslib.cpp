@@ -4,6 +4,8 @@
 // boxes of this project the file is NOT compiled and the tested ingestion path is the binary read container (dn_host.h), which holds
 // exactly the fields extracted here.  It produces DNAscent::ReadInput, i.e. what DNAscent::read's constructor (reads.h:210-287) and
 // pod5_getSignal (pod5.cpp:24-105) take from the files; everything downstream is the tested path.
+// Round 5: the BAM half exists WITHOUT htslib in dn_bam.cpp (BGZF + record + aux tags over zlib, compiled and tested: tests/test_bam.py); this file is what a
+// deployment that has htslib / libpod5 would compile instead, and the only place the POD5 half can live.
 //
 // Differences from the reference that matter at >= 5 Msamples/s/GPU x 8: POD5 files stay open in a small cache instead
 // of pod5_open_file / pod5_close_and_free_reader per read (pod5.cpp:30,101), and records are filtered before any signal is fetched.
