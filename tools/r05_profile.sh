@@ -36,7 +36,7 @@ python3 bench.py --scope mixed --order long-first --no-cpu-baseline --fp32-steps
 #   (7) the PRODUCT driver at configs[2] size: container -> run_detect -> .detect (tools/time_run_detect.py)
 python3 tools/time_run_detect.py --reads 10000 --stats $OUT/run_detect_stats.json --keep > $OUT/run_detect.log 2>&1
 python3 tools/time_run_detect.py --reads 10000 --stats $OUT/run_detect_stats_warm.json --reuse > $OUT/run_detect_warm.log 2>&1
-python3 tools/time_run_detect.py --reads 10000 --ranks 2 --sha --reuse --stats $OUT/run_detect_2ranks_gloo_stats.json > $OUT/run_detect_2ranks.log 2>&1
+python3 tools/time_run_detect.py --reads 10000 --ranks 2 --inflight 3 --sha --reuse --stats $OUT/run_detect_2ranks_gloo_stats.json > $OUT/run_detect_2ranks.log 2>&1     # two ranks share ONE GPU here: 3 contexts each (8 each do not fit 288 GB)
 python3 tools/time_run_detect.py --reads 10000 --sha --reuse > $OUT/run_detect_1rank_sha.log 2>&1
 DN_RUN_DETECT_SLOW_EXIT=1 python3 tools/time_run_detect.py --reads 10000 --reuse > $OUT/run_detect_slow_exit.log 2>&1
 #   (8) the fused 64-channel block against the 13 launches it replaces (bit for bit + time), with its phase stamps
