@@ -194,7 +194,9 @@ def main():
     full = args.scope in ("full", "mixed")
     rps = args.reads_per_step or (500 if full else 1000)
     bases = args.bases or (50000 if full else 20000)
-    inflight = args.inflight or 8                          # full, one session (round 3, gpurun_out/r3i): 6 -> 665, 8 -> 675, 10 -> 659 Msamples/s; 8 x 21 GB of workspaces + 4 CNN lanes = 238 of 309 GB
+    # contexts (batches) in flight.  Full pipeline, one session of round 5 (gpurun_out/r5w, --steps 14): 4 -> 808 / 805, 5 -> 813 / 813, 6 -> 821 / 822, 8 -> 816 / 814
+    # Msamples/s; 6 x 14.5 GB of workspaces + 4 CNN lanes x 16 GiB = 159 of 309 GB (8: 189).  The banded scope (no network) keeps 8.
+    inflight = args.inflight or (6 if full else 8)
     os.environ.setdefault("DN_CNN_ROWS", str(4 << 20))      # activation rows resident per CNN pass and lane: 4 Mi rows = 16 GiB (2 Mi: -6 %, 8 Mi: -3 %)
 
     rank = int(os.environ.get("RANK", "0"))

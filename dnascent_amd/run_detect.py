@@ -77,7 +77,9 @@ def main(argv=None):
     ap.add_argument("--out", required=True)
     ap.add_argument("--model", default=None, help="CNN description prefix (tools/convert_savedmodel.py); default: synthetic weights")
     ap.add_argument("--pore-model", default=None)
-    ap.add_argument("--inflight", type=int, default=8, help="batches in flight on the GPU (one context each: ~21 GB of HBM per 300 M samples; 8 measured best, bench.py)")
+    ap.add_argument("--inflight", type=int, default=5, help="batches in flight on the GPU (one context each: ~14.5 GB of HBM per 300 M samples at the default event bound).  "
+                    "4-8 stream alike (bench.py: within 1.5 %%); from 6 up the contexts' 160+ GB of hipMalloc, which run beside the first batches, took 3.5 s instead of 1 "
+                    "in most runs (gpurun_out/r5v: 10 000 x 50 kb in 7.8-7.9 s at 4 and 5, 10.0-10.6 s at 6, 7.9-10.0 s at 8)")
     ap.add_argument("--batch-samples", type=float, default=300e6, help="sample budget of one batch")
     ap.add_argument("--batch-reads", type=int, default=4096)
     ap.add_argument("--window-batches", type=float, default=2.0,

@@ -71,12 +71,12 @@ for n in ("bench_default.json", "bench_under_rocprof.json", "bench_banded.json",
 st = glob.glob(src + "/stats/**/*kernel_stats.csv", recursive=True)
 if st:
     shutil.copy(st[0], "profiles/r05_kernel_stats.csv")
-# ---- full scope: --steps 8 --warmup 1 --inflight 8 + the untimed solo batch = 10 batches through the whole pipeline (the set-up uploads run nothing)
+# ---- full scope: --steps 8 --warmup 1 --inflight 6 + the untimed solo batch = 10 batches through the whole pipeline (the set-up uploads run nothing)
 bd = json.load(open(src + "/bench_default.json")) if os.path.exists(src + "/bench_default.json") else None
 full = build("full", bd, 10)
 if full and bd:
-    full["workload"] = {"reads_per_step": bd["config"]["reads_per_step"], "bases": bd["config"]["bases_per_read"], "cnn_math": "f16x3", "inflight": 8, "steps": 8,
-                        "command": "rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --steps 8 --warmup 1 --inflight 8 --no-cpu-baseline --fp32-steps 0"}
+    full["workload"] = {"reads_per_step": bd["config"]["reads_per_step"], "bases": bd["config"]["bases_per_read"], "cnn_math": "f16x3", "inflight": 6, "steps": 8,
+                        "command": "rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --steps 8 --warmup 1 --inflight 6 --no-cpu-baseline --fp32-steps 0"}
     json.dump(full, open("profiles/r05_pmc_bench.json", "w"), indent=1)
     k3 = {k: v for k, v in full["kernels"].items() if k.startswith("k3_")}
     json.dump({"command": full["workload"]["command"].replace("<counter>", "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"),

@@ -17,7 +17,7 @@ rm -f $OUT/stats/*kernel_trace.csv $OUT/stats/*/*kernel_trace.csv
 PMC_MFMA="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 for c in WRITE_SIZE FETCH_SIZE MFMA; do
   ctr=$c; [ $c = MFMA ] && ctr="$PMC_MFMA"
-  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_full_$c -o p -- python3 bench.py --steps 8 --warmup 1 --inflight 8 --no-cpu-baseline --fp32-steps 0 > $OUT/pmc_full_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_full_$c -o p -- python3 bench.py --steps 8 --warmup 1 --inflight 6 --no-cpu-baseline --fp32-steps 0 > $OUT/pmc_full_$c.log 2>&1
   rm -f $OUT/pmc_full_$c/*kernel_trace.csv $OUT/pmc_full_$c/*/*kernel_trace.csv
 done
 python3 bench.py --scope banded --no-cpu-baseline --steps 32 --warmup 8 > $OUT/bench_banded.log 2>&1; tail -1 $OUT/bench_banded.log > $OUT/bench_banded.json

@@ -9,7 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reads", type=int, default=10000)
 ap.add_argument("--bases", type=int, default=50000)
 ap.add_argument("--dir", default="/tmp")
-ap.add_argument("--inflight", type=int, default=8)
+ap.add_argument("--inflight", type=int, default=5)
 ap.add_argument("--stats", default=None)
 ap.add_argument("--keep", action="store_true")
 ap.add_argument("--reuse", action="store_true", help="do not rewrite the container if --dir already holds one (repeated timings in one session; implies --keep)")
