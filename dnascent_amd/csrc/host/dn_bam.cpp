@@ -187,17 +187,20 @@ bool BamReader::open(const std::string &path) {
     uint8_t m[8];
     if (z.read(m, 8) != 8 || memcmp(m, "BAM\1", 4) != 0) return false;
     const uint32_t lt = le32(m + 4);
+    if (lt > (1u << 30)) return false;                    // a header text of more than 1 GB is a damaged file, not an allocation to attempt
     text_.resize(lt);
     if (lt && z.read(&text_[0], lt) != lt) return false;
     while (!text_.empty() && text_.back() == '\0') text_.pop_back();
     uint8_t q[4];
     if (z.read(q, 4) != 4) return false;
     const uint32_t nref = le32(q);
+    if (nref > (1u << 24)) return false;
     for (uint32_t i = 0; i < nref; i++) {
         if (z.read(q, 4) != 4) return false;
         const uint32_t ln = le32(q);
+        if (ln == 0 || ln > (1u << 16)) return false;
         std::string name(ln, '\0');
-        if (ln == 0 || z.read(&name[0], ln) != ln || z.read(q, 4) != 4) return false;
+        if (z.read(&name[0], ln) != ln || z.read(q, 4) != 4) return false;
         name.resize(ln - 1);                              // NUL-terminated in the file
         refs_.push_back({name, le32(q)});
     }
