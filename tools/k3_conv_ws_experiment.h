@@ -13,12 +13,15 @@
 // cout / 32 workgroups share a stripe (one per column slice); they sit on the same XCD (blockIdx % 8), so the input rows they all read come from its L2.
 // NOT bit-identical to k3_conv_split: a product's three MFMAs keep their order, but K is summed per wavefront and then across wavefronts (conv_split: one chain).
 //
-// RESULT (gpurun_out/r6a, 1.2 M rows): within 1.05e-5 of k3_conv_split on every shape, and SLOWER: 17 x 128 -> 256 + add 3 308 us against 3 113 (same box), 9 x 128 -> 128
-// 1 156 against 852, 9 x 64 -> 128 723 against 511.  Its stamps: a step is 5 700 ticks for 3 264 of MFMAs per SIMD; the two wavefronts of a SIMD issue their
-// 102 MFMAs in ~4 650 ticks (46 per MFMA, 70 % of the pipe -- what k3_conv_split's counter says of it too) and the reduction, split and partial-sum traffic are not
-// hidden behind them.  Variants that made it worse: two barriers per step with the reduction as its own phase (3 805 us: the residual's load latency sat in it;
-// 3 324 with that prefetched), fragment reads pinned a whole pair ahead + the two wavefronts of a SIMD in antiphase (256 registers, 30 spilled: 3 982 us).
-// Weight-stationary convolutions do not beat the streamed-weight kernel here; recorded, not pursued.
+// RESULT (gpurun_out/r6a, 1.2 M rows): within 1.05e-5 of k3_conv_split on every shape, and SLOWER: 17 x 128 -> 256 + add 3 308-3 389 us against 3 113-3 240 (same
+// process), 9 x 128 -> 128 1 156-1 201 against 852-1 020, 9 x 64 -> 128 723-766 against 506-511.  Its stamps (-DCW_TRACE): a step is 5 500-5 700 ticks for 3 264 of
+// MFMAs per SIMD; the two wavefronts of a SIMD issue their 102 MFMAs in ~4 300-4 650 ticks (42-46 per MFMA) and the later one's reduction, split and partial-sum
+// traffic (~1 100 ticks) is hidden behind nothing.  What was tried on that, all slower: the reduction as its own phase between two barriers (3 805 us with the
+// residual's load inside it, 3 324 with that prefetched); the fragment reads of the next group pinned in front of a group's MFMAs (-DCW_PIN=1: 3 446 -- the ISA is
+// exactly tools/ubench_mfma_lds.hip's loop, which runs at 35 cycles per MFMA bare, on one wavefront per SIMD or two); two barriers per step with the two wavefronts
+// of a SIMD in antiphase, one multiplying while the other reduces / splits / stores (-DCW_ANTIPHASE=1: 3 649-3 706; stamps: the wavefront that multiplies ALONE on
+// its SIMD needs 3 200-3 600 ticks for its 54 MFMAs, 60-66 each, pinned reads or not -- unexplained: not the fragment latency, not the LDS traffic of the others, which
+// are waiting at the barrier by then).  Weight-stationary convolutions do not beat the streamed-weight kernel here; recorded, not pursued.
 #pragma once
 
 #define CW_RING 128                                         // rows of the plane ring: a chunk's window (32 + KW - 1 <= 48) + the 32 rows split for the next chunk while it is read
@@ -119,12 +122,7 @@ __global__ __launch_bounds__(512, 2) void k3_conv_ws(const CwArgs A) {
         const int G = S0 + 32 * c;
         CW_T(0);
         // ---- chunk c - 1: the eight partial sums of rows 4 wave .. 4 wave + 3 (reads first: they are long back when the adds issue) ----
-        f2 pv[8];
         const int row = 4 * wave + rr;
-        if (c > 0) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) pv[u] = *reinterpret_cast<const f2 *>(&Ps[(c - 1) & 1][u][row * CW_PP + c2]);
-        }
         const unsigned vb_prev = vb; const f2 add_prev = addv;
         const int grow = 32 * c + row;                        // relative to the stripe (the descriptors start there)
         if (c < nch) {                                      // chunk c's validity byte and residual: requested now, used a step later
@@ -135,50 +133,73 @@ __global__ __launch_bounds__(512, 2) void k3_conv_ws(const CwArgs A) {
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[q] = 0.0f;
-        auto pair = [&](int i) {
-            const int p = wave + 8 * i;
+#ifndef CW_PIN
+#define CW_PIN 0                                            /* (3 446 us pinned against 3 308-3 389 unpinned: see the header) 1: the four A fragments of pair i + 1 are requested before pair i's six MFMAs issue (pinned with sched_barrier); 0: left to the scheduler, which issues every pair of reads right in front of the MFMA that waits for them */
+#endif
+        // the A fragments of group g + 1 (a group = one k16 half of a pair: 2 fragment reads, 3 MFMAs) are requested BEFORE group g's MFMAs issue (CW_PIN: pinned with
+        // sched_barrier).  Left to the scheduler every pair of reads sits right in front of the MFMA that waits for it: a wavefront alone on its SIMD then needs 66 cycles
+        // per MFMA (stamps), where the bare loop of tools/ubench_mfma_lds.hip needs 35 with the reads one group ahead.
+        u32x4 fa[2][2];                                     // [buffer][piece: 0 = hi, 1 = lo]
+        auto frags = [&](int g, u32x4 (&f)[2]) {
+            const int p = wave + 8 * (g >> 1), k16 = g & 1;
             const int cb = p / KW, tap = p % KW;
             const int slot = (G - half + tap + n + CW_RING) & (CW_RING - 1);
-            const uint16_t *ap = &Pl[0][0][0] + cb * (2 * PLANE) + slot * CNN_BP + 8 * hh;
+            const uint16_t *ap = &Pl[0][0][0] + cb * (2 * PLANE) + slot * CNN_BP + 8 * hh + k16 * 16;
+            f[0] = *reinterpret_cast<const u32x4 *>(ap);
+            f[1] = *reinterpret_cast<const u32x4 *>(ap + PLANE);
+        };
+        auto mul = [&](int g, const u32x4 (&f)[2]) {
+            const int i = g >> 1, k16 = g & 1;
+            acc = mfma16<2>(f[1], bw[i][k16][0], acc);
+            acc = mfma16<2>(f[0], bw[i][k16][1], acc);
+            acc = mfma16<2>(f[0], bw[i][k16][0], acc);
+        };
+        constexpr int NFULL = NPAIR / 8;                    // pairs every wavefront has; the first NPAIR % 8 wavefronts have one more
+        const bool extra = NPAIR % 8 && wave < NPAIR % 8;
+        auto multiply = [&]() {
+            if (c < nch) {
+                frags(0, fa[0]);
 #pragma unroll
-            for (int k16 = 0; k16 < 2; k16++) {
-                const u32x4 ah = *reinterpret_cast<const u32x4 *>(ap + k16 * 16);
-                const u32x4 al = *reinterpret_cast<const u32x4 *>(ap + PLANE + k16 * 16);
-                acc = mfma16<2>(al, bw[i][k16][0], acc);
-                acc = mfma16<2>(ah, bw[i][k16][1], acc);
-                acc = mfma16<2>(ah, bw[i][k16][0], acc);
+                for (int g = 0; g < 2 * NFULL; g++) {
+                    if (g + 1 < 2 * NFULL) frags(g + 1, fa[(g + 1) & 1]);
+                    else if (extra) frags(2 * NFULL, fa[0]);
+                    if (CW_PIN) __builtin_amdgcn_sched_barrier(0);
+                    mul(g, fa[g & 1]);
+                    if (CW_PIN) __builtin_amdgcn_sched_barrier(0);
+                }
+                if (extra) { frags(2 * NFULL + 1, fa[1]); if (CW_PIN) __builtin_amdgcn_sched_barrier(0); mul(2 * NFULL, fa[0]); mul(2 * NFULL + 1, fa[1]); }
+                float *pw = &Ps[c & 1][wave][(4 * hh) * CW_PP + n];
+#pragma unroll
+                for (int q = 0; q < 16; q++) pw[((q & 3) + 8 * (q >> 2)) * CW_PP] = acc[q];
             }
         };
-        if (c < nch) {
-            // the pairs every wavefront has, as ONE straight line (behind a branch per pair the compiler kept every pair's four fragment reads in its own block: no
-            // read ran ahead of the previous pair's MFMAs); then the one only the first NPAIR % 8 wavefronts have
+        auto post = [&]() {
+            if (c > 0) {                                    // chunk c - 1: sum in the order 0 .. 7, epilogue, store
+                f2 pv[8];
 #pragma unroll
-            for (int i = 0; i < NPAIR / 8; i++) pair(i);
-            if (NPAIR % 8 && wave < NPAIR % 8) pair(NPAIR / 8);
-        }
-        CW_T(1);
-        if (c > 0) {                                        // chunk c - 1: sum in the order 0 .. 7, epilogue, store
-            f2 v = pv[0];
+                for (int u = 0; u < 8; u++) pv[u] = *reinterpret_cast<const f2 *>(&Ps[(c - 1) & 1][u][row * CW_PP + c2]);
+                f2 v = pv[0];
 #pragma unroll
-            for (int u = 1; u < 8; u++) v += pv[u];
-            float y0 = __builtin_fmaf(v[0], sc0, sh0), y1 = __builtin_fmaf(v[1], sc1, sh1);
-            if (ADD) { y0 += add_prev[0]; y1 += add_prev[1]; }
-            y0 = __builtin_fmaxf(y0, floor_); y1 = __builtin_fmaxf(y1, floor_);
-            const bool ok = (vb_prev & 0xffu) != 0;
-            y0 = ok ? y0 : 0.0f; y1 = ok ? y1 : 0.0f;
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(b64u2, f2{y0, y1}), rY, ((grow - 32) * cout + col) * 4, 0, 0);
-        }
-        CW_T(2);
-        if (c + 1 < nch) {                                  // the next chunk's new rows: G + 32 + half .. G + 64 + half
-            lstore(G + 32 + half, 32);
-            gload(G + 64 + half);                           // (past the stripe: loaded, never used)
-        }
-        CW_T(3);
-        if (c < nch) {
-            float *pw = &Ps[c & 1][wave][(4 * hh) * CW_PP + n];
-#pragma unroll
-            for (int q = 0; q < 16; q++) pw[((q & 3) + 8 * (q >> 2)) * CW_PP] = acc[q];
-        }
+                for (int u = 1; u < 8; u++) v += pv[u];
+                float y0 = __builtin_fmaf(v[0], sc0, sh0), y1 = __builtin_fmaf(v[1], sc1, sh1);
+                if (ADD) { y0 += add_prev[0]; y1 += add_prev[1]; }
+                y0 = __builtin_fmaxf(y0, floor_); y1 = __builtin_fmaxf(y1, floor_);
+                const bool ok = (vb_prev & 0xffu) != 0;
+                y0 = ok ? y0 : 0.0f; y1 = ok ? y1 : 0.0f;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(b64u2, f2{y0, y1}), rY, ((grow - 32) * cout + col) * 4, 0, 0);
+            }
+            if (c + 1 < nch) {                              // the next chunk's new rows: G + 32 + half .. G + 64 + half
+                lstore(G + 32 + half, 32);
+                gload(G + 64 + half);                       // (past the stripe: loaded, never used)
+            }
+        };
+#ifndef CW_ANTIPHASE
+#define CW_ANTIPHASE 0                                      /* (3 649-3 706 us: a wavefront alone on its SIMD multiplies at 60-66 cycles per MFMA, see the header) 1: TWO barriers per step, and the two wavefronts of a SIMD (w, w + 4) take its halves in opposite order -- one multiplies while the other reduces the previous chunk, stores it and splits the next rows; 0: one barrier, every wavefront multiplies, then does the rest */
+#endif
+        if (CW_ANTIPHASE) {
+            if (wave < 4) { multiply(); CW_T(1); b64_barrier(); CW_T(2); post(); CW_T(3); }
+            else { post(); CW_T(1); b64_barrier(); CW_T(2); multiply(); CW_T(3); }
+        } else { multiply(); CW_T(1); post(); CW_T(3); }
         CW_T(4);
         b64_barrier();
         CW_T(5);
