@@ -8,16 +8,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int WAVES, int CHAINS, int AHEAD>   // AHEAD: groups (1 group = 2 reads + 3 MFMAs) between a read and its use
+template <int WAVES, int CHAINS, int AHEAD, int RANDOM = 0>   // RANDOM: operands with random mantissas / signs / exponents (fp16 values in [-4, 4]) instead of 1.0 everywhere.  AHEAD: groups (1 group = 2 reads + 3 MFMAs) between a read and its use
 __global__ __launch_bounds__(64 * WAVES) void k(float *out, unsigned long long *ticks, int iters) {
     __shared__ __attribute__((aligned(16))) unsigned lds[32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 32768; i += blockDim.x) lds[i] = 0x3c003c00u + (i & 7);
+    auto rnd16 = [](unsigned x) -> unsigned { x *= 2654435761u; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; const unsigned m = x & 0x3ff, e = 13 + ((x >> 10) & 3), sg = (x >> 12) & 1; return (sg << 15) | (e << 10) | m; };
+    for (int i = tid; i < 32768; i += blockDim.x) lds[i] = RANDOM ? (rnd16(2 * i + 1) << 16 | rnd16(2 * i + 2)) : 0x3c003c00u + (i & 7);
     __syncthreads();
     f32x16 acc[2];
     for (int j = 0; j < 2; j++) for (int q = 0; q < 16; q++) acc[j][q] = 0.f;
     u32x4 bw[8];
-    for (int i = 0; i < 8; i++) bw[i] = u32x4{0x3c003c00u, 0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u};
+    for (int i = 0; i < 8; i++) bw[i] = RANDOM ? u32x4{rnd16(lane * 64 + i * 8 + 1) << 16 | rnd16(lane * 64 + i * 8 + 2), rnd16(lane * 64 + i * 8 + 3) << 16 | rnd16(lane * 64 + i * 8 + 4), rnd16(lane * 64 + i * 8 + 5) << 16 | rnd16(lane * 64 + i * 8 + 6), rnd16(lane * 64 + i * 8 + 7) << 16 | rnd16(lane * 64 + i * 8 + 8)}
+                                              : u32x4{0x3c003c00u, 0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u};
     const unsigned *base = lds + wave * 2048 + (lane & 31) * 20 + (lane >> 5) * 4;       // rows of 80 B, 16 B per lane half
     constexpr int G = 12;                                  // groups per iteration
     u32x4 fh[AHEAD + 1], fl[AHEAD + 1];
@@ -43,20 +45,27 @@ __global__ __launch_bounds__(64 * WAVES) void k(float *out, unsigned long long *
     if (sum == 1234.5f) out[0] = sum;
     if (lane == 0 && blockIdx.x == 100) ticks[wave] = t1 - t0;
 }
-template <int WAVES, int CHAINS, int AHEAD> void run(float *out, unsigned long long *tk) {
-    const int iters = 2000;
-    hipLaunchKernelGGL((k<WAVES, CHAINS, AHEAD>), dim3(256), dim3(64 * WAVES), 0, 0, out, tk, iters);
+template <int WAVES, int CHAINS, int AHEAD, int RANDOM = 0> void run(float *out, unsigned long long *tk) {
+    const int iters = 20000;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k<WAVES, CHAINS, AHEAD, RANDOM>), dim3(256), dim3(64 * WAVES), 0, 0, out, tk, iters);
+    (void)hipEventRecord(e1, 0);
     (void)hipDeviceSynchronize();
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[8]; (void)hipMemcpy(h, tk, 64, hipMemcpyDeviceToHost);
     unsigned long long mx = 0; for (int w = 0; w < WAVES; w++) mx = h[w] > mx ? h[w] : mx;
     // MFMAs per SIMD = waves on it x 36 per iteration
-    printf("%d wavefront(s) per SIMD, %d chain(s), fragment reads %d group(s) ahead: %.1f cycles per MFMA on the SIMD (%.1f per wavefront's MFMA)\n", WAVES / 4, CHAINS, AHEAD,
-           (double)mx / (iters * 36.0 * (WAVES / 4)), (double)mx / (iters * 36.0));
+    const double nm = iters * 36.0 * (WAVES / 4);            // MFMAs per SIMD
+    printf("%d wavefront(s) per SIMD, %d chain(s), reads %d group(s) ahead, %s operands: %.1f ticks per MFMA on the SIMD; %.2f ns per MFMA by the host's events = %.2f ticks per ns; %.0f TFLOP/s\n", WAVES / 4, CHAINS, AHEAD,
+           RANDOM ? "RANDOM" : "all-ones", (double)mx / nm, ms * 1e6 / nm, (double)mx / (ms * 1e6), nm * 1024.0 * 2.0 * 32 * 32 * 16 / (ms * 1e-3) / 1e12);
 }
 int main() {
     float *out; unsigned long long *tk;
     (void)hipMalloc(&out, 64); (void)hipMalloc(&tk, 64);
     run<4, 1, 1>(out, tk); run<4, 1, 2>(out, tk); run<4, 1, 4>(out, tk); run<4, 2, 2>(out, tk);
     run<8, 1, 1>(out, tk); run<8, 1, 2>(out, tk); run<8, 1, 4>(out, tk); run<8, 2, 2>(out, tk); run<8, 2, 4>(out, tk);
+    run<4, 1, 1, 1>(out, tk); run<4, 1, 2, 1>(out, tk); run<8, 1, 1, 1>(out, tk); run<8, 1, 2, 1>(out, tk); run<8, 2, 2, 1>(out, tk);
+    run<8, 1, 1, 0>(out, tk); run<8, 1, 1, 1>(out, tk);
     return 0;
 }
