@@ -1482,6 +1482,8 @@ __global__ __launch_bounds__(256) void k3_dense_softmax(const float *__restrict_
 }
 
 #include "k3_block64.h"
+#include "k3_pair128.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------------------
 // host-side walker over the op list
@@ -1599,6 +1601,45 @@ static void k3_launch_block64(const CnnRun &c, int i, int span, const float *x, 
     else hipLaunchKernelGGL((k3_block64<false>), dim3(grid), dim3(512), 0, st, a);
 }
 
+// ---- two consecutive 9-tap separable layers of the 128-channel stage in one launch (k3_pair128.h) ----
+// DN_CNN_PAIR128: 1 = on, 0 = layer by layer.  k3_pair128_force (>= 0) overrides the environment (tools/k3_pair128_check.hip).
+int k3_pair128_force = -1;
+#ifndef K3_PAIR128_DEFAULT
+#define K3_PAIR128_DEFAULT 0
+#endif
+static int k3_pair128_mode() { static const int env = k3_env_int("DN_CNN_PAIR128", K3_PAIR128_DEFAULT); return k3_pair128_force >= 0 ? k3_pair128_force : env; }
+// Do ops i .. i + 3 form such a pair?  DWCONV 9 x cin0 -> CONV 1 x cin0 -> 128 -> DWCONV 9 x 128 -> CONV 1 x 128 -> 128 (cin0 = 64 or 128), each a fusable pair, chained,
+// no residual add on either, and the first layer's output read by nothing but the second layer's filter.
+static bool k3_takes_pair128(const CnnRun &c, int i) {
+    if (k3_pair128_mode() <= 0 || c.pieces != 2 || !c.wts_split || i < 0 || i + 3 >= c.n_ops) return false;
+    if (c.rows.rows % 256) return false;
+    if (!k3_can_fuse(c, i) || !k3_can_fuse(c, i + 2)) return false;
+    const dn_cnn_op &d0 = c.ops[i], &p0 = c.ops[i + 1], &d1 = c.ops[i + 2], &p1 = c.ops[i + 3];
+    if (d0.k != 9 || d1.k != 9 || (d0.cin != 64 && d0.cin != 128) || p0.cout != 128 || d1.cin != 128 || p1.cout != 128) return false;
+    if (p0.op != DN_CNN_CONV || p1.op != DN_CNN_CONV || d1.src != p0.dst) return false;
+    for (int j = i + 3; j < c.n_ops; j++) {                // is the first layer's output read again before it is overwritten (by p1 itself, usually)?
+        const dn_cnn_op &o = c.ops[j];
+        if (j > i + 3) {
+            const bool reads = (o.op != DN_CNN_ENCODE_GRU && o.src == p0.dst) || ((o.op == DN_CNN_ADD_RELU || o.op == DN_CNN_CONV_ADD) && o.a == p0.dst) || (o.op == DN_CNN_ADD_RELU && o.b == p0.dst);
+            if (reads) return false;
+        }
+        if (o.dst == p0.dst) break;
+    }
+    return true;
+}
+static void k3_launch_pair128(const CnnRun &c, int i, const float *x, float *y, hipStream_t st) {
+    P128Args a{};
+    a.X = x; a.Y = y; a.valid = c.valid; a.live = c.live; a.rows = (int)c.rows.rows;
+    for (int j = 0; j < 2; j++) {
+        const dn_cnn_op &d = c.ops[i + 2 * j], &p = c.ops[i + 2 * j + 1];
+        a.L[j].wd = c.wts + d.w; a.L[j].wb = c.wts_split + c.wb_off[i + 2 * j + 1]; a.L[j].scale = c.wts + p.scale; a.L[j].shift = c.wts + p.shift;
+        a.L[j].range = c.range_flag + 2 + 2 * (i + 2 * j); a.L[j].post = c.post[i + 2 * j + 1]; a.L[j].relu = p.relu;
+    }
+    const unsigned grid = std::max(1u, std::min(k3_cu_count(), c.rows.rows / 32u));
+    if (c.ops[i].cin == 64) hipLaunchKernelGGL((k3_pair128<64>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k3_pair128<128>), dim3(grid), dim3(256), 0, st, a);
+}
+
 // Which fused kernel: the wave-specialised one pays off where the depthwise filter is long and the layer wide (17 taps, 256
 // output channels: one workgroup covers ALL 256 columns, so the filter is applied once per row tile); the short filters of the
 // narrow layers are memory-side and run better as k3_sep_split with 2-3 workgroups per CU.
@@ -1649,6 +1690,13 @@ int k3_run(const CnnRun &c, hipStream_t st) {
             // (resp. the last pointwise op's); the buffers in between are never touched, so no logical buffers swap
             k3_launch_block64(c, i, span, pb[o.src], span == 13 ? pb[c.ops[i + 12].dst] : pb[c.ops[i + 11].dst], st);
             i += span - 1;
+            continue;
+        }
+        if (k3_takes_pair128(c, i)) {                      // two separable layers, one launch: into the first depthwise op's own destination (never an input of the pair)
+            const dn_cnn_op &p1 = c.ops[i + 3];
+            k3_launch_pair128(c, i, pb[o.src], pb[o.dst], st);
+            { float *t = pb[p1.dst]; pb[p1.dst] = pb[o.dst]; pb[o.dst] = t; }       // the result now IS the second pointwise op's destination
+            i += 3;
             continue;
         }
         if (k3_can_fuse(c, i)) {
@@ -1753,6 +1801,15 @@ int k3_describe(const CnnRun &c, int i, char *buf, size_t cap) {
             if (j < i) return 0;
             snprintf(buf, cap, "k3_block64<%s>", span == 13 ? "true" : "false");
             return 1;
+        }
+        if (!span && k3_takes_pair128(c, j)) {              // four ops, one launch: reported under the first
+            if (i < j + 4) {
+                if (j < i) return 0;
+                snprintf(buf, cap, "k3_pair128<%d>", o.cin);
+                return 1;
+            }
+            j += 4;
+            continue;
         }
         j += span ? span : (k3_can_fuse(c, j) ? 2 : 1);
     }
