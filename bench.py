@@ -519,6 +519,12 @@ def main():
                         q = ops[j]
                         fl += 2.0 * (q["k"] * q["c"] if q["op"] == "dwconv" else q["k"] * q["cin"] * q["cout"])
                     return fl, 4.0 * (64 + 64 + (64 if span == 13 else 0))
+                if name_i.startswith("k3_pair128"):        # two separable layers in one launch: the work of both, the bytes of ONE pass (first layer's input in, second layer's output out)
+                    fl = 0.0
+                    for j in range(i, i + 4):
+                        q = ops[j]
+                        fl += 2.0 * (q["k"] * q["c"] if q["op"] == "dwconv" else q["k"] * q["cin"] * q["cout"])
+                    return fl, 4.0 * (ops[i + 1]["cin"] + ops[i + 3]["cout"])
                 if o["op"] == "dwconv" and i + 1 < len(ops) and lay.get(i, [0, 0, ""])[2].startswith("k3_sep"):
                     p = ops[i + 1]
                     return 2.0 * (o["k"] * o["c"] + p["cin"] * p["cout"]), 4.0 * (p["cin"] + p["cout"] + (p["cout"] if p.get("add", -1) >= 0 else 0))

@@ -1605,7 +1605,7 @@ static void k3_launch_block64(const CnnRun &c, int i, int span, const float *x, 
 // DN_CNN_PAIR128: 1 = on, 0 = layer by layer.  k3_pair128_force (>= 0) overrides the environment (tools/k3_pair128_check.hip).
 int k3_pair128_force = -1;
 #ifndef K3_PAIR128_DEFAULT
-#define K3_PAIR128_DEFAULT 0
+#define K3_PAIR128_DEFAULT 1
 #endif
 static int k3_pair128_mode() { static const int env = k3_env_int("DN_CNN_PAIR128", K3_PAIR128_DEFAULT); return k3_pair128_force >= 0 ? k3_pair128_force : env; }
 // Do ops i .. i + 3 form such a pair?  DWCONV 9 x cin0 -> CONV 1 x cin0 -> 128 -> DWCONV 9 x 128 -> CONV 1 x 128 -> 128 (cin0 = 64 or 128), each a fusable pair, chained,

@@ -36,26 +36,40 @@ __device__ unsigned long long p128_trace[4][8];
 #define P128_T(i) do { } while (0)
 #endif
 
-// the MFMAs of one chunk: planes [CB][piece][32 x CNN_BP] x resident B fragments [CB][k16][piece][column tile]
+// the MFMAs of one chunk: planes [CB][piece][32 x CNN_BP] x resident B fragments [CB][k16][piece][column tile].  One wavefront per SIMD: nobody covers an LDS wait,
+// so the two A fragments of group g + 1 (a group = one k16 half of a channel block: 2 reads, 6 MFMAs) are requested BEFORE group g's MFMAs issue (P128_PIN: pinned
+// with sched_barrier; left to the scheduler the reads sit right in front of the MFMA that waits for them: 42 cycles per MFMA in the first version's stamps)
+#ifndef P128_PIN
+#define P128_PIN 1
+#endif
 template <int CB>
 __device__ __forceinline__ void p128_multiply(const uint16_t *Pb, const u32x4 (&bw)[4][2][2][2], const int n, const int hh, f32x16 (&acc)[2]) {
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[j][q] = 0.0f;
+    u32x4 fa[2][2];                                         // [buffer][piece: 0 = hi, 1 = lo]
+    const uint16_t *ab = Pb + n * CNN_BP + 8 * hh;
+    auto frags = [&](int g, u32x4 (&f)[2]) {
+        const int cb = g >> 1, k16 = g & 1;
+        f[0] = *reinterpret_cast<const u32x4 *>(ab + cb * (2 * B64_APL) + k16 * 16);
+        f[1] = *reinterpret_cast<const u32x4 *>(ab + cb * (2 * B64_APL) + B64_APL + k16 * 16);
+    };
+    frags(0, fa[0]);
 #pragma unroll
-    for (int cb = 0; cb < CB; cb++)
+    for (int g = 0; g < 2 * CB; g++) {
+        if (g + 1 < 2 * CB) frags(g + 1, fa[(g + 1) & 1]);
+        if (P128_PIN) __builtin_amdgcn_sched_barrier(0);
+        const int cb = g >> 1, k16 = g & 1;
+        const u32x4 ah = fa[g & 1][0], al = fa[g & 1][1];
 #pragma unroll
-        for (int k16 = 0; k16 < 2; k16++) {
-            const u32x4 ah = *reinterpret_cast<const u32x4 *>(Pb + cb * (2 * B64_APL) + n * CNN_BP + k16 * 16 + 8 * hh);
-            const u32x4 al = *reinterpret_cast<const u32x4 *>(Pb + cb * (2 * B64_APL) + B64_APL + n * CNN_BP + k16 * 16 + 8 * hh);
+        for (int j = 0; j < 2; j++) acc[j] = mfma16<2>(al, bw[cb][k16][0][j], acc[j]);
 #pragma unroll
-            for (int j = 0; j < 2; j++) acc[j] = mfma16<2>(al, bw[cb][k16][0][j], acc[j]);
+        for (int j = 0; j < 2; j++) acc[j] = mfma16<2>(ah, bw[cb][k16][1][j], acc[j]);
 #pragma unroll
-            for (int j = 0; j < 2; j++) acc[j] = mfma16<2>(ah, bw[cb][k16][1][j], acc[j]);
-#pragma unroll
-            for (int j = 0; j < 2; j++) acc[j] = mfma16<2>(ah, bw[cb][k16][0][j], acc[j]);
-        }
+        for (int j = 0; j < 2; j++) acc[j] = mfma16<2>(ah, bw[cb][k16][0][j], acc[j]);
+        if (P128_PIN) __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // the last layer's epilogue: folded BatchNorm, ReLU, padding mask -> global memory, [row][128] fp32 (b64_epilogue's expressions; 512-byte rows)

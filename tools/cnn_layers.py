@@ -24,6 +24,12 @@ for r in last:
         key = "block k5 64 (%d ops)" % span
         a = agg.setdefault(key, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += dt; a[2] += fl; a[3] += npos * (64 + 64 + (64 if span == 13 else 0)) * 4
         i += span; continue
+    if "k3_pair128" in r["Kernel_Name"]:                    # two separable layers (4 ops) in one launch
+        p0, p1 = ops[i + 1], ops[i + 3]
+        fl = sum(2 * (q["k"] * q["c"] if q["op"] == "dwconv" else q["k"] * q["cin"] * q["cout"]) for q in ops[i:i + 4]) * npos
+        key = "pair  k9 %3d->128->128" % p0["cin"]
+        a = agg.setdefault(key, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += dt; a[2] += fl; a[3] += npos * (p0["cin"] + p1["cout"]) * 4
+        i += 4; continue
     if "k3_sep" in r["Kernel_Name"]:
         pw = ops[i + 1]
         kind = "ws" if "k3_sep_ws" in r["Kernel_Name"] else "un" if "k3_sep_uni" in r["Kernel_Name"] else "  "
@@ -43,6 +49,6 @@ for k, (c, dt, fl, by) in agg.items():
     extra = ""
     if fl: extra += "%7.1f TFLOP/s" % (fl / dt / 1e6)
     if by: extra += "  %5.0f GB/s of layer I/O" % (by / dt / 1e3)
-    print("%-20s x%-2d %9.1f us %s" % (k, c, dt, extra))
+    print("%-22s x%-2d %9.1f us %s" % (k, c, dt, extra))
 print("%-20s x%-2d %9.1f us" % ("encoder sort", 1, sort_us / runs)); tot += sort_us / runs
 print("total %.2f ms" % (tot / 1e3))

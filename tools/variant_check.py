@@ -45,7 +45,7 @@ print("default        ", base)
 ok = True
 for name, env in (("conv BM=128", {"DN_CNN_BM256": "0"}),
                   ("sep no-ws", {"DN_CNN_SEP_WS": "0"}), ("sep unfused", {"DN_CNN_FUSE": "0"}), ("theilsen full", {"DN_TS_FULL": "1"}),
-                  ("block64 off", {"DN_CNN_BLOCK64": "0"}), ("block64 sep", {"DN_CNN_BLOCK64": "1"})):
+                  ("block64 off", {"DN_CNN_BLOCK64": "0"}), ("block64 sep", {"DN_CNN_BLOCK64": "1"}), ("pair128 off", {"DN_CNN_PAIR128": "0"}), ("pair128 on", {"DN_CNN_PAIR128": "1"})):
     d = run(env)
     print("%-15s" % name, d, "same" if d == base else "DIFFERENT")
     ok = ok and d == base
