@@ -66,7 +66,7 @@ def copy(n, dst=None):
 
 for n in ("bench_default.json", "bench_under_rocprof.json", "bench_banded.json", "k3_layers.txt", "k3_math_modes.txt", "bench_mixed.json", "bench_mixed_longfirst.json",
           "run_detect_stats.json", "run_detect.log", "run_detect_stats_warm.json", "run_detect_warm.log", "run_detect_2ranks_gloo_stats.json", "run_detect_2ranks.log",
-          "run_detect_1rank_sha.log", "k3_block64_check.txt", "k3_block64_phase_trace.txt", "k3_block64_v3_check.txt", "run_detect_slow_exit.log"):
+          "run_detect_1rank_sha.log", "k3_block64_check.txt", "k3_block64_phase_trace.txt", "k3_block64_v3_check.txt", "k3_pair128_check.txt", "run_detect_slow_exit.log"):
     copy(n)
 st = glob.glob(src + "/stats/**/*kernel_stats.csv", recursive=True)
 if st:

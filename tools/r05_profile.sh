@@ -42,6 +42,11 @@ DN_RUN_DETECT_SLOW_EXIT=1 python3 tools/time_run_detect.py --reads 10000 --reuse
 #   (8) the fused 64-channel block against the 13 launches it replaces (bit for bit + time), with its phase stamps
 tools/_bin/k3_block64_check 1200128 5 > $OUT/k3_block64_check.txt 2>&1
 tools/_bin/k3_block64_trace 1200128 3 2>&1 | grep -E "phase|stage|conv|workgroup" > $OUT/k3_block64_phase_trace.txt
+#   (10) two fused separable layers of the 128-channel stage against the two launches they replace (bit for bit + time), a whole chain of six, and the phase stamps
+tools/_bin/k3_pair128_check 1200128 128 4 > $OUT/k3_pair128_check.txt 2>&1
+tools/_bin/k3_pair128_check 1200128 64 4 >> $OUT/k3_pair128_check.txt 2>&1
+tools/_bin/k3_pair128_check 1200128 128 3 6 >> $OUT/k3_pair128_check.txt 2>&1
+tools/_bin/k3_pair128_trace 1200128 128 3 2>&1 | grep -E "phase|wavefront" >> $OUT/k3_pair128_check.txt
 #   (9) the third version of the block (filter in the accumulator layout), same session: bit for bit + time + stamps + ablations
 tools/_bin/k3_block64_check3 1200128 5 > $OUT/k3_block64_v3_check.txt 2>&1
 tools/_bin/k3_b64_v3t 1200128 3 2>&1 | grep -E "phase|stage|conv|workgroup" >> $OUT/k3_block64_v3_check.txt
