@@ -205,7 +205,10 @@ __global__ __launch_bounds__(256) void k3_pair128(const P128Args A) {
         const int xb = max(0, S0 - 64), xrows = min(rows, S0 + 32 * nch + 96) - xb;
         const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b64_uniform_ptr(A.X + (size_t)xb * CIN0)), 0, xrows * CIN0 * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b64_uniform_ptr(A.Y + (size_t)S0 * 128)), 0, min(rows - S0, 32 * mych) * 512, 0x00020000);
-        b64u2 xp[3][NCBF][16];
+#ifndef P128_SETS
+#define P128_SETS 3                                         /* register sets of input rows = chunks requested ahead + 1 */
+#endif
+        b64u2 xp[P128_SETS][NCBF][16];
         // dw_0's output chunk c = rows [S0 - 28 + 32 c, + 32) (layer 0's grid); output row 8 rq + i needs input rows 8 rq + i - 4 .. + 4: j = i + t, t = 0 .. 8, from row og - 4 + 8 rq
         const int xlane = ((8 * rq - 4) * CIN0 + 2 * cpl) * 4;
         auto gloadX = [&](int c, int set) {
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256) void k3_pair128(const P128Args A) {
 #pragma unroll
                 for (int j = 0; j < 16; j++) xp[set][f][j] = __builtin_bit_cast(b64u2, __builtin_amdgcn_raw_buffer_load_b64(rX, base + f * 128 + j * CIN0 * 4, 0, 0));
         };
-        gloadX(0, 0); gloadX(1, 1);
+        gloadX(0, 0); if (P128_SETS == 3) gloadX(1, 1);
         float amax0 = 0.0f;
         // one step; SET = s % 3 is a compile-time constant (the three register sets rotate; the loop below is unrolled by three)
         auto step = [&](const int s, auto SETC) {
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256) void k3_pair128(const P128Args A) {
             const int g1 = S0 - 32 + 32 * c1;               // first row of layer 1's chunk
             const unsigned vb = __builtin_amdgcn_raw_buffer_load_b8(rV, g1 + n, 0, 0);      // no branch around it (see b64_stage); outside the pass it reads 0 and nobody looks
             if (s < nch) {                                  // wave-uniform: layer 0's filter, chunk s
-                gloadX(s + 2, (SET + 2) % 3);               // (past the stripe: loaded, never used)
+                gloadX(s + P128_SETS - 1, (SET + P128_SETS - 1) % P128_SETS);      // (past the stripe: loaded, never used)
                 const int og0 = S0 - 28 + 32 * s;
                 const bool edge = og0 < 0 || og0 + 32 > rows;
                 float am = 0.0f;
@@ -266,10 +269,10 @@ __global__ __launch_bounds__(256) void k3_pair128(const P128Args A) {
             b64_barrier();
             P128_T(5);
         };
-        for (int s = 0; s < nsteps; s += 3) {
+        for (int s = 0; s < nsteps; s += P128_SETS) {
             step(s, std::integral_constant<int, 0>{});
             if (s + 1 < nsteps) step(s + 1, std::integral_constant<int, 1>{});
-            if (s + 2 < nsteps) step(s + 2, std::integral_constant<int, 2>{});
+            if (P128_SETS == 3 && s + 2 < nsteps) step(s + 2, std::integral_constant<int, 2 % P128_SETS>{});
         }
         range_report(amax0, A.L[0].range, lane);
     }
