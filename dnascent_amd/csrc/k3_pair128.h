@@ -131,12 +131,16 @@ __global__ __launch_bounds__(256) void k3_pair128(const P128Args A) {
         b64f2 carry[8];                                     // this layer's rows 24 .. 31 of the chunk before (upper lane half)
 #pragma unroll
         for (int i = 0; i < 8; i++) carry[i] = b64f2{0.f, 0.f};
+        // the validity bytes of a chunk's rows are requested a WHOLE STEP before the epilogue votes on them (asked for at the top of the chunk's own step they came back
+        // ~2 000 ticks after the MFMAs had finished: the first version's stamps showed the epilogue "taking" 2 030 ticks)
+        unsigned vb_next = __builtin_amdgcn_raw_buffer_load_b8(rV, S0 - 28 + n, 0, 0);
         for (int s = 0; s < nsteps; s++) {
             const int c = s - 1;
             P128_T(0);
+            const unsigned vb = vb_next;
+            vb_next = __builtin_amdgcn_raw_buffer_load_b8(rV, S0 - 28 + 32 * (c + 1) + n, 0, 0);      // (outside the pass it reads 0 and nobody looks)
             if (c >= 0 && c < nch) {                        // wave-uniform
                 const int og0 = S0 - 28 + 32 * c;           // first row of layer 0's chunk; layer 1's starts four rows earlier
-                const unsigned vb = __builtin_amdgcn_raw_buffer_load_b8(rV, og0 + n, 0, 0);
                 const bool edge = og0 - 4 < 0 || og0 + 28 > rows;
                 f32x16 acc[2];
                 p128_multiply<CB0>(&P0[c & 1][0][0], bw, n, hh, acc);
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(256) void k3_pair128(const P128Args A) {
                 b64f2 Y[16];
                 if (vm == 0xffffffffu) b64_epilogue_regs<false>(acc, sc, sh, floor_, vml, Y);
                 else { asm volatile("; chunk with padding rows" ::: "memory"); b64_epilogue_regs<true>(acc, sc, sh, floor_, vml, Y); }
+                P128_T(6);
                 // ---- 24 consecutive rows per lane: W[w] = row w - 8 (lower half) / row w + 8 (upper half) of the chunk ----
                 b64f2 W[24];
 #pragma unroll
@@ -153,6 +158,7 @@ __global__ __launch_bounds__(256) void k3_pair128(const P128Args A) {
                     b64f2 a = Y[i], b = Y[8 + i]; b64_swap(a, b); W[8 + i] = a; W[12 + i] = b;              // a: rows i | 16 + i,      b: rows 4 + i | 20 + i
                     b64f2 a2 = Y[4 + i], b2 = Y[12 + i]; b64_swap(a2, b2); W[16 + i] = a2; W[20 + i] = b2; // a2: rows 8 + i | 24 + i, b2: rows 12 + i | 28 + i
                 }
+                P128_T(7);
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     b64f2 p = carry[i], d = W[16 + i];
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256) void k3_pair128(const P128Args A) {
         const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b64_uniform_ptr(A.X + (size_t)xb * CIN0)), 0, xrows * CIN0 * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b64_uniform_ptr(A.Y + (size_t)S0 * 128)), 0, min(rows - S0, 32 * mych) * 512, 0x00020000);
 #ifndef P128_SETS
-#define P128_SETS 3                                         /* register sets of input rows = chunks requested ahead + 1 */
+#define P128_SETS 2                                         /* register sets of input rows = chunks requested ahead + 1.  Three would cover more latency, but 2 x 32 newer loads + the stores exceed what s_waitcnt vmcnt can count (63): the wait for a set then also waits for the NEXT one's first load (measured: 440 us with 3, 432 with 2) */
 #endif
         b64u2 xp[P128_SETS][NCBF][16];
         // dw_0's output chunk c = rows [S0 - 28 + 32 c, + 32) (layer 0's grid); output row 8 rq + i needs input rows 8 rq + i - 4 .. + 4: j = i + t, t = 0 .. 8, from row og - 4 + 8 rq
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(256) void k3_pair128(const P128Args A) {
 #pragma unroll
             for (int f = 0; f < NCBF; f++)
 #pragma unroll
-                for (int j = 0; j < 16; j++) xp[set][f][j] = __builtin_bit_cast(b64u2, __builtin_amdgcn_raw_buffer_load_b64(rX, base + f * 128 + j * CIN0 * 4, 0, 0));
+                for (int j = 0; j < 16; j++) xp[set][f][j] = __builtin_bit_cast(b64u2, __builtin_amdgcn_raw_buffer_load_b64(rX, base, f * 128 + j * CIN0 * 4, 0));      // the row / block part as the SCALAR offset: one lane offset for the 32 loads (as immediates they do not fit 12 bits: 41 vector adds per step)
         };
         gloadX(0, 0); if (P128_SETS == 3) gloadX(1, 1);
         float amax0 = 0.0f;

@@ -118,8 +118,8 @@ int main(int argc, char **argv) {
     {
         unsigned long long tr[4][8]; CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(p128_trace), sizeof(tr)));
         unsigned long long t0 = ~0ull; for (int w = 0; w < 4; w++) if (tr[w][0] && tr[w][0] < t0) t0 = tr[w][0];
-        printf("phase stamps of workgroup %d, step 40 (ticks after the earliest start)\n", (int)P128_TRACE);
-        for (int w = 0; w < 4; w++) { printf("  wavefront %d", w); for (int i = 0; i < 6; i++) printf(" %6lld", tr[w][i] ? (long long)(tr[w][i] - t0) : -1ll); printf("\n"); }
+        printf("phase stamps of workgroup %d, step 40 (ticks after the earliest start): 0 start | 1 multiplied | 2 exchanged (wavefronts 0, 1) / multiplied (2, 3) | 3 filtered | 4 planes stored / rows stored | 5 after the barrier | 6 epilogue done | 7 main exchange done\n", (int)P128_TRACE);
+        for (int w = 0; w < 4; w++) { printf("  wavefront %d", w); for (int i = 0; i < 8; i++) printf(" %6lld", tr[w][i] ? (long long)(tr[w][i] - t0) : -1ll); printf("\n"); }
     }
 #endif
     printf("speed-up: %.2fx\n", best[0] / best[1]);
