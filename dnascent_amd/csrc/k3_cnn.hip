@@ -419,7 +419,7 @@ template <int BN, bool ADD>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][BN / 64], float *__restrict__ Y, const float *__restrict__ scale,
                                               const float *__restrict__ shift, const float *__restrict__ Add,
                                               const uint8_t *__restrict__ valid, int m0, int n0, int wm, int wn, int lane, int cout, int relu,
-                                              float post = 1.0f, int wave_rows = 64) {
+                                              float post = 1.0f, int wave_rows = 64, int vbyte = -1) {
     // y = max(acc * scale + shift (+ residual), floor), zero on padding rows.  An accumulator register q of row block i holds row
     // 32 i + 8 (q >> 2) + (q & 3) + 4 (lane >> 5): the row is wave-uniform up to the lane half, so per (i, q) the row's base
     // address and its padding mask are SCALAR (one SGPR pair each: the select is a v_cndmask on that pair, the address an SGPR
@@ -427,7 +427,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][BN / 64], float *
     // version computed a 64-bit address and a shifted mask bit per element in the vector unit: ~10 vector instructions per
     // element, 6.8 k ticks per 128 x 256 tile -- a seventh of the 17-tap layer's time and the whole of the short layers' tail.
     constexpr int NJ = BN / 64;
-    const unsigned long long vmask = __ballot(valid[m0 + wm * 64 + lane] != 0);
+    // vbyte >= 0: the caller fetched this lane's validity byte (valid[m0 + wm * 64 + lane]) long before -- K3_VB_AHEAD: fetched here, the epilogue of every tile starts with a
+    // load it waits for (k3_pair128's stamps showed such a wait at ~2 000 ticks inside a busy kernel)
+    const unsigned long long vmask = __ballot((vbyte >= 0 ? vbyte : (int)valid[m0 + wm * 64 + lane]) != 0);
     const bool all_valid = vmask == ~0ull;                 // wave-uniform
     const float floor_ = relu ? 0.0f : -3.402823466e38f;
     const int colb = n0 + wn * (BN / 2) + (lane & 31);
@@ -613,6 +615,9 @@ __device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, bf16x8 
 //   2  the maximum as ONE v_max3_f32 (amax, |x0|, |x1|) per pair;
 //   1  that, and the rest x - (float) h as ONE v_fma_mix_f32 per element, which reads the fp16 half in place (h x -1.0 + x: exact, the same value).
 // Same values in all three (tools/variant_check.py); what differs is the producers' instruction count, which is what the separable layers wait for.
+#ifndef K3_VB_AHEAD
+#define K3_VB_AHEAD 1                                       /* the persistent separable kernels request a tile's validity bytes at the top of the tile instead of inside its epilogue */
+#endif
 #ifndef K3_SPLIT_MIX
 #define K3_SPLIT_MIX 1
 #endif
@@ -705,6 +710,8 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
     const int wm = wave >> 1, wn = wave & 1;
     int m0, n0;
     if (!conv_tile(cout, BN, rows, m0, n0, BM)) return;
+    // the epilogue's validity byte, requested before the whole tile -- in the 128-row form only: the 256-row form runs under a 128-register cap and spilled the one register
+    const int vb_ahead = (K3_VB_AHEAD && BM == 128) ? (int)valid[m0 + ((int)threadIdx.x >> 7) * 64 + ((int)threadIdx.x & 63)] : -1;
     constexpr int NJ = BN / 64;
     constexpr int LR = BM / 2;                            // rows one loader pass covers (4 threads per row)
     constexpr int NBQ = BN / LR;                          // 16-byte B chunks per thread per piece
@@ -862,7 +869,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
     // were three of the 256-row form's spilled registers (it runs under a 128-register cap)
     int tid_e = (int)threadIdx.x;
     asm volatile("" : "+v"(tid_e));
-    conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, m0, n0, tid_e >> 7, (tid_e >> 6) & 1, tid_e & 63, cout, relu, post);
+    conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, m0, n0, tid_e >> 7, (tid_e >> 6) & 1, tid_e & 63, cout, relu, post, 64, vb_ahead);
 }
 
 // (Round 3: k3_conv_dma -- the weight tile by LDS-DMA (global_load_lds_dwordx4, swizzled through the source address) into two buffers,
@@ -1051,6 +1058,7 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
     depthwise();
     const int fm = lane & 31, fk = (lane >> 5) * 8;
     for (int it = 0; it < my_tiles; it++) {
+        const int vb_ahead = K3_VB_AHEAD ? (int)valid[tile_m0(it) + wm * 64 + lane] : -1;      // the epilogue's validity byte, requested a whole tile before it is voted on
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -1109,7 +1117,7 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
                 SP_T(7 + 6 * cb);
             }
         }
-        conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, tile_m0(it), n0, wm, wn, lane, cout, relu, post);
+        conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, tile_m0(it), n0, wm, wn, lane, cout, relu, post, 64, vb_ahead);
         SP_T(40);
     }
     if (NP == 2) range_report(amax, range_flag, lane);
@@ -1353,6 +1361,7 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     };
     for (int it = 0; it < my_tiles; it++) {
         const bool tr = it == WS_TRACE_TILE; (void)tr;
+        const int vb_a0 = K3_VB_AHEAD ? (int)valid[tile_m0(it) + lane] : -1, vb_a1 = K3_VB_AHEAD ? (int)valid[tile_m0(it) + 64 + lane] : -1;
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -1375,8 +1384,8 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
             if (tr) WS_T(6 + 3 * cb);
         }
         // two row halves, each the epilogue of a 64 x (BN / 4)-column wavefront tile of a BN / 2-wide workgroup tile
-        conv_epilogue<BN / 2, ADD>(*reinterpret_cast<f32x16 (*)[2][CJ]>(&acc[0]), Y, scale, shift, Add, valid, tile_m0(it), n0 + (cw >> 1) * (BN / 2), 0, cw & 1, lane, cout, relu, post);
-        conv_epilogue<BN / 2, ADD>(*reinterpret_cast<f32x16 (*)[2][CJ]>(&acc[2]), Y, scale, shift, Add, valid, tile_m0(it), n0 + (cw >> 1) * (BN / 2), 1, cw & 1, lane, cout, relu, post);
+        conv_epilogue<BN / 2, ADD>(*reinterpret_cast<f32x16 (*)[2][CJ]>(&acc[0]), Y, scale, shift, Add, valid, tile_m0(it), n0 + (cw >> 1) * (BN / 2), 0, cw & 1, lane, cout, relu, post, 64, vb_a0);
+        conv_epilogue<BN / 2, ADD>(*reinterpret_cast<f32x16 (*)[2][CJ]>(&acc[2]), Y, scale, shift, Add, valid, tile_m0(it), n0 + (cw >> 1) * (BN / 2), 1, cw & 1, lane, cout, relu, post, 64, vb_a1);
         if (tr) WS_T(40);
     }
 }
