@@ -25,11 +25,13 @@ for cb in range(0, 8, 2):
 names_c = {3: "[tile start]", 40: "epilogue"}
 for cb in range(8):
     names_c.update({4 + 3 * cb: "mma0(%d)" % cb, 5 + 3 * cb: "mma1", 6 + 3 * cb: "barrier"})
-ws16 = os.environ.get("DN_CNN_WS16", "1") != "0"
+ws16 = os.environ.get("DN_CNN_WS16", "0") != "0"       # the 16-wavefront form was an experiment (tools/k3_sep_ws16_experiment.hip); the product kernel has 4 consumers + 4 producers
 ncons = 8 if ws16 else 4
 for w in range(16 if ws16 else 8):
     names = names_c if w < ncons else names_p
     idx = [i for i in sorted(names) if t[w, i] > 0]
+    if not idx:
+        continue
     line = []
     prev = None
     for i in idx:
