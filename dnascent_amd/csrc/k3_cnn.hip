@@ -415,7 +415,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // epilogue shared by the conv kernels: C/D layout of 32x32 tiles: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) +
 // 4 * (lane >> 5).  Row validity of the wavefront's 64 rows is one ballot; the residual values are fetched 16 at a time
 // (no load -> wait -> load chains).
-template <int BN, bool ADD>
+// PAIR (K3_EPI_PAIR; needs two column tiles per wavefront): lane n of column tile j holds column 2 n + j instead of 32 j + n (the kernel fetches its B fragments in that
+// order: a different address, nothing else), so a lane's two tiles are ADJACENT columns and a row leaves as one 8-byte store per lane (a lane half = 256 contiguous bytes)
+// instead of two 4-byte ones -- the epilogues are bound by the number of store instructions they issue (k3_sep_ws's stamps: 8 350 of a tile's 40 000 ticks for 128 stores
+// per lane, during which its producers wait at the barrier), and BatchNorm runs packed over the column pair.  Same expression per element: bit-identical.
+#ifndef K3_EPI_PAIR
+#define K3_EPI_PAIR 1
+#endif
+template <int BN, bool ADD, bool PAIR = false>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][BN / 64], float *__restrict__ Y, const float *__restrict__ scale,
                                               const float *__restrict__ shift, const float *__restrict__ Add,
                                               const uint8_t *__restrict__ valid, int m0, int n0, int wm, int wn, int lane, int cout, int relu,
@@ -432,6 +439,48 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][BN / 64], float *
     const unsigned long long vmask = __ballot((vbyte >= 0 ? vbyte : (int)valid[m0 + wm * 64 + lane]) != 0);
     const bool all_valid = vmask == ~0ull;                 // wave-uniform
     const float floor_ = relu ? 0.0f : -3.402823466e38f;
+    if constexpr (PAIR) {
+        static_assert(BN == 128, "the column-pair epilogue needs exactly two column tiles per wavefront");
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const int colp = n0 + wn * (BN / 2) + 2 * (lane & 31);
+        const f32x2 sc2 = {scale[colp] * post, scale[colp + 1] * post}, sh2 = {shift[colp], shift[colp + 1]};
+        auto uniform_ptr = [](const void *p) {
+            const unsigned long long v = (unsigned long long)p;
+            return (void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+        };
+        const size_t wbase = (size_t)(m0 + wm * 64) * cout;
+        const int wbytes = max(min(wave_rows, 64), 0) * cout * 4;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(Y + wbase), 0, wbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float *>(ADD ? Add + wbase : Y + wbase)), 0, wbytes, 0x00020000);
+        const int voff = (4 * (lane >> 5) * cout + colp) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            f32x2 addv[16];
+            if (ADD) {                                      // all residual loads of the row block first: the stores below may not pass them
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int soff = __builtin_amdgcn_readfirstlane((i * 32 + (q & 3) + 8 * (q >> 2)) * cout * 4);
+                    addv[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ra, voff, soff, 0));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int row = i * 32 + (q & 3) + 8 * (q >> 2);                   // + 4 for the upper lane half
+                const int soff = __builtin_amdgcn_readfirstlane(row * cout * 4);
+                f32x2 y = __builtin_elementwise_fma(f32x2{acc[i][0][q], acc[i][1][q]}, sc2, sh2);
+                if (ADD) y += addv[q];
+                float y0 = fmaxf(y[0], floor_), y1 = fmaxf(y[1], floor_);
+                if (!all_valid) {
+                    const unsigned long long k0 = (((vmask >> row) & 1ull) ? 0x00000000ffffffffull : 0ull) | (((vmask >> (row + 4)) & 1ull) ? 0xffffffff00000000ull : 0ull);
+                    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(y0) : "v"(y0), "s"(k0));
+                    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(y1) : "v"(y1), "s"(k0));
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{y0, y1}), ry, voff, soff, 0);
+            }
+        }
+        return;
+    }
     const int colb = n0 + wn * (BN / 2) + (lane & 31);
     float sc[NJ], sh[NJ];
 #pragma unroll
@@ -1159,6 +1208,15 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     const int ntiles = (rows + CNN_BM - 1) / CNN_BM;
     const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     if (my_tiles == 0) return;
+#ifndef K3_WS_STAGGER
+#define K3_WS_STAGGER 0
+#endif
+    // experiment: the persistent workgroups run their equal tiles in lockstep, so all 256 CUs store their 128 KB of results in the same ~3 us (10 TB/s asked of the memory)
+    // and all load in the same phases; K3_WS_STAGGER = n delays workgroup b by ((37 b) mod 256) / 256 of n x ~4 us before its first tile
+    if (K3_WS_STAGGER) {
+        const int units = (int)(((unsigned)blockIdx.x * 37u) & 255u) * K3_WS_STAGGER * 127 / 256;      // s_sleep units of 64 clocks
+        for (int u = 0; u < units; u += 127) __builtin_amdgcn_s_sleep(127);
+    }
     const int n0 = 0;
     constexpr int NJ = BN / 64;
     constexpr int NBQ = BN / 64;
@@ -1325,13 +1383,14 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
     // kept this workgroup off every CU where a per-read stage of another batch held some LDS, and half of its LDS traffic.
     // Double-buffered per k16 step: the loads of step s + 1 are in flight during the MFMAs of step s.
     const int fm = lane & 31, fk = (lane >> 5) * 8;
-    const uint16_t *wlane = Wb + ((size_t)(n0 + cw * (BN / 4) + fm)) * 32 + fk;
+    constexpr bool EPAIR = K3_EPI_PAIR && CJ == 2;         // column tile j of lane fm = column 2 fm + j (conv_epilogue's PAIR form) instead of 32 j + fm
+    const uint16_t *wlane = Wb + ((size_t)(n0 + cw * (BN / 4) + (EPAIR ? 2 * fm : fm))) * 32 + fk;
     auto loadB = [&](u32x4 (&b)[CJ][NP], int step) {            // step = 2 * cb + k16
         const int cb = (step >> 1) % cblocks, k16 = step & 1;          // the weights of a step depend on its channel block only
 #pragma unroll
         for (int pc = 0; pc < NP; pc++)
 #pragma unroll
-            for (int j = 0; j < CJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(wlane + ((size_t)(cb * NP + pc) * cout + j * 32) * 32 + k16 * 16);
+            for (int j = 0; j < CJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(wlane + ((size_t)(cb * NP + pc) * cout + (EPAIR ? j : j * 32)) * 32 + k16 * 16);
     };
     u32x4 b0[CJ][NP], b1[CJ][NP];
     loadB(b0, 0);
@@ -1384,8 +1443,8 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
             if (tr) WS_T(6 + 3 * cb);
         }
         // two row halves, each the epilogue of a 64 x (BN / 4)-column wavefront tile of a BN / 2-wide workgroup tile
-        conv_epilogue<BN / 2, ADD>(*reinterpret_cast<f32x16 (*)[2][CJ]>(&acc[0]), Y, scale, shift, Add, valid, tile_m0(it), n0 + (cw >> 1) * (BN / 2), 0, cw & 1, lane, cout, relu, post, 64, vb_a0);
-        conv_epilogue<BN / 2, ADD>(*reinterpret_cast<f32x16 (*)[2][CJ]>(&acc[2]), Y, scale, shift, Add, valid, tile_m0(it), n0 + (cw >> 1) * (BN / 2), 1, cw & 1, lane, cout, relu, post, 64, vb_a1);
+        conv_epilogue<BN / 2, ADD, EPAIR>(*reinterpret_cast<f32x16 (*)[2][CJ]>(&acc[0]), Y, scale, shift, Add, valid, tile_m0(it), n0 + (cw >> 1) * (BN / 2), 0, cw & 1, lane, cout, relu, post, 64, vb_a0);
+        conv_epilogue<BN / 2, ADD, EPAIR>(*reinterpret_cast<f32x16 (*)[2][CJ]>(&acc[2]), Y, scale, shift, Add, valid, tile_m0(it), n0 + (cw >> 1) * (BN / 2), 1, cw & 1, lane, cout, relu, post, 64, vb_a1);
         if (tr) WS_T(40);
     }
 }
