@@ -872,7 +872,13 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
     // row blocks and the k16 half are immediate offsets of the ds_read_b128 (the compiler used to rebuild the row index from the wavefront
     // number with a 64-bit multiply-add every step, and kept that number in scratch)
     const uint16_t *aF = &As[0][(wm * 64 + fm) * CNN_BP + fk];
-    const uint16_t *bF = &Bs[0][(wn * (BN / 2) + fm) * CNN_BP + fk];
+    // column tile j of lane fm = column 2 fm + j (conv_epilogue's PAIR form: 8-byte stores) instead of 32 j + fm: measured SLOWER here (17 x 128 -> 256: 3 021-3 024 us against
+    // 2 969-2 974; 9 x 128 -> 128: 828-842 against 816-826; gpurun_out/r6l) -- the epilogue is 2-4 % of these tiles and the fragment reads' new order costs more: -DK3_EPI_PAIR_CONV=1 only
+#ifndef K3_EPI_PAIR_CONV
+#define K3_EPI_PAIR_CONV 0
+#endif
+    constexpr bool EPAIR = K3_EPI_PAIR && K3_EPI_PAIR_CONV && BN == 128 && NP == 2;
+    const uint16_t *bF = &Bs[0][(wn * (BN / 2) + (EPAIR ? 2 * fm : fm)) * CNN_BP + fk];
     constexpr int APL = (BM + 16) * CNN_BP, BPL = BN * CNN_BP;            // plane strides (elements)
     int tap = 0, cb = 0;
     for (int s = 0; s < steps; s++) {
@@ -889,7 +895,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
 #pragma unroll
                 for (int i = 0; i < 2; i++) a[i][pc] = *reinterpret_cast<const u32x4 *>(aT + pc * APL + i * 32 * CNN_BP + k16 * 16);
 #pragma unroll
-                for (int j = 0; j < NJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(bF + pc * BPL + j * 32 * CNN_BP + k16 * 16);
+                for (int j = 0; j < NJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(bF + pc * BPL + (EPAIR ? j : j * 32) * CNN_BP + k16 * 16);
             }
             // smallest terms first, so the big h h' product meets an accumulator that already holds the corrections
             constexpr int NT = NP == 3 ? 6 : 3;
@@ -918,7 +924,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 4 : 1) void k3_conv_split(const
     // were three of the 256-row form's spilled registers (it runs under a 128-register cap)
     int tid_e = (int)threadIdx.x;
     asm volatile("" : "+v"(tid_e));
-    conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, m0, n0, tid_e >> 7, (tid_e >> 6) & 1, tid_e & 63, cout, relu, post, 64, vb_ahead);
+    conv_epilogue<BN, ADD, EPAIR>(acc, Y, scale, shift, Add, valid, m0, n0, tid_e >> 7, (tid_e >> 6) & 1, tid_e & 63, cout, relu, post, 64, vb_ahead);
 }
 
 // (Round 3: k3_conv_dma -- the weight tile by LDS-DMA (global_load_lds_dwordx4, swizzled through the source address) into two buffers,
@@ -997,6 +1003,7 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
     } else if (!conv_tile(cout, BN, rows, m0f, n0)) return;
     auto tile_m0 = [&](int it) { return cout == BN ? (t0 + it * tstride) * CNN_BM : m0f; };
     constexpr int NJ = BN / 64;
+    constexpr bool SPAIR = K3_EPI_PAIR && K3_EPI_PAIR_CONV && BN == 128 && NP == 2;      // adjacent columns per lane (conv_epilogue's PAIR form): off with the convolutions' (see k3_conv_split)
     constexpr int NBQ = BN / 64;
     constexpr int half = (KW - 1) / 2;
     f32x16 acc[2][NJ];
@@ -1140,7 +1147,7 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
 #pragma unroll
                     for (int i = 0; i < 2; i++) a[i][pc] = *reinterpret_cast<const u32x4 *>(&As[pc][(wm * 64 + i * 32 + fm) * CNN_BP + k16 * 16 + fk]);
 #pragma unroll
-                    for (int j = 0; j < NJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(&Bs[pc][(wn * (BN / 2) + j * 32 + fm) * CNN_BP + k16 * 16 + fk]);
+                    for (int j = 0; j < NJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(&Bs[pc][(wn * (BN / 2) + (SPAIR ? 2 * fm + j : j * 32 + fm)) * CNN_BP + k16 * 16 + fk]);
                 }
                 constexpr int NT = NP == 3 ? 6 : 3;
 #pragma unroll
@@ -1166,7 +1173,7 @@ __global__ __launch_bounds__(256, (NP == 3 && BN == 128) ? 1 : 2) void k3_sep_sp
                 SP_T(7 + 6 * cb);
             }
         }
-        conv_epilogue<BN, ADD>(acc, Y, scale, shift, Add, valid, tile_m0(it), n0, wm, wn, lane, cout, relu, post, 64, vb_ahead);
+        conv_epilogue<BN, ADD, SPAIR>(acc, Y, scale, shift, Add, valid, tile_m0(it), n0, wm, wn, lane, cout, relu, post, 64, vb_ahead);
         SP_T(40);
     }
     if (NP == 2) range_report(amax, range_flag, lane);
