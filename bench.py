@@ -206,7 +206,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     cpu_base = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # DN_BENCH_FORCE_DIST=1: a process group of ONE over RCCL (torchrun --nproc-per-node 1): the N > 1 code path -- torch.cuda beside the library's own contexts,
+    # communicator set-up, device-tensor collectives -- executed on a 1-GPU box
+    force_dist = os.environ.get("DN_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ["DN_SHARD_FORCE_COLLECTIVES"] = "1"
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not force_dist:
         # FIRST, before this process touches the GPU: its CNN leg forks one worker per core
         from dnascent_amd import synth as _synth
         cpu_base = cpu_baseline(_synth.pore_model(), 30000 if mixed else bases, 1000003, full)
@@ -214,7 +219,7 @@ def main():
             cpu_base["sample"] += " (mixed scope: 30 kb reads, the mean of the length law)"
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or force_dist:
         # the host side (read generation, record formatting) is OpenMP over reads: the ranks of a node share its cores
         # (torch.distributed.run exports OMP_NUM_THREADS=1 for its workers: the per-rank share replaces that launcher default)
         if os.environ.get("OMP_NUM_THREADS", "1") == "1":
@@ -223,6 +228,7 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         # DN_BENCH_BACKEND=gloo (+ ranks sharing a device) exists only to exercise the N > 1 code path on a 1-GPU box
         backend = os.environ.get("DN_BENCH_BACKEND", "nccl")
         ndev = max(1, torch.cuda.device_count())
@@ -298,7 +304,7 @@ def main():
             c.sync()
         if dist is not None:
             torch.cuda.synchronize()
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank % ndev]) if red_dev == "cuda" else dist.barrier()   # RCCL: name the device instead of letting it guess from the rank
 
     gather_s = 0.0
     if full:

@@ -97,7 +97,12 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     dev_t = "cpu"
-    if world > 1:
+    # DN_RUN_DETECT_FORCE_DIST=1: a process group of ONE (under torch.distributed.run --nproc-per-node 1): the N > 1 code path -- torch.cuda and a RCCL communicator
+    # beside the library's contexts, the counters and statistics as device-tensor collectives -- executed on a 1-GPU box
+    force_dist = os.environ.get("DN_RUN_DETECT_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ["DN_SHARD_FORCE_COLLECTIVES"] = "1"
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -105,6 +110,10 @@ def main(argv=None):
             torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
             dev_t = "cuda:%d" % (local % max(1, torch.cuda.device_count()))
         dist.init_process_group(a.backend, rank=rank, world_size=world)
+    def _barrier():
+        # RCCL: name the device instead of letting the backend guess it from the rank
+        dist.barrier(device_ids=[int(dev_t.split(":")[1])]) if dev_t != "cpu" else dist.barrier()
+
     from dnascent_amd import cnn_model, hip, host, shard, synth
     t0 = time.time()
     sizes, offsets = host.container_index(a.container)
@@ -161,8 +170,24 @@ def main(argv=None):
         out_f = open(a.out, "wb")
         if head:
             out_f.write(head); out_f.flush()
+    warm = None
     if dist is not None:
-        dist.barrier()                                         # the file exists (and is empty but for the header) before anybody else opens it
+        # the file exists (and is empty but for the header) before anybody else opens it: a key in the group's store, not a barrier -- over RCCL the first
+        # collective pays the communicator's set-up (seconds), which instead rides beside the stream on a helper thread (shard.warm_collectives)
+        from torch.distributed.distributed_c10d import _get_default_store
+        store = _get_default_store()
+        ready_key = "dn_run_detect/file_ready/%d" % int(store.add("dn_run_detect/runs/r%d" % rank, 1))
+        if rank == 0:
+            store.set(ready_key, "1")
+        else:
+            t_w = time.time()
+            while not store.check([ready_key]):                # polled: TCPStore.wait() would hold this client's lock for the whole wait
+                if time.time() - t_w > 600:
+                    raise RuntimeError("run_detect: rank 0 never announced the output file")
+                time.sleep(0.005)
+        warm = shard.warm_collectives(dist, dev_t)
+        if warm is not None and a.central_writer:
+            warm.join()                                        # that form's gather thread issues point-to-point operations during the stream
     if rank != 0 and not a.central_writer:
         out_f = open(a.out, "r+b")                             # every rank writes its own records in place: same file, own descriptor
 
@@ -190,16 +215,26 @@ def main(argv=None):
     bg = None
     try:
         if len(batches):
+            t_l = time.time()
             b0, acc0 = load(batches[0])
+            if os.environ.get("DN_RUN_DETECT_TIMING") == "1":
+                print("run_detect: rank %d first batch loaded in %.3f s" % (rank, time.time() - t_l), file=sys.stderr)
             if b0.size():
                 per_sample = ctxs[0].workspace_bytes(b0.desc()) / max(1, b0.samples())
                 biggest = max(int(sizes[b].sum()) for b in batches)
                 want = (int(per_sample * biggest * 1.04), int(biggest / 12.5 * 0.3 * 29 * 1.3))
 
+                timing = os.environ.get("DN_RUN_DETECT_TIMING") == "1"
+
                 def prepare(c, bt):
+                    ta = time.time()
                     c.reserve(want[0], collect_bytes=want[1])
+                    tb = time.time()
                     bt.upload(c)                               # the side tables (per-read mirrors) take their size from a real batch
+                    tc = time.time()
                     c.sync()
+                    if timing:
+                        print("run_detect: rank %d context set-up: reserve %.3f s, upload %.3f s, sync %.3f s" % (rank, tb - ta, tc - tb, time.time() - tc), file=sys.stderr)
                 prepare(ctxs[0], b0)
 
                 def prepare_rest():
@@ -258,6 +293,8 @@ def main(argv=None):
             hbm_info = {"used_GB": round((totl.value - fr.value) / 1e9, 1), "total_GB": round(totl.value / 1e9, 1)}
     except OSError:
         pass
+    if warm is not None:
+        warm.join()
     tot = shard.reduce_counters(dist, [drv.n_ok, drv.n_fail, int(st.samples), 0 if ok else 1], device=dev_t)
     if drv.failure is not None:
         print("run_detect: rank %d aborted: %r" % (rank, drv.failure), file=sys.stderr)
@@ -294,7 +331,7 @@ def main(argv=None):
     for c in ctxs:
         c.close()
     if dist is not None:
-        dist.barrier()
+        _barrier()
         dist.destroy_process_group()
     if rank == 0 and not failed:
         print("run_detect: process %.2f s = imports %.2f + index / plan %.2f + contexts %.2f + first workspace %.2f + stream %.2f + close %.2f (+ counters, stats)" % (

@@ -16,6 +16,7 @@ Two ways to divide the reads:
     order, while the next window is already running: memory on every rank is bounded by the window, never by the run.
 """
 import heapq
+import os
 
 import numpy as np
 
@@ -65,9 +66,37 @@ def make_batches(sample_counts, max_samples, max_reads=4096):
     return out
 
 
+def _solo(dist):
+    """no process group, or a group of one: the helpers below return the rank's own data without touching torch.  DN_SHARD_FORCE_COLLECTIVES=1 sends a group
+    of one through the collectives anyway -- the only way to execute the RCCL code path (device tensors, all_reduce / all_gather) on a 1-GPU box."""
+    if dist is None or not dist.is_initialized():
+        return True
+    return dist.get_world_size() == 1 and os.environ.get("DN_SHARD_FORCE_COLLECTIVES") != "1"
+
+
+def warm_collectives(dist, device="cpu"):
+    """Start the backend's communicator set-up NOW, on a helper thread: over RCCL the first collective of a process creates the communicator (3.5 s measured for a
+    group of one on an MI355X box, `profiles/r05_run_detect_rccl_group_of_one.log`) -- paid where that collective stands.  run_detect's stream needs no collective
+    at all (counters and statistics at the very end), so the set-up rides beside the stream instead of in front of it.  Returns the thread (join() it before the
+    first real collective -- collectives of one group must be issued in one order on every rank), or None when there is nothing to warm."""
+    if _solo(dist) or device == "cpu":
+        return None
+    import threading
+
+    import torch
+
+    def run():
+        t = torch.zeros(1, dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+    th = threading.Thread(target=run, name="dn-rccl-warm", daemon=True)
+    th.start()
+    return th
+
+
 def reduce_counters(dist, values, device="cpu"):
     """SUM all-reduce of a small vector of counters (reads ok, reads failed, samples, ...)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _solo(dist):
         return [float(v) for v in values]                       # one rank: no torch import at all (run_detect's start-up, round-4 verdict item 3c)
     import torch
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
@@ -76,7 +105,7 @@ def reduce_counters(dist, values, device="cpu"):
 
 
 def reduce_max(dist, value, device="cpu"):
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _solo(dist):
         return float(value)
     import torch
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
@@ -87,7 +116,7 @@ def reduce_max(dist, value, device="cpu"):
 def gather_stats(dist, obj, device="cpu"):
     """a small JSON-able dict of every rank to every rank (run statistics: a few hundred bytes through gather_bytes' all_gather path)"""
     import json
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _solo(dist):
         return [obj]
     import torch
     raw = json.dumps(obj).encode()
@@ -110,7 +139,7 @@ def gather_bytes(dist, blob, dst=0, device="cpu"):
     world x max bytes to every rank).  blob: uint8 numpy array.  Returns the list of per-rank uint8 arrays on `dst`, None elsewhere."""
     import torch
     blob = np.ascontiguousarray(blob, dtype=np.uint8)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _solo(dist):
         return [blob]
     world, rank = dist.get_world_size(), dist.get_rank()
     ln = torch.tensor([blob.shape[0]], dtype=torch.int64, device=device)
@@ -326,7 +355,7 @@ def exchange_window(dist, keys, key, n, blob, error, dst=0, device="cpu", chunk_
     """One window's blobs to the writer (protocol above).  Returns ([(n_r, blob_r)] by rank, any_error) on `dst`, (None, None) elsewhere.
     stats (a dict): "recv_groups" collects the number of receives of every grouped call the writer made."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:   # point-to-point only: nothing to run in a group of one
         return [(n, blob)], bool(error)
     world, rank = dist.get_world_size(), dist.get_rank()
     if error:

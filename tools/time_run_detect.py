@@ -15,6 +15,7 @@ ap.add_argument("--keep", action="store_true")
 ap.add_argument("--reuse", action="store_true", help="do not rewrite the container if --dir already holds one (repeated timings in one session; implies --keep)")
 ap.add_argument("--ranks", type=int, default=1, help="> 1: under torch.distributed.run with the gloo backend, the ranks SHARING this GPU (what the 8-GPU node runs over RCCL, "
                                                      "exercised at full payload size; not a throughput figure)")
+ap.add_argument("--rccl-group-of-one", action="store_true", help="ONE rank under torch.distributed.run with the nccl backend (DN_RUN_DETECT_FORCE_DIST=1): RCCL executed on a 1-GPU box")
 ap.add_argument("--sha", action="store_true", help="print the SHA-256 of the .detect file (1- and N-rank runs must agree)")
 a, extra = ap.parse_known_args()
 from dnascent_amd import host, synth
@@ -32,6 +33,10 @@ if a.ranks > 1:
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.ranks), "--master-addr", "127.0.0.1", "--master-port", str(port),
            "-m", "dnascent_amd.run_detect", "--backend", "gloo"] + tail
+elif a.rccl_group_of_one:
+    env["DN_RUN_DETECT_FORCE_DIST"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29577",
+           "-m", "dnascent_amd.run_detect", "--backend", "nccl"] + tail
 else:
     cmd = [sys.executable, "-m", "dnascent_amd.run_detect"] + tail
 t0 = time.time()
