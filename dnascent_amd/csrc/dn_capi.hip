@@ -327,7 +327,9 @@ static CnnLane *lane_get(dn_ctx *c) {
             made = hipExtStreamCreateWithCUMask(&L->stream, 8, m) == hipSuccess;
             if (!made) (void)hipGetLastError();
         }
-        if (!made && hipStreamCreateWithPriority(&L->stream, hipStreamNonBlocking, lo) != hipSuccess) { delete L; return nullptr; }
+        const char *lp = getenv("DN_LANE_PRIO");                   // experiment switch: 0 lowest (default), 1 the middle of the range, 2 highest
+        const int lane_prio = !lp || lp[0] == '0' ? lo : lp[0] == '2' ? hi : (lo + hi) / 2;
+        if (!made && hipStreamCreateWithPriority(&L->stream, hipStreamNonBlocking, lane_prio) != hipSuccess) { delete L; return nullptr; }
         g_lane[c->device][c->lane_id] = L;
     }
     g_lane[c->device][c->lane_id]->users++;               // counted in while g_lane_mu is held: from here on lanes_free_device leaves the lane alone
@@ -439,7 +441,7 @@ int dn_ctx_create(int device, void *hip_stream, dn_ctx **out) {
             made = hipExtStreamCreateWithCUMask(&c->stream, 8, m) == hipSuccess;
             if (!made) { (void)hipGetLastError(); fprintf(stderr, "dnascent_hip: CU-masked stream unavailable, using a plain one\n"); }
         }
-        if (!made && (prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { ctx_unregister(c); delete c; return DN_ERR_HIP; }
+        if (!made && (prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pe && pe[0] == '2' ? lo : hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { ctx_unregister(c); delete c; return DN_ERR_HIP; }
         c->own_stream = true;
     }
     if (hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) {
