@@ -1399,8 +1399,13 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
 #pragma unroll
             for (int j = 0; j < CJ; j++) b[j][pc] = *reinterpret_cast<const u32x4 *>(wlane + ((size_t)(cb * NP + pc) * cout + (EPAIR ? j : j * 32)) * 32 + k16 * 16);
     };
-    u32x4 b0[CJ][NP], b1[CJ][NP];
+#ifndef K3_WS_BDEPTH
+#define K3_WS_BDEPTH 1                                     // 2: the weight fragments of a whole channel block (both k16 steps) are requested a channel block ahead
+#endif
+    constexpr bool BDEEP = K3_WS_BDEPTH == 2 && NP == 2;
+    u32x4 b0[CJ][NP], b1[CJ][NP], b2[BDEEP ? CJ : 1][BDEEP ? NP : 1], b3[BDEEP ? CJ : 1][BDEEP ? NP : 1];
     loadB(b0, 0);
+    if constexpr (BDEEP) loadB(b1, 1);
     __syncthreads();
     __syncthreads();
     auto mma = [&](int cur, int k16, u32x4 (&b)[CJ][NP]) {
@@ -1435,6 +1440,29 @@ __global__ __launch_bounds__(512) void k3_sep_ws(const float *__restrict__ X, fl
 #pragma unroll
                 for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
         if (tr) WS_T(3);
+        if constexpr (BDEEP) {
+            // a channel block's eight fragments arrive while the 48 MFMAs of the block before it run (one k16 step ahead, 24 MFMAs = 770 ticks, is less than a
+            // load from L2 takes under this kernel's own traffic: the stamps had the 48 MFMAs of a block at 3.35 k ticks for 1.5 k of matrix time)
+            for (int cb = 0; cb < cblocks; cb += 2) {
+                const int step = it * cblocks + cb;
+                loadB(*reinterpret_cast<u32x4 (*)[CJ][NP]>(&b2), 2 * step + 2); loadB(*reinterpret_cast<u32x4 (*)[CJ][NP]>(&b3), 2 * step + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(0, 0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(0, 1, b1);
+                if (tr) WS_T(5 + 3 * cb);
+                __syncthreads();
+                if (tr) WS_T(6 + 3 * cb);
+                loadB(b0, 2 * step + 4); loadB(b1, 2 * step + 5);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(1, 0, *reinterpret_cast<u32x4 (*)[CJ][NP]>(&b2));
+                __builtin_amdgcn_sched_barrier(0);
+                mma(1, 1, *reinterpret_cast<u32x4 (*)[CJ][NP]>(&b3));
+                if (tr) WS_T(5 + 3 * (cb + 1));
+                __syncthreads();
+                if (tr) WS_T(6 + 3 * (cb + 1));
+            }
+        } else
         for (int cb = 0; cb < cblocks; cb++) {
             const int cur = cb & 1, step = it * cblocks + cb;
             loadB(b1, 2 * step + 1);
