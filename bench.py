@@ -200,7 +200,8 @@ def main():
     # contexts (batches) in flight.  Full pipeline, one session of round 5 (gpurun_out/r5w, --steps 14): 4 -> 808 / 805, 5 -> 813 / 813, 6 -> 821 / 822, 8 -> 816 / 814
     # Msamples/s; 6 x 14.5 GB of workspaces + 4 CNN lanes x 16 GiB = 159 of 309 GB (8: 189).  The banded scope (no network) keeps 8.
     inflight = args.inflight or (6 if full else 8)
-    os.environ.setdefault("DN_CNN_ROWS", str(4 << 20))      # activation rows resident per CNN pass and lane: 4 Mi rows = 16 GiB (2 Mi: -6 %, 8 Mi: -3 %)
+    os.environ.setdefault("DN_CNN_ROWS", str(8 << 20))      # activation rows resident per CNN pass and lane: 8 Mi rows = 32 GiB, three passes per 500 x 50 kb batch (round 5, with the persistent
+    # whole-CU kernels in the network: 4 Mi 853-857, 6 Mi 862-863, 8 Mi 870-874 Msamples/s, profiles/r05_cnn_pass_rows_ab.txt; round 4: 2 Mi -6 %, 8 Mi -3 %)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -1393,20 +1393,38 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned
     memcpy(c->p_cnn_iooff, io_off, n * sizeof(uint64_t));
     struct Pass { uint32_t r0, r1; unsigned rows, max_pos, n_pos; };
     std::vector<Pass> passes;
-    uint64_t rows = 8; unsigned max_pos = 1, pass_pos = 0; uint32_t r0 = 0; uint64_t max_rows = 0;
+    // BALANCED passes (round 5): the fewest passes the cap allows, of about equal size -- cut where the running total crosses k / P of the batch, not where the cap is
+    // hit.  Filled to the cap, 500 reads of 50 kb at 4 Mi rows were six passes of 83 reads and a seventh of TWO (48 launches over 100 k rows: ~1 % of the step).
+    // Sequences are indivisible, so P passes may not hold the batch although P x cap rows would: then P + 1 balanced ones are cut (a few tries at most).
+    uint64_t total = 0, max_rows = 0;
     for (uint32_t r = 0; r < n; r++) {
-        const unsigned np = ub[r];
-        if (rows + np + 8 > cap && r > r0) {
-            const uint64_t rr = (rows + 255) / 256 * 256;
-            passes.push_back({ r0, r, (unsigned)rr, max_pos, pass_pos }); max_rows = std::max(max_rows, rr);
-            r0 = r; rows = 8; max_pos = 1; pass_pos = 0;
-        }
-        row_off[r] = (unsigned)rows;
-        rows += np + 8; pass_pos += np;
-        if (rows >= (1ull << 31)) return fail(c, DN_ERR_OVERFLOW, "sequence %u has too many positions for one CNN pass", r);
-        max_pos = std::max(max_pos, np);
+        total += (uint64_t)ub[r] + 8;
+        if ((uint64_t)ub[r] + 16 >= (1ull << 31)) return fail(c, DN_ERR_OVERFLOW, "sequence %u has too many positions for one CNN pass", r);
     }
-    { const uint64_t rr = (rows + 255) / 256 * 256; passes.push_back({ r0, n, (unsigned)rr, max_pos, pass_pos }); max_rows = std::max(max_rows, rr); }
+    auto cut = [&](uint64_t n_pass) {
+        passes.clear(); max_rows = 0;
+        uint64_t rows = 8, done_rows = 0; unsigned max_pos = 1, pass_pos = 0; uint32_t r0 = 0;
+        for (uint32_t r = 0; r < n; r++) {
+            const unsigned np = ub[r];
+            const bool quota = passes.size() + 1 < n_pass && (done_rows + rows - 8) * n_pass >= total * (passes.size() + 1);
+            if ((rows + np + 8 > cap || quota) && r > r0) {
+                done_rows += rows - 8;
+                const uint64_t rr = (rows + 255) / 256 * 256;
+                passes.push_back({ r0, r, (unsigned)rr, max_pos, pass_pos }); max_rows = std::max(max_rows, rr);
+                r0 = r; rows = 8; max_pos = 1; pass_pos = 0;
+            }
+            row_off[r] = (unsigned)rows;
+            rows += np + 8; pass_pos += np;
+            max_pos = std::max(max_pos, np);
+        }
+        const uint64_t rr = (rows + 255) / 256 * 256; passes.push_back({ r0, n, (unsigned)rr, max_pos, pass_pos }); max_rows = std::max(max_rows, rr);
+    };
+    {
+        static const bool greedy = getenv("DN_CNN_GREEDY_PASSES") && atoi(getenv("DN_CNN_GREEDY_PASSES")) != 0;     // the old partition (A / B)
+        uint64_t n_pass = greedy ? 1 : std::max<uint64_t>(1, (total + 8 + cap - 1) / cap);
+        for (int tries = 0; tries < 4; tries++, n_pass++) { cut(n_pass); if (greedy || passes.size() <= n_pass) break; }
+        if (max_rows >= (1ull << 31)) return fail(c, DN_ERR_OVERFLOW, "a CNN pass of %llu rows", (unsigned long long)max_rows);
+    }
     CnnLane *L = lane_get(c);
     if (!L) return fail(c, DN_ERR_HIP, "cannot create the CNN lane of device %d", c->device);
     LaneUse lane_use(L);                                   // declared before the lock: released after it (a concurrent dn_shutdown sees the lane busy until then)

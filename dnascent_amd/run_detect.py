@@ -44,7 +44,7 @@ import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # the host library's OpenMP teams must SLEEP between their loops: spinning threads starve the HIP runtime's callback thread (dn_host.cpp hostThreads)
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-os.environ.setdefault("DN_CNN_ROWS", str(4 << 20))         # activation rows resident per CNN pass and lane (bench.py's setting: 2 Mi -6 %, 8 Mi -3 %)
+os.environ.setdefault("DN_CNN_ROWS", str(8 << 20))         # activation rows resident per CNN pass and lane (bench.py's setting: 32 GiB per lane; 4 Mi -2 %)
 if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "DN_HOST_THREADS" not in os.environ:
     # N ranks share the host's cores: each rank's loader / packer / formatter loops take their share (dn_host.cpp hostThreads)
     from dnascent_amd.host import usable_cpus as _usable                   # the cgroup's CPU quota, not the hardware threads in sight
