@@ -1368,6 +1368,31 @@ static void cnn_note_escalation(dn_ctx *c, unsigned flag) {
     }
 }
 
+// the lane's activation buffers for passes of up to lane_rows rows (caller holds L->mu)
+static int lane_size(dn_ctx *c, CnnLane *L, uint64_t lane_rows) {
+    int rc;
+    for (int b = 0; b < c->cnn_nbuf; b++)
+        if ((rc = lane_grow(c, L, L->buf[b], (size_t)lane_rows * 256 * sizeof(float)))) return rc;
+    if ((rc = lane_grow(c, L, L->enclen, (size_t)lane_rows)) || (rc = lane_grow(c, L, L->enchist, 64 * sizeof(unsigned))) ||
+        (rc = lane_grow(c, L, L->permsrc, (size_t)lane_rows * sizeof(uint64_t))) || (rc = lane_grow(c, L, L->permrow, (size_t)lane_rows * sizeof(unsigned))) ||
+        (rc = lane_grow(c, L, L->valid, (size_t)lane_rows + 256)) || (rc = lane_grow(c, L, L->live, 256))) return rc;    // + 256: k3_sep_pair's 120-row tiles look up to 127 rows past the pass
+    return DN_OK;
+}
+
+int dn_cnn_reserve(dn_ctx *c, uint64_t rows) {
+    if (!c) return DN_ERR_ARG;
+    if (c->cnn_ops.empty()) return fail(c, DN_ERR_STATE, "dn_load_cnn must be called first");
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return fail(c, DN_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    const uint64_t cap_rows = (cnn_row_cap() + 255) / 256 * 256;
+    const uint64_t want = rows ? std::min<uint64_t>((rows + 255) / 256 * 256, cap_rows) : cap_rows;
+    CnnLane *L = lane_get(c);
+    if (!L) return fail(c, DN_ERR_HIP, "cannot create the CNN lane of device %d", c->device);
+    LaneUse lane_use(L);
+    std::lock_guard<std::mutex> lane_lock(L->mu);
+    return lane_size(c, L, want);
+}
+
 // the CNN over n sequences whose input tensors (core, residual, signal) are already on the device.
 // ub[r] (host) bounds the positions of sequence r; the actual counts are on the device (d_npos: 0 = nothing to do).  Activation
 // rows are laid out from the BOUNDS -- sequence r owns ub[r] rows + CNN_PAD zero rows, of which the first d_npos[r] are live and
@@ -1435,11 +1460,7 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned
     // fills a quarter of a pass gets the full pass allocated once; small calls (tests, dn_cnn_infer of a few reads) keep small buffers.
     const uint64_t cap_rows = (cap + 255) / 256 * 256;
     const uint64_t lane_rows = max_rows >= cap_rows / 4 ? std::max(max_rows, cap_rows) : max_rows;
-    for (int b = 0; b < c->cnn_nbuf; b++)
-        if ((rc = lane_grow(c, L, L->buf[b], (size_t)lane_rows * 256 * sizeof(float)))) return rc;
-    if ((rc = lane_grow(c, L, L->enclen, (size_t)lane_rows)) || (rc = lane_grow(c, L, L->enchist, 64 * sizeof(unsigned))) ||
-        (rc = lane_grow(c, L, L->permsrc, (size_t)lane_rows * sizeof(uint64_t))) || (rc = lane_grow(c, L, L->permrow, (size_t)lane_rows * sizeof(unsigned))) ||
-        (rc = lane_grow(c, L, L->valid, (size_t)lane_rows + 256)) || (rc = lane_grow(c, L, L->live, 256))) return rc;    // + 256: k3_sep_pair's 120-row tiles look up to 127 rows past the pass
+    if ((rc = lane_size(c, L, lane_rows))) return rc;
     if ((rc = dgrow(c, c->cnn_rowoff, n * sizeof(unsigned))) || (rc = dgrow(c, c->cnn_iooff, n * sizeof(uint64_t)))) return rc;
     if (!c->p_cnn_flag) HIPCHK(c, hipHostMalloc((void **)&c->p_cnn_flag, sizeof(unsigned), hipHostMallocDefault));
     // hand the batch over to the lane: everything the context's stream has enqueued so far (eventalign, the position counts)

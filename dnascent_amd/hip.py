@@ -18,7 +18,7 @@ for _i, _n in enumerate(K_NAMES):
 
 # every symbol include/dnascent_hip.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = ["dn_abi_version", "dn_device_count", "dn_ctx_create", "dn_ctx_destroy", "dn_last_error", "dn_sync",
-           "dn_load_pore_model", "dn_batch_upload", "dn_host_alloc", "dn_host_free", "dn_host_register", "dn_host_unregister", "dn_run_detect", "dn_collect", "dn_batch_workspace_bytes", "dn_ctx_reserve", "dn_ctx_set_event_bound", "dn_ctx_get_event_bound", "dn_debug_emission", "dn_debug_keep_k1", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded",
+           "dn_load_pore_model", "dn_batch_upload", "dn_host_alloc", "dn_host_free", "dn_host_register", "dn_host_unregister", "dn_run_detect", "dn_collect", "dn_batch_workspace_bytes", "dn_ctx_reserve", "dn_cnn_reserve", "dn_ctx_set_event_bound", "dn_ctx_get_event_bound", "dn_debug_emission", "dn_debug_keep_k1", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded",
            "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_set_align_table", "dn_get_align_rows", "dn_get_align_table", "dn_load_cnn", "dn_cnn_set_math", "dn_cnn_range_escalations", "dn_run_cnn", "dn_get_probabilities", "dn_cnn_infer", "dn_load_fit_models", "dn_run_hmm", "dn_get_hmm_calls", "dn_get_summaries", "dn_get_prefix_sums",
            "dn_get_tstats", "dn_get_scrappie_events", "dn_get_events", "dn_get_kmer_ranks", "dn_get_alignment",
            "dn_get_cleaned", "dn_get_trace", "dn_get_positions", "dn_get_windows", "dn_profile_enable", "dn_profile_get",
@@ -113,6 +113,7 @@ def lib():
         L.dn_collect.argtypes = [C.c_void_p, C.POINTER(ResultBatch)]
         L.dn_batch_workspace_bytes.argtypes = [C.c_void_p, C.POINTER(BatchDesc), C.POINTER(C.c_uint64)]
         L.dn_ctx_reserve.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.dn_cnn_reserve.argtypes = [C.c_void_p, C.c_uint64]
         L.dn_ctx_set_event_bound.argtypes = [C.c_void_p, C.c_uint32]
         L.dn_ctx_get_event_bound.restype = C.c_uint32
         L.dn_ctx_get_event_bound.argtypes = [C.c_void_p]
@@ -248,6 +249,10 @@ class Context:
     def reserve(self, workspace_bytes, collect_bytes=0):
         """dn_ctx_reserve: make the workspace slab hold at least workspace_bytes now (no regrowth -- a device-wide wait -- in the middle of a stream)"""
         self._chk(lib().dn_ctx_reserve(self.h, C.c_uint64(int(workspace_bytes)), C.c_uint64(int(collect_bytes))), "dn_ctx_reserve")
+
+    def cnn_reserve(self, rows=0):
+        """dn_cnn_reserve: the activation buffers of this context's CNN lane now (rows = 0: a full pass) instead of inside the first pass's enqueue"""
+        self._chk(lib().dn_cnn_reserve(self.h, C.c_uint64(int(rows))), "dn_cnn_reserve")
 
     def set_event_bound(self, samples_per_event):
         """dn_ctx_set_event_bound: a read's workspace holds samples / samples_per_event + 64 events (default 2 = the detector's own bound; tighter bounds need

@@ -44,7 +44,10 @@ import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # the host library's OpenMP teams must SLEEP between their loops: spinning threads starve the HIP runtime's callback thread (dn_host.cpp hostThreads)
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-os.environ.setdefault("DN_CNN_ROWS", str(8 << 20))         # activation rows resident per CNN pass and lane (bench.py's setting: 32 GiB per lane; 4 Mi -2 %)
+# activation rows resident per CNN pass and lane: 4 Mi = 16 GiB per lane.  bench.py takes 8 Mi (steady state +2 %); here the footprint decides: a run that starts right
+# behind another process's exit gets memory the driver is still clearing, and its first uploads into every fresh allocation wait for that -- seconds that grow with
+# what the process allocates (profiles/r05_run_detect_back_to_back.txt: 149 GB at 4 Mi, 218 GB at 8 Mi; cold, the two differ by 0.2 s of a 7.4 s stream)
+os.environ.setdefault("DN_CNN_ROWS", str(4 << 20))
 if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "DN_HOST_THREADS" not in os.environ:
     # N ranks share the host's cores: each rank's loader / packer / formatter loops take their share (dn_host.cpp hostThreads)
     from dnascent_amd.host import usable_cpus as _usable                   # the cgroup's CPU quota, not the hardware threads in sight
@@ -229,6 +232,7 @@ def main(argv=None):
                 def prepare(c, bt):
                     ta = time.time()
                     c.reserve(want[0], collect_bytes=want[1])
+                    c.cnn_reserve(0)                           # its CNN lane's activation buffers (shared by the contexts of a lane: the first one pays)
                     tb = time.time()
                     bt.upload(c)                               # the side tables (per-read mirrors) take their size from a real batch
                     tc = time.time()

@@ -208,6 +208,11 @@ int dn_collect(dn_ctx *ctx, dn_result_batch *out);
  * batches (the context's stream is waited for).  The reference has no counterpart: its per-read buffers are malloc'ed per read. */
 int dn_batch_workspace_bytes(dn_ctx *ctx, const dn_batch_desc *batch, uint64_t *bytes);
 int dn_ctx_reserve(dn_ctx *ctx, uint64_t workspace_bytes, uint64_t collect_bytes);
+/* dn_cnn_reserve: give the CNN lane this context runs on its activation buffers NOW, for passes of up to `rows` rows (0 = the pass cap, DN_CNN_ROWS),
+ * instead of at the first pass that needs them: 16-32 GiB of hipMalloc per lane, which a host can take on a helper thread while its stream already runs on
+ * the lanes that have theirs (run_detect: 1 s per lane right behind another process's exit, 4 lanes, inside the stream's enqueue path before this call existed).
+ * Needs dn_load_cnn.  No reference counterpart (tensor.cpp's session allocates per call). */
+int dn_cnn_reserve(dn_ctx *ctx, uint64_t rows);
 /* ABI 5.  How many events a read's workspace holds: samples / samples_per_event + 64 (default 2: scrappie's detector cannot place more than one peak per
  * two samples -- its shortest window is 3, event_detection.h:19-25 -- so that bound never overflows).  The event, alignment and trace arrays are sized from it
  * (13 of the 21 GB of a 500 x 50 kb batch at the default); R10.4.1 reads carry one event per 5-8 samples, so a host that RETRIES may ask for 3 .. 16: a read

@@ -2,7 +2,7 @@
 # Round-5 evidence, everything into gpurun_out/r05/ (tools/r05_collect.py turns it into profiles/r05_*):
 #   (1) the default bench exactly as the driver runs it (BASELINE configs[2]: 10 000 x 50 kb, full pipeline, CPU baseline + fp32 leg)
 #   (2) the same command line under rocprofv3 --kernel-trace --stats (the per-kernel averages must agree with the bench line's own HIP-event means)
-#   (3) counter passes AT THE BENCH'S LAUNCH SHAPE (500 x 50 kb per step, 4 Mi-row CNN passes) and at the bench's DEPTH (8 batches in flight:
+#   (3) counter passes AT THE BENCH'S LAUNCH SHAPE (500 x 50 kb per step, 8 Mi-row CNN passes) and at the bench's DEPTH (8 batches in flight:
 #       round-3 verdict / advisor -- the committed passes were taken with one), each its own run:
 #       WRITE_SIZE | FETCH_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 #   (4) configs[1] (banded scope) bench, and the same three counter passes for it

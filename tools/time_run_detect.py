@@ -26,7 +26,7 @@ if a.reuse and os.path.exists(cont) and host.container_count(cont) == a.reads:
 else:
     n = host.write_synth_container(cont, synth.pore_model(), 1000003, a.reads, a.bases)
     print("container: %d reads, %.2f GB, written in %.1f s" % (n, os.path.getsize(cont) / 1e9, time.time() - t0), flush=True)
-env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), DN_CNN_ROWS=os.environ.get("DN_CNN_ROWS", str(8 << 20)))
+env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))       # DN_CNN_ROWS: run_detect's own default unless the caller exports one
 tail = ["--container", cont, "--out", out, "--inflight", str(a.inflight)] + (["--stats", a.stats] if a.stats else []) + extra
 if a.ranks > 1:
     import socket
