@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 5
+#define DN_ABI_VERSION 6
 #define DN_KMER 9            /* config.h:45 */
 #define DN_NKMER 262144      /* 4^9, data_IO.cpp:177 */
 #define DN_BANDWIDTH 100     /* config.h:41 AdaptiveBanded_Params.bandwidth */
@@ -208,7 +208,7 @@ int dn_collect(dn_ctx *ctx, dn_result_batch *out);
  * batches (the context's stream is waited for).  The reference has no counterpart: its per-read buffers are malloc'ed per read. */
 int dn_batch_workspace_bytes(dn_ctx *ctx, const dn_batch_desc *batch, uint64_t *bytes);
 int dn_ctx_reserve(dn_ctx *ctx, uint64_t workspace_bytes, uint64_t collect_bytes);
-/* dn_cnn_reserve: give the CNN lane this context runs on its activation buffers NOW, for passes of up to `rows` rows (0 = the pass cap, DN_CNN_ROWS),
+/* ABI 6.  dn_cnn_reserve: give the CNN lane this context runs on its activation buffers NOW, for passes of up to `rows` rows (0 = the pass cap, DN_CNN_ROWS),
  * instead of at the first pass that needs them: 16-32 GiB of hipMalloc per lane, which a host can take on a helper thread while its stream already runs on
  * the lanes that have theirs (run_detect: 1 s per lane right behind another process's exit, 4 lanes, inside the stream's enqueue path before this call existed).
  * Needs dn_load_cnn.  No reference counterpart (tensor.cpp's session allocates per call). */

@@ -128,3 +128,34 @@ def test_event_bound_overflow_is_reported_and_retried(model):
     with pytest.raises(hip.DnError):
         ctx.collect()
     ctx.close()
+
+
+def test_cnn_lane_reserved_ahead_of_the_first_pass(model, monkeypatch):
+    """ABI 6 (dn_cnn_reserve): a lane's activation buffers taken before any batch -- an error before dn_load_cnn, and the stream's records are the same with a
+    lane sized ahead (smaller than, equal to and larger than what the batch needs: the pass grows what it lacks) as without the call."""
+    from dnascent_amd import cnn_model
+    monkeypatch.setenv("DN_CNN_ROWS", str(1 << 16))          # the cap the call rounds to (rows = 0 means a full pass)
+    desc, blob, _ = cnn_model.default_model()
+    reads = [synth.make_read(7400 + i, 2500 + 300 * i, model=model, is_reverse=bool(i & 1)) for i in range(4)]
+    bare = hip.Context(0)
+    with pytest.raises(hip.DnError):
+        bare.cnn_reserve(0)
+    bare.close()
+
+    def stream(rows):
+        ctx = hip.Context(0)
+        ctx.load_pore_model(model, 0.14); ctx.load_cnn(desc, blob)
+        if rows is not None:
+            ctx.cnn_reserve(rows)
+        b = host.ReadBatch()
+        for r in reads:
+            assert b.add_synth(r) >= 0
+        ds = host.DetectStream([ctx], emit=True)
+        ds.submit(b, 3)
+        out = ds.collect()
+        ds.close(); ctx.close()
+        return out["text"]
+    want = stream(None)
+    assert want.count(b">") == 4
+    for rows in (256, 0, 1 << 20):
+        assert stream(rows) == want
