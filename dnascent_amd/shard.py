@@ -88,7 +88,7 @@ def warm_collectives(dist, device="cpu"):
     def run():
         t = torch.zeros(1, dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        torch.cuda.synchronize()
+        t.item()                                                # waits for torch's own stream only: a device-wide synchronise would wait for the library's streams too
     th = threading.Thread(target=run, name="dn-rccl-warm", daemon=True)
     th.start()
     return th
