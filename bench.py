@@ -500,7 +500,8 @@ def main():
                                                                                           ", .detect records formatted" + (" and written" if args.out else "") if args.emit else ""),
                 "reads_per_step": rps, "bases_per_read": bases, "reads_per_gpu": args.steps * rps, "samples_per_gpu": int(st.samples),
                 "reads_passing_qc_per_gpu": int(st.reads_ok), "calls_per_gpu": int(st.calls),
-                "parallelism": "reads sharded, %d rank(s), %d batches in flight per GPU, one host thread per rank" % (world, nctx)}
+                "parallelism": "reads sharded, %d rank(s), %d batches in flight per GPU, one host thread per rank" % (world, nctx),
+                "cnn_rows_per_pass": int(os.environ.get("DN_CNN_ROWS", 4 << 20)), "cnn_lanes": int(os.environ.get("DN_CNN_LANES", "4"))}
             # ---- the network, layer by layer, from THIS run: HIP events bracket every launch of every op on the CNN lane's stream
             #      (dn_profile_get_layer); ops are grouped by the kernel they take (named as rocprofv3 prints it) and kernels by family
             #      (the template name).  A fused separable layer is one op (its pointwise half reports nothing).
@@ -672,7 +673,8 @@ def main():
                                          "banded alignment + backtrack/QC + Theil-Sen), batch resident in HBM, CNN stubbed" % (rps, bases // 1000),
                              "reads_per_gpu": rps, "bases_per_read": bases, "samples_per_gpu_step": int(samples_step),
                              "reads_passing_qc": int(np.sum(summ["status"] == 0)),
-                             "parallelism": "reads sharded, %d rank(s), %d batches in flight per GPU, one host thread per rank" % (world, nctx)}
+                             "parallelism": "reads sharded, %d rank(s), %d batches in flight per GPU, one host thread per rank" % (world, nctx),
+                "cnn_rows_per_pass": int(os.environ.get("DN_CNN_ROWS", 4 << 20)), "cnn_lanes": int(os.environ.get("DN_CNN_LANES", "4"))}
             out["roofline"] = roof_banded
             out["roofline_k1"] = roof_k1
         if cpu_base is not None:
