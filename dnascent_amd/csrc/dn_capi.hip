@@ -164,6 +164,7 @@ struct dn_ctx {
     unsigned long long *p_call_off = nullptr; dn_read_summary *p_summary = nullptr;
     bool upload_pinned = false;
     bool keep_k1 = false;                               // dn_debug_keep_k1
+    int seg_warm = DN_SEG_WARM;                         // dn_debug_seg_warm
     size_t n_ref_T = 0; char *d_col = nullptr;
     unsigned *p_cnn_rowoff = nullptr; uint64_t *p_cnn_iooff = nullptr; size_t cnn_meta_cap = 0; unsigned *p_cnn_flag = nullptr; bool cnn_pending = false;
     FillConstsH fc{};
@@ -595,6 +596,7 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
     BatchDev &B = c->B;
     memset(&B, 0, sizeof(B));
     B.n_reads = (int)n;
+    B.seg_warm = c->seg_warm;
     B.model_mean = c->d_model; B.sigma = c->sigma;
     B.model_pos = c->d_model_pos; B.model_sorted = c->d_model_sorted;
     c->h_samp_off.assign(d->adc_off, d->adc_off + n + 1);
@@ -665,7 +667,7 @@ int dn_batch_upload(dn_ctx *c, const dn_batch_desc *d) {
 #define AL(field, cnt) if ((rc = dalloc(c, &B.field, (size_t)(cnt)))) return rc
     AL(carry, 4 * NCH + n);
     if (c->keep_k1) { AL(psum, S); AL(t1, S); AL(t2, S); AL(et_start, NEV); AL(et_mean, NEV); }      // parity taps only: every prefix sum and both t-statistics in HBM
-    AL(chunk_npk, NCH); AL(chunk_peaks, NCH * DN_SEG_PEAKCAP); AL(chunk_psum, NCH * DN_SEG_PEAKCAP); AL(chunk_in, NCH); AL(chunk_out, NCH);
+    AL(chunk_npk, NCH); AL(chunk_peaks, NCH * DN_SEG_PEAKCAP); AL(chunk_psum, NCH * DN_SEG_PEAKCAP); AL(chunk_in, NCH); AL(chunk_out, NCH); AL(chunk_sums, NCH);
     AL(ev_mean, NEV); AL(ev_start, NEV); AL(ev_len, NEV); AL(ev_x, NEV);
     AL(rank_q, NB); AL(rank_r, NR); AL(mu_q, NB);
     AL(aln_event, NAL); AL(aln_kmer, NAL); AL(cl_sig, NAL); AL(cl_rank, NAL);
@@ -1073,6 +1075,12 @@ int dn_host_unregister(void *p) { return (p && hipHostUnregister(p) == hipSucces
 int dn_debug_keep_k1(dn_ctx *c, int on) {
     if (!c) return DN_ERR_ARG;
     c->keep_k1 = on != 0;
+    return DN_OK;
+}
+
+int dn_debug_seg_warm(dn_ctx *c, uint32_t samples) {
+    if (!c || samples > DN_SEG_WARM) return DN_ERR_ARG;
+    c->seg_warm = (int)samples;
     return DN_OK;
 }
 

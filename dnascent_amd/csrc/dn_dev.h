@@ -61,6 +61,8 @@ struct BatchDev {
     unsigned *chunk_peaks;   // [chunks * DN_SEG_PEAKCAP] peak positions ...
     double *chunk_psum;      // [chunks * DN_SEG_PEAKCAP] ... and the exact prefix sum sum[peak] that goes with each (event means need nothing else)
     SegState *chunk_in, *chunk_out;   // [chunks]
+    double2 *chunk_sums;     // [chunks] {sum[short.peak_pos], sum[long.peak_pos]} of the peaks pending in chunk_out (k1_events' exact redo starts from them)
+    int seg_warm;            // detector warm-up before a chunk: DN_SEG_WARM; dn_debug_seg_warm shortens it so that tests reach the redo path
     // scrappie events + DNAscent events; capacity per read = ev_off[r+1]-ev_off[r]
     const uint64_t *ev_off;  // [n+1]
     unsigned *et_start; float *et_mean;     // TAP ONLY (null unless keep_k1): scrappie event_t (start, mean); length = start[i+1]-start[i]

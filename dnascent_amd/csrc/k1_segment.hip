@@ -361,7 +361,7 @@ __device__ __forceinline__ void seg_body13(const float *row, const int A /* samp
 // walks chunk `c` of read r on every lane that `have`s one.  REDO: all lanes walk the same chunk from state `st`.
 template <bool REDO>
 __device__ __forceinline__ void seg_walk(const BatchDev &B, float *tile /* [64 * SEG_PITCH] */, unsigned *lds_pos /* [SINK_N * 64] */, double *lds_sum /* [SINK_N * 64] */,
-                                         const int r, const int cbase, const int c, const bool have, SegState &st, unsigned &npk) {
+                                         const int r, const int cbase, const int c, const bool have, SegState &st, double &ss, double &ls, unsigned &npk) {
     const int lane = threadIdx.x;
     const uint64_t s0 = B.samp_off[r];
     const int n = (int)(B.samp_off[r + 1] - s0);
@@ -376,11 +376,10 @@ __device__ __forceinline__ void seg_walk(const BatchDev &B, float *tile /* [64 *
     double rs[13], rq[13];
 #pragma unroll
     for (int k = 0; k < 13; k++) { rs[k] = S; rq[k] = Q; }       // never read by a live statistic: the detector starts >= 64 samples in
-    double ss = 0.0, ls = 0.0;
     PeakSink sink{ B.chunk_peaks + (c0 + cc) * DN_SEG_PEAKCAP, B.chunk_psum + (c0 + cc) * DN_SEG_PEAKCAP, lds_pos + lane, lds_sum + lane };
     const int chunk_lo = cc * DN_SEG_CHUNK;
     const int det_hi = have ? min(n, chunk_lo + DN_SEG_CHUNK) : 0;
-    const int det_lo = REDO ? chunk_lo : max(1, chunk_lo - DN_SEG_WARM);     // sample 0 is always masked (:140)
+    const int det_lo = REDO ? chunk_lo : max(1, chunk_lo - B.seg_warm);      // sample 0 is always masked (:140); seg_warm = DN_SEG_WARM unless a test shortened it
     SegState *save = (!REDO && have) ? &B.chunk_in[c0 + cc] : nullptr;
     for (int t = 0; t < SEG_TILES; t++) {
         __syncthreads();
@@ -419,10 +418,14 @@ __global__ __launch_bounds__(64) void k1_detect(BatchDev B) {
     const bool have = c < nch;
     SegState st = seg_initial();
     unsigned npk = 0;
-    seg_walk<false>(B, tile, lds_pos, lds_sum, r, cbase, c, have, st, npk);
+    double ss = 0.0, ls = 0.0;          // sum[peak_pos] of the short / long detector's pending peak: set whenever a detector moves its peak
+    seg_walk<false>(B, tile, lds_pos, lds_sum, r, cbase, c, have, st, ss, ls, npk);
     if (have) {
         B.chunk_npk[c0 + c] = npk;
         B.chunk_out[c0 + c] = st;
+        // a peak still pending at the chunk's end was placed by THIS walk (it started from "no peak"), so its sum is the true one
+        // whenever the state is -- k1_events hands both to the next chunk's redo if that chunk's speculation missed
+        B.chunk_sums[c0 + c] = make_double2(ss, ls);
     }
 }
 
@@ -469,14 +472,18 @@ __global__ __launch_bounds__(64) void k1_events(BatchDev B) {
         // slow path (rare): walk the chain of chunks, redo every chunk whose assumed start state was wrong -- the whole wavefront
         // walks that one chunk from the true state (wave-uniform; every lane computes and stores the same values)
         SegState tru = B.chunk_out[c0];
+        double2 trs = B.chunk_sums[c0];                           // {sum[short.peak_pos], sum[long.peak_pos]} that go with `tru`
         for (int c = 1; c < nch; c++) {
             const SegState in = B.chunk_in[c0 + c];
-            if (seg_equal(tru, in, c * DN_SEG_CHUNK)) { tru = B.chunk_out[c0 + c]; continue; }
+            if (seg_equal(tru, in, c * DN_SEG_CHUNK)) { tru = B.chunk_out[c0 + c]; trs = B.chunk_sums[c0 + c]; continue; }
             SegState st = tru;
             unsigned npk = 0;
-            seg_walk<true>(B, tile, lds_pos, lds_sum, r, 0, c, true, st, npk);
-            if (lane == 0) { B.chunk_npk[c0 + c] = npk; B.chunk_out[c0 + c] = st; }
-            tru = st;
+            // a peak pending in `tru` lies BEFORE this chunk: the walk cannot recompute the prefix sum at its position, so it travels
+            // with the state (without it the event on either side of such a peak would get a wrong mean)
+            double ss = trs.x, ls = trs.y;
+            seg_walk<true>(B, tile, lds_pos, lds_sum, r, 0, c, true, st, ss, ls, npk);
+            if (lane == 0) { B.chunk_npk[c0 + c] = npk; B.chunk_out[c0 + c] = st; B.chunk_sums[c0 + c] = make_double2(ss, ls); }
+            tru = st; trs = make_double2(ss, ls);
             rechecks++;
         }
         __threadfence_block();

@@ -10,6 +10,8 @@ import numpy as np
 from . import build as _build
 
 DN_OK = 0
+# dn_read_status (include/dnascent_hip.h)
+READ_OK, READ_FAIL_BANDED_QC, READ_FAIL_SCALING, READ_FAIL_NO_END_CELL, READ_FAIL_NEGATIVE_LOG, READ_FAIL_TOO_SHORT, READ_FAIL_WINDOW_EVENTS = range(7)
 K_NAMES = ["DN_K_SCAN", "DN_K_TSTAT", "DN_K_DETECT", "DN_K_EVENTS", "DN_K_RANKS", "DN_K_QUANTILE", "DN_K_PREP",
            "DN_K_BAND_FILL", "DN_K_BAND_TRACE", "DN_K_THEILSEN", "DN_K_VITERBI", "DN_K_CNN", "DN_K_HMM"]
 DN_K_COUNT = len(K_NAMES)
@@ -18,7 +20,7 @@ for _i, _n in enumerate(K_NAMES):
 
 # every symbol include/dnascent_hip.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = ["dn_abi_version", "dn_device_count", "dn_ctx_create", "dn_ctx_destroy", "dn_last_error", "dn_sync",
-           "dn_load_pore_model", "dn_batch_upload", "dn_host_alloc", "dn_host_free", "dn_host_register", "dn_host_unregister", "dn_run_detect", "dn_collect", "dn_batch_workspace_bytes", "dn_ctx_reserve", "dn_cnn_reserve", "dn_ctx_set_event_bound", "dn_ctx_get_event_bound", "dn_debug_emission", "dn_debug_keep_k1", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded",
+           "dn_load_pore_model", "dn_batch_upload", "dn_host_alloc", "dn_host_free", "dn_host_register", "dn_host_unregister", "dn_run_detect", "dn_collect", "dn_batch_workspace_bytes", "dn_ctx_reserve", "dn_cnn_reserve", "dn_ctx_set_event_bound", "dn_ctx_get_event_bound", "dn_debug_emission", "dn_debug_keep_k1", "dn_debug_seg_warm", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded",
            "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_set_align_table", "dn_get_align_rows", "dn_get_align_table", "dn_load_cnn", "dn_cnn_set_math", "dn_cnn_range_escalations", "dn_run_cnn", "dn_get_probabilities", "dn_cnn_infer", "dn_load_fit_models", "dn_run_hmm", "dn_get_hmm_calls", "dn_get_summaries", "dn_get_prefix_sums",
            "dn_get_tstats", "dn_get_scrappie_events", "dn_get_events", "dn_get_kmer_ranks", "dn_get_alignment",
            "dn_get_cleaned", "dn_get_trace", "dn_get_positions", "dn_get_windows", "dn_profile_enable", "dn_profile_get",
@@ -119,6 +121,7 @@ def lib():
         L.dn_ctx_get_event_bound.argtypes = [C.c_void_p]
         L.dn_debug_emission.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dn_debug_keep_k1.argtypes = [C.c_void_p, C.c_int]
+        L.dn_debug_seg_warm.argtypes = [C.c_void_p, C.c_uint32]
         L.dn_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
         L.dn_host_free.argtypes = [C.c_void_p]
         L.dn_host_register.argtypes = [C.c_void_p, C.c_size_t]
@@ -277,6 +280,10 @@ class Context:
     def keep_k1(self, on=True):
         """prefix sums / t-statistics also go to HBM for the batches uploaded from now on (taps prefix_sums() / tstats())"""
         self._chk(lib().dn_debug_keep_k1(self.h, int(on)), "dn_debug_keep_k1")
+
+    def seg_warm(self, samples):
+        """dn_debug_seg_warm: warm-up of the speculative peak detector (default 192 samples; 0 sends every chunk with a pending peak through the exact redo)"""
+        self._chk(lib().dn_debug_seg_warm(self.h, C.c_uint32(int(samples))), "dn_debug_seg_warm")
 
     def debug_emission(self, x, mu):
         x = np.ascontiguousarray(x, np.float64); mu = np.ascontiguousarray(mu, np.float64)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 6
+#define DN_ABI_VERSION 7
 #define DN_KMER 9            /* config.h:45 */
 #define DN_NKMER 262144      /* 4^9, data_IO.cpp:177 */
 #define DN_BANDWIDTH 100     /* config.h:41 AdaptiveBanded_Params.bandwidth */
@@ -229,6 +229,11 @@ uint32_t dn_ctx_get_event_bound(const dn_ctx *ctx);
 /* prefix sums and t-statistics live only in registers / LDS of the segmentation kernels; dn_debug_keep_k1(ctx, 1) BEFORE
  * dn_batch_upload makes the next batches also write them to HBM (24 bytes per sample) so that the two taps below work */
 int dn_debug_keep_k1(dn_ctx *ctx, int on);
+/* ABI 7.  The peak detector (event_detection.c:122-198) is a serial state machine; the device runs it speculatively per 1 024-sample chunk from the default
+ * state `samples` (default and maximum 192) before the chunk, verifies every hand-off exactly and re-walks a chunk from the true state when the
+ * speculation missed (dn_read_summary.detector_rechecks counts those).  A shorter warm-up changes no result -- it only makes the exact redo run more
+ * often: tests call dn_debug_seg_warm(ctx, 0) BEFORE dn_batch_upload to put every chunk with a peak pending at its start through that path. */
+int dn_debug_seg_warm(dn_ctx *ctx, uint32_t samples);
 int dn_get_prefix_sums(dn_ctx *ctx, uint32_t read, uint64_t cap /* samples */, double *sum /* [cap+1] */, double *sumsq /* [cap+1] */);
 int dn_get_tstats(dn_ctx *ctx, uint32_t read, uint64_t cap /* samples */, float *t_short, float *t_long /* [n_samples] */);
 int dn_get_scrappie_events(dn_ctx *ctx, uint32_t read, uint64_t cap, uint32_t *start, float *length, float *mean /* [n_scrappie] */);

@@ -1,0 +1,132 @@
+"""Hostile raw signals for the segmentation (scrappie/event_detection.c:60-115,122-198,213-266): what real nanopore signal has
+and the synthetic generator (csrc/host/dn_synth.c: geometric dwell + Gaussian noise) never produces -- stalls, runs of identical
+samples, open-pore spikes, square waves, drift, the densest event rate the detector can emit, reads shorter than a window.
+
+Shared by tests/golden/make_golden.py (which runs the REFERENCE over them and stores its event tables) and the tests (oracle on
+CPU, the HIP segmentation on the GPU).  Everything here is integer arithmetic on a splitmix64 stream or a splice of dn_synth
+reads: no numpy generator whose stream could change between numpy versions.  The fixture stores a SHA-256 of every signal.
+"""
+import numpy as np
+
+CAL = (-240.0, 0.1755)         # calibration offset / scale of the synthetic reads
+
+
+def _splitmix(seed, n):
+    """n uint64 draws of splitmix64, vectorised"""
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) + np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _levels(seed, n, lo=300, hi=1100):
+    """n pseudo-random ADC levels in [lo, hi) with consecutive levels at least 40 counts (7 pA) apart"""
+    u = (_splitmix(seed, n) % np.uint64(hi - lo)).astype(np.int64) + lo
+    for i in range(1, n):
+        if abs(int(u[i]) - int(u[i - 1])) < 40:
+            u[i] = lo + (int(u[i - 1]) - lo + 200) % (hi - lo)
+    return u
+
+
+def _steps(seed, run, n_samples):
+    """piecewise-constant, noise-free: a new level every `run` samples"""
+    nl = (n_samples + run - 1) // run
+    return np.repeat(_levels(seed, nl), run)[:n_samples].astype(np.int16)
+
+
+def _square(period, n_samples, lo=500, hi=900):
+    half = period // 2
+    return np.where((np.arange(n_samples) // half) % 2 == 0, lo, hi).astype(np.int16)
+
+
+def _noise16(seed, n, amp):
+    """integer noise in [-amp, amp], triangular (sum of two uniform draws)"""
+    a = (_splitmix(seed, n) % np.uint64(amp + 1)).astype(np.int64)
+    b = (_splitmix(seed ^ 0x5DEECE66D, n) % np.uint64(amp + 1)).astype(np.int64)
+    return a - b
+
+
+def normal_read(seed, n_bases, model):
+    from dnascent_amd import synth
+    return synth.make_read(seed, n_bases, model=model).adc.astype(np.int64)
+
+
+def splice(base, at, piece):
+    return np.concatenate([base[:at], piece, base[at:]])
+
+
+def stall(seed, length, level, noise_amp):
+    """a stalled pore: `length` samples at one level, exactly flat (noise_amp 0) or with a few counts of noise"""
+    if noise_amp == 0:
+        return np.full(length, level, np.int64)
+    return level + _noise16(seed, length, noise_amp)
+
+
+def cases(model):
+    """name -> int16 signal.  Every case the reference's detect_events accepts (at least one peak)."""
+    c = {}
+    base = normal_read(7001, 2500, model)                                  # ~31 k samples
+    n0 = base.shape[0]
+    # a 6 000-sample stall inside a normal read: exactly flat (zero-variance windows: eta = FLT_MIN, event_detection.c:104) and noisy
+    c["stall6000_flat"] = splice(base, n0 // 2, stall(1, 6000, 640, 0))
+    c["stall6000_noisy"] = splice(base, n0 // 2, stall(2, 6000, 640, 9))
+    # the flat stall entered right after a sub-threshold bump, so that a detector carries a pending peak across every chunk of it
+    c["stall3000_after_bump"] = splice(base, 5000, np.concatenate([np.full(40, 700), np.full(7, 703), stall(3, 3000, 700, 0)]))
+    # a NOISY stall running straight into an exactly flat one: in pure noise a detector usually holds a sub-threshold peak, and on flat signal (both
+    # t-statistics 0) nothing ever replaces it -- the state at every later chunk start depends on history more than a warm-up back
+    c["stall_noisy_then_flat"] = splice(base, 9000, np.concatenate([stall(4, 900, 620, 8), stall(5, 4200, 620, 0)]))
+    # a bare full-range ramp: the t-statistics are constant up to integer rounding (6.36 / 15.5: above both thresholds), peaks come from rounding alone
+    c["bare_ramp"] = -32768 + (np.arange(4000) * 65535) // 3999
+    # runs of 3 / 6 / 10 identical samples, steps of 2 / 3 / 4 samples (3: one event per 3.0 samples, the densest the detector emits)
+    for run in (2, 3, 4, 6, 10):
+        c["steps_%d" % run] = _steps(100 + run, run, 6000)
+    # square waves (period 2 and 4 give no peak at all: see no_peak_cases)
+    for period in (6, 8, 12):
+        c["square_%d" % period] = _square(period, 5000)
+    # +-full-scale spikes (open pore / saturation) in a normal read
+    sp = base.copy()
+    for k, at in enumerate(range(1500, n0 - 100, 2111)):
+        sp[at:at + 1 + (k % 3)] = 32767 if k % 2 == 0 else -32768
+    c["spikes"] = sp
+    # slow drift on a normal read (+-2 000 counts over the read)
+    c["drift_up"] = base + (np.arange(n0) * 2000) // n0
+    c["drift_down"] = base - (np.arange(n0) * 2000) // n0
+    # uniform int16 noise
+    c["uniform_int16"] = (_splitmix(77, 20000) % np.uint64(65536)).astype(np.int64) - 32768
+    # a ramp over the full range with a normal read's texture on top (a bare ramp has a constant t-statistic: no peak)
+    ramp = -30000 + (np.arange(n0) * 60000) // n0
+    c["ramp_textured"] = ramp + (base - 600)
+    # reads around the window lengths (w = 3: n >= 6; w = 6: n >= 12, event_detection.c:76-81)
+    tiny = _steps(500, 5, 64)
+    for n in (16, 40):
+        c["tiny_%d" % n] = tiny[:n]
+    # saturation plateaus: clipped at +-full scale for hundreds of samples
+    sat = base.copy()
+    sat[3000:3400] = 32767; sat[9000:9800] = -32768
+    c["saturated_plateaus"] = sat
+    return {k: np.clip(v, -32768, 32767).astype(np.int16) for k, v in c.items()}
+
+
+STALLS50 = ((60011, 300, 655, 0), (150017, 1200, 540, 7), (260003, 5000, 700, 0), (400009, 2200, 610, 11), (520019, 800, 590, 0))
+
+
+def read50kb_with_stalls(model):
+    """ONE 50 kb synthetic read (the headline length) with five stalls of 300-5 000 samples spliced in (three flat, two noisy)"""
+    x = normal_read(7050, 50000, model)
+    for at, length, level, amp in sorted(STALLS50, reverse=True):
+        x = splice(x, at, stall(at, length, level, amp))
+    return np.clip(x, -32768, 32767).astype(np.int16)
+
+
+def no_peak_cases():
+    """Signals on which the detector emits NO peak.  The reference then reads peaks[-1] and aborts (create_events :262 ->
+    assert(start < nsample), event_detection.c:215); this repo returns the one event [0, n) (documented divergence)."""
+    c = {}
+    c["flat"] = np.full(3000, 640, np.int16)
+    c["saturated_hi"] = np.full(3000, 32767, np.int16)
+    c["saturated_lo"] = np.full(2000, -32768, np.int16)
+    c["square_2"] = _square(2, 3000)
+    c["square_4"] = _square(4, 3000)
+    c["shorter_than_a_window"] = _steps(501, 2, 5)
+    return c

@@ -10,6 +10,10 @@ Files:
   ref_segmentation.npz   for each case: adc (int16), cal_offset, cal_scale -> reference detect_events (start, length,
                          mean, stdv) with the reference's default detector parameters (event_detection.h:19-25)
   ref_segmentation_50kb.npz  the same for ONE 50 kb read (the headline read length): the reference's event table only, the signal by seed + SHA-256
+  ref_segmentation_adversarial.npz   hostile signals (tests/adversarial_signals.py: stalls, runs of identical samples, full-scale spikes, steps of
+                         2 / 3 / 4 samples, square waves, drift, ramps, uniform noise, 16- and 40-sample reads, a 50 kb read with five stalls) -> the
+                         reference's event table (start, mean, stdv; length = the starts' differences) per case, the signal by SHA-256; and the list of
+                         no-peak signals with what the reference did on each (it aborts: event_detection.c:215) -- run in a forked child
   ref_common.npz         IUPAC sequences -> reference reverseComplement; fp64 vectors -> reference vectorMean (common.h)
   ref_logspace.npz       argument grids -> reference eexp / eln / lnSum / lnProd / lnGreaterThan / normalPDF (bit patterns)
   ref_emission.npz       (level, observation) pairs -> reference eln(normalPDF(level, 0.14, observation)): builtinViterbi's emission
@@ -30,7 +34,65 @@ from dnascent_amd import synth  # noqa: E402
 SEG50 = (950, 50000, dict(sub_rate=0.002, ins_rate=0.001, del_rate=0.001))      # the 50 kb segmentation golden (tests/test_golden.py uses the same tuple)
 
 
+def _ref_child(conn, raw):
+    conn.send(po.ref_detect_events(raw))
+    conn.close()
+
+
+def ref_detect_events_forked(raw):
+    """the reference's detect_events in a forked child: None when the child died (assert -> abort)"""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    rx, tx = ctx.Pipe(duplex=False)
+    p = ctx.Process(target=_ref_child, args=(tx, raw))
+    p.start()
+    tx.close()
+    try:
+        out = rx.recv()
+    except EOFError:
+        out = None
+    p.join()
+    return out if p.exitcode == 0 else None
+
+
+def adversarial(model):
+    import hashlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import adversarial_signals as adv
+    sigs = dict(adv.cases(model))
+    sigs["read50kb_with_stalls"] = adv.read50kb_with_stalls(model)
+    out = {"names": np.array(sorted(sigs)), "cal": np.array(adv.CAL, np.float32)}
+    for name in sorted(sigs):
+        adc = sigs[name]
+        raw = ((adc.astype(np.float32) + np.float32(adv.CAL[0])) * np.float32(adv.CAL[1])).astype(np.float64)      # pod5.cpp:60
+        st, ln, mn, sd = po.ref_detect_events(raw)
+        assert np.array_equal(ln, np.diff(np.concatenate([st, [adc.shape[0]]])).astype(np.float32))                 # length is redundant: not stored
+        out["sha_" + name] = np.frombuffer(hashlib.sha256(adc.tobytes()).digest(), np.uint8)
+        out["n_" + name] = np.int64(adc.shape[0])
+        out["start_" + name] = st.astype(np.uint32)
+        out["mean_" + name] = mn
+        out["stdv_" + name] = sd
+        print("  %-24s %7d samples -> %6d events (one per %.2f samples)" % (name, adc.shape[0], st.shape[0], adc.shape[0] / st.shape[0]))
+    nop = adv.no_peak_cases()
+    out["nopeak_names"] = np.array(sorted(nop))
+    fate = []
+    for name in sorted(nop):
+        adc = nop[name]
+        raw = ((adc.astype(np.float32) + np.float32(adv.CAL[0])) * np.float32(adv.CAL[1])).astype(np.float64)
+        r = ref_detect_events_forked(raw)
+        fate.append(-1 if r is None else int(r[0].shape[0]))                      # -1: the reference aborted
+        out["nopeak_sha_" + name] = np.frombuffer(hashlib.sha256(adc.tobytes()).digest(), np.uint8)
+        print("  %-24s %7d samples -> reference %s" % (name, adc.shape[0], "ABORTS (event_detection.c:215)" if r is None else "%d events" % r[0].shape[0]))
+    out["nopeak_reference_events"] = np.array(fate, np.int64)
+    np.savez_compressed(os.path.join(HERE, "ref_segmentation_adversarial.npz"), **out)
+    print("ref_segmentation_adversarial.npz", os.path.getsize(os.path.join(HERE, "ref_segmentation_adversarial.npz")), "bytes")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "adversarial":      # only this fixture (the others do not change when it does)
+        if po.ref() is None:
+            raise SystemExit("oracle/_ref/libref.so missing: run `make -C oracle` where /root/reference exists")
+        return adversarial(synth.pore_model())
     ref = po.ref()
     if ref is None:
         raise SystemExit("oracle/_ref/libref.so missing: run `make -C oracle` where /root/reference exists")
@@ -100,6 +162,7 @@ def main():
                         **{"seq_%d" % i: np.frombuffer(q, np.uint8) for i, q in enumerate(seqs)},
                         **{"rc_%d" % i: np.frombuffer(q, np.uint8) for i, q in enumerate(rc)},
                         **{"vm_in_%d" % i: v for i, v in enumerate(vm_in)})
+    adversarial(model)
     for f in ("ref_segmentation.npz", "ref_segmentation_50kb.npz", "ref_logspace.npz", "ref_emission.npz", "ref_common.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 

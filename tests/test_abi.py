@@ -22,7 +22,7 @@ def test_header_symbols_exported():
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert set(hip.SYMBOLS) == declared
-    assert L.dn_abi_version() == 6
+    assert L.dn_abi_version() == 7
 
 
 def test_no_cpu_fallback():
