@@ -1,3 +1,6 @@
+// NEVER COMPILED: neither htslib nor libpod5 exists in the image this project is built and tested in.  Kept under contrib/ (not in the product tree) as the
+// starting point for a deployment that has both libraries; dnascent_amd/build.py: build_io() compiles it when DN_HTSLIB_INC / DN_POD5_INC point at the headers.
+//
 // dn_io_htslib.cpp -- OPTIONAL ingestion through the reference's own I/O libraries: htslib for the BAM records,
 // libpod5 for the signal.  Compiled only where those libraries exist (dnascent_amd/build.py: build_io(); -DDN_WITH_HTSLIB /
 // -DDN_WITH_POD5) -- this image and the reference checkout have neither (empty submodules, no network), so on the build and GPU

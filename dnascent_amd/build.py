@@ -77,7 +77,7 @@ def build_host(force=False):
 
 
 def build_io(force=False):
-    """OPTIONAL: BAM / POD5 ingestion through htslib and libpod5 (csrc/host/dn_io_htslib.cpp) -> lib/libdnascent_io.so.  Built only
+    """OPTIONAL: BAM / POD5 ingestion through htslib and libpod5 (contrib/dn_io_htslib.cpp: never compiled in this image) -> lib/libdnascent_io.so.  Built only
     where the headers exist: DN_HTSLIB_INC / DN_POD5_INC (or /usr/include/htslib/sam.h, /usr/include/pod5_format/c_api.h).  Neither
     library is in this image; the function then returns None and the binary read container remains the ingestion path."""
     hts = os.environ.get("DN_HTSLIB_INC") or ("/usr/include" if os.path.exists("/usr/include/htslib/sam.h") else None)
@@ -85,7 +85,7 @@ def build_io(force=False):
     if not hts and not pod:
         return None
     out = os.path.join(LIB, "libdnascent_io.so")
-    src = os.path.join(CSRC, "host", "dn_io_htslib.cpp")
+    src = os.path.join(ROOT, "contrib", "dn_io_htslib.cpp")
     if not force and not _newer(out, [src]):
         return out
     build_host(False)

@@ -1,6 +1,6 @@
 // dn_bam.cpp -- BAM ingestion and modbam emission WITHOUT htslib: a BGZF + BAM record reader / writer written from the SAM/BAM specification (SAMv1 s4:
 // BGZF blocks = gzip members with a BC extra subfield; BAM = magic, header text, reference dictionary, records) over zlib's raw deflate, which IS in this image
-// (htslib, the reference's I/O library, is not: its submodule is empty and there is no network -- csrc/host/dn_io_htslib.cpp stays the optional htslib /
+// (htslib, the reference's I/O library, is not: its submodule is empty and there is no network -- contrib/dn_io_htslib.cpp stays the optional htslib /
 // libpod5 path and has never been compiled).  What the reference takes from a BAM record lives in three places, mirrored here:
 //   reads.h:210-287          DNAscent::read's constructor: qname, Dorado tags ns / ts / pi / sp, CIGAR, target name, query sequence, strand
 //   htsInterface.cpp:59-180  parseCigar (host/dn_host.cpp parseCigar takes the CIGAR as read here), getQuerySequence (4-bit codes; anything but A C G T N throws)
