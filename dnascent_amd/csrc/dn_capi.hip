@@ -37,6 +37,7 @@ struct CnnRun { const dn_cnn_op *ops; int n_ops; const float *wts; float *buf[8]
                  void (*mark)(void *who, int begin, int kind, hipStream_t st); void *mark_who;
                  unsigned *row_off_w; int *live; };
 int k3_run(const CnnRun &, hipStream_t);
+void k3_launch_canary_compare(const float *, const float *, const CnnRows &, unsigned, float, unsigned *, hipStream_t);
 int k3_describe(const CnnRun &, int, char *, size_t);
 struct HmmConstsH { double D2D, D2M, I2M, M2D, M2I, I2I, ln025, ln05; };
 struct HmmReadH { double iM2M, eM2M, endM; };
@@ -171,6 +172,7 @@ struct dn_ctx {
     std::vector<int64_t> cnn_wb_off, cnn_wh_off; uint16_t *d_cnn_wb = nullptr, *d_cnn_wh = nullptr; size_t cnn_nwb = 0, cnn_nwh = 0; int cnn_math = DN_CNN_MATH_F16X3;
     std::vector<float> cnn_post, cnn_one; unsigned *d_cnn_flag = nullptr; uint64_t cnn_escalations = 0; bool cnn_f16_off = false;
     unsigned cnn_underflow_streak = 0; bool cnn_bf16_once = false;        // see cnn_note_escalation
+    DevBuf cnn_canary; uint64_t cnn_canaries = 0;                         // the canary's probabilities (cnn_execute); how many canaries ran
     std::vector<dn_cnn_op> cnn_ops; float *d_cnn_w = nullptr; size_t cnn_nw = 0; int cnn_nbuf = 0; DevBuf cnn_rowoff, cnn_npos, cnn_iooff, cnn_in[3], cnn_out;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;    // hand-over to / from the device's CNN lane
     unsigned lane_id = 0;
@@ -493,7 +495,7 @@ void dn_ctx_destroy(dn_ctx *c) {
     for (auto *p : c->d_fit) if (p) hipFree(p);
     for (DevBuf *b : { &c->hmm_poi, &c->hmm_npoi, &c->hmm_nev, &c->hmm_ok, &c->hmm_la, &c->hmm_lt, &c->hmm_reads, &c->al_coord, &c->al_rpos,
                        &c->al_val, &c->al_kind, &c->al_off, &c->al_n }) if (b->p) hipFree(b->p);
-    for (DevBuf *b : { &c->cnn_rowoff, &c->cnn_npos, &c->cnn_iooff, &c->cnn_in[0], &c->cnn_in[1], &c->cnn_in[2], &c->cnn_out }) if (b->p) hipFree(b->p);
+    for (DevBuf *b : { &c->cnn_rowoff, &c->cnn_npos, &c->cnn_iooff, &c->cnn_in[0], &c->cnn_in[1], &c->cnn_in[2], &c->cnn_out, &c->cnn_canary }) if (b->p) hipFree(b->p);
     if (c->ev_ready) hipEventDestroy(c->ev_ready);
     if (c->ev_done) hipEventDestroy(c->ev_done);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -1372,9 +1374,22 @@ static void cnn_note_escalation(dn_ctx *c, unsigned flag) {
     if (!said) {
         said = true;
         fprintf(stderr, "dnascent_hip: a CNN pass was repeated with bf16 pieces (%s); dn_cnn_range_escalations counts the repeats\n",
-                (flag & 1u) ? "an activation beyond fp16's range: the context stays on bf16 pieces" : "a whole layer below 2^-6: fp16's low pieces would be subnormal");
+                (flag & 1u) ? "an activation beyond fp16's range: the context stays on bf16 pieces"
+                : (flag & 2u) ? "a whole layer below 2^-6: fp16's low pieces would be subnormal"
+                : "the canary sequences' probabilities differ between fp16 and bf16 pieces by more than the tolerance");
     }
 }
+
+// THE CANARY (round 6).  The range report above sees a layer's MAXIMUM only: a layer whose values are mostly ~1e-5 beside a few of O(1) keeps the absolute
+// 2^-25 error of subnormal low pieces on the small ones and nothing says so.  Instead of guessing from statistics which distributions hurt, the first
+// sequences of every batch (>= 4 096 positions, <= 8 sequences) go through the network a second time with bf16 pieces (fp32's exponent range) and the two
+// sets of probabilities are compared ON THE DEVICE: a difference above the tolerance (default 1e-4, the contract's bar; DN_CNN_CANARY_TOL) raises bit 2 of
+// the report word and the batch is repeated with bf16 pieces exactly as for an overflow.  It measures the contract's own quantity -- whatever the cause:
+// range, a cancellation the 22-bit products cannot carry, a kernel bug -- on a sample of ~0.2 % of a 500-read batch (DN_CNN_CANARY=0 switches it off).
+// (read per batch, not cached: a test switches the canary off and on inside one process)
+static bool cnn_canary_enabled() { const char *e = getenv("DN_CNN_CANARY"); return !(e && atoi(e) == 0); }
+static float cnn_canary_tol() { const char *e = getenv("DN_CNN_CANARY_TOL"); return e ? (float)atof(e) : 1e-4f; }
+uint64_t dn_cnn_canaries(dn_ctx *c) { return c ? c->cnn_canaries : 0; }
 
 // the lane's activation buffers for passes of up to lane_rows rows (caller holds L->mu)
 static int lane_size(dn_ctx *c, CnnLane *L, uint64_t lane_rows) {
@@ -1479,6 +1494,7 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned
     if (c->prof) kc_launch_nop(st);     // the profiling event below must be stamped AFTER the hand-over wait: behind a kernel it is
     {
     Timed t(c, DN_K_CNN, st);
+    bool canary_due = cnn_canary_enabled() && c->d_cnn_wb != nullptr;     // once per call: on its first pass (if that pass runs on fp16 pieces at all)
     for (const Pass &ps : passes) {
         HIPCHK(c, hipMemsetAsync(L->valid.p, 0, (size_t)ps.rows, st));
         CnnRun run{};
@@ -1503,6 +1519,23 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned
             run.post = math == DN_CNN_MATH_F16X3 ? c->cnn_post.data() : c->cnn_one.data();
             run.range_flag = c->d_cnn_flag;
             if (k3_run(run, st)) return fail(c, DN_ERR_ARG, "unsupported op in the CNN description");
+            if (math == DN_CNN_MATH_F16X3 && canary_due) {
+                // the pass's first sequences once more, with bf16 pieces, into a buffer of their own; then compared with what the fp16 pass wrote
+                canary_due = false;
+                uint32_t k1 = ps.r0; uint64_t crows = 8, cpos = 0; unsigned cmax = 1;
+                while (k1 < ps.r1 && k1 - ps.r0 < 8 && cpos < 4096) { crows += ub[k1] + 8; cpos += ub[k1]; cmax = std::max(cmax, ub[k1]); k1++; }
+                const uint64_t span = io_off[k1 - 1] + ub[k1 - 1] - io_off[ps.r0];                 // positions from the first canary sequence's first to the last one's bound
+                if ((rc = dgrow(c, c->cnn_canary, (size_t)span * 3 * sizeof(float)))) return rc;
+                CnnRun cr = run;
+                cr.rows.r1 = k1; cr.rows.rows = (unsigned)((crows + 255) / 256 * 256); cr.max_pos = cmax; cr.n_pass_pos = (unsigned)cpos;
+                cr.wts_split = c->d_cnn_wb; cr.wb_off = c->cnn_wb_off.data(); cr.pieces = 3; cr.post = c->cnn_one.data();
+                cr.probs = (float *)c->cnn_canary.p - 3 * io_off[ps.r0];                            // k3_dense_softmax writes at probs + 3 (io_off[r] + p)
+                cr.mark = nullptr;
+                HIPCHK(c, hipMemsetAsync(L->valid.p, 0, (size_t)ps.rows, st));
+                if (k3_run(cr, st)) return fail(c, DN_ERR_ARG, "unsupported op in the CNN description");
+                k3_launch_canary_compare(d_probs, cr.probs, cr.rows, cmax, cnn_canary_tol(), c->d_cnn_flag, st);
+                c->cnn_canaries++;
+            }
             if (math != DN_CNN_MATH_F16X3 || !check_now) break;
             HIPCHK(c, hipMemcpyAsync(c->p_cnn_flag, c->d_cnn_flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));

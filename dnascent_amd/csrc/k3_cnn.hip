@@ -1584,6 +1584,20 @@ __global__ __launch_bounds__(256) void k3_dense_softmax(const float *__restrict_
     }
 }
 
+// The canary's comparison (dn_capi.hip cnn_execute): probabilities of sequences [r0, r1) as the fp16 pass wrote them against the same sequences' from bf16
+// pieces; a difference above tol anywhere (or a NaN on either side) raises bit 2 of the report word the host reads.
+__global__ __launch_bounds__(256) void k3_canary_compare(const float *__restrict__ a, const float *__restrict__ b, CnnRows R, float tol, unsigned *flag) {
+    const unsigned r = R.r0 + blockIdx.y;
+    const unsigned np = R.n_pos[r];
+    const uint64_t o = R.io_off[r] * 3;
+    bool bad = false;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < np * 3; i += gridDim.x * 256) bad = bad || !(fabsf(a[o + i] - b[o + i]) <= tol);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 4u);
+}
+void k3_launch_canary_compare(const float *probs, const float *canary, const CnnRows &rows, unsigned max_pos, float tol, unsigned *flag, hipStream_t st) {
+    hipLaunchKernelGGL(k3_canary_compare, dim3((max_pos * 3 + 255) / 256 < 64u ? (max_pos * 3 + 255) / 256 : 64u, rows.r1 - rows.r0), dim3(256), 0, st, probs, canary, rows, tol, flag);
+}
+
 #include "k3_block64.h"
 #include "k3_pair128.h"
 #include <type_traits>

@@ -106,6 +106,7 @@ def lib():
         L.dn_run_cnn.argtypes = [C.c_void_p]
         L.dn_cnn_set_math.argtypes = [C.c_void_p, C.c_int]
         L.dn_cnn_range_escalations.argtypes = [C.c_void_p]; L.dn_cnn_range_escalations.restype = C.c_uint64
+        L.dn_cnn_canaries.argtypes = [C.c_void_p]; L.dn_cnn_canaries.restype = C.c_uint64
         L.dn_load_fit_models.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.dn_run_hmm.argtypes = [C.c_void_p]
         L.dn_get_hmm_calls.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 7
@@ -198,6 +199,10 @@ class Context:
 
     def cnn_range_escalations(self):
         return int(lib().dn_cnn_range_escalations(self.h))
+
+    def cnn_canaries(self):
+        """how many canaries ran (the first sequences of a batch repeated with bf16 pieces and compared on the device)"""
+        return int(lib().dn_cnn_canaries(self.h))
 
     def load_fit_models(self, unl_mean, unl_std, ana_mean, ana_std):
         a = [np.ascontiguousarray(x, np.float64) for x in (unl_mean, unl_std, ana_mean, ana_std)]

@@ -126,10 +126,14 @@ int dn_load_cnn(dn_ctx *ctx, const dn_cnn_op *ops, uint32_t n_ops, const float *
  *           narrow exponent range: a pass in which some activation exceeds 65504 -- or in which a whole layer's activations are
  *           below 2^-6, where the low pieces are subnormal and the split keeps an absolute 2^-25 instead of a relative 2^-22 --
  *           is detected on the device and repeated in BF16X6 automatically, and the context then stays on BF16X6 until the next
- *           dn_load_cnn / dn_cnn_set_math; dn_cnn_range_escalations counts those repeats. */
+ *           dn_load_cnn / dn_cnn_set_math; dn_cnn_range_escalations counts those repeats.
+ *           ABI 7, the canary: the maximum cannot see a layer that is mostly tiny beside a few large values, so the first sequences of every batch
+ *           (>= 4 096 positions) also run with bf16 pieces and the two sets of probabilities are compared on the device; a difference above 1e-4
+ *           (DN_CNN_CANARY_TOL; DN_CNN_CANARY=0: off) repeats the batch in BF16X6 like a range report.  dn_cnn_canaries: how many ran. */
 enum { DN_CNN_MATH_FP32 = 0, DN_CNN_MATH_BF16X6 = 1, DN_CNN_MATH_F16X3 = 2 };
 int dn_cnn_set_math(dn_ctx *ctx, int mode);
 uint64_t dn_cnn_range_escalations(dn_ctx *ctx);
+uint64_t dn_cnn_canaries(dn_ctx *ctx);
 int dn_run_cnn(dn_ctx *ctx);            /* runCNN for every read that passed eventalign */
 int dn_get_probabilities(dn_ctx *ctx, uint32_t read, uint64_t cap /* positions `probs` holds */, float *probs /* [n_positions * 3] */);
 /* the TF_SessionRun seam itself (detect.cpp:653): n_seq sequences given as the three host tensors runCNN builds --

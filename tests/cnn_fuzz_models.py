@@ -15,7 +15,7 @@ import torch
 import cnn_torch_ref
 from dnascent_amd import cnn_model
 
-FAMILIES = ("gaussian", "student_t", "bn_wide", "channel_spread", "large_act", "tiny_act", "cancelling")
+FAMILIES = ("gaussian", "student_t", "bn_wide", "channel_spread", "large_act", "tiny_act", "cancelling", "tiny_with_outliers", "huge_with_tiny")
 
 
 class FuzzSource(cnn_model.RandomSource):
@@ -27,6 +27,14 @@ class FuzzSource(cnn_model.RandomSource):
         self.family = family
         self.log = []
         self.act = {"large_act": 6000.0, "tiny_act": 2.0 ** -16}.get(family, 1.0)     # scale of every BatchNorm output
+        # round 6: layers that are MOSTLY tiny beside a few large channels -- what a guard on a layer's maximum cannot see.  Per CHANNEL: one in 16 at the
+        # large scale, the others at the tiny one (a fixed pattern per channel count, so that the two BatchNorms a residual join adds agree); every convolution
+        # divides its input channels by the same scales, so the tiny channels carry as much of the result as the large ones while their fp16 low pieces are
+        # subnormal (at 2^-16 an absolute 2^-25 is a relative 2^-9)
+        self.mix = {"tiny_with_outliers": (2.0 ** -16, 1.0), "huge_with_tiny": (2.0 ** -12, 6000.0)}.get(family)
+
+    def _mix_scale(self, c):
+        return np.where((np.arange(c) * 7 + 3) % 16 == 0, self.mix[1], self.mix[0])
 
     def _w(self, shape, std):
         if self.family == "student_t":                     # heavy tails: df 2.2 has a variance (11) and kurtosis none; rescaled to the Gaussian's variance
@@ -51,6 +59,8 @@ class FuzzSource(cnn_model.RandomSource):
         elif f == "cancelling":                            # a large common offset under O(1) variation: the next layer's products are ~50x its sums
             beta = 50.0 + self.rng.normal(0, 0.05, c)
         gamma, beta = gamma * self.act, beta * self.act
+        if self.mix:
+            gamma, beta = gamma * self._mix_scale(c), beta * self._mix_scale(c)
         p = dict(gamma=gamma.astype(np.float32), beta=beta.astype(np.float32), mean=np.zeros(c, np.float32), var=np.ones(c, np.float32))
         self.log.append(("bn", p))
         return p
@@ -63,6 +73,8 @@ class FuzzSource(cnn_model.RandomSource):
             w[:, 1::2, :] = -w[:, 0::2, :] + (1e-3 * np.sqrt(2.0 / (k * cin)) * self.rng.normal(0, 1, w[:, 0::2, :].shape)).astype(np.float32)
         if layer >= 4:                                     # every convolution behind a BatchNorm output (scale `act`) brings its own output back to O(1): the
             w = w / np.float32(self.act)                   # large / tiny values live exactly where the 16-bit split happens, at the convolutions' inputs
+            if self.mix:
+                w = w / self._mix_scale(cin).astype(np.float32)[None, :, None]     # per input channel: the tiny channels count as much as the large ones
         b = (self.rng.normal(0, 0.05, cout).astype(np.float32) if bias else np.zeros(cout, np.float32))
         self.log.append(("conv", (w, b)))
         return w, b
