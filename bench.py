@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--cnn-math", choices=["f16x3", "bf16x6", "fp32"], default=None)
     ap.add_argument("--pin", type=int, default=0, help="page-lock the input batches (dn_host_register, before the timed region): uploads become asynchronous")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bf16-steps", type=int, default=3, help="full scope, 1 GPU: after the run, this many steps again with the CNN on bf16 pieces (value_bf16x6: what "
+                                                              "the pipeline delivers after an fp16 range / canary escalation); 0 = off")
     ap.add_argument("--fp32-steps", type=int, default=4, help="full scope, 1 GPU: after the run, this many steps again with the CNN in exact fp32 MFMA "
                                                               "arithmetic (value_fp32: the headline metric without the 16-bit split); 0 = off")
     args = ap.parse_args()
@@ -343,6 +345,9 @@ def main():
         dt = time.perf_counter() - t0
         barrier()
         samples_total = float(st.samples)
+        cnn_guard = {"canaries_run": int(sum(c.cnn_canaries() for c in ctxs)), "escalations": int(sum(c.cnn_range_escalations() for c in ctxs)),
+                     "note": "warm-up + timed steps: per batch its first sequences (>= 4 096 positions) run a second time with bf16 pieces and are compared on the "
+                             "device (1e-4); an escalation repeats the batch with bf16 pieces.  Inside the timed region."}
         last = ctxs[(len(timed) - 1) % nctx]
         last.n_reads = timed[-1].size()
         summ = last.summaries()
@@ -409,20 +414,30 @@ def main():
         summ = c.summaries()
         solo_positions = float(np.sum(summ["n_positions"][summ["status"] == 0]))
 
-    # the same pipeline with the network's products in exact fp32 (v_mfma_f32_32x32x2_f32): a few steps, timed the same way, after the run
-    fp32_leg = None
-    if full and world == 1 and args.fp32_steps > 0 and cnn_math != "fp32":
-        for c in ctxs:
-            c.cnn_set_math("fp32")
-        leg = batches[-min(args.fp32_steps, len(batches)):]
-        host.stream_detect(ctxs, leg[:1], emit=bool(args.emit), out_path=None)          # first fp32 pass: its kernels' code objects load here
-        for c in ctxs:
-            c.sync()
-        t1 = time.perf_counter()
-        st32 = host.stream_detect(ctxs, leg, emit=bool(args.emit), out_path=None)
-        dt32 = time.perf_counter() - t1
-        fp32_leg = {"value_fp32": float(st32.samples) / dt32 / 1e6, "steps": len(leg), "ms_per_step": dt32 / len(leg) * 1e3,
-                    "note": "the same full pipeline with --cnn-math fp32 (exact fp32 MFMA products), %d steps of %d reads after the main run" % (len(leg), rps)}
+    # the same pipeline in the network's two other arithmetics, a few steps each, timed the same way, after the run: bf16x6 (fp32 operands split EXACTLY into three
+    # bf16 pieces, six products: what a range / canary escalation switches a context to) and exact fp32 (v_mfma_f32_32x32x2_f32)
+    fp32_leg = bf16_leg = None
+    if full and world == 1:
+        for mode, steps in (("bf16x6", args.bf16_steps), ("fp32", args.fp32_steps)):
+            if steps <= 0 or cnn_math == mode:
+                continue
+            for c in ctxs:
+                c.cnn_set_math(mode)
+            leg = batches[-min(steps, len(batches)):]
+            host.stream_detect(ctxs, leg[:1], emit=bool(args.emit), out_path=None)          # first pass in this mode: its kernels' code objects load here
+            for c in ctxs:
+                c.sync()
+            t1 = time.perf_counter()
+            stm = host.stream_detect(ctxs, leg, emit=bool(args.emit), out_path=None)
+            dtm = time.perf_counter() - t1
+            res = {"value_" + mode: float(stm.samples) / dtm / 1e6, "steps": len(leg), "ms_per_step": dtm / len(leg) * 1e3,
+                   "note": "the same full pipeline with --cnn-math %s (%s), %d steps of %d reads after the main run" % (
+                       mode, "exact fp32 MFMA products" if mode == "fp32" else "three bf16 pieces per operand, six products: fp32-equivalent, fp32's exponent range -- "
+                       "the arithmetic a context switches to after a range or canary escalation", len(leg), rps)}
+            if mode == "fp32":
+                fp32_leg = res
+            else:
+                bf16_leg = res
         for c in ctxs:
             c.cnn_set_math(cnn_math)
 
@@ -655,6 +670,9 @@ def main():
                     roof_banded["valu_insts_per_launch"] = kf["valu_insts_per_launch"]
             out["roofline_banded"] = roof_banded
             out["roofline_k1"] = roof_k1
+            if bf16_leg:
+                out["value_bf16x6"] = bf16_leg["value_bf16x6"]
+                out["bf16x6_leg"] = bf16_leg
             if fp32_leg:
                 out["value_fp32"] = fp32_leg["value_fp32"]
                 out["fp32_leg"] = fp32_leg
@@ -663,6 +681,7 @@ def main():
                                 "gather_s_max": max(r["gather_s"] for r in rank_stats), "per_rank": rank_stats,
                                 "note": "busy_s: a rank's own stream (first upload to its last records on the host); gather_s: its part of the RCCL gather of the "
                                         "per-call results to rank 0, inside the timed region"}
+            out["cnn_guard"] = cnn_guard
             out["hbm"] = _hbm_info()
             out["host"] = {"datagen_s": t_gen, "upload_s": st.seconds_upload, "enqueue_s": st.seconds_run, "collect_wait_s": st.seconds_collect, "emit_s": st.seconds_emit,
                            "gather_s": gather_s, "overflow_retries": int(st.overflow_retries), "emission": {"records_per_s": st.calls / st.seconds_emit if st.seconds_emit > 0 else None,
