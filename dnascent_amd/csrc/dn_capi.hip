@@ -28,7 +28,7 @@ int k2_selftest_run(hipStream_t);
 void k2_launch_fill(const BatchDev &, const void *, const void *, hipStream_t);
 void k2_launch_chase(const BatchDev &, uint8_t *, hipStream_t);
 void k2_launch_post(const BatchDev &, const uint8_t *, float *, const void *, hipStream_t);
-void k2b_launch(const BatchDev &, const void *, const void *, const void *, unsigned, hipStream_t);
+hipError_t k2b_launch(const BatchDev &, const void *, const void *, const void *, unsigned, hipStream_t);
 struct CnnRows { const unsigned *row_off; const uint8_t *valid; unsigned rows, r0, r1; const unsigned *n_pos; const uint64_t *io_off; };
 struct CnnRun { const dn_cnn_op *ops; int n_ops; const float *wts; float *buf[8]; int n_buf; CnnRows rows; uint8_t *valid;
                  const float *core, *resid, *sig; float *probs; unsigned max_pos; const uint16_t *wts_split; const int64_t *wb_off;
@@ -897,7 +897,7 @@ int dn_run_eventalign(dn_ctx *c) {
         c->ea.al_kind = (unsigned char *)c->al_kind.p; c->ea.al_off = (const unsigned long long *)c->al_off.p; c->ea.al_n = (unsigned *)c->al_n.p;
         c->have_align = true;
     }
-    { Timed t(c, DN_K_VITERBI); k2b_launch(c->B, &c->ea, c->d_vitread, &c->vc, c->max_ref, c->stream); }
+    { Timed t(c, DN_K_VITERBI); HIPCHK(c, k2b_launch(c->B, &c->ea, c->d_vitread, &c->vc, c->max_ref, c->stream)); }
     HIPCHK(c, hipGetLastError());
     c->stage = 6;
     return DN_OK;

@@ -16,6 +16,7 @@
 // (<= 1 ulp) where the reference calls glibc: scores can differ in the last bits (tolerance stated in the tests), the
 // arg-max decisions are compared exactly.
 #include "dn_dev.h"
+#include <atomic>
 
 #define VT_TMAX 512          // observations per window the lattice is sized for at most (a window spans <= 65 positions, ~2.2 events each)
 #define VT_TFAST 224         // ... and in the first pass: a window of the synthetic workloads holds 110-160.  The backtrace block is
@@ -624,22 +625,30 @@ void k2b_emission_tap_launch(const double *x, const double *mu, double *out, uns
     hipLaunchKernelGGL(k2b_emission_tap, dim3((n + 63) / 64), dim3(64), 0, st, x, mu, out, n, *reinterpret_cast<const VitConsts *>(vc));
 }
 
-void k2b_launch(const BatchDev &B, const void *ea, const void *vr, const void *vc, unsigned max_ref, hipStream_t st) {
+// Returns hipSuccess, or the error of the dynamic-LDS opt-in (a launch that needs 88 KB of LDS without it fails opaquely later).
+hipError_t k2b_launch(const BatchDev &B, const void *ea, const void *vr, const void *vc, unsigned max_ref, hipStream_t st) {
     const EaDev O = *reinterpret_cast<const EaDev *>(ea);
     const VitConsts V = *reinterpret_cast<const VitConsts *>(vc);
     hipMemsetAsync(O.redo, 0, (size_t)B.n_reads, st);
     const dim3 gf((B.n_reads + K2B_W - 1) / K2B_W), bf(64 * K2B_W);
     const size_t lf = K2B_WAVES_EU > 0 ? sizeof(K2bLds<VT_TFAST>) * K2B_W : 0, lm = K2B_WAVES_EU > 0 ? sizeof(K2bLds<VT_TMAX>) : 0;     // dynamic LDS of the budgeted build
     if (K2B_WAVES_EU > 0) {
-        static const bool once = [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k2b_eventalign<VT_TFAST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(K2bLds<VT_TFAST>) * K2B_W));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k2b_eventalign<VT_TMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K2bLds<VT_TMAX>));
-            return true; }();
-        (void)once;
+        // the opt-in is a property of the function ON A DEVICE: one process may hold contexts on several (dn_ctx_create(device = k)), so it is made once per
+        // device, under the device the caller's context made current (round-5 advisor: a process-wide flag covered only the first device, return codes were dropped)
+        static std::atomic<unsigned char> done[64];
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= 64 || !done[dev].load(std::memory_order_acquire)) {
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k2b_eventalign<VT_TFAST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(K2bLds<VT_TFAST>) * K2B_W))) != hipSuccess) return e;
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k2b_eventalign<VT_TMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K2bLds<VT_TMAX>))) != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) done[dev].store(1, std::memory_order_release);
+        }
     }
     hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, gf, bf, lf, st, B, O, (const VitRead *)vr, V, 0);
     hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), lm, st, B, O, (const VitRead *)vr, V, 1);
     hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, gf, bf, lf, st, B, O, (const VitRead *)vr, V, 2);
     hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), lm, st, B, O, (const VitRead *)vr, V, 3);
     hipLaunchKernelGGL(k2b_features, dim3((max_ref + 255) / 256, B.n_reads), dim3(256), 0, st, B, O);
+    return hipSuccess;
 }

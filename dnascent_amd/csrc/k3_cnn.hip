@@ -1688,19 +1688,24 @@ static int k3_block64_span(const CnnRun &c, int i) {
     }
     const dn_cnn_op &sc = c.ops[i + 12];
     if (sc.op != DN_CNN_CONV_ADD || sc.k != 5 || sc.cin != 64 || sc.cout != 64 || sc.src != bX || sc.a != prev || sc.dst == bX) return 0;
-    if (mode == 1) return 12;
-    for (int j = 0; j < 12; j++) {                         // every buffer the layer-by-layer path would have written on the way
+    // Liveness of what the layer-by-layer path would have written on the way.  The 12-op launch materialises ONLY the chain's result (`prev`, the last pointwise
+    // output), the 13-op launch only the shortcut's destination: an intermediate buffer that a later op reads before it is overwritten rules the fused form
+    // out altogether (0: layer by layer), and the chain's result being read later keeps the shortcut its own launch (12).  (Round-5 advisor: the check used to
+    // answer 12 for ANY live buffer and was skipped in mode 1 -- a description with distinct buffers per layer would have read stale data.)
+    bool prev_live = false;
+    for (int j = 0; j < 12; j++) {
         const int b = c.ops[i + j].dst;
         if (b == sc.dst) continue;
         for (int q = i + 13; q < c.n_ops; q++) {
             const dn_cnn_op &o = c.ops[q];
             const bool reads = (o.op != DN_CNN_ENCODE_GRU && o.src == b) || ((o.op == DN_CNN_ADD_RELU || o.op == DN_CNN_CONV_ADD) && o.a == b) ||
                                (o.op == DN_CNN_ADD_RELU && o.b == b);
-            if (reads) return 12;                          // still needed later: keep the shortcut (and with it the chain's result) materialised
+            if (reads) { if (b != prev) return 0; prev_live = true; break; }
             if (o.dst == b) break;
         }
     }
-    return 13;
+    // (`prev` is also written by earlier layers of a ping-pong chain; what a later reader sees is the chain's result, which the 12-op launch does write)
+    return (mode == 1 || prev_live) ? 12 : 13;
 }
 static void k3_launch_block64(const CnnRun &c, int i, int span, const float *x, float *y, hipStream_t st) {
     B64Args a{};

@@ -21,7 +21,7 @@ for _i, _n in enumerate(K_NAMES):
 # every symbol include/dnascent_hip.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = ["dn_abi_version", "dn_device_count", "dn_ctx_create", "dn_ctx_destroy", "dn_last_error", "dn_sync",
            "dn_load_pore_model", "dn_batch_upload", "dn_host_alloc", "dn_host_free", "dn_host_register", "dn_host_unregister", "dn_run_detect", "dn_collect", "dn_batch_workspace_bytes", "dn_ctx_reserve", "dn_cnn_reserve", "dn_ctx_set_event_bound", "dn_ctx_get_event_bound", "dn_debug_emission", "dn_debug_keep_k1", "dn_debug_seg_warm", "dn_run_segment", "dn_run_rough_scaling", "dn_run_banded",
-           "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_set_align_table", "dn_get_align_rows", "dn_get_align_table", "dn_load_cnn", "dn_cnn_set_math", "dn_cnn_range_escalations", "dn_run_cnn", "dn_get_probabilities", "dn_cnn_infer", "dn_load_fit_models", "dn_run_hmm", "dn_get_hmm_calls", "dn_get_summaries", "dn_get_prefix_sums",
+           "dn_run_theilsen", "dn_run_normalise", "dn_run_eventalign", "dn_set_align_table", "dn_get_align_rows", "dn_get_align_table", "dn_load_cnn", "dn_cnn_set_math", "dn_cnn_range_escalations", "dn_cnn_canaries", "dn_run_cnn", "dn_get_probabilities", "dn_cnn_infer", "dn_load_fit_models", "dn_run_hmm", "dn_get_hmm_calls", "dn_get_summaries", "dn_get_prefix_sums",
            "dn_get_tstats", "dn_get_scrappie_events", "dn_get_events", "dn_get_kmer_ranks", "dn_get_alignment",
            "dn_get_cleaned", "dn_get_trace", "dn_get_positions", "dn_get_windows", "dn_profile_enable", "dn_profile_get",
            "dn_profile_reset", "dn_profile_get_layer", "dn_kernel_name", "dn_device_bytes", "dn_shutdown"]

@@ -181,7 +181,8 @@ def main(argv=None):
         store = _get_default_store()
         ready_key = "dn_run_detect/file_ready/%d" % int(store.add("dn_run_detect/runs/r%d" % rank, 1))
         if rank == 0:
-            store.set(ready_key, "1")
+            fst = os.fstat(out_f.fileno())
+            store.set(ready_key, "%d:%d" % (fst.st_dev, fst.st_ino))       # which file it is: the other ranks must see the SAME one (below)
         else:
             t_w = time.time()
             while not store.check([ready_key]):                # polled: TCPStore.wait() would hold this client's lock for the whole wait
@@ -192,7 +193,20 @@ def main(argv=None):
         if warm is not None and a.central_writer:
             warm.join()                                        # that form's gather thread issues point-to-point operations during the stream
     if rank != 0 and not a.central_writer:
-        out_f = open(a.out, "r+b")                             # every rank writes its own records in place: same file, own descriptor
+        # every rank writes its own records in place: same file, own descriptor.  That needs ONE file system under all ranks (one node, or a shared mount): a
+        # rank that cannot open the path -- or opens a different file of the same name -- says so now instead of dying later or writing where nobody looks
+        # (round-5 advisor).  st_dev is compared only between ranks of one host (device numbers of a network mount differ from host to host).
+        try:
+            out_f = open(a.out, "r+b")
+        except OSError as e:
+            raise SystemExit("run_detect: rank %d cannot open %s (%s): without a writer rank every rank writes into the output file itself -- put --out on a file "
+                             "system all ranks share, or use --central-writer" % (rank, a.out, e))
+        want = store.get(ready_key).decode().split(":")
+        fst = os.fstat(out_f.fileno())
+        same_host = os.environ.get("LOCAL_WORLD_SIZE", str(world)) == str(world)
+        if str(fst.st_ino) != want[1] or (same_host and str(fst.st_dev) != want[0]):
+            raise SystemExit("run_detect: rank %d sees a different file at %s than rank 0 (inode %s vs %s): use a shared file system or --central-writer" % (
+                rank, a.out, fst.st_ino, want[1]))
 
     def write(text, ordinals, record_bytes):                   # --central-writer: on the writer's gather thread, the group's text by several threads at once
         t_w = time.time()
@@ -308,6 +322,8 @@ def main(argv=None):
                                              upload_s=round(st.seconds_upload, 3), enqueue_s=round(st.seconds_run, 3), collect_wait_s=round(st.seconds_collect, 3), load_wait_s=round(drv.load_wait_s, 3), load_s=round(drv.load_s, 3), driver_submit_s=round(drv.t_submit, 3), driver_collect_s=round(drv.t_collect, 3), driver_engine_collect_s=round(drv.t_engine_collect, 3), driver_hand_over_s=round(drv.t_hand_over, 3),
                                              pack_s=round(st.seconds_emit, 3)), device=dev_t)
     failed = tot[3] > 0
+    # the file's record text: without a writer rank drv.text_bytes is what THIS rank formatted, while every rank keeps the same running file position
+    text_bytes_all = int(drv.text_bytes) if a.central_writer else int(drv.file_pos) - len(head)
     if out_f is not None:
         out_f.close()
     if rank == 0:
@@ -318,7 +334,7 @@ def main(argv=None):
         else:
             busy = [p["busy_s"] for p in per_rank]
             print("run_detect: %d reads ok, %d failed, %.1f M samples, %d rank(s), %d batches in %d window(s), %.2f s (%.1f Msamples/s incl. "
-                  "indexing, context set-up and ingestion; the stream itself -- first batch loaded to last record written -- %.2f s = %.1f Msamples/s); per-rank busy %.2f .. %.2f s, gather %.2f s max, formatting %.2f s (rank 0), at most %.1f MB of packed results "
+                  "indexing, context set-up and ingestion; the stream itself -- first batch loaded to last record written -- %.2f s = %.1f Msamples/s); per-rank busy %.2f .. %.2f s, gather %.2f s max, formatting %.2f s (rank 0's share), at most %.1f MB of packed results "
                   "buffered on a rank" %
                   (tot[0], tot[1], tot[2] / 1e6, world, len(batches), drv.n_windows, dt, tot[2] / 1e6 / dt, t_stream, tot[2] / 1e6 / t_stream, min(busy), max(busy),
                    max(p["gather_s"] for p in per_rank), drv.format_s, max(p["peak_buffered_bytes"] for p in per_rank) / 1e6))
@@ -327,7 +343,7 @@ def main(argv=None):
             json.dump(dict(world=world, batches=len(batches), windows=drv.n_windows, seconds=dt, samples=tot[2], Msamples_per_s=tot[2] / 1e6 / dt,
                            imports_s=round(t0 - t_proc, 3), contexts_s=round(t_ctx, 3), event_bound=a.event_bound, overflow_retries=int(st.overflow_retries),
                            hbm=hbm_info,
-                           reads_ok=tot[0], reads_failed=tot[1], text_bytes=int(drv.text_bytes), index_s=round(t_index, 3), inflight=len(ctxs),
+                           reads_ok=tot[0], reads_failed=tot[1], text_bytes=int(text_bytes_all), index_s=round(t_index, 3), inflight=len(ctxs),
                            setup_s=round(t_setup, 3), stream_s=round(t_stream, 3), Msamples_per_s_stream=tot[2] / 1e6 / t_stream,
                            recv_groups=drv.stats.get("recv_groups", []), ranks=per_rank, failed=failed), stats_f)
     t_close = time.time()
@@ -348,7 +364,12 @@ if __name__ == "__main__":
     # Everything this process owes anyone is on disk and closed by now (the output, --stats), the contexts are released.  What is left between here and the
     # shell's prompt is the interpreter's and the HIP runtime's own tear-down (module unloading, code objects, the allocator's pools) -- seconds of it measured
     # from outside (tools/time_run_detect.py: process wall against the in-process account) -- which the kernel does for an exiting process anyway.
+    # NOT when somebody else has work to do at exit (round-5 advisor): a profiler's preloaded tool library (rocprofv3: ROCP_TOOL_LIBRARIES / LD_PRELOAD), coverage,
+    # torchrun's elastic agent expecting finalisers -- they write their results from atexit handlers / destructors, which os._exit skips.
     sys.stdout.flush(); sys.stderr.flush()
-    if os.environ.get("DN_RUN_DETECT_SLOW_EXIT", "0") == "1":
+    tool_attached = any(os.environ.get(k) for k in ("ROCP_TOOL_LIBRARIES", "LD_PRELOAD", "ROCPROFILER_REGISTER_FORCE_LOAD", "COVERAGE_PROCESS_START", "COV_CORE_SOURCE",
+                                                    "TORCHELASTIC_RUN_ID"))
+    slow = os.environ.get("DN_RUN_DETECT_SLOW_EXIT")
+    if slow == "1" or (slow is None and tool_attached):
         sys.exit(rc)
     os._exit(rc)

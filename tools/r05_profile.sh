@@ -8,8 +8,9 @@
 #   (4) configs[1] (banded scope) bench, and the same three counter passes for it
 #   (5) K3 alone on 64 x 20 kb reads (1.2 M positions): per-layer table from the kernel trace, math modes
 # The program goes straight after `--` (python3 bench.py ...): no env / sh -c hop under rocprofv3.
-OUT=gpurun_out/r05; rm -rf $OUT; mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+cd "${GRAFT_REPO_ROOT:?run under gpurun (it exports GRAFT_REPO_ROOT)}" || exit 1
+export TMPDIR=/tmp
+OUT="$GRAFT_REPO_ROOT/gpurun_out/r05"; rm -rf "$OUT"; mkdir -p "$OUT"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.log 2>&1; tail -1 $OUT/bench_default.log > $OUT/bench_default.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --no-cpu-baseline --fp32-steps 0 --steps 20 --warmup 5 > $OUT/bench_under_rocprof.log 2>&1
 grep '^{"metric' $OUT/bench_under_rocprof.log | tail -1 > $OUT/bench_under_rocprof.json
