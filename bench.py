@@ -228,6 +228,11 @@ def main():
         if os.environ.get("OMP_NUM_THREADS", "1") == "1":
             from dnascent_amd import host as _h
             os.environ["OMP_NUM_THREADS"] = str(max(1, _h.usable_cpus() // world))
+        if "DN_HOST_THREADS" not in os.environ:
+            # said explicitly, as run_detect does (a share of ONE would otherwise fall through to "all cores" in dn_host.cpp hostThreads); at least two: the
+            # formatter at two threads holds 2 x one GPU's record rate (tests/test_format_budget.py)
+            from dnascent_amd import host as _h
+            os.environ["DN_HOST_THREADS"] = str(max(2, min(64, _h.usable_cpus() // int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -445,7 +450,8 @@ def main():
     rank_stats = None
     if dist is not None:
         busy_local = float(st.seconds_total) if st is not None else dt
-        rank_stats = shard.gather_stats(dist, dict(rank=rank, busy_s=busy_local, gather_s=gather_s, elapsed_s=dt, datagen_s=t_gen, distinct_batches=n_distinct),
+        rank_stats = shard.gather_stats(dist, dict(rank=rank, busy_s=busy_local, gather_s=gather_s, elapsed_s=dt, datagen_s=t_gen, distinct_batches=n_distinct,
+                                                   format_threads=host.host_threads(), emit_s=float(st.seconds_emit) if st is not None else None),
                                         device=red_dev)
         dt = shard.reduce_max(dist, dt, device=red_dev)
         samples_total = shard.reduce_counters(dist, [samples_total], device=red_dev)[0]

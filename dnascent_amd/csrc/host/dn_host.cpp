@@ -1,5 +1,7 @@
 // dn_host.cpp -- host side above the C-ABI: read model, CIGAR flattening, batch packing, stage drivers.
 #include "dn_host.h"
+#include <emmintrin.h>
+#include <mutex>
 #include "dn_synth.h"
 
 #include <math.h>
@@ -358,20 +360,28 @@ void ReadContainerReader::close() { if (f) fclose((FILE *)f); f = nullptr; }
 // 10^6 = 2^6 * 15625 with 15625 < 2^14, so p * 1e6 is EXACT in double (<= 38 bits) and rint() -- nearest, ties to even on an
 // exact value -- is the integer glibc prints.  Anything outside [0, 1] (or NaN) takes snprintf.  tests/test_output.py compares
 // both on every float around the rounding boundaries.
+// Round 6: two digits per table lookup and the rounding as ONE cvtsd2si (MXCSR's default mode is nearest, ties to even -- what rint() computes through a
+// libm call on baseline x86-64): at N ranks per host a rank formats on its share of the cores (2 of 16 at N = 8), where the formatter's 86 ns per line were
+// barely faster than one GPU produces lines (tests/test_format_budget.py).
+static const char DIGIT_PAIRS[201] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
 static inline char *put_prob(char *o, float pf) {
     const double p = (double)pf;
     if (!(p >= 0.0 && p <= 1.0) || signbit(p)) return o + snprintf(o, 48, "%f", p);
-    unsigned n = (unsigned)rint(p * 1e6);
+    const unsigned n = (unsigned)_mm_cvtsd_si32(_mm_set_sd(p * 1e6));
     if (n >= 1000000u) { memcpy(o, "1.000000", 8); return o + 8; }
+    const unsigned a = n / 10000u, r = n - a * 10000u, b = r / 100u, c = r - b * 100u;
     o[0] = '0'; o[1] = '.';
-    for (int i = 7; i >= 2; i--) { o[i] = (char)('0' + n % 10u); n /= 10u; }
+    memcpy(o + 2, DIGIT_PAIRS + 2 * a, 2); memcpy(o + 4, DIGIT_PAIRS + 2 * b, 2); memcpy(o + 6, DIGIT_PAIRS + 2 * c, 2);
     return o + 8;
 }
+static inline size_t u32_len(uint32_t v);
 static inline char *put_u32(char *o, uint32_t v) {
-    char t[10]; int k = 0;
-    do { t[k++] = (char)('0' + v % 10u); v /= 10u; } while (v);
-    while (k) *o++ = t[--k];
-    return o;
+    const size_t len = u32_len(v);
+    char *e = o + len;
+    while (v >= 100u) { const uint32_t q = v / 100u; e -= 2; memcpy(e, DIGIT_PAIRS + 2 * (v - q * 100u), 2); v = q; }
+    if (v >= 10u) memcpy(e - 2, DIGIT_PAIRS + 2 * v, 2); else e[-1] = (char)('0' + v);
+    return o + len;
 }
 
 char *formatProbForTest(char *o, float p) { return put_prob(o, p); }
@@ -501,6 +511,10 @@ void packedSizes(size_t n, const uint64_t *meta3, const uint8_t *const *read_ptr
         record_bytes[r] = len;
     }
 }
+static const struct Km3Table {
+    char t[512][4];
+    Km3Table() { for (unsigned v = 0; v < 512; v++) { for (int z = 0; z < 3; z++) t[v][z] = "ACGTN???"[(v >> (3 * z)) & 7u]; t[v][3] = 0; } }
+} KM3;
 bool formatPacked(size_t n, const uint64_t *meta3 /* [n][3]: count, header bytes, flags */, const uint8_t *const *read_ptr, RawVec<char> &text,
                   uint64_t *record_bytes /* [n] */) {
     std::vector<uint64_t> off(n + 1, 0);
@@ -521,8 +535,8 @@ bool formatPacked(size_t n, const uint64_t *meta3 /* [n][3]: count, header bytes
             const uint64_t i = rev ? cnt - 1 - q : q;
             uint32_t w[4]; float e, b;
             memcpy(w, p + 16 * i, 16); memcpy(&e, &w[1], 4); memcpy(&b, &w[2], 4);
-            char km[9];
-            for (int z = 0; z < 9; z++) km[z] = "ACGTN???"[(w[3] >> (3 * z)) & 7u];
+            char km[12];                                     // three bases per lookup (512 x 4 bytes, built once)
+            memcpy(km, KM3.t[w[3] & 511u], 4); memcpy(km + 3, KM3.t[(w[3] >> 9) & 511u], 4); memcpy(km + 6, KM3.t[(w[3] >> 18) & 511u], 4);
             o = put_call(o, w[0], e, b, km, rev);
         }
         if ((uint64_t)(o - text.data()) != off[(size_t)r + 1]) bad = 1;
@@ -1041,8 +1055,17 @@ uint64_t dnh_pack_calls(void *batch, const dn_result_batch *res, void *result) {
     return R.packed_meta.size() / 4;
 }
 // the writer rank's formatter: n reads in output order, read_ptr[i] = address of read i's payload; returns a text handle
+// The formatter's text buffers are recycled (two at most): a window's 200-400 MB fresh from malloc are fresh from mmap, i.e. ~50-100 k page faults with the
+// kernel zeroing every page -- a fifth of the formatter's time at two threads (round 6).  dnh_text_free hands a buffer back; its capacity stays.
+static std::mutex text_pool_mu;
+static std::vector<DNAscent::RawVec<char> *> text_pool;
 void *dnh_format_packed(uint64_t n, const uint64_t *meta3, const uint64_t *read_ptr, uint64_t *record_bytes) {
-    DNAscent::RawVec<char> *t = new DNAscent::RawVec<char>();
+    DNAscent::RawVec<char> *t = nullptr;
+    {
+        std::lock_guard<std::mutex> g(text_pool_mu);
+        if (!text_pool.empty()) { t = text_pool.back(); text_pool.pop_back(); }
+    }
+    if (!t) t = new DNAscent::RawVec<char>();
     static_assert(sizeof(uint64_t) == sizeof(const uint8_t *), "64-bit host");
     if (!DNAscent::formatPacked((size_t)n, meta3, (const uint8_t *const *)read_ptr, *t, record_bytes)) { delete t; return nullptr; }
     return t;
@@ -1099,7 +1122,15 @@ int dnh_pwrite_scatter(int fd, const void *buf, uint64_t n, const uint64_t *src_
 }
 const char *dnh_text_data(void *t) { return ((DNAscent::RawVec<char> *)t)->data(); }
 uint64_t dnh_text_size(void *t) { return ((DNAscent::RawVec<char> *)t)->size(); }
-void dnh_text_free(void *t) { delete (DNAscent::RawVec<char> *)t; }
+void dnh_text_free(void *t) {
+    DNAscent::RawVec<char> *v = (DNAscent::RawVec<char> *)t;
+    if (!v) return;
+    {
+        std::lock_guard<std::mutex> g(text_pool_mu);
+        if (text_pool.size() < 2) { v->clear(); text_pool.push_back(v); return; }
+    }
+    delete v;
+}
 void dnh_stream_stats(void *s, DNAscent::StreamStats *st) { *st = ((DNAscent::DetectStream *)s)->stats(); }
 int dnh_host_threads(void) { return DNAscent::hostThreads(); }                    // what the parallel loops of this library use (cgroup quota applied)
 int dnh_batch_pin(void *b) { return ((ReadBatch *)b)->pin(); }
