@@ -387,11 +387,11 @@ static inline char *put_u32(char *o, uint32_t v) {
 char *formatProbForTest(char *o, float p) { return put_prob(o, p); }
 
 // one line of a record: "coord\tEdU\tBrdU\tkmer\n" (detect.cpp:716-721); km = the strand 9-mer, printed reverse-complemented for reverse reads (:699)
-static inline char *put_call(char *o, uint32_t coord, float pEdU, float pBrdU, const char *km, bool isReverse) {
+static inline char *put_call(char *o, uint32_t coord, float pEdU, float pBrdU, const char *km, bool isReverse, bool oriented = false) {
     o = put_u32(o, coord); *o++ = '\t';
     o = put_prob(o, pEdU); *o++ = '\t';
     o = put_prob(o, pBrdU); *o++ = '\t';
-    if (isReverse) {                                         // reverseComplement of the 9-mer (:699): A/C/G/T only reach here (T-centred, ACGT windows)
+    if (isReverse && !oriented) {                                         // reverseComplement of the 9-mer (:699): A/C/G/T only reach here (T-centred, ACGT windows)
         for (int z = 0; z < 9; z++) {
             const char c = km[8 - z];
             o[z] = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'G' ? 'C' : c == 'C' ? 'G' : c;
@@ -512,8 +512,17 @@ void packedSizes(size_t n, const uint64_t *meta3, const uint8_t *const *read_ptr
     }
 }
 static const struct Km3Table {
-    char t[512][4];
-    Km3Table() { for (unsigned v = 0; v < 512; v++) { for (int z = 0; z < 3; z++) t[v][z] = "ACGTN???"[(v >> (3 * z)) & 7u]; t[v][3] = 0; } }
+    char t[512][4], rc[512][4];                             // three bases as packed; the same three reversed and complemented (detect.cpp:699 for reverse reads)
+    Km3Table() {
+        for (unsigned v = 0; v < 512; v++) {
+            for (int z = 0; z < 3; z++) {
+                const char c = "ACGTN???"[(v >> (3 * z)) & 7u];
+                t[v][z] = c;
+                rc[v][2 - z] = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'G' ? 'C' : c == 'C' ? 'G' : c;
+            }
+            t[v][3] = rc[v][3] = 0;
+        }
+    }
 } KM3;
 bool formatPacked(size_t n, const uint64_t *meta3 /* [n][3]: count, header bytes, flags */, const uint8_t *const *read_ptr, RawVec<char> &text,
                   uint64_t *record_bytes /* [n] */) {
@@ -535,9 +544,10 @@ bool formatPacked(size_t n, const uint64_t *meta3 /* [n][3]: count, header bytes
             const uint64_t i = rev ? cnt - 1 - q : q;
             uint32_t w[4]; float e, b;
             memcpy(w, p + 16 * i, 16); memcpy(&e, &w[1], 4); memcpy(&b, &w[2], 4);
-            char km[12];                                     // three bases per lookup (512 x 4 bytes, built once)
-            memcpy(km, KM3.t[w[3] & 511u], 4); memcpy(km + 3, KM3.t[(w[3] >> 9) & 511u], 4); memcpy(km + 6, KM3.t[(w[3] >> 18) & 511u], 4);
-            o = put_call(o, w[0], e, b, km, rev);
+            char km[12];                                     // three bases per lookup (512 x 4 bytes, built once), already in the orientation the line prints
+            if (rev) { memcpy(km, KM3.rc[(w[3] >> 18) & 511u], 4); memcpy(km + 3, KM3.rc[(w[3] >> 9) & 511u], 4); memcpy(km + 6, KM3.rc[w[3] & 511u], 4); }
+            else { memcpy(km, KM3.t[w[3] & 511u], 4); memcpy(km + 3, KM3.t[(w[3] >> 9) & 511u], 4); memcpy(km + 6, KM3.t[(w[3] >> 18) & 511u], 4); }
+            o = put_call(o, w[0], e, b, km, rev, true);
         }
         if ((uint64_t)(o - text.data()) != off[(size_t)r + 1]) bad = 1;
     }
