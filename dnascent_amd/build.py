@@ -16,7 +16,7 @@ HIP_SO = os.path.join(LIB, "libdnascent_hip.so")
 HOST_SO = os.path.join(LIB, "libdnascent_host.so")
 
 HIP_SOURCES = ["dn_capi.hip", "k1_segment.hip", "k2_banded.hip", "k_scaling.hip", "k2b_viterbi.hip", "k3_cnn.hip", "k_hmm.hip", "k_collect.hip"]
-HOST_SOURCES = ["host/dn_synth.c", "host/dn_host.cpp", "host/dn_bam.cpp"]       # dn_bam.cpp: BGZF / BAM over zlib (libz is in the image; htslib is not)
+HOST_SOURCES = ["host/dn_synth.c", "host/dn_host.cpp", "host/dn_bam.cpp", "host/dn_vbz.cpp"]       # dn_bam.cpp: BGZF / BAM over zlib (libz is in the image; htslib is not); dn_vbz.cpp: POD5's signal codec (zstd through dlopen)
 
 
 def _newer(target, deps):

@@ -446,6 +446,39 @@ class _TextOwner:
             pass
 
 
+def vbz_available():
+    """is libzstd.so.1 loadable (POD5's VBZ signal compression = svb16 + zstd)?"""
+    return bool(lib().dnh_vbz_available())
+
+
+def vbz_decode(chunk, n_samples):
+    """one VBZ chunk (a cell of a POD5 signal table's `signal` column) -> int16 samples (csrc/host/dn_vbz.cpp; pod5.cpp:57 receives them from libpod5)"""
+    src = np.frombuffer(bytes(chunk), np.uint8)
+    out = np.zeros(int(n_samples), np.int16)
+    L = lib()
+    L.dnh_vbz_decode.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.dnh_vbz_last_error.restype = C.c_char_p
+    rc = L.dnh_vbz_decode(src.ctypes.data, src.shape[0], int(n_samples), out.ctypes.data)
+    if rc != 0:
+        raise ValueError("vbz_decode (%d): %s" % (rc, L.dnh_vbz_last_error().decode()))
+    return out
+
+
+def vbz_encode(samples, level=1):
+    """int16 samples -> one VBZ chunk (bytes)"""
+    a = np.ascontiguousarray(samples, np.int16)
+    L = lib()
+    L.dnh_vbz_bound.restype = C.c_uint64; L.dnh_vbz_bound.argtypes = [C.c_uint64]
+    L.dnh_vbz_encode.restype = C.c_uint64; L.dnh_vbz_encode.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int]
+    L.dnh_vbz_last_error.restype = C.c_char_p
+    cap = int(L.dnh_vbz_bound(a.shape[0]))
+    dst = np.zeros(max(cap, 64), np.uint8)
+    n = int(L.dnh_vbz_encode(a.ctypes.data, a.shape[0], dst.ctypes.data, dst.shape[0], int(level)))
+    if n == 0:
+        raise ValueError("vbz_encode: %s" % L.dnh_vbz_last_error().decode())
+    return dst[:n].tobytes()
+
+
 def host_threads():
     """threads of the library's parallel loops: min(64, cores, the cgroup CPU quota), or DN_HOST_THREADS"""
     return int(lib().dnh_host_threads())
