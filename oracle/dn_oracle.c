@@ -750,6 +750,71 @@ done:
     return rc;
 }
 
+/* TEST / ANALYSIS ONLY (tools/k2b_resync_sim.py): the window chain of eventalign (alignment.cpp:556-740) started at an ARBITRARY state (ri0, readHead0), walked for at most
+ * max_w windows that reach the Viterbi; records every such window's state at the moment its events are gathered: the reference index and readHead AFTER the scan's
+ * reset-on-first-hit (:616-618) -- two chains that agree on that pair at one window agree on everything after it.  Returns the number of windows recorded.
+ * seq_only: no Viterbi -- every window's last match is assumed at its last position (ri += N), readHead left to the scan: what the sequence alone predicts. */
+size_t dno_eventalign_chain(const dno_model *m, const dno_read *r, const dno_norm *nm, unsigned int ri0, int readHead0, size_t max_w, uint32_t *out_ri, int32_t *out_rh, int seq_only) {
+    const unsigned k = DNO_K, totalW = 50;
+    const size_t n_ref = r->n_ref;
+    size_t tcap = 4096, nw = 0;
+    double *tmeans = (double *)malloc(tcap * 8);
+    uint8_t *lst = NULL; uint32_t *lpos = NULL; size_t lcap = 0;
+    int readHead = readHead0;
+    unsigned int ri = ri0;
+    while (ri < n_ref - k + 1 && nw < max_w) {
+        unsigned int toEnd = (unsigned int)(n_ref - ri);
+        unsigned int W = toEnd < totalW ? toEnd : totalW;
+        if ((double)toEnd > 1.5 * totalW) {
+            const char *snip = r->refseq + ri;
+            size_t sl = (size_t)(1.5 * W);
+            if (!ref_defined(snip, sl)) { ri += W; continue; }
+            const double lim = 1.5 * W - k - 1;
+            for (unsigned int i = W; (double)i < lim; i++) {
+                double mu = m->mean[dno_kmer2index(snip + i, k)], mb = m->mean[dno_kmer2index(snip + i - 1, k)], mf = m->mean[dno_kmer2index(snip + i + 1, k)];
+                if (fabs(mu - mf) > 0.75 && fabs(mu - mb) > 0.75) { W = i + k; break; }
+            }
+        }
+        const char *seq = r->refseq + ri;
+        if (!ref_defined(seq, W)) { ri += W; continue; }
+        const uint32_t qlo = r->ref2query[ri], qhi = r->ref2query[ri + W - k + 1];
+        size_t nt = 0; int first = 1;
+        for (unsigned int j = (unsigned int)readHead; j < nm->n_aln; j++) {
+            uint32_t q = nm->aln_kmer[j];
+            if (qlo <= q && q < qhi) {
+                if (first) { readHead = (int)j; first = 0; }
+                double em = nm->events[nm->aln_event[j]].mean;
+                if (0. < em && em < 250.) {
+                    if (nt == tcap) { tcap *= 2; tmeans = (double *)realloc(tmeans, tcap * 8); }
+                    tmeans[nt++] = em;
+                }
+            }
+            if (q >= qhi) break;
+        }
+        if (nt < 2) { ri += W; continue; }
+        const size_t N = W - k + 1;
+        if (seq_only) {                                                  /* the chain the SEQUENCE alone predicts: every window's last match at its last position */
+            out_ri[nw] = ri; out_rh[nw] = readHead; nw++;
+            ri += (unsigned int)N;
+            continue;
+        }
+        if (nt + N + 2 > lcap) { lcap = 2 * (nt + N + 2); lst = (uint8_t *)realloc(lst, lcap); lpos = (uint32_t *)realloc(lpos, lcap * 4); }
+        double vs; int verr = 0;
+        size_t nl = dno_viterbi(m, tmeans, nt, seq, W, nm->shift, nm->scale, nm->events_per_base, &vs, lst, lpos, &verr);
+        if (verr) break;
+        out_ri[nw] = ri; out_rh[nw] = readHead; nw++;
+        size_t lastM_ev = 0, lastM_ref = 0, evIdx = 0;
+        for (size_t i = 0; i < nl; i++) {
+            if (lst[i] == 1) { lastM_ev = evIdx; lastM_ref = lpos[i]; }
+            if (lst[i] != 0) evIdx++;
+        }
+        readHead += (int)lastM_ev + 1;
+        ri += (unsigned int)lastM_ref + 1;
+    }
+    free(tmeans); free(lst); free(lpos);
+    return nw;
+}
+
 void dno_align_free(dno_align *a) {
     free(a->coord); free(a->query_idx); free(a->ref_idx); free(a->indel_score); free(a->kmer); free(a->n_signal);
     free(a->signal); free(a->core); free(a->residual); free(a->win_ref); free(a->win_len); free(a->win_T); free(a->win_score);
