@@ -129,7 +129,7 @@ def load_pmc(reads_per_step, bases, what, inflight=None):
     bytes per launch and per step, vector instructions of k2_fill, MFMA busy cycles.  Only used when they were taken at THIS workload's shape;
     the number of batches in flight during the counter pass is part of the shape for the chip-level figures (round-3 advisor): the caller
     gets it back as d["workload"]["inflight"] and labels `roofline_chip` with it."""
-    for rnd in ("r05", "r04", "r03"):
+    for rnd in ("r06", "r05", "r04", "r03"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, "banded" if what == "banded" else "bench"))
         if not os.path.exists(path):
             continue
