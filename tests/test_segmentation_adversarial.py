@@ -95,7 +95,7 @@ def _check_read(ctx, s, i, gs, gm, n_samples, taps, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("warm", [192, 0])
+@pytest.mark.parametrize("warm", [192, 64, 5, 0])
 def test_hip_segmentation_matches_reference_on_hostile_signals(model, warm):
     """Every hostile signal in ONE ragged batch (16 samples .. 585 k), between two ordinary reads: scrappie table through the tap and the DNAscent
     events the product path keeps == the reference's, bit for bit.  warm = 192 (the product's): the redo path runs where the speculation
@@ -128,11 +128,13 @@ def test_hip_segmentation_matches_reference_on_hostile_signals(model, warm):
         _check_read(ctx, s, len(reads) - 1, *ends[1], taps, "last ordinary read")
         ctx.close()
     print("detector_rechecks at warm-up %d: %s" % (warm, ", ".join("%s %d" % kv for kv in sorted(rechecks.items()) if kv[1])))
-    if warm == 192:
+    if warm in (64, 5):
+        assert sum(rechecks.values()) > 0                  # intermediate warm-ups: results identical (checked above), the redo runs on some chunks
+    elif warm == 192:
         # tools/seg_speculation_sim.py (the CPU model of the speculation) predicts 4 and 1; any miss at all is what the test is for
         assert rechecks["stall_noisy_then_flat"] > 0 and rechecks["bare_ramp"] > 0
         assert rechecks["read50kb_with_stalls"] == 0 and rechecks["spikes"] == 0
-    else:
+    elif warm == 0:
         for nm in names:
             nch = (sigs[nm].shape[0] + 1023) // 1024
             assert rechecks[nm] >= (nch - 1) // 2, (nm, rechecks[nm], nch)       # the CPU model: all but a handful of the nch - 1 hand-offs
@@ -225,3 +227,53 @@ def test_dense_event_read_overflows_the_drivers_bound_and_is_retried(model):
     assert st_g == st_w and np_g == np_w and got == want
     assert st_w[0] == 0 and st_w[2] == 0 and want.count(b">") >= 2
     print("dense read: %d events in %d samples (one per %.2f), status %d, %d positions" % (ev.shape[0], reads[1].adc.shape[0], reads[1].adc.shape[0] / ev.shape[0], st_w[1], np_w[1]))
+
+
+@pytest.mark.gpu
+def test_hostile_reads_through_the_whole_path_match_the_oracle(model):
+    """The hostile signals that are a REAL read's signal with something done to it (stalls spliced in, spikes, drift, saturation, a ramp underneath), each with that
+    read's own sequence and mapping, and the 50 kb read with five stalls: normaliseEvents + eventalign on the device == the oracle -- status (the four stall reads and the 50 kb
+    read pass everything; spikes / drift / saturation / ramp fail the banded QC, identically), event counts, rough scaling, every alignment pair, the QC triple, final shift /
+    scale bit for bit, positions, coordinates and feature tensors."""
+    from dnascent_amd import hip, host, synth
+    sigs = adv.cases(model)
+    reads = []
+    for nm in ("stall6000_flat", "stall6000_noisy", "stall3000_after_bump", "stall_noisy_then_flat", "spikes", "drift_up", "drift_down", "saturated_plateaus", "ramp_textured"):
+        r = synth.make_read(7001, 2500, model=model)       # the read adversarial_signals.cases() built them from
+        r.adc = sigs[nm]; r.cal_offset, r.cal_scale = adv.CAL
+        reads.append((nm, r))
+    r = synth.make_read(7050, 50000, model=model)
+    r.adc = adv.read50kb_with_stalls(model); r.cal_offset, r.cal_scale = adv.CAL
+    reads.append(("read50kb_with_stalls", r))
+    ctx = hip.Context(0)
+    ctx.load_pore_model(model, 0.14)
+    b = host.ReadBatch()
+    for _, q in reads:
+        assert b.add_synth(q) >= 0
+    b.upload(ctx)
+    ctx.run("normalise"); ctx.run("eventalign"); ctx.sync()
+    s = ctx.summaries()
+    passed = []
+    for i, (nm, q) in enumerate(reads):
+        o = po.OracleRead(q, model)
+        st = o.normalise()
+        n = o.norm
+        assert s["status"][i] == st, (nm, s["status"][i], st)
+        assert s["n_scrappie"][i] == n.n_scrappie and s["n_events"][i] == n.n_events and s["n_aligned"][i] == n.n_aln and s["n_cleaned"][i] == n.n_cleaned, nm
+        assert np.float64(s["rough_shift"][i]).tobytes() == np.float64(n.q_shift).tobytes() and np.float64(s["rough_scale"][i]).tobytes() == np.float64(n.q_scale).tobytes(), nm
+        if n.n_aln:
+            assert np.float64(s["avg_log_emission"][i]).tobytes() == np.float64(n.avg_log_emission).tobytes() and s["max_gap"][i] == n.max_gap and s["spanned"][i] == n.spanned, nm
+        if st == 0:
+            passed.append(nm)
+            assert np.float64(s["shift"][i]).tobytes() == np.float64(n.shift).tobytes() and np.float64(s["scale"][i]).tobytes() == np.float64(n.scale).tobytes(), nm
+            ae, ak = ctx.alignment(i, int(s["n_aligned"][i]))
+            we, wk = o.alignment()
+            assert np.array_equal(ae, we) and np.array_equal(ak, wk), nm
+            assert o.eventalign() == 0 and int(s["n_positions"][i]) == o.align.n_pos, nm
+            got, want = ctx.positions(i, int(s["n_positions"][i])), o.positions()
+            for k in ("coord", "query_idx", "ref_idx", "indel", "n_signal", "core", "residual", "kmer"):
+                assert np.array_equal(got[k], want[k]), (nm, k)
+            assert got["signal"].tobytes() == want["signal"].tobytes(), nm
+        o.free()
+    ctx.close()
+    assert passed == ["stall6000_flat", "stall6000_noisy", "stall3000_after_bump", "stall_noisy_then_flat", "read50kb_with_stalls"]
