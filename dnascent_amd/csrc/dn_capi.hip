@@ -28,7 +28,8 @@ int k2_selftest_run(hipStream_t);
 void k2_launch_fill(const BatchDev &, const void *, const void *, hipStream_t);
 void k2_launch_chase(const BatchDev &, uint8_t *, hipStream_t);
 void k2_launch_post(const BatchDev &, const uint8_t *, float *, const void *, hipStream_t);
-hipError_t k2b_launch(const BatchDev &, const void *, const void *, const void *, unsigned, hipStream_t);
+hipError_t k2b_launch(const BatchDev &, const void *, const void *, const void *, unsigned, void *, hipStream_t);
+size_t k2b_huge_scratch_bytes();
 struct CnnRows { const unsigned *row_off; const uint8_t *valid; unsigned rows, r0, r1; const unsigned *n_pos; const uint64_t *io_off; };
 struct CnnRun { const dn_cnn_op *ops; int n_ops; const float *wts; float *buf[8]; int n_buf; CnnRows rows; uint8_t *valid;
                  const float *core, *resid, *sig; float *probs; unsigned max_pos; const uint16_t *wts_split; const int64_t *wb_off;
@@ -182,7 +183,7 @@ struct dn_ctx {
     bool want_align = false, have_align = false; DevBuf al_coord, al_rpos, al_val, al_kind, al_off, al_n; std::vector<unsigned long long> h_al_off; std::vector<unsigned> h_al_n;
     std::vector<unsigned> h_npoi, h_nhmm;
     std::vector<int32_t> h_ref_start, h_ref_end; std::vector<uint8_t> h_is_rev;
-    VitConstsH vc{}; EaDevH ea{}; VitReadH *d_vitread = nullptr; unsigned max_ref = 0;
+    VitConstsH vc{}; EaDevH ea{}; VitReadH *d_vitread = nullptr; unsigned max_ref = 0; void *d_k2b_huge = nullptr;
     // profiling
     bool prof = false;
     std::vector<ProfRec> pending;
@@ -492,6 +493,7 @@ void dn_ctx_destroy(dn_ctx *c) {
     if (c->d_cnn_wb) hipFree(c->d_cnn_wb);
     if (c->d_cnn_wh) hipFree(c->d_cnn_wh);
     if (c->d_cnn_flag) hipFree(c->d_cnn_flag);
+    if (c->d_k2b_huge) hipFree(c->d_k2b_huge);
     for (auto *p : c->d_fit) if (p) hipFree(p);
     for (DevBuf *b : { &c->hmm_poi, &c->hmm_npoi, &c->hmm_nev, &c->hmm_ok, &c->hmm_la, &c->hmm_lt, &c->hmm_reads, &c->al_coord, &c->al_rpos,
                        &c->al_val, &c->al_kind, &c->al_off, &c->al_n }) if (b->p) hipFree(b->p);
@@ -897,7 +899,11 @@ int dn_run_eventalign(dn_ctx *c) {
         c->ea.al_kind = (unsigned char *)c->al_kind.p; c->ea.al_off = (const unsigned long long *)c->al_off.p; c->ea.al_n = (unsigned *)c->al_n.p;
         c->have_align = true;
     }
-    { Timed t(c, DN_K_VITERBI); HIPCHK(c, k2b_launch(c->B, &c->ea, c->d_vitread, &c->vc, c->max_ref, c->stream)); }
+    if (!c->d_k2b_huge) {                                 // once per context: the global-memory lattices of the reads a > 512-observation window stops (6 MB)
+        HIPCHK(c, hipMalloc(&c->d_k2b_huge, k2b_huge_scratch_bytes()));
+        c->dev_bytes += k2b_huge_scratch_bytes();
+    }
+    { Timed t(c, DN_K_VITERBI); HIPCHK(c, k2b_launch(c->B, &c->ea, c->d_vitread, &c->vc, c->max_ref, c->d_k2b_huge, c->stream)); }
     HIPCHK(c, hipGetLastError());
     c->stage = 6;
     return DN_OK;

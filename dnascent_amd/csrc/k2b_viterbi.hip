@@ -23,6 +23,10 @@
                              // (T + 1) x 66 bytes of LDS per wavefront: 34 KB at 512 kept the occupancy at 3 wavefronts per CU and
                              // the CNN's large workgroups off every CU an eventalign wavefront sat on; at 224 it is 15 KB (22 KB in
                              // all).  A read with a longer window is redone by a second launch of the 512 variant.
+#define VT_THUGE 8192        // round 6: windows of up to this many observations (a stalled pore: hundreds to thousands of events rough-aligned to one k-mer) are walked with
+                             // the lattice in GLOBAL memory (k2b_eventalign<VT_THUGE>, below); the reference has no limit, beyond this one a read fails
+#define VT_HUGE_WGS 8        // ... by that many wavefronts per launch, each with its own 790 KB of scratch,
+#define VT_HUGE_ROUNDS 4     // ... in that many launches: up to 32 such reads per batch (more: DN_READ_FAIL_WINDOW_EVENTS as before)
 #define VT_NS 66             // backtrace row stride (positions per window <= 65)
 
 struct VitConsts {           // alignment.cpp:199-204 (host libm), normalPDF constants, deletion chain before the first event
@@ -186,23 +190,35 @@ template <int TMAX> struct K2bLds {
 #else
 #define K2B_BOUNDS(threads) __launch_bounds__(threads)
 #endif
+#define K2B_HUGE_HEAD 4096                                 /* bytes: the list of parked reads (count, then up to 1 023 read indices) in front of the lattices */
+#define K2B_HUGE_STRIDE ((sizeof(K2bLds<VT_THUGE>) + 255) & ~(size_t)255)
 static_assert(sizeof(K2bLds<VT_TFAST>) * K2B_W <= 160 * 1024 && sizeof(K2bLds<VT_TMAX>) <= 160 * 1024, "K2B_W wavefronts' lattices must fit gfx950's 160 KB of LDS per CU");
 template <int TMAX>
-__global__ K2B_BOUNDS(64 * (TMAX <= VT_TFAST ? K2B_W : 1)) void k2b_eventalign(BatchDev B, EaDev O, const VitRead *vrs, VitConsts vc, int mode) {
+__global__ K2B_BOUNDS(64 * (TMAX <= VT_TFAST ? K2B_W : 1)) void k2b_eventalign(BatchDev B, EaDev O, const VitRead *vrs, VitConsts vc, int mode, unsigned char *huge) {
     constexpr int WPB = TMAX <= VT_TFAST ? K2B_W : 1;     // the 512-observation lattice holds 50 KB: one per workgroup as before (it runs for a handful of windows)
+    constexpr bool HUGE = TMAX > VT_TMAX;                 // round 6: the lattice in global memory (`huge`: a list of the parked reads, then VT_HUGE_WGS lattices)
 #if K2B_WAVES_EU > 0
     extern __shared__ __attribute__((aligned(16))) unsigned char k2b_dyn_lds_[];
-    K2bLds<TMAX> *lds_ = reinterpret_cast<K2bLds<TMAX> *>(k2b_dyn_lds_);
+    K2bLds<TMAX> *lds_ = reinterpret_cast<K2bLds<TMAX> *>(HUGE ? huge + K2B_HUGE_HEAD + (size_t)blockIdx.x * K2B_HUGE_STRIDE : k2b_dyn_lds_);
 #else
-    __shared__ __attribute__((aligned(16))) K2bLds<TMAX> lds_[WPB];
+    __shared__ __attribute__((aligned(16))) K2bLds<HUGE ? 1 : TMAX> lds_s_[WPB];
+    K2bLds<TMAX> *lds_ = reinterpret_cast<K2bLds<TMAX> *>(HUGE ? huge + K2B_HUGE_HEAD + (size_t)blockIdx.x * K2B_HUGE_STRIDE : (unsigned char *)lds_s_);
 #endif
     K2bLds<TMAX> &L_ = lds_[WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0];
     double *xs = L_.xs; unsigned *tk_start = L_.tk_start, *tk_len = L_.tk_len, *ev_slot = L_.ev_slot, *ev_cnt0 = L_.ev_cnt0, *ps_p = L_.ps_p, *ps_cnt = L_.ps_cnt;
     unsigned short *evlab = L_.evlab; unsigned char *bt = L_.bt; unsigned *ev_aoff = L_.ev_aoff;
-    const int r = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WPB + (threadIdx.x >> 6))) : (int)blockIdx.x;     // wave-uniform, and the compiler must know it
+    int r_;
+    if (HUGE) {                                           // mode = 5 + round: this wavefront's entry of the list k2b_huge_list made (count in word 0)
+        const unsigned *list = reinterpret_cast<const unsigned *>(huge);
+        const unsigned idx = (unsigned)(mode - 5) * VT_HUGE_WGS + blockIdx.x;
+        if (idx >= list[0]) return;
+        r_ = __builtin_amdgcn_readfirstlane((int)list[1 + idx]);
+    } else r_ = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WPB + (threadIdx.x >> 6))) : (int)blockIdx.x;     // wave-uniform, and the compiler must know it
+    const int r = r_;
     if (r >= B.n_reads) return;
     const int lane = threadIdx.x & 63;
-    if (mode != 0 && O.redo[r] != mode) return;           // later passes: only the reads the pass before handed over
+    if (!HUGE && mode != 0 && O.redo[r] != mode) return;  // later passes: only the reads the pass before handed over
+    if (HUGE && O.redo[r] != 5) return;
     ReadRes &R = B.res[r];
     const VitRead vr = vrs[r];
     if (R.status == 0 && vr.fail) {                       // eln() of a negative number: the reference throws NegativeLog (probability.cpp:45)
@@ -235,7 +251,7 @@ __global__ K2B_BOUNDS(64 * (TMAX <= VT_TFAST ? K2B_W : 1)) void k2b_eventalign(B
     unsigned al_rows = 0;                                 // rows of the align table written so far
     int fail = 0;
     unsigned *const saved = O.resume + 8 * (size_t)r;
-    if (mode != 0) { ri = (int)saved[0]; readHead = saved[1]; npos = saved[2]; nwin = saved[3]; al_rows = saved[4]; }   // wave-uniform loads
+    if (mode != 0) { ri = (int)saved[0]; readHead = saved[1]; npos = saved[2]; nwin = saved[3]; al_rows = saved[4]; }   // wave-uniform loads (the huge passes: mode >= 5)
     auto park = [&](unsigned char next) {                 // stop here; the pass `next` picks the walk up at this window
         if (lane == 0) { saved[0] = (unsigned)ri; saved[1] = readHead; saved[2] = npos; saved[3] = nwin; saved[4] = al_rows; O.redo[r] = next; }
     };
@@ -298,8 +314,9 @@ __global__ K2B_BOUNDS(64 * (TMAX <= VT_TFAST ? K2B_W : 1)) void k2b_eventalign(B
         const int indel = (int)(qhi - qlo) - (int)(W - DN_K + 1);       // :635-638
         if (nt < 2) { ri += W; continue; }                // :641
         if (nt > (unsigned)TMAX) {
-            if (TMAX < VT_TMAX) { park(mode == 0 ? 1 : 3); return; }          // wave-uniform: THIS window goes to the large lattice (readHead already
-            fail = 6; break;                                                  // points at its first event: gathering it again gives the same events)
+            if (TMAX == VT_TFAST) { park(mode == 0 ? 1 : 3); return; }        // wave-uniform: THIS window goes to the large lattice (readHead already
+            if (TMAX == VT_TMAX && huge) { park(5); return; }                 // points at its first event: gathering it again gives the same events);
+            fail = 6; break;                                                  // beyond 512: the read goes on in global memory; beyond 8 192 (or no scratch): it fails
         }
         const int T = __builtin_amdgcn_readfirstlane((int)nt);
         K2B_SYNC();
@@ -578,6 +595,30 @@ __global__ K2B_BOUNDS(64 * (TMAX <= VT_TFAST ? K2B_W : 1)) void k2b_eventalign(B
     }
 }
 
+// Round 6: the reads that a window of more than 512 observations stopped (redo == 5), in read order: list[0] = how many, list[1 ..] = which.  A stalled pore leaves
+// hundreds to thousands of events rough-aligned to ONE k-mer (a 6 000-sample noisy stall: ~1 100 events in one window; found by tests/test_segmentation_adversarial.py:
+// the device failed such a read where the reference, which allocates per window, passes it).  They are rare: VT_HUGE_ROUNDS launches of VT_HUGE_WGS wavefronts walk
+// them to their ends with the SAME code (k2b_eventalign<VT_THUGE>), the lattice (96 bytes per observation) in global memory -- no LDS is asked for, so these launches
+// never wait for a CU to drain.  A batch with more such reads than the rounds cover fails the surplus as before (DN_READ_FAIL_WINDOW_EVENTS).
+__global__ __launch_bounds__(64) void k2b_huge_list(BatchDev B, EaDev O, unsigned char *huge) {
+    unsigned *list = reinterpret_cast<unsigned *>(huge);
+    const int lane = threadIdx.x;
+    unsigned n = 0;
+    for (int base = 0; base < B.n_reads; base += 64) {
+        const int r = base + lane;
+        const bool p = r < B.n_reads && O.redo[r] == 5;
+        const unsigned long long m = __ballot(p);
+        const unsigned at = n + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        if (p) {
+            if (at < VT_HUGE_WGS * VT_HUGE_ROUNDS) list[1 + at] = (unsigned)r;
+            else { B.res[r].status = 6; B.res[r].n_positions = 0; if (O.al_n) O.al_n[r] = 0u; O.redo[r] = 0; }
+        }
+        n += (unsigned)__popcll(m);
+    }
+    if (lane == 0) list[0] = min(n, (unsigned)(VT_HUGE_WGS * VT_HUGE_ROUNDS));
+}
+size_t k2b_huge_scratch_bytes() { return K2B_HUGE_HEAD + (size_t)VT_HUGE_WGS * K2B_HUGE_STRIDE; }
+
 // core / residual indices of every aligned position (reads.h:112-138, +1), one thread per position
 __global__ __launch_bounds__(256) void k2b_features(BatchDev B, EaDev O) {
     const int r = blockIdx.y;
@@ -626,7 +667,7 @@ void k2b_emission_tap_launch(const double *x, const double *mu, double *out, uns
 }
 
 // Returns hipSuccess, or the error of the dynamic-LDS opt-in (a launch that needs 88 KB of LDS without it fails opaquely later).
-hipError_t k2b_launch(const BatchDev &B, const void *ea, const void *vr, const void *vc, unsigned max_ref, hipStream_t st) {
+hipError_t k2b_launch(const BatchDev &B, const void *ea, const void *vr, const void *vc, unsigned max_ref, void *huge_scratch, hipStream_t st) {
     const EaDev O = *reinterpret_cast<const EaDev *>(ea);
     const VitConsts V = *reinterpret_cast<const VitConsts *>(vc);
     hipMemsetAsync(O.redo, 0, (size_t)B.n_reads, st);
@@ -645,10 +686,17 @@ hipError_t k2b_launch(const BatchDev &B, const void *ea, const void *vr, const v
             if (dev >= 0 && dev < 64) done[dev].store(1, std::memory_order_release);
         }
     }
-    hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, gf, bf, lf, st, B, O, (const VitRead *)vr, V, 0);
-    hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), lm, st, B, O, (const VitRead *)vr, V, 1);
-    hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, gf, bf, lf, st, B, O, (const VitRead *)vr, V, 2);
-    hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), lm, st, B, O, (const VitRead *)vr, V, 3);
+    unsigned char *hs = K2B_WAVES_EU > 0 ? (unsigned char *)huge_scratch : nullptr;     // (the static-LDS experiment build has no huge variant)
+    hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, gf, bf, lf, st, B, O, (const VitRead *)vr, V, 0, hs);
+    hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), lm, st, B, O, (const VitRead *)vr, V, 1, hs);
+    hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, gf, bf, lf, st, B, O, (const VitRead *)vr, V, 2, hs);
+    hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), lm, st, B, O, (const VitRead *)vr, V, 3, hs);
+    if (hs) {
+        // the reads a window of more than 512 observations stopped (in pass 1 or 3): listed, then walked to their ends with the lattice in global memory
+        hipLaunchKernelGGL(k2b_huge_list, dim3(1), dim3(64), 0, st, B, O, hs);
+        for (int round = 0; round < VT_HUGE_ROUNDS; round++)
+            hipLaunchKernelGGL(k2b_eventalign<VT_THUGE>, dim3(VT_HUGE_WGS), dim3(64), 0, st, B, O, (const VitRead *)vr, V, 5 + round, hs);
+    }
     hipLaunchKernelGGL(k2b_features, dim3((max_ref + 255) / 256, B.n_reads), dim3(256), 0, st, B, O);
     return hipSuccess;
 }

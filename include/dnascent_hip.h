@@ -48,8 +48,9 @@ enum {
     DN_READ_FAIL_NO_END_CELL = 3, /* path left the band / no end cell: undefined behaviour in the reference */
     DN_READ_FAIL_NEGATIVE_LOG = 4,/* probability.cpp:45 NegativeLog */
     DN_READ_FAIL_TOO_SHORT = 5,
-    DN_READ_FAIL_WINDOW_EVENTS = 6/* more than 512 events inside one eventalign window (alignment.cpp:611-632 has no limit; a 50-base
-                                     window holds ~120): the device lattice is sized for 512, the read is reported failed */
+    DN_READ_FAIL_WINDOW_EVENTS = 6/* more than 8 192 events inside one eventalign window (alignment.cpp:611-632 has no limit; a 50-base window holds ~120, a
+                                     stalled pore thousands): up to 224 / 512 the lattice lives in LDS, up to 8 192 in global memory (round 6; at most 32 such
+                                     reads per batch), beyond that the read is reported failed */
 };
 
 typedef struct dn_ctx dn_ctx;

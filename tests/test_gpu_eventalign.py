@@ -166,10 +166,8 @@ def test_oversized_windows_resume_where_they_stopped(model):
         assert o.normalise() == 0 and o.eventalign() == 0
         wr, wl, wt, ws = o.windows()
         big.append(int((wt > 224).sum()))
-        if (wt > 512).any():
-            assert s["status"][i] == 6 and s["n_positions"][i] == 0                      # DN_READ_FAIL_WINDOW_EVENTS
-            o.free()
-            continue
+        if i == 4:
+            assert (wt > 512).any() and (wt <= 8192).all()                               # the global-memory lattice's read
         assert s["status"][i] == 0 and s["n_windows"][i] == wr.shape[0]
         gr, gl, gt, gs = ctx.windows(i, wr.shape[0])
         assert np.array_equal(gr, wr) and np.array_equal(gl, wl) and np.array_equal(gt, wt)

@@ -277,3 +277,57 @@ def test_hostile_reads_through_the_whole_path_match_the_oracle(model):
         o.free()
     ctx.close()
     assert passed == ["stall6000_flat", "stall6000_noisy", "stall3000_after_bump", "stall_noisy_then_flat", "read50kb_with_stalls"]
+
+
+@pytest.mark.gpu
+def test_stalled_reads_beyond_the_lds_lattices(model):
+    """What the whole-path test above found (round 6): a noisy 6 000-sample stall leaves ~1 100 events rough-aligned to one k-mer -- one eventalign window with more
+    observations than the 512-observation LDS lattice holds -- and the device failed the read (DN_READ_FAIL_WINDOW_EVENTS) where the reference, which allocates per
+    window (alignment.cpp:611-632), passes it.  Such reads now go on with their lattice in global memory (up to 8 192 observations per window, 32 reads per batch).
+    Here: 34 copies of that read and one whose stall (60 000 noisy samples) exceeds even that, in one batch: the first 31 copies equal the oracle bit for bit, the
+    60 000-sample read and the three copies beyond the batch's 32 slots are reported as failed (the documented limits), nothing else is disturbed."""
+    from dnascent_amd import hip, host, synth
+    sigs = adv.cases(model)
+    big = synth.make_read(7060, 30000, model=model)          # long enough that 11 000 stall events do not upset its rough scaling: it passes the banded QC
+    at = big.adc.shape[0] // 2
+    big.adc = np.clip(adv.splice(big.adc.astype(np.int64), at, adv.stall(77, 60000, int(np.median(big.adc[at:at + 6])), 9)), -32768, 32767).astype(np.int16)
+    big.read_id = "stall-60000"
+    reads = [big]
+    for k in range(34):
+        q = synth.make_read(7001, 2500, model=model)
+        q.adc = sigs["stall6000_noisy"]; q.cal_offset, q.cal_scale = adv.CAL
+        q.read_id = "stall-6000-%02d" % k
+        reads.append(q)
+    reads.append(synth.make_read(7003, 3000, model=model, is_reverse=True))
+    o = po.OracleRead(reads[1], model)
+    assert o.normalise() == 0 and o.eventalign() == 0
+    wr, wl, wt, ws = o.windows()
+    assert 512 < wt.max() <= 8192
+    want = o.positions()
+    ob = po.OracleRead(big, model)
+    assert ob.normalise() == 0 and ob.eventalign() == 0 and ob.windows()[2].max() > 8192          # the reference has no limit
+    ob.free()
+    ctx = hip.Context(0)
+    ctx.load_pore_model(model, 0.14)
+    b = host.ReadBatch()
+    for q in reads:
+        assert b.add_synth(q) >= 0
+    b.upload(ctx)
+    ctx.run("normalise"); ctx.run("eventalign"); ctx.sync()
+    s = ctx.summaries()
+    assert s["status"][0] == hip.READ_FAIL_WINDOW_EVENTS and s["n_positions"][0] == 0          # > 8 192 observations in one window
+    for k in range(34):
+        i = 1 + k
+        if k < 31:
+            assert s["status"][i] == 0 and s["n_windows"][i] == wr.shape[0] and s["n_positions"][i] == want["coord"].shape[0], (k, s["status"][i])
+            gr, gl, gt, gs = ctx.windows(i, wr.shape[0])
+            assert np.array_equal(gr, wr) and np.array_equal(gl, wl) and np.array_equal(gt, wt) and np.allclose(gs, ws, rtol=1e-9, atol=0.0, equal_nan=True)
+            got = ctx.positions(i, int(s["n_positions"][i]))
+            for f in ("coord", "query_idx", "ref_idx", "indel", "n_signal", "core", "residual", "kmer"):
+                assert np.array_equal(got[f], want[f]), (k, f)
+            assert got["signal"].tobytes() == want["signal"].tobytes()
+        else:
+            assert s["status"][i] == hip.READ_FAIL_WINDOW_EVENTS and s["n_positions"][i] == 0, (k, s["status"][i])      # beyond the batch's 32 slots
+    assert s["status"][35] == 0 and s["n_positions"][35] > 2500
+    o.free()
+    ctx.close()
