@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64) void k1_events(BatchDev B) {
     __shared__ float tile[64 * SEG_PITCH];                        // the exact redo's signal tile ...
     __shared__ unsigned lds_pos[SINK_N * 64];                          // ... and peak staging
     __shared__ double lds_sum[SINK_N * 64];
-    __shared__ unsigned pre[4096];                                // peaks per chunk (<= 4M samples / read)
+    __shared__ unsigned pre[4096];                                // peaks per chunk, cached for the first 4 096 chunks (4 M samples) of a read; beyond: read back from HBM
     __shared__ unsigned t_pos[EV_TILE + DN_SEG_PEAKCAP + 1];      // the streaming tile: start and prefix sum of consecutive scrappie events
     __shared__ double t_sum[EV_TILE + DN_SEG_PEAKCAP + 1];
     __shared__ float k_mean[65];                                  // kept events of one 64-wide step, slot 0 = the previous kept one
@@ -497,13 +497,15 @@ __global__ __launch_bounds__(64) void k1_events(BatchDev B) {
     // rawStart of the PREVIOUS kept index (0.0 / 0 for the first) and the raw span up to start[kept_j] - 1.  Nothing but the
     // recorded peaks is read and nothing but the events is written (the scrappie table itself only as a parity tap).
     unsigned running = 0;
-    int overflow = nch > 4096;
-    const int nchc = min(nch, 4096);
+    // (round 6: a read of more than 4 096 chunks -- 4.2 M samples, ~350 kb -- used to be an OVERFLOW of the whole batch; the reference has no such limit.  The counts
+    // of the chunks beyond the cache are read back one by one in the streaming loop below: ultra-long reads pay a load per chunk there, nothing else changes)
+    int overflow = 0;
+    const int nchc = nch;
     for (int cb = 0; cb < nchc; cb += 64) {
         const int c = cb + lane;
         unsigned cnt = (c < nchc) ? B.chunk_npk[c0 + c] : 0u;
         if (cnt > DN_SEG_PEAKCAP) { overflow = 1; cnt = DN_SEG_PEAKCAP; }
-        if (c < nchc) pre[c] = cnt;
+        if (c < min(nchc, 4096)) pre[c] = cnt;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
         running += cnt;
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(64) void k1_events(BatchDev B) {
     __syncthreads();
     for (int c = 0; c < max(nchc, 1); c++) {
         if (c < nchc) {
-            const unsigned cnt = min(pre[c], n_et - taken);
+            const unsigned cnt = min(c < 4096 ? pre[c] : min(B.chunk_npk[c0 + c], (unsigned)DN_SEG_PEAKCAP), n_et - taken);
             const unsigned *pk = B.chunk_peaks + (c0 + c) * DN_SEG_PEAKCAP;
             const double *pks = B.chunk_psum + (c0 + c) * DN_SEG_PEAKCAP;
             for (unsigned j = lane; j < cnt; j += 64) { t_pos[fill + j] = pk[j]; t_sum[fill + j] = pks[j]; }

@@ -49,6 +49,35 @@ def test_ragged_batch_with_200kb_read(model):
     ctx.close()
 
 
+def test_ultra_long_read_beyond_4096_detector_chunks(model):
+    """A 400 kb read (4.6 M samples = 4 492 detector chunks): until round 6 a read of more than 4 096 chunks made the WHOLE batch fail with DN_ERR_OVERFLOW (k1_events cached
+    the chunks' peak counts in a 4 096-entry LDS array); the reference has no such limit.  Now: normaliseEvents + eventalign bit-exact against the oracle, a short read
+    beside it untouched."""
+    reads = [synth.make_read(8401, 1500, model=model), synth.make_read(8400, 400000, model=model, sub_rate=0.002, ins_rate=0.001, del_rate=0.001)]
+    assert (reads[1].adc.shape[0] + 1023) // 1024 > 4096
+    ctx = hip.Context(0)
+    ctx.load_pore_model(model, 0.14)
+    _batch(ctx, reads)
+    ctx.run("normalise"); ctx.run("eventalign"); ctx.sync()
+    s = ctx.summaries()
+    for i, r in enumerate(reads):
+        o = po.OracleRead(r, model)
+        assert o.normalise() == 0 and s["status"][i] == 0
+        assert s["n_scrappie"][i] == o.norm.n_scrappie and s["n_events"][i] == o.norm.n_events and s["n_aligned"][i] == o.norm.n_aln
+        assert s["shift"][i] == o.norm.shift and s["scale"][i] == o.norm.scale
+        ae, ak = ctx.alignment(i, int(s["n_aligned"][i]))
+        we, wk = o.alignment()
+        assert np.array_equal(ae, we) and np.array_equal(ak, wk)
+        assert o.eventalign() == 0 and int(s["n_positions"][i]) == o.align.n_pos
+        got = ctx.positions(i, int(s["n_positions"][i])); want = o.positions()
+        for k in ("coord", "query_idx", "ref_idx", "indel", "n_signal", "core", "residual", "kmer"):
+            assert np.array_equal(got[k], want[k]), (i, k)
+        assert got["signal"].tobytes() == want["signal"].tobytes()
+        o.free()
+    assert s["n_positions"][1] > 350000
+    ctx.close()
+
+
 def test_empty_batch_and_all_failed(model):
     ctx = hip.Context(0)
     ctx.load_pore_model(model, 0.14)
