@@ -686,7 +686,10 @@ hipError_t k2b_launch(const BatchDev &B, const void *ea, const void *vr, const v
             if (dev >= 0 && dev < 64) done[dev].store(1, std::memory_order_release);
         }
     }
-    unsigned char *hs = K2B_WAVES_EU > 0 ? (unsigned char *)huge_scratch : nullptr;     // (the static-LDS experiment build has no huge variant)
+#ifndef K2B_HUGE
+#define K2B_HUGE 1                                          /* experiment builds: -DK2B_HUGE=0 = round 5's behaviour (a window beyond 512 observations fails the read) */
+#endif
+    unsigned char *hs = (K2B_WAVES_EU > 0 && K2B_HUGE) ? (unsigned char *)huge_scratch : nullptr;     // (the static-LDS experiment build has no huge variant)
     hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, gf, bf, lf, st, B, O, (const VitRead *)vr, V, 0, hs);
     hipLaunchKernelGGL(k2b_eventalign<VT_TMAX>, dim3(B.n_reads), dim3(64), lm, st, B, O, (const VitRead *)vr, V, 1, hs);
     hipLaunchKernelGGL(k2b_eventalign<VT_TFAST>, gf, bf, lf, st, B, O, (const VitRead *)vr, V, 2, hs);
