@@ -331,3 +331,50 @@ def test_stalled_reads_beyond_the_lds_lattices(model):
     assert s["status"][35] == 0 and s["n_positions"][35] > 2500
     o.free()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_every_failure_the_hostile_signals_cause_is_the_oracles(model):
+    """All 22 hostile signals on short carrier reads (their sequence has nothing to do with the signal) + the no-peak signals + a read with exactly one event per base:
+    whatever normaliseEvents / eventalign make of them -- banded-QC failures (status 1), no end cell (3: the 16- and 40-sample reads), eventsPerBase <= 1 (4: the reference
+    throws NegativeLog, probability.cpp:45), no event at all (5) -- the device reports the oracle's status, event counts, rough scaling and pair counts for every one."""
+    from dnascent_amd import hip, host, synth
+    sigs = dict(adv.cases(model))
+    for k, v in adv.no_peak_cases().items():
+        if v.shape[0] >= 16:
+            sigs["nopeak_" + k] = v
+    reads = [(nm, _carrier(model, 7600 + i, sigs[nm])) for i, nm in enumerate(sorted(sigs))]
+    one = synth.make_read(7700, 3000, model=model)           # three noise-free samples per base: one event per base, eventsPerBase = 0.998
+    code = np.zeros(256, np.int64); code[ord("T")] = 1; code[ord("G")] = 2; code[ord("C")] = 3
+    c = code[one.refseq]
+    rank = np.zeros(c.shape[0] - 8, np.int64)
+    for j in range(9):
+        rank = rank * 4 + c[j:j + rank.shape[0]]
+    one.adc = np.repeat(np.rint((model[rank] * 14.0 + 95.0) / 0.1755 + 240.0).astype(np.int16), 3)
+    reads.append(("one_event_per_base", one))
+    ctx = hip.Context(0)
+    ctx.load_pore_model(model, 0.14)
+    b = host.ReadBatch()
+    for _, q in reads:
+        assert b.add_synth(q) >= 0
+    b.upload(ctx)
+    ctx.run("normalise"); ctx.run("eventalign"); ctx.sync()
+    s = ctx.summaries()
+    seen = {}
+    for i, (nm, q) in enumerate(reads):
+        o = po.OracleRead(q, model)
+        st = o.normalise()
+        n = o.norm
+        if st == 0:
+            st = o.eventalign()                                # 4 where eln() meets a negative number (eventsPerBase <= 1)
+        assert s["status"][i] == st, (nm, s["status"][i], st)
+        assert s["n_scrappie"][i] == n.n_scrappie and s["n_events"][i] == n.n_events and s["n_aligned"][i] == n.n_aln and s["n_cleaned"][i] == n.n_cleaned, nm
+        if n.n_events:
+            assert np.float64(s["rough_shift"][i]).tobytes() == np.float64(n.q_shift).tobytes() and np.float64(s["rough_scale"][i]).tobytes() == np.float64(n.q_scale).tobytes(), nm
+        if st != 0:
+            assert s["n_positions"][i] == 0, nm
+        seen[int(st)] = seen.get(int(st), 0) + 1
+        o.free()
+    ctx.close()
+    print("statuses:", seen)
+    assert seen.get(1, 0) >= 15 and seen.get(3, 0) == 2 and seen.get(4, 0) == 1 and seen.get(5, 0) == 5
