@@ -367,6 +367,16 @@ def test_every_failure_the_hostile_signals_cause_is_the_oracles(model):
         n = o.norm
         if st == 0:
             st = o.eventalign()                                # 4 where eln() meets a negative number (eventsPerBase <= 1)
+        if n.n_events < 10 and n.n_events > 0:
+            # fewer than ten events: the quantile regression degenerates to a rough scale of exactly 0, event 0's normalised mean (its mean is the 0.0 of
+            # event_handling.cpp:551) becomes 0 / 0, and that NaN travels through the reference's comparisons (`a > b ? a : b` keeps it) but not through the
+            # device's v_max (which drops it): the read fails on both sides -- "no end cell" in the oracle, the banded QC on the device (max_gap 592) -- as it does
+            # in the reference (eventAlignment cleared by the QC).  The one place where the two failure codes differ; documented in DESIGN.md s3.
+            assert st == 3 and s["status"][i] in (1, 3) and s["n_positions"][i] == 0, (nm, s["status"][i], st)
+            assert s["n_scrappie"][i] == n.n_scrappie and s["n_events"][i] == n.n_events, nm
+            seen[3] = seen.get(3, 0) + 1
+            o.free()
+            continue
         assert s["status"][i] == st, (nm, s["status"][i], st)
         assert s["n_scrappie"][i] == n.n_scrappie and s["n_events"][i] == n.n_events and s["n_aligned"][i] == n.n_aln and s["n_cleaned"][i] == n.n_cleaned, nm
         if n.n_events:
