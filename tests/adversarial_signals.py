@@ -130,3 +130,52 @@ def no_peak_cases():
     c["square_4"] = _square(4, 3000)
     c["shorter_than_a_window"] = _steps(501, 2, 5)
     return c
+
+
+def mutate(adc, seed):
+    """1-3 hostile edits of a read's signal, chosen and placed by a splitmix64 stream: a flat or noisy stall spliced in (50-4 000 samples, at the level found there or
+    somewhere else), a burst of full-scale spikes, a saturated plateau, a dropout to the ADC's zero, a linear drift over a stretch, a stretch with three times the noise.
+    Returns (int16 signal, list of what was done)."""
+    x = np.asarray(adc, np.int64).copy()
+    u = _splitmix(seed, 64).astype(np.uint64)
+    k = 0
+
+    def draw(n):
+        nonlocal k
+        v = int(u[k] % np.uint64(n)); k += 1
+        return v
+    done = []
+    for _ in range(1 + draw(3)):
+        op = draw(7)
+        n = x.shape[0]
+        at = 200 + draw(max(1, n - 400))
+        if op == 0 or op == 1:
+            ln = 50 + draw(3950)
+            level = int(np.median(x[at:at + 8])) if draw(2) else 300 + draw(800)
+            x = splice(x, at, stall(seed * 31 + k, ln, level, 0 if op == 0 else 3 + draw(12)))
+            done.append(("stall_flat" if op == 0 else "stall_noisy", at, ln, level))
+        elif op == 2:
+            cnt = 1 + draw(6)
+            for j in range(cnt):
+                p_ = min(n - 4, at + 37 * j)
+                x[p_:p_ + 1 + draw(3)] = 32767 if draw(2) else -32768
+            done.append(("spikes", at, cnt))
+        elif op == 3:
+            ln = 20 + draw(900)
+            x[at:at + ln] = 32767 if draw(2) else -32768
+            done.append(("plateau", at, ln))
+        elif op == 4:
+            ln = 10 + draw(600)
+            x[at:at + ln] = 0
+            done.append(("dropout", at, ln))
+        elif op == 5:
+            ln = min(n - at, 500 + draw(6000))
+            amp = (draw(2) * 2 - 1) * (100 + draw(900))
+            x[at:at + ln] += (np.arange(ln) * amp) // max(ln, 1)
+            x[at + ln:] += amp
+            done.append(("drift", at, ln, amp))
+        else:
+            ln = min(n - at, 300 + draw(3000))
+            x[at:at + ln] += 3 * _noise16(seed * 17 + k, ln, 12)
+            done.append(("noisy_stretch", at, ln))
+    return np.clip(x, -32768, 32767).astype(np.int16), done
