@@ -93,3 +93,40 @@ def _compare_batch(model, reads, specs, min_ok, min_fail):
         o.free()
     assert n_ok >= min_ok and n_fail >= min_fail          # the sweep covers both outcomes
     ctx.close()
+
+
+def test_a_homopolymer_tie_is_broken_by_the_last_bits_of_libm(model):
+    """Found by tools/gpu_shape_fuzz.py (600 mutated reads, round 6): ONE label difference, in a window whose reference holds GGGGGGGGGG.  Inside a homopolymer of ten or
+    more the 9-mers of adjacent positions are THE SAME k-mer, so "match here, delete the next" and "delete here, match the next" have the same emission and the same
+    transitions in another order: a mathematical tie.  The reference breaks it by whichever sum rounds higher -- which depends on the last bits of its libm's exp / log
+    (alignment.cpp:273,347: eln(normalPDF())); the device's emission is log c + arg (a few ulps from that), so the coin can land the other way.  Pinned here as what it is:
+    the window scores agree, every position outside that homopolymer agrees, and the one event lands on the neighbouring copy of the same k-mer."""
+    import adversarial_signals as adv
+    seed, nb = 20505, 4000
+    r = synth.make_read(seed, nb, model=model, is_reverse=bool(seed & 1), sub_rate=0.002, ins_rate=0.001, del_rate=0.001, noise_pa=[1.6, 1.0, 2.5][seed % 3])
+    r.adc, _ = adv.mutate(r.adc, seed)
+    ctx = hip.Context(0)
+    ctx.load_pore_model(model, 0.14)
+    b = host.ReadBatch()
+    assert b.add_synth(r) >= 0
+    b.upload(ctx)
+    ctx.run("normalise"); ctx.run("eventalign"); ctx.sync()
+    s = ctx.summaries()
+    o = po.OracleRead(r, model)
+    assert o.normalise() == 0 and o.eventalign() == 0 and s["status"][0] == 0
+    wr, wl, wt, ws = o.windows()
+    gr, gl, gt, gs = ctx.windows(0, int(s["n_windows"][0]))
+    assert np.array_equal(gr, wr) and np.array_equal(gl, wl) and np.array_equal(gt, wt) and np.allclose(gs, ws, rtol=1e-12, atol=0.0)     # same windows, same scores
+    got, want = ctx.positions(0, int(s["n_positions"][0])), o.positions()
+    assert got["coord"].shape == want["coord"].shape
+    diff = np.flatnonzero(got["ref_idx"] != want["ref_idx"])
+    assert diff.shape[0] <= 1                              # (0 if a libm ever agrees to the last bit)
+    for k in diff:
+        a, c = int(got["ref_idx"][k]), int(want["ref_idx"][k])
+        assert abs(a - c) == 1
+        assert r.refseq[a - 4:a + 5].tobytes() == r.refseq[c - 4:c + 5].tobytes() and len(set(r.refseq[min(a, c) - 4:max(a, c) + 5].tobytes())) == 1      # the same 9-mer: a homopolymer
+        assert got["n_signal"][k] == want["n_signal"][k] and got["signal"][k].tobytes() == want["signal"][k].tobytes()                 # the same event, the neighbouring copy
+    same = np.ones(got["coord"].shape[0], bool); same[diff] = False
+    for f in ("coord", "query_idx", "ref_idx", "n_signal", "core", "residual", "kmer"):
+        assert np.array_equal(got[f][same], want[f][same]), f
+    o.free(); ctx.close()

@@ -1,0 +1,30 @@
+"""Exploration beyond tests/test_gpu_fuzz.py::test_signal_shape_fuzz_matches_oracle: many more mutated reads (tests/adversarial_signals.py mutate()), batch after batch,
+device against oracle; prints the first mismatch of every failing batch instead of stopping.   python tools/gpu_shape_fuzz.py [batches] [seed0]"""
+import os, sys, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+import adversarial_signals as adv
+import test_gpu_fuzz as tf
+from dnascent_amd import synth
+
+nb_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+model = synth.pore_model()
+bad = 0
+for b in range(nb_batches):
+    reads, specs = [], []
+    for i in range(40):
+        seed = seed0 + 40 * b + i
+        nb = [800, 1500, 2500, 4000, 6000, 9000][seed % 6]
+        r = synth.make_read(seed, nb, model=model, is_reverse=bool(seed & 1), sub_rate=0.002, ins_rate=0.001, del_rate=0.001, noise_pa=[1.6, 1.0, 2.5][seed % 3])
+        r.adc, done = adv.mutate(r.adc, seed)
+        reads.append(r); specs.append((seed, nb, done))
+    try:
+        tf._compare_batch(model, reads, specs, 0, 0)
+        print("batch %d ok" % b, flush=True)
+    except AssertionError:
+        bad += 1
+        print("batch %d MISMATCH:" % b, traceback.format_exc()[-1500:], flush=True)
+print("batches with a mismatch: %d of %d" % (bad, nb_batches))
