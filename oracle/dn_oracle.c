@@ -59,6 +59,21 @@ double dno_normalPDF(double mu, double sigma, double x) {                /* :145
     return (1.0 / sqrt(2.0 * pow(sigma, 2.0) * M_PI)) * exp(-pow(x - mu, 2.0) / (2.0 * pow(sigma, 2.0)));
 }
 
+/* ANALYSIS ONLY (tools/gpu_sequence_fuzz.py, tests/test_gpu_fuzz.py): the Viterbi's emission eln(normalPDF(mu, sigma, x)) evaluated the way the DEVICE lattice does
+ * (csrc/k2b_viterbi.hip emission(): log c + arg, arg = -(x - mu)^2 / (2 s^2) through an FMA-corrected reciprocal; the literal exp -> log chain only where exp() would be
+ * subnormal) instead of the reference's log(c * exp(arg)).  The two agree to a few ulps; inside low-complexity sequence (identical or periodically repeating k-mers) the
+ * Viterbi has exact ties that those last bits decide.  With this switch on, the oracle's labels must equal the device's bit for bit -- which is how the claim "the only
+ * difference is the emission's last bits" is TESTED rather than believed.  Off (the default) the oracle is the reference's arithmetic. */
+static int g_device_emission = 0;
+void dno_set_device_emission(int on) { g_device_emission = on; }
+static double viterbi_emission(double mu, double sigma, double x) {
+    if (!g_device_emission) return dno_eln(dno_normalPDF(mu, sigma, x), NULL);
+    const double s2 = sigma * sigma, d2 = s2 + s2, rd2 = 1.0 / d2, c = 1.0 / sqrt(M_PI * d2), logc = log(c);     /* dn_capi.hip: the host computes them with its libm */
+    const double d = x - mu, sq = d * d, n = -sq, q = n * rd2, rem = fma(-q, d2, n), arg = fma(rem, rd2, q);
+    if (arg < -708.0) { const double p_ = c * exp(arg); return p_ == 0.0 ? NAN : log(p_); }
+    return logc + arg;
+}
+
 /* ------------------------------------------------------------------------------------------
  * data_IO.cpp:129-141  kmer2index: A0 T1 G2 C3, big-endian base 4; anything else -> 0
  * (std::map::operator[] default-inserts 0 for an unknown one-letter key).
@@ -530,14 +545,14 @@ size_t dno_viterbi(const dno_model *m, const double *obs, size_t T, const char *
         const double xs = (obs[t] - shift) / scale;
         uint8_t *cI = bI + (t + 1) * N, *cM = bM + (t + 1) * N, *cD = bD + (t + 1) * N;
         int a; double v[4];
-        double e0 = dno_eln(dno_normalPDF(mu[0], m->sigma, xs), NULL);   /* :273 */
+        double e0 = viterbi_emission(mu[0], m->sigma, xs);               /* :273 */
         v[0] = Ip[0] + I2I + 0.0; v[1] = Mp[0] + M2I + 0.0; v[2] = start_prev + M2I + 0.0;   /* :278-285 */
         Ic[0] = vmax(v, 3, &a); cI[0] = (uint8_t)a;                      /* 0:I0 1:M0 2:START */
         v[0] = Mp[0] + iM2M + e0; v[1] = start_prev + eOrI + e0;         /* :305-310 */
         Mc[0] = vmax(v, 2, &a); cM[0] = (uint8_t)(a == 0 ? 2 : 4);       /* 2:M_i 4:START */
         Dc[0] = dno_lnProd(NAN, M2D); cD[0] = 2;                         /* :326-328 */
         for (size_t i = 1; i < N; i++) {
-            double e = dno_eln(dno_normalPDF(mu[i], m->sigma, xs), NULL);/* :347 */
+            double e = viterbi_emission(mu[i], m->sigma, xs);            /* :347 */
             v[0] = Ip[i] + I2I + 0.0; v[1] = Mp[i] + M2I + 0.0;          /* :351-356 */
             Ic[i] = vmax(v, 2, &a); cI[i] = (uint8_t)a;
             v[0] = Ip[i - 1] + I2M + e; v[1] = Mp[i - 1] + eM2M + e;     /* :372-381 */

@@ -145,6 +145,8 @@ typedef struct {
 } dno_align;
 
 int  dno_eventalign(const dno_model *m, const dno_read *r, const dno_norm *n, dno_align *out);
+/* analysis only: the Viterbi's emission as the device evaluates it (see dn_oracle.c); 0 = the reference's arithmetic (default) */
+void dno_set_device_emission(int on);
 /* analysis only (tools/k2b_resync_sim.py): the window chain from an arbitrary start state; see dn_oracle.c */
 size_t dno_eventalign_chain(const dno_model *m, const dno_read *r, const dno_norm *nm, unsigned int ri0, int readHead0, size_t max_w, uint32_t *out_ri, int32_t *out_rh, int seq_only);
 void dno_align_free(dno_align *a);
