@@ -179,3 +179,54 @@ def mutate(adc, seed):
             x[at:at + ln] += 3 * _noise16(seed * 17 + k, ln, 12)
             done.append(("noisy_stretch", at, ln))
     return np.clip(x, -32768, 32767).astype(np.int16), done
+
+
+# ---- low-complexity REFERENCE sequences (round 6): homopolymer runs of 5-40, di- / tri-nucleotide and longer tandem repeats, two-letter stretches, the odd N, with a signal
+# that follows the pore model (geometric dwell, Gaussian noise) -- forward reads, perfect CIGAR.  numpy's Generator is used here (exploration + one pinned test whose
+# expectations do not depend on the exact stream: device == oracle on whatever it draws).
+ACGT = np.frombuffer(b"ACGT", np.uint8)
+
+
+def low_complexity(rng, n):
+    out = []
+    while sum(len(x) for x in out) < n:
+        kind = rng.integers(0, 6)
+        if kind == 0:
+            out.append(ACGT[rng.integers(0, 4, rng.integers(20, 200))])                       # ordinary stretch
+        elif kind == 1:
+            out.append(np.full(rng.integers(5, 41), ACGT[rng.integers(0, 4)], np.uint8))      # homopolymer
+        elif kind == 2:
+            out.append(np.tile(ACGT[rng.integers(0, 4, 2)], rng.integers(4, 25)))             # dinucleotide repeat
+        elif kind == 3:
+            out.append(np.tile(ACGT[rng.integers(0, 4, 3)], rng.integers(4, 20)))             # trinucleotide repeat
+        elif kind == 4:
+            two = ACGT[rng.choice(4, 2, replace=False)]
+            out.append(two[rng.integers(0, 2, rng.integers(20, 120))])                        # two-letter stretch
+        else:
+            u = np.tile(ACGT[rng.integers(0, 4, rng.integers(5, 12))], rng.integers(2, 6))    # longer tandem repeat
+            out.append(u)
+    return np.concatenate(out)[:n]
+
+
+def low_complexity_read(model, seed, n):
+    rng = np.random.default_rng(seed)
+    from dnascent_amd import synth
+    r = synth.make_read(seed, n, model=model)               # carrier for the fields; everything that matters is replaced
+    seq = low_complexity(rng, n)
+    code = np.zeros(256, np.int64); code[ord("T")] = 1; code[ord("G")] = 2; code[ord("C")] = 3
+    c = code[seq]
+    rank = np.zeros(n - 8, np.int64)
+    for j in range(9):
+        rank = rank * 4 + c[j:j + n - 8]
+    dwell = 1 + rng.geometric(1.0 / 11.5, n - 8)
+    pa = np.repeat(model[rank] * 14.0 + 95.0, dwell) + rng.normal(0, 1.6, int(dwell.sum()))
+    r.adc = np.clip(np.rint(pa / 0.1755 + 240.0), -32768, 32767).astype(np.int16)
+    r.cal_offset, r.cal_scale = -240.0, 0.1755
+    if rng.random() < 0.3:
+        seq = seq.copy(); seq[rng.integers(50, n - 50, rng.integers(1, 4))] = ord("N")         # the signal keeps the base that was there
+    r.refseq = seq.copy(); r.basecall = seq.copy()
+    r.cigar_op = np.array([0], np.uint32); r.cigar_len = np.array([n], np.uint32)
+    r.is_reverse = False; r.ref_end = r.ref_start + n
+    return r
+
+

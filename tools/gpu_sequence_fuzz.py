@@ -13,49 +13,7 @@ import numpy as np
 import pyoracle as po
 from dnascent_amd import hip, host, synth
 
-ACGT = np.frombuffer(b"ACGT", np.uint8)
-
-
-def low_complexity(rng, n):
-    out = []
-    while sum(len(x) for x in out) < n:
-        kind = rng.integers(0, 6)
-        if kind == 0:
-            out.append(ACGT[rng.integers(0, 4, rng.integers(20, 200))])                       # ordinary stretch
-        elif kind == 1:
-            out.append(np.full(rng.integers(5, 41), ACGT[rng.integers(0, 4)], np.uint8))      # homopolymer
-        elif kind == 2:
-            out.append(np.tile(ACGT[rng.integers(0, 4, 2)], rng.integers(4, 25)))             # dinucleotide repeat
-        elif kind == 3:
-            out.append(np.tile(ACGT[rng.integers(0, 4, 3)], rng.integers(4, 20)))             # trinucleotide repeat
-        elif kind == 4:
-            two = ACGT[rng.choice(4, 2, replace=False)]
-            out.append(two[rng.integers(0, 2, rng.integers(20, 120))])                        # two-letter stretch
-        else:
-            u = np.tile(ACGT[rng.integers(0, 4, rng.integers(5, 12))], rng.integers(2, 6))    # longer tandem repeat
-            out.append(u)
-    return np.concatenate(out)[:n]
-
-
-def make(model, seed, n):
-    rng = np.random.default_rng(seed)
-    r = synth.make_read(seed, n, model=model)               # carrier for the fields; everything that matters is replaced
-    seq = low_complexity(rng, n)
-    code = np.zeros(256, np.int64); code[ord("T")] = 1; code[ord("G")] = 2; code[ord("C")] = 3
-    c = code[seq]
-    rank = np.zeros(n - 8, np.int64)
-    for j in range(9):
-        rank = rank * 4 + c[j:j + n - 8]
-    dwell = 1 + rng.geometric(1.0 / 11.5, n - 8)
-    pa = np.repeat(model[rank] * 14.0 + 95.0, dwell) + rng.normal(0, 1.6, int(dwell.sum()))
-    r.adc = np.clip(np.rint(pa / 0.1755 + 240.0), -32768, 32767).astype(np.int16)
-    r.cal_offset, r.cal_scale = -240.0, 0.1755
-    if rng.random() < 0.3:
-        seq = seq.copy(); seq[rng.integers(50, n - 50, rng.integers(1, 4))] = ord("N")         # the signal keeps the base that was there
-    r.refseq = seq.copy(); r.basecall = seq.copy()
-    r.cigar_op = np.array([0], np.uint32); r.cigar_len = np.array([n], np.uint32)
-    r.is_reverse = False; r.ref_end = r.ref_start + n
-    return r
+from adversarial_signals import low_complexity_read as make  # noqa: E402
 
 
 def main():
