@@ -15,9 +15,10 @@ model = synth.pore_model()
 bad = 0
 for b in range(nb_batches):
     reads, specs = [], []
-    for i in range(40):
+    for i in range(int(os.environ.get("DN_FUZZ_READS", "40"))):
         seed = seed0 + 40 * b + i
-        nb = [800, 1500, 2500, 4000, 6000, 9000][seed % 6]
+        sizes = [int(x) for x in os.environ.get("DN_FUZZ_BASES", "800,1500,2500,4000,6000,9000").split(",")]
+        nb = sizes[seed % len(sizes)]
         r = synth.make_read(seed, nb, model=model, is_reverse=bool(seed & 1), sub_rate=0.002, ins_rate=0.001, del_rate=0.001, noise_pa=[1.6, 1.0, 2.5][seed % 3])
         r.adc, done = adv.mutate(r.adc, seed)
         reads.append(r); specs.append((seed, nb, done))
