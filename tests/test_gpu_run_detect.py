@@ -91,3 +91,51 @@ def test_bench_two_ranks_gloo():
     # all distinct) and says what generating them cost
     assert d["roofline_k1"]["frac"] > 0 and d["roofline_k1"]["algorithmic_bytes_per_launch"] > 0 and 2.0 < d["roofline_k1"]["bytes_per_sample"] < 6.0
     assert all(p["datagen_s"] > 0 and p["distinct_batches"] == 4 for p in d["ranks"]["per_rank"])
+
+
+def test_hostile_reads_through_the_product_driver(model, tmp_path):
+    """Round 6: the reads that broke something on the way -- a stalled read whose eventalign window exceeds both LDS lattices, the dense-event read that overflows the
+    drivers' event workspaces (retried inside DetectStream), a 400 kb read (more than 4 096 detector chunks: it used to fail its whole batch), flat and saturated signals,
+    a 16-sample read -- mixed with ordinary reads in one container, through `python -m dnascent_amd.run_detect` at its default event bound: exit code 0, the file equals a
+    plain single-context run at the detector's own bound, the passing reads are exactly those the oracle passes, in input order."""
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(ROOT, "tests")); _sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import adversarial_signals as adv
+    import pyoracle as po
+    import test_segmentation_adversarial as tsa
+    sigs = adv.cases(model)
+    nop = adv.no_peak_cases()
+    stalled = synth.make_read(7001, 2500, model=model); stalled.adc = sigs["stall6000_noisy"]; stalled.cal_offset, stalled.cal_scale = adv.CAL; stalled.read_id = "stalled"
+    reads = [synth.make_read(9901, 3000, model=model), stalled, tsa._dense_read(model, 9902, 4000), tsa._carrier(model, 9903, nop["flat"]),
+             synth.make_read(9904, 2500, model=model, is_reverse=True), tsa._carrier(model, 9905, nop["saturated_hi"]), tsa._carrier(model, 9906, sigs["tiny_16"]),
+             synth.make_read(8400, 400000, model=model, sub_rate=0.002, ins_rate=0.001, del_rate=0.001), tsa._carrier(model, 9907, sigs["spikes"]),
+             synth.make_read(9908, 3500, model=model)]
+    for k, r in enumerate(reads):
+        r.read_id = "hostile-%02d" % k
+    cont = str(tmp_path / "hostile.dnrc")
+    host.write_container(cont, reads)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = str(tmp_path / "hostile.detect")
+    r = subprocess.run([_sys.executable, "-m", "dnascent_amd.run_detect", "--container", cont, "--out", out, "--inflight", "2", "--header", "#hdr\n"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    got = open(out, "rb").read()
+    want_ids = []
+    for q in reads:
+        o = po.OracleRead(q, model)
+        if o.normalise() == 0 and o.eventalign() == 0:
+            want_ids.append(q.read_id)
+        o.free()
+    ids = [l.split()[0][1:].decode() for l in got.split(b"\n") if l.startswith(b">")]
+    assert ids == want_ids and ids == ["hostile-00", "hostile-01", "hostile-02", "hostile-04", "hostile-07", "hostile-09"]
+    ctx = hip.Context(0); ctx.load_pore_model(model, 0.14)
+    desc, blob, _ = cnn_model.default_model(); ctx.load_cnn(desc, blob)
+    bt = host.ReadBatch()
+    for rd in reads:
+        assert bt.add_synth(rd) >= 0
+    bt.upload(ctx); ctx.run("normalise"); ctx.run("eventalign"); ctx.sync()
+    ref = str(tmp_path / "ref.detect")
+    assert bt.detect_write(ctx, ref, header="#hdr\n") == 6
+    assert open(ref, "rb").read() == got
+    ctx.close()
