@@ -230,3 +230,60 @@ def low_complexity_read(model, seed, n):
     return r
 
 
+
+
+def big_indel_read(model, seed, n):
+    """a read against an iid reference with LARGE indels in its mapping -- deletions and insertions of 6-120 bases, reference skips (CIGAR N), soft clips of up to 150 at both
+    ends -- forward or reverse; the signal follows the READ's sequence (geometric dwell, Gaussian noise).  Stresses the reference <-> query maps (htsInterface.cpp:59-157) on
+    the host and everything on the device that looks through them (cleaned pairs, eventalign's window bounds and indel scores, --HMM)."""
+    from dnascent_amd import synth
+    rng = np.random.default_rng(seed)
+    r = synth.make_read(seed, max(n, 600), model=model)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    ref = acgt[rng.integers(0, 4, n)]                          # strand direction
+    ops, q = [], []                                            # ops in strand direction: (op code, length); BAM codes M0 I1 D2 N3 S4
+    head = int(rng.integers(0, 151)) if rng.random() < 0.5 else 0
+    if head:
+        ops.append((4, head)); q.append(acgt[rng.integers(0, 4, head)])
+    pos = 0
+    while pos < n:
+        m = int(min(n - pos, rng.integers(150, 900)))
+        ops.append((0, m)); q.append(ref[pos:pos + m]); pos += m
+        if pos >= n - 200:
+            if pos < n:
+                ops.append((0, n - pos)); q.append(ref[pos:]); pos = n
+            break
+        kind = rng.integers(0, 3)
+        ln = int(rng.integers(6, 121))
+        if kind == 0:
+            ops.append((1, ln)); q.append(acgt[rng.integers(0, 4, ln)])
+        else:
+            ln = min(ln, n - pos - 150)
+            ops.append((2 if kind == 1 else 3, ln)); pos += ln
+    tail = int(rng.integers(0, 151)) if rng.random() < 0.5 else 0
+    if tail:
+        ops.append((4, tail)); q.append(acgt[rng.integers(0, 4, tail)])
+    merged = []
+    for o, l in ops:
+        if merged and merged[-1][0] == o:
+            merged[-1][1] += l
+        else:
+            merged.append([o, l])
+    query = np.concatenate(q)
+    code = np.zeros(256, np.int64); code[ord("T")] = 1; code[ord("G")] = 2; code[ord("C")] = 3
+    c = code[query]
+    nk = query.shape[0] - 8
+    rank = np.zeros(nk, np.int64)
+    for j in range(9):
+        rank = rank * 4 + c[j:j + nk]
+    dwell = 1 + rng.geometric(1.0 / 11.5, nk)
+    pa = np.repeat(model[rank] * 14.0 + 95.0, dwell) + rng.normal(0, 1.6, int(dwell.sum()))
+    r.adc = np.clip(np.rint(pa / 0.1755 + 240.0), -32768, 32767).astype(np.int16)
+    r.cal_offset, r.cal_scale = -240.0, 0.1755
+    r.is_reverse = bool(rng.integers(0, 2))
+    if r.is_reverse:
+        merged = merged[::-1]                                  # BAM keeps the CIGAR in reference-forward order (dn_synth.c does the same)
+    r.refseq = ref.copy(); r.basecall = query.copy()
+    r.cigar_op = np.array([o for o, _ in merged], np.uint32); r.cigar_len = np.array([l for _, l in merged], np.uint32)
+    r.ref_end = r.ref_start + n
+    return r

@@ -13,7 +13,8 @@ import numpy as np
 import pyoracle as po
 from dnascent_amd import hip, host, synth
 
-from adversarial_signals import low_complexity_read as make  # noqa: E402
+import adversarial_signals as _adv  # noqa: E402
+make = _adv.big_indel_read if os.environ.get("DN_FUZZ_KIND") == "indel" else _adv.low_complexity_read      # DN_FUZZ_KIND=indel: large indels / skips / clips in the mapping
 
 
 def main():
