@@ -49,6 +49,17 @@ def test_signal_shape_fuzz_matches_oracle(model):
     _compare_batch(model, reads, specs, 18, 15)
 
 
+def test_large_indels_skips_and_clips_in_the_mapping_match_oracle(model):
+    """Round 6: 24 reads whose CIGARs hold deletions, insertions and reference skips of 6-120 bases and soft clips of up to 150, forward and reverse
+    (tests/adversarial_signals.py big_indel_read; the synthetic generator only makes single-base indels): the reference <-> query maps of htsInterface.cpp:59-157 on the
+    host, and everything on the device that looks through them -- cleaned pairs, eventalign's window bounds and indel scores, the --HMM windows -- against the oracle's own
+    rendering of the maps.  (240 more through tools/gpu_sequence_fuzz.py with DN_FUZZ_KIND=indel: all bit-exact.)"""
+    import adversarial_signals as adv
+    reads = [adv.big_indel_read(model, 91000 + i, [1500, 3000, 5000, 8000][i % 4]) for i in range(24)]
+    assert any(r.is_reverse for r in reads) and any(not r.is_reverse for r in reads) and any((r.cigar_op == 3).any() for r in reads)
+    _compare_batch(model, reads, [(91000 + i, r.basecall.shape[0], "indel") for i, r in enumerate(reads)], 20, 0)
+
+
 def _compare_batch(model, reads, specs, min_ok, min_fail):
     fit = synth.fit_models()
     ctx = hip.Context(0)
