@@ -21,6 +21,13 @@ for b in range(nb_batches):
         nb = sizes[seed % len(sizes)]
         r = synth.make_read(seed, nb, model=model, is_reverse=bool(seed & 1), sub_rate=0.002, ins_rate=0.001, del_rate=0.001, noise_pa=[1.6, 1.0, 2.5][seed % 3])
         r.adc, done = adv.mutate(r.adc, seed)
+        if os.environ.get("DN_FUZZ_CAL"):                    # another digitisation: a random calibration (offset, scale), the signal re-quantised to it
+            rng = np.random.default_rng(seed)
+            sc = np.float32(rng.uniform(0.04, 0.45)); off = np.float32(rng.uniform(-600, 600) if rng.random() < 0.5 else rng.integers(-600, 600))
+            pa = (r.adc.astype(np.float64) + r.cal_offset) * r.cal_scale
+            r.adc = np.clip(np.rint(pa / float(sc) - float(off)), -32768, 32767).astype(np.int16)
+            r.cal_offset, r.cal_scale = float(off), float(sc)
+            done = done + [("cal", float(off), float(sc))]
         reads.append(r); specs.append((seed, nb, done))
     try:
         tf._compare_batch(model, reads, specs, 0, 0)
