@@ -3,7 +3,7 @@ host's cores -- usable_cpus() // 8, i.e. two threads under the GPU pool's 16-CPU
 .detect text per 5.75 G samples) produces 0.60 GB/s of text; this test times DNAscent::formatPacked + dnh_pwrite_scatter on a full 500 x 50 kb batch's calls
 (11 600 thymidine calls per read, 16 bytes each packed, 196 MB of text) at exactly that thread count, in a process of its own (the library reads DN_HOST_THREADS
 once), and asserts 1.5 x the rank's rate.  Round 6 made it hold: 0.65 GB/s at two threads before (two digits per table lookup, cvtsd2si instead of rint(),
-three bases per lookup, recycled text buffers: 1.2 GB/s on the build container's 2.1 GHz Xeon)."""
+three bases per lookup in either orientation, recycled text buffers: 1.4 GB/s on the build container's 2.1 GHz Xeon)."""
 import json
 import os
 import subprocess
