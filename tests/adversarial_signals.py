@@ -226,7 +226,7 @@ def low_complexity_read(model, seed, n):
         seq = seq.copy(); seq[rng.integers(50, n - 50, rng.integers(1, 4))] = ord("N")         # the signal keeps the base that was there
     r.refseq = seq.copy(); r.basecall = seq.copy()
     r.cigar_op = np.array([0], np.uint32); r.cigar_len = np.array([n], np.uint32)
-    r.is_reverse = False; r.ref_end = r.ref_start + n
+    r.is_reverse = bool(seed % 3 == 1); r.ref_end = r.ref_start + n       # (strand-direction sequences: a reverse read differs only in how the host orients them)
     return r
 
 
