@@ -12,7 +12,7 @@ from dnascent_amd import synth
 nb_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 model = synth.pore_model()
-bad = 0
+bad = ties = 0
 for b in range(nb_batches):
     reads, specs = [], []
     for i in range(int(os.environ.get("DN_FUZZ_READS", "40"))):
@@ -33,6 +33,18 @@ for b in range(nb_batches):
         tf._compare_batch(model, reads, specs, 0, 0)
         print("batch %d ok" % b, flush=True)
     except AssertionError:
-        bad += 1
-        print("batch %d MISMATCH:" % b, traceback.format_exc()[-1500:], flush=True)
-print("batches with a mismatch: %d of %d" % (bad, nb_batches))
+        first = traceback.format_exc()[-600:]
+        # a tie the emission's last bits decide?  Then the oracle with the DEVICE's emission formula agrees with the device
+        import ctypes, pyoracle as po
+        L = po.oracle(); L.dno_set_device_emission.argtypes = [ctypes.c_int]
+        L.dno_set_device_emission(1)
+        try:
+            tf._compare_batch(model, reads, specs, 0, 0)
+            ties += 1
+            print("batch %d: a label differs from the reference-arithmetic oracle and agrees with the oracle that uses the device's emission formula (a tie): %s" % (b, first.strip().splitlines()[-1][:300]), flush=True)
+        except AssertionError:
+            bad += 1
+            print("batch %d MISMATCH (also with the device's emission formula):" % b, traceback.format_exc()[-1500:], flush=True)
+        finally:
+            L.dno_set_device_emission(0)
+print("batches with a real mismatch: %d of %d; batches with a libm-decided tie: %d" % (bad, nb_batches, ties))
