@@ -1531,7 +1531,8 @@ static int cnn_execute(dn_ctx *c, uint32_t n, const unsigned *ub, const unsigned
                 uint32_t k1 = ps.r0; uint64_t crows = 8, cpos = 0; unsigned cmax = 1;
                 while (k1 < ps.r1 && k1 - ps.r0 < 8 && cpos < 4096) { crows += ub[k1] + 8; cpos += ub[k1]; cmax = std::max(cmax, ub[k1]); k1++; }
                 const uint64_t span = io_off[k1 - 1] + ub[k1 - 1] - io_off[ps.r0];                 // positions from the first canary sequence's first to the last one's bound
-                if ((rc = dgrow(c, c->cnn_canary, (size_t)span * 3 * sizeof(float)))) return rc;
+                // (sized once for any read up to 512 k positions: regrowing frees, and hipFree waits for the whole device -- every batch in flight drained)
+                if ((rc = dgrow(c, c->cnn_canary, (size_t)std::max<uint64_t>(span, 512u << 10) * 3 * sizeof(float)))) return rc;
                 CnnRun cr = run;
                 cr.rows.r1 = k1; cr.rows.rows = (unsigned)((crows + 255) / 256 * 256); cr.max_pos = cmax; cr.n_pass_pos = (unsigned)cpos;
                 cr.wts_split = c->d_cnn_wb; cr.wb_off = c->cnn_wb_off.data(); cr.pieces = 3; cr.post = c->cnn_one.data();
